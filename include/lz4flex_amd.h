@@ -1,0 +1,209 @@
+/*
+ * lz4flex_amd.h -- C ABI of the MI355X-native LZ4 block codec (drop-in boundary).
+ *
+ * lz4_flex has no FFI of its own: its boundary IS its public Rust API.  Each entry point
+ * below names the lz4_flex item it replaces (paths relative to the lz4_flex v0.12.0 tree);
+ * INTEGRATION.md shows the Rust `extern "C"` shim a maintainer would add on the reference
+ * side.  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * Every compute entry point runs hand-written HIP kernels on the GPU.  There is NO CPU
+ * fallback: without a usable HIP device the calls return -LZ4FLEX_E_NO_DEVICE / -LZ4FLEX_E_HIP.
+ *
+ * Return convention for scalar calls: >= 0 is the byte count (Ok(usize)), < 0 is -code (Err).
+ */
+#ifndef LZ4FLEX_AMD_H
+#define LZ4FLEX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ------------------------------------------------------------------------- */
+/* block::DecompressError, variant order of src/block/mod.rs:82-98 */
+#define LZ4FLEX_OK 0
+#define LZ4FLEX_E_OUTPUT_TOO_SMALL 1       /* also block::CompressError::OutputTooSmall, mod.rs:103-106 */
+#define LZ4FLEX_E_LITERAL_OUT_OF_BOUNDS 2
+#define LZ4FLEX_E_EXPECTED_ANOTHER_BYTE 3
+#define LZ4FLEX_E_OFFSET_ZERO 4
+#define LZ4FLEX_E_OFFSET_OUT_OF_BOUNDS 5
+/* frame::Error, src/frame/mod.rs:35-72 */
+#define LZ4FLEX_FE_COMPRESSION 16
+#define LZ4FLEX_FE_DECOMPRESSION 17
+#define LZ4FLEX_FE_IO 18
+#define LZ4FLEX_FE_UNSUPPORTED_BLOCKSIZE 19
+#define LZ4FLEX_FE_UNSUPPORTED_VERSION 20
+#define LZ4FLEX_FE_WRONG_MAGIC 21
+#define LZ4FLEX_FE_RESERVED_BITS 22
+#define LZ4FLEX_FE_INVALID_BLOCK_INFO 23
+#define LZ4FLEX_FE_BLOCK_TOO_BIG 24
+#define LZ4FLEX_FE_HEADER_CHECKSUM 25
+#define LZ4FLEX_FE_BLOCK_CHECKSUM 26
+#define LZ4FLEX_FE_CONTENT_CHECKSUM 27
+#define LZ4FLEX_FE_SKIPPABLE_FRAME 28
+#define LZ4FLEX_FE_DICTIONARY_NOT_SUPPORTED 29
+#define LZ4FLEX_FE_CONTENT_LENGTH 30
+#define LZ4FLEX_FE_OUTPUT_FULL 31          /* one-shot helpers only: caller's flat buffer too small */
+/* library/runtime errors (API misuse or device failure; the reference would panic) */
+#define LZ4FLEX_E_INVALID_ARG 64
+#define LZ4FLEX_E_NO_DEVICE 65
+#define LZ4FLEX_E_HIP 66
+#define LZ4FLEX_E_NOMEM 67
+#define LZ4FLEX_E_UNSUPPORTED 68         /* entry point declared but its GPU path is not built yet */
+
+typedef struct lz4flex_err_detail {
+    uint64_t expected; /* OutputTooSmall{expected}, ContentLengthError{expected}, SkippableFrame(len), ... */
+    uint64_t actual;   /* OutputTooSmall{actual},   ContentLengthError{actual} */
+    int32_t inner;     /* frame: block error code wrapped by DecompressionError */
+    int32_t hip_error; /* hipError_t when the code is LZ4FLEX_E_HIP */
+} lz4flex_err_detail;
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* Owns the device workspace (staging arena, per-block descriptor arrays) and a HIP stream.
+ * One context per thread; distinct contexts are independent (reference: no global state,
+ * all fns reentrant).  The scalar calls below use a lazily created per-thread default context
+ * on the current HIP device. */
+typedef struct lz4flex_ctx lz4flex_ctx;
+int lz4flex_ctx_create(lz4flex_ctx **ctx, int device /* -1 = current */);
+void lz4flex_ctx_destroy(lz4flex_ctx *ctx);
+int lz4flex_device_count(void);
+const char *lz4flex_version(void);
+/* last HIP error string seen by this thread (diagnostics) */
+const char *lz4flex_last_error(void);
+
+/* ---- block: scalar, lz4_flex signatures ---------------------------------------------------- */
+/* block::get_maximum_output_size, src/block/compress.rs:588-590 */
+size_t lz4flex_get_maximum_output_size(size_t input_len);
+/* block::compress_into, src/block/compress.rs:599-601.  Err(OutputTooSmall) up front iff
+ * out_cap < get_maximum_output_size(in_len) (:338-340). Output bytes identical to lz4_flex's. */
+int64_t lz4flex_compress_into(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap);
+/* block::compress_into_with_dict, src/block/compress.rs:610-616 */
+int64_t lz4flex_compress_into_with_dict(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                                        const uint8_t *dict, size_t dict_len);
+/* block::compress_prepend_size, src/block/compress.rs:673-675 (LE u32 length prefix) */
+int64_t lz4flex_compress_prepend_size(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap);
+/* block::decompress_into, src/block/decompress.rs:454-456 */
+int64_t lz4flex_decompress_into(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                                lz4flex_err_detail *detail /* nullable */);
+/* block::decompress_into_with_dict, src/block/decompress.rs:462-468 */
+int64_t lz4flex_decompress_into_with_dict(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                                          const uint8_t *dict, size_t dict_len, lz4flex_err_detail *detail);
+/* block::uncompressed_size, src/block/mod.rs:151-157: returns the LE u32 prefix or -EXPECTED_ANOTHER_BYTE */
+int64_t lz4flex_uncompressed_size(const uint8_t *in, size_t in_len);
+/* block::decompress_size_prepended, src/block/decompress.rs:493-496; out_cap must be >= the prefix */
+int64_t lz4flex_decompress_size_prepended(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                                          lz4flex_err_detail *detail);
+
+/* ---- block: batched (the hot entry; the frame layer's per-block calls
+ *      src/frame/compress.rs:282-298 and src/frame/decompress.rs:288-305, batched) ------------ */
+#define LZ4FLEX_MEM_HOST 0   /* every pointer is host memory; the call stages through the ctx arena and is synchronous */
+#define LZ4FLEX_MEM_DEVICE 1 /* every pointer (data AND descriptor/result arrays) is device memory; asynchronous on `stream` */
+/* OR into mem_kind for DEVICE compress batches that may hold blocks > 64 KiB (selects the u32 hash table;
+ * HOST batches detect it themselves) */
+#define LZ4FLEX_MEM_BIG_BLOCKS 0x100
+
+/* per-block compress flags */
+#define LZ4FLEX_BLOCK_DEFAULT 0u            /* block::compress_into: table/hash picked by length (compress.rs:559-566) */
+/* bit 1: the FrameEncoder's table (HashTable4K + 5-byte hash whatever the length,
+ * src/frame/compress.rs:76,141) with a freshly zeroed table: block 0 of a frame */
+#define LZ4FLEX_BLOCK_FRAME_FIRST 2u
+/* bits 1|0: block k>0 of an Independent frame: same table, every entry unreachable, position 0
+ * is probed (src/frame/compress.rs:357-367, src/block/compress.rs:353-359,422-429) */
+#define LZ4FLEX_BLOCK_FRAME_CONTINUATION 3u
+
+/* Compress n independent blocks.  Block i reads in_base[in_off[i] .. +in_len[i]] and writes at
+ * out_base[out_off[i] ..], capacity out_cap[i] (must be >= get_maximum_output_size(in_len[i]),
+ * else status[i] = LZ4FLEX_E_OUTPUT_TOO_SMALL and nothing is written).  out_len[i] = bytes
+ * written.  flags may be NULL.  hip_stream: a hipStream_t (NULL = the ctx stream).
+ * Returns 0 or -code for call-level failures; per-block results are in status[]. */
+int lz4flex_compress_batch(lz4flex_ctx *ctx, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
+                           const uint32_t *flags, uint32_t n, void *out_base, const uint64_t *out_off,
+                           const uint32_t *out_cap, uint32_t *out_len, int32_t *status, int mem_kind,
+                           void *hip_stream);
+
+/* Decompress n independent blocks.  out_cap[i] >= true size (larger allowed, as
+ * decompress_into).  status[i] = 0 or a DecompressError code; detail (nullable, 2*n u64:
+ * expected, actual) is filled for OutputTooSmall. */
+int lz4flex_decompress_batch(lz4flex_ctx *ctx, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
+                             uint32_t n, void *out_base, const uint64_t *out_off, const uint32_t *out_cap,
+                             uint32_t *out_len, int32_t *status, uint64_t *detail, int mem_kind,
+                             void *hip_stream);
+
+/* Optional per-block extras for decoding: an external dictionary (block::decompress_into_with_dict,
+ * src/block/decompress.rs:462-468) and/or an initial sink position: the output region
+ * [out_off, out_off+out_pos) already holds earlier bytes that matches may reference (the prefix mode
+ * of Linked frames, src/frame/decompress.rs:293-306); out_len counts only the new bytes. */
+typedef struct lz4flex_decompress_ext {
+    const void *dict_base;     /* nullable */
+    const uint64_t *dict_off;
+    const uint32_t *dict_len;
+    const uint32_t *out_pos;   /* nullable */
+} lz4flex_decompress_ext;
+int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
+                                uint32_t n, void *out_base, const uint64_t *out_off, const uint32_t *out_cap,
+                                uint32_t *out_len, int32_t *status, uint64_t *detail,
+                                const lz4flex_decompress_ext *ext, int mem_kind, void *hip_stream);
+
+/* Tuning knobs for measurements: "decompress_lanes" (8/16/32/64), "compress_lanes" (8/16) = lanes
+ * of a wavefront cooperating on one block. */
+int lz4flex_set_tuning(lz4flex_ctx *ctx, const char *key, int value);
+
+/* ---- frame (src/frame/) ------------------------------------------------------------------ */
+typedef struct lz4flex_frame_info {   /* frame::FrameInfo, src/frame/header.rs:130-149 */
+    int32_t has_content_size;
+    uint64_t content_size;
+    int32_t block_size;       /* frame::BlockSize: 0 Auto, 4 Max64KB, 5 Max256KB, 6 Max1MB, 7 Max4MB, 8 Max8MB */
+    int32_t block_mode;       /* frame::BlockMode: 0 Independent, 1 Linked */
+    int32_t block_checksums;
+    int32_t content_checksum;
+    int32_t legacy_frame;
+} lz4flex_frame_info;
+
+/* io::Write / io::Read stand-ins: return bytes written/read, or < 0 for an I/O error */
+typedef int64_t (*lz4flex_write_fn)(void *user, const uint8_t *buf, size_t len);
+typedef int64_t (*lz4flex_read_fn)(void *user, uint8_t *buf, size_t len);
+
+typedef struct lz4flex_frame_encoder lz4flex_frame_encoder;
+/* FrameEncoder::with_frame_info, src/frame/compress.rs:133-151 (info NULL => FrameEncoder::new) */
+lz4flex_frame_encoder *lz4flex_frame_encoder_new(const lz4flex_frame_info *info, lz4flex_write_fn w, void *user);
+/* io::Write::write, :375-396 */
+int64_t lz4flex_frame_encoder_write(lz4flex_frame_encoder *e, const uint8_t *buf, size_t len);
+/* io::Write::flush, :398-403 */
+int lz4flex_frame_encoder_flush(lz4flex_frame_encoder *e);
+/* try_finish, :173-187 */
+int lz4flex_frame_encoder_try_finish(lz4flex_frame_encoder *e, lz4flex_err_detail *detail);
+/* frame_info(), :159-161 */
+void lz4flex_frame_encoder_frame_info(lz4flex_frame_encoder *e, lz4flex_frame_info *out);
+/* how many uncompressed bytes the encoder gathers per kernel launch (default 64 MiB); before the first write */
+int lz4flex_frame_encoder_set_batch_bytes(lz4flex_frame_encoder *e, size_t bytes);
+void lz4flex_frame_encoder_free(lz4flex_frame_encoder *e);
+
+typedef struct lz4flex_frame_decoder lz4flex_frame_decoder;
+/* FrameDecoder::new, src/frame/decompress.rs:76-89 */
+lz4flex_frame_decoder *lz4flex_frame_decoder_new(lz4flex_read_fn r, void *user);
+/* io::Read::read, :353-367: bytes read, 0 at end of frame / EOF, < 0 = -code */
+int64_t lz4flex_frame_decoder_read(lz4flex_frame_decoder *d, uint8_t *buf, size_t len, lz4flex_err_detail *detail);
+int lz4flex_frame_decoder_set_batch_bytes(lz4flex_frame_decoder *d, size_t bytes);
+void lz4flex_frame_decoder_free(lz4flex_frame_decoder *d);
+
+/* One-shot helpers over flat host buffers: FrameEncoder::with_frame_info + write_all + finish,
+ * and FrameDecoder::new + read_to_end (first frame only; *consumed = input bytes read). */
+int64_t lz4flex_frame_compress(const uint8_t *in, size_t in_len, const lz4flex_frame_info *info,
+                               uint8_t *out, size_t out_cap, lz4flex_err_detail *detail);
+int64_t lz4flex_frame_decompress(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                                 size_t *consumed, lz4flex_err_detail *detail);
+/* worst-case frame size for `in_len` bytes under `info` (header + per-block overhead + EndMark) */
+size_t lz4flex_frame_compress_bound(size_t in_len, const lz4flex_frame_info *info);
+/* frame::FrameInfo::write / read, src/frame/header.rs:232-373 */
+int64_t lz4flex_frame_info_write(const lz4flex_frame_info *info, uint8_t *out, size_t out_cap);
+int64_t lz4flex_frame_info_read(const uint8_t *in, size_t in_len, lz4flex_frame_info *info,
+                                lz4flex_err_detail *detail);
+/* XXH32 as used by the frame format (twox-hash in the reference) */
+uint32_t lz4flex_xxh32(const uint8_t *data, size_t len, uint32_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LZ4FLEX_AMD_H */

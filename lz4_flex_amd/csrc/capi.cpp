@@ -1,0 +1,439 @@
+// capi.cpp -- host side of the C ABI declared in include/lz4flex_amd.h: context / device
+// workspace management, the batched entry points (host- or device-resident buffers) and the
+// lz4_flex-shaped scalar calls, which are 1-block batches through the same HIP kernels.
+// There is no CPU codec in this library: every call that produces bytes launches a kernel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/lz4flex_amd.h"
+#include "lz4_device.h"
+
+using namespace lz4flex_dev;
+
+static thread_local std::string g_last_error;
+static thread_local int g_last_hip = 0;
+
+static int hip_fail(hipError_t e, const char* what) {
+    g_last_hip = (int)e;
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return -LZ4FLEX_E_HIP;
+}
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return hip_fail(_e, #expr); \
+    } while (0)
+
+struct lz4flex_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint8_t* d_arena = nullptr;   // device staging for MEM_HOST calls
+    size_t arena_cap = 0;
+    uint8_t* h_pin = nullptr;     // pinned host staging for descriptor / result arrays
+    size_t pin_cap = 0;
+    int dec_lanes = 16;           // lanes per block, decode
+    int comp_lanes = 8;           // lanes per block, encode
+};
+
+static int ensure_arena(lz4flex_ctx* c, size_t need) {
+    if (need <= c->arena_cap) return 0;
+    if (c->d_arena) { (void)hipFree(c->d_arena); c->d_arena = nullptr; c->arena_cap = 0; }
+    size_t cap = std::max<size_t>(need + need / 4, 1u << 20);
+    HIP_TRY(hipMalloc((void**)&c->d_arena, cap));
+    c->arena_cap = cap;
+    return 0;
+}
+static int ensure_pin(lz4flex_ctx* c, size_t need) {
+    if (need <= c->pin_cap) return 0;
+    if (c->h_pin) { (void)hipHostFree(c->h_pin); c->h_pin = nullptr; c->pin_cap = 0; }
+    size_t cap = std::max<size_t>(need + need / 4, 1u << 16);
+    HIP_TRY(hipHostMalloc((void**)&c->h_pin, cap, hipHostMallocDefault));
+    c->pin_cap = cap;
+    return 0;
+}
+
+extern "C" {
+
+const char* lz4flex_version(void) { return "lz4flex-amd 0.1.0 (gfx950)"; }
+const char* lz4flex_last_error(void) { return g_last_error.c_str(); }
+
+int lz4flex_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
+    if (!out) return -LZ4FLEX_E_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_last_error = "no HIP device available: the MI355X kernels are the only codec in this library";
+        return -LZ4FLEX_E_NO_DEVICE;
+    }
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= n) return -LZ4FLEX_E_INVALID_ARG;
+    lz4flex_ctx* c = new (std::nothrow) lz4flex_ctx();
+    if (!c) return -LZ4FLEX_E_NOMEM;
+    c->device = device;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) { delete c; return hip_fail(e, "ctx_create"); }
+    *out = c;
+    return 0;
+}
+
+void lz4flex_ctx_destroy(lz4flex_ctx* c) {
+    if (!c) return;
+    if (c->d_arena) (void)hipFree(c->d_arena);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
+    if (!c || !key) return -LZ4FLEX_E_INVALID_ARG;
+    if (!strcmp(key, "decompress_lanes")) {
+        if (value != 8 && value != 16 && value != 32 && value != 64) return -LZ4FLEX_E_INVALID_ARG;
+        c->dec_lanes = value;
+        return 0;
+    }
+    if (!strcmp(key, "compress_lanes")) {
+        if (value != 8 && value != 16) return -LZ4FLEX_E_INVALID_ARG;
+        c->comp_lanes = value;
+        return 0;
+    }
+    return -LZ4FLEX_E_INVALID_ARG;
+}
+
+size_t lz4flex_get_maximum_output_size(size_t input_len) {
+    return 16 + 4 + (size_t)((uint64_t)input_len * 110 / 100);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// host-resident batches: mirror the caller's layout in the device arena, run, copy back
+namespace {
+
+struct Span { uint64_t lo = ~0ull, hi = 0; };
+static Span span_of(const uint64_t* off, const uint32_t* len, uint32_t n) {
+    Span s;
+    for (uint32_t i = 0; i < n; i++) {
+        s.lo = std::min<uint64_t>(s.lo, off[i]);
+        s.hi = std::max<uint64_t>(s.hi, off[i] + len[i]);
+    }
+    if (n == 0 || s.lo > s.hi) { s.lo = 0; s.hi = 0; }
+    return s;
+}
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct HostBatch {
+    // device views
+    uint8_t *d_in = nullptr, *d_out = nullptr, *d_dict = nullptr;
+    uint64_t *d_in_off = nullptr, *d_out_off = nullptr, *d_dict_off = nullptr, *d_detail = nullptr;
+    uint32_t *d_in_len = nullptr, *d_out_cap = nullptr, *d_out_len = nullptr, *d_flags = nullptr, *d_dict_len = nullptr,
+             *d_out_pos = nullptr;
+    int32_t* d_status = nullptr;
+    Span in_span, out_span, dict_span;
+};
+
+}  // namespace
+
+struct lz4flex_decompress_ext_ {
+    const void* dict_base;
+    const uint64_t* dict_off;
+    const uint32_t* dict_len;
+    const uint32_t* out_pos;
+};
+
+static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base, const uint64_t* in_off,
+                          const uint32_t* in_len, const uint32_t* flags, uint32_t n, uint8_t* out_base,
+                          const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len, int32_t* status,
+                          uint64_t* detail, const lz4flex_decompress_ext_* ext) {
+    if (n == 0) return 0;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    HIP_TRY(hipSetDevice(c->device));
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
+
+    HostBatch hb;
+    hb.in_span = span_of(in_off, in_len, n);
+    hb.out_span = span_of(out_off, out_cap, n);
+    const bool has_dict = ext && ext->dict_base && ext->dict_off && ext->dict_len;
+    const bool has_pos = ext && ext->out_pos;
+    if (has_dict) hb.dict_span = span_of(ext->dict_off, ext->dict_len, n);
+    const size_t in_bytes = (size_t)(hb.in_span.hi - hb.in_span.lo);
+    const size_t out_bytes = (size_t)(hb.out_span.hi - hb.out_span.lo);
+    const size_t dict_bytes = has_dict ? (size_t)(hb.dict_span.hi - hb.dict_span.lo) : 0;
+    // descriptor block (pinned host mirror and device copy share one layout)
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 16); return at; };
+    const size_t at_in_off = take(8ull * n), at_out_off = take(8ull * n), at_dict_off = take(has_dict ? 8ull * n : 0),
+                 at_in_len = take(4ull * n), at_out_cap = take(4ull * n), at_flags = take(flags ? 4ull * n : 0),
+                 at_dict_len = take(has_dict ? 4ull * n : 0), at_out_pos = take(has_pos ? 4ull * n : 0);
+    const size_t desc_in_bytes = o;
+    const size_t at_out_len = take(4ull * n), at_status = take(4ull * n), at_detail = take(16ull * n);
+    const size_t desc_bytes = o;
+    int rc;
+    if ((rc = ensure_pin(c, desc_bytes))) return rc;
+    const size_t a_in = 0, a_out = align_up(in_bytes + 64, 256), a_dict = a_out + align_up(out_bytes + 64, 256),
+                 a_desc = a_dict + align_up(dict_bytes + 64, 256);
+    if ((rc = ensure_arena(c, a_desc + desc_bytes + 256))) return rc;
+    uint8_t* hp = c->h_pin;
+    for (uint32_t i = 0; i < n; i++) {
+        ((uint64_t*)(hp + at_in_off))[i] = in_off[i] - hb.in_span.lo;
+        ((uint64_t*)(hp + at_out_off))[i] = out_off[i] - hb.out_span.lo;
+        ((uint32_t*)(hp + at_in_len))[i] = in_len[i];
+        ((uint32_t*)(hp + at_out_cap))[i] = out_cap[i];
+        if (flags) ((uint32_t*)(hp + at_flags))[i] = flags[i];
+        if (has_dict) {
+            ((uint64_t*)(hp + at_dict_off))[i] = ext->dict_off[i] - hb.dict_span.lo;
+            ((uint32_t*)(hp + at_dict_len))[i] = ext->dict_len[i];
+        }
+        if (has_pos) ((uint32_t*)(hp + at_out_pos))[i] = ext->out_pos[i];
+    }
+    uint8_t* d = c->d_arena;
+    hipStream_t s = c->stream;
+    if (in_bytes) HIP_TRY(hipMemcpyAsync(d + a_in, in_base + hb.in_span.lo, in_bytes, hipMemcpyHostToDevice, s));
+    if (dict_bytes)
+        HIP_TRY(hipMemcpyAsync(d + a_dict, (const uint8_t*)ext->dict_base + hb.dict_span.lo, dict_bytes,
+                               hipMemcpyHostToDevice, s));
+    if (has_pos && out_bytes) {
+        // prefix mode: the sink already holds bytes [0, out_pos) that matches may reference
+        HIP_TRY(hipMemcpyAsync(d + a_out, out_base + hb.out_span.lo, out_bytes, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(hipMemcpyAsync(d + a_desc, hp, desc_in_bytes, hipMemcpyHostToDevice, s));
+    uint8_t* dd = d + a_desc;
+    hipError_t le;
+    if (compress) {
+        CompressArgs a{};
+        a.in_base = d + a_in; a.in_off = (const uint64_t*)(dd + at_in_off); a.in_len = (const uint32_t*)(dd + at_in_len);
+        a.flags = flags ? (const uint32_t*)(dd + at_flags) : nullptr;
+        a.out_base = d + a_out; a.out_off = (const uint64_t*)(dd + at_out_off); a.out_cap = (const uint32_t*)(dd + at_out_cap);
+        a.out_len = (uint32_t*)(dd + at_out_len); a.status = (int32_t*)(dd + at_status); a.n = n;
+        bool big = false;
+        for (uint32_t i = 0; i < n; i++) big |= in_len[i] > 65536u;
+        le = launch_compress(a, c->comp_lanes | (big ? 0x100 : 0), s);
+    } else {
+        DecompressArgs a{};
+        a.in_base = d + a_in; a.in_off = (const uint64_t*)(dd + at_in_off); a.in_len = (const uint32_t*)(dd + at_in_len);
+        a.out_base = d + a_out; a.out_off = (const uint64_t*)(dd + at_out_off); a.out_cap = (const uint32_t*)(dd + at_out_cap);
+        a.out_pos = has_pos ? (const uint32_t*)(dd + at_out_pos) : nullptr;
+        a.dict_base = has_dict ? d + a_dict : nullptr;
+        a.dict_off = has_dict ? (const uint64_t*)(dd + at_dict_off) : nullptr;
+        a.dict_len = has_dict ? (const uint32_t*)(dd + at_dict_len) : nullptr;
+        a.out_len = (uint32_t*)(dd + at_out_len); a.status = (int32_t*)(dd + at_status);
+        a.detail = (uint64_t*)(dd + at_detail); a.n = n;
+        le = launch_decompress(a, c->dec_lanes, s);
+    }
+    if (le != hipSuccess) return hip_fail(le, "kernel launch");
+    HIP_TRY(hipMemcpyAsync(hp + at_out_len, dd + at_out_len, desc_bytes - at_out_len, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t* r_len = (const uint32_t*)(hp + at_out_len);
+    const int32_t* r_st = (const int32_t*)(hp + at_status);
+    const uint64_t* r_det = (const uint64_t*)(hp + at_detail);
+    uint64_t produced = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        out_len[i] = r_len[i];
+        status[i] = r_st[i];
+        if (detail) { detail[2 * i] = compress ? 0 : r_det[2 * i]; detail[2 * i + 1] = compress ? 0 : r_det[2 * i + 1]; }
+        if (r_st[i] == 0) produced += r_len[i];
+    }
+    // copy results back: dense outputs in one transfer, sparse ones block by block
+    if (out_bytes && produced * 2 >= out_bytes && !has_pos) {
+        // every successful block owns [out_off, out_off+len); failed blocks must leave the caller's bytes alone
+        bool all_ok = true;
+        for (uint32_t i = 0; i < n; i++) all_ok &= (r_st[i] == 0 && r_len[i] == out_cap[i]);
+        if (all_ok) {
+            HIP_TRY(hipMemcpyAsync(out_base + hb.out_span.lo, d + a_out, out_bytes, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            return 0;
+        }
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        if (r_st[i] != 0 || r_len[i] == 0) continue;
+        const uint32_t pos = has_pos ? ext->out_pos[i] : 0u;
+        HIP_TRY(hipMemcpyAsync(out_base + out_off[i] + pos, d + a_out + (out_off[i] - hb.out_span.lo) + pos, r_len[i],
+                               hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+static int run_device_batch(lz4flex_ctx* c, bool compress, const void* in_base, const uint64_t* in_off,
+                            const uint32_t* in_len, const uint32_t* flags, uint32_t n, void* out_base,
+                            const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len, int32_t* status,
+                            uint64_t* detail, const lz4flex_decompress_ext_* ext, void* hip_stream, int big_hint) {
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    hipError_t le;
+    if (compress) {
+        CompressArgs a{};
+        a.in_base = (const uint8_t*)in_base; a.in_off = in_off; a.in_len = in_len; a.flags = flags;
+        a.out_base = (uint8_t*)out_base; a.out_off = out_off; a.out_cap = out_cap; a.out_len = out_len;
+        a.status = status; a.n = n;
+        le = launch_compress(a, c->comp_lanes | (big_hint ? 0x100 : 0), s);
+    } else {
+        DecompressArgs a{};
+        a.in_base = (const uint8_t*)in_base; a.in_off = in_off; a.in_len = in_len;
+        a.out_base = (uint8_t*)out_base; a.out_off = out_off; a.out_cap = out_cap;
+        a.out_pos = ext ? ext->out_pos : nullptr;
+        a.dict_base = ext ? (const uint8_t*)ext->dict_base : nullptr;
+        a.dict_off = ext ? ext->dict_off : nullptr;
+        a.dict_len = ext ? ext->dict_len : nullptr;
+        a.out_len = out_len; a.status = status; a.detail = detail; a.n = n;
+        le = launch_decompress(a, c->dec_lanes, s);
+    }
+    if (le != hipSuccess) return hip_fail(le, "kernel launch");
+    return 0;
+}
+
+static thread_local lz4flex_ctx* g_default_ctx = nullptr;
+struct DefaultCtxReaper { ~DefaultCtxReaper() { /* device teardown order at exit is not ours to fix: leak */ } };
+static int default_ctx(lz4flex_ctx** out) {
+    if (!g_default_ctx) {
+        int rc = lz4flex_ctx_create(&g_default_ctx, -1);
+        if (rc) return rc;
+    }
+    *out = g_default_ctx;
+    return 0;
+}
+
+extern "C" {
+
+int lz4flex_compress_batch(lz4flex_ctx* ctx, const void* in_base, const uint64_t* in_off, const uint32_t* in_len,
+                           const uint32_t* flags, uint32_t n, void* out_base, const uint64_t* out_off,
+                           const uint32_t* out_cap, uint32_t* out_len, int32_t* status, int mem_kind,
+                           void* hip_stream) {
+    int rc;
+    if (!ctx && (rc = default_ctx(&ctx))) return rc;
+    if (n && (!in_off || !in_len || !out_off || !out_cap || !out_len || !status)) return -LZ4FLEX_E_INVALID_ARG;
+    if (mem_kind == LZ4FLEX_MEM_HOST)
+        return run_host_batch(ctx, true, (const uint8_t*)in_base, in_off, in_len, flags, n, (uint8_t*)out_base, out_off,
+                              out_cap, out_len, status, nullptr, nullptr);
+    if ((mem_kind & 0xFF) == LZ4FLEX_MEM_DEVICE)
+        return run_device_batch(ctx, true, in_base, in_off, in_len, flags, n, out_base, out_off, out_cap, out_len, status,
+                                nullptr, nullptr, hip_stream, (mem_kind & LZ4FLEX_MEM_BIG_BLOCKS) != 0);
+    return -LZ4FLEX_E_INVALID_ARG;
+}
+
+int lz4flex_decompress_batch_ex(lz4flex_ctx* ctx, const void* in_base, const uint64_t* in_off, const uint32_t* in_len,
+                                uint32_t n, void* out_base, const uint64_t* out_off, const uint32_t* out_cap,
+                                uint32_t* out_len, int32_t* status, uint64_t* detail,
+                                const lz4flex_decompress_ext* ext, int mem_kind, void* hip_stream) {
+    int rc;
+    if (!ctx && (rc = default_ctx(&ctx))) return rc;
+    if (n && (!in_off || !in_len || !out_off || !out_cap || !out_len || !status)) return -LZ4FLEX_E_INVALID_ARG;
+    lz4flex_decompress_ext_ e{};
+    if (ext) { e.dict_base = ext->dict_base; e.dict_off = ext->dict_off; e.dict_len = ext->dict_len; e.out_pos = ext->out_pos; }
+    if (mem_kind == LZ4FLEX_MEM_HOST)
+        return run_host_batch(ctx, false, (const uint8_t*)in_base, in_off, in_len, nullptr, n, (uint8_t*)out_base, out_off,
+                              out_cap, out_len, status, detail, ext ? &e : nullptr);
+    if ((mem_kind & 0xFF) == LZ4FLEX_MEM_DEVICE)
+        return run_device_batch(ctx, false, in_base, in_off, in_len, nullptr, n, out_base, out_off, out_cap, out_len,
+                                status, detail, ext ? &e : nullptr, hip_stream, 0);
+    return -LZ4FLEX_E_INVALID_ARG;
+}
+
+int lz4flex_decompress_batch(lz4flex_ctx* ctx, const void* in_base, const uint64_t* in_off, const uint32_t* in_len,
+                             uint32_t n, void* out_base, const uint64_t* out_off, const uint32_t* out_cap,
+                             uint32_t* out_len, int32_t* status, uint64_t* detail, int mem_kind, void* hip_stream) {
+    return lz4flex_decompress_batch_ex(ctx, in_base, in_off, in_len, n, out_base, out_off, out_cap, out_len, status,
+                                       detail, nullptr, mem_kind, hip_stream);
+}
+
+// ---- scalar, lz4_flex-shaped --------------------------------------------------------------
+int64_t lz4flex_compress_into(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap) {
+    if (in_len > 0xFFFFFFFFull) return -LZ4FLEX_E_INVALID_ARG;
+    // compress.rs:338-340: OutputTooSmall is decided up front, before anything is written
+    if (out_cap < lz4flex_get_maximum_output_size(in_len)) return -LZ4FLEX_E_OUTPUT_TOO_SMALL;
+    lz4flex_ctx* c;
+    int rc = default_ctx(&c);
+    if (rc) return rc;
+    const uint64_t off0 = 0;
+    const uint32_t len = (uint32_t)in_len, cap = (uint32_t)std::min<size_t>(out_cap, 0xFFFFFFFFull);
+    uint32_t olen = 0;
+    int32_t st = 0;
+    static const uint8_t empty = 0;
+    rc = run_host_batch(c, true, in ? in : &empty, &off0, &len, nullptr, 1, out, &off0, &cap, &olen, &st, nullptr, nullptr);
+    if (rc) return rc;
+    if (st) return -(int64_t)st;
+    return (int64_t)olen;
+}
+
+int64_t lz4flex_compress_into_with_dict(const uint8_t*, size_t, uint8_t*, size_t, const uint8_t*, size_t) {
+    g_last_error = "compress_into_with_dict: the dictionary-seeded encoder kernel is not built yet (SURVEY 8(f) f1)";
+    return -LZ4FLEX_E_UNSUPPORTED;
+}
+
+int64_t lz4flex_compress_prepend_size(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap) {
+    // compress.rs:624-634: 4-byte LE length, then the block
+    if (out_cap < 4 || out_cap - 4 < lz4flex_get_maximum_output_size(in_len)) return -LZ4FLEX_E_OUTPUT_TOO_SMALL;
+    const uint32_t n = (uint32_t)in_len;
+    out[0] = (uint8_t)n; out[1] = (uint8_t)(n >> 8); out[2] = (uint8_t)(n >> 16); out[3] = (uint8_t)(n >> 24);
+    int64_t r = lz4flex_compress_into(in, in_len, out + 4, out_cap - 4);
+    return r < 0 ? r : r + 4;
+}
+
+static int64_t decompress_common(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, const uint8_t* dict,
+                                 size_t dict_len, bool use_dict, lz4flex_err_detail* detail) {
+    if (in_len > 0xFFFFFFFFull || out_cap > 0xFFFFFFFFull || dict_len > 0xFFFFFFFFull) return -LZ4FLEX_E_INVALID_ARG;
+    if (detail) memset(detail, 0, sizeof *detail);
+    lz4flex_ctx* c;
+    int rc = default_ctx(&c);
+    if (rc) { if (detail) detail->hip_error = g_last_hip; return rc; }
+    const uint64_t off0 = 0;
+    const uint32_t len = (uint32_t)in_len, cap = (uint32_t)out_cap, dlen = (uint32_t)dict_len;
+    uint32_t olen = 0;
+    int32_t st = 0;
+    uint64_t det[2] = {0, 0};
+    static const uint8_t empty = 0;
+    lz4flex_decompress_ext_ e{};
+    e.dict_base = dict ? dict : &empty; e.dict_off = &off0; e.dict_len = &dlen; e.out_pos = nullptr;
+    static uint8_t sink_dummy = 0;
+    rc = run_host_batch(c, false, in ? in : &empty, &off0, &len, nullptr, 1, out ? out : &sink_dummy, &off0, &cap, &olen,
+                        &st, det, use_dict ? &e : nullptr);
+    if (rc) { if (detail) detail->hip_error = g_last_hip; return rc; }
+    if (st) {
+        if (detail) { detail->expected = det[0]; detail->actual = det[1]; }
+        return -(int64_t)st;
+    }
+    return (int64_t)olen;
+}
+
+int64_t lz4flex_decompress_into(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap,
+                                lz4flex_err_detail* detail) {
+    return decompress_common(in, in_len, out, out_cap, nullptr, 0, false, detail);
+}
+
+int64_t lz4flex_decompress_into_with_dict(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap,
+                                          const uint8_t* dict, size_t dict_len, lz4flex_err_detail* detail) {
+    return decompress_common(in, in_len, out, out_cap, dict, dict_len, true, detail);
+}
+
+int64_t lz4flex_uncompressed_size(const uint8_t* in, size_t in_len) {
+    if (in_len < 4) return -LZ4FLEX_E_EXPECTED_ANOTHER_BYTE;   // mod.rs:152
+    return (int64_t)((uint32_t)in[0] | ((uint32_t)in[1] << 8) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 24));
+}
+
+int64_t lz4flex_decompress_size_prepended(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap,
+                                          lz4flex_err_detail* detail) {
+    const int64_t sz = lz4flex_uncompressed_size(in, in_len);
+    if (sz < 0) return sz;
+    if ((uint64_t)sz > out_cap) return -LZ4FLEX_E_INVALID_ARG;   // the Vec variant allocates `sz`; here the caller must
+    // decompress.rs:493-496 -> decompress(input, uncompressed_size): capacity is exactly the prefix
+    return decompress_common(in + 4, in_len - 4, out, (size_t)sz, nullptr, 0, false, detail);
+}
+
+}  // extern "C"

@@ -1,0 +1,614 @@
+// frame.cpp -- host side of the LZ4 frame layer (lz4_flex::frame::{FrameEncoder, FrameDecoder,
+// FrameInfo}; reference src/frame/{compress,decompress,header}.rs).  Header (de)serialisation,
+// block framing, store-raw rule, checksums and the io::Write / io::Read behaviour live here;
+// every block's bytes are produced by the batched HIP kernels through the C ABI.  Where the
+// reference calls the block codec once per block (src/frame/compress.rs:282-298,
+// src/frame/decompress.rs:288-305) this layer gathers up to `batch_blocks` blocks per launch.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/lz4flex_amd.h"
+#include "xxh32.h"
+
+namespace {
+
+using lz4flex::XxHash32;
+
+// src/frame/header.rs:11-34
+constexpr uint8_t FLG_RESERVED_MASK = 0x02, FLG_VERSION_MASK = 0xC0, FLG_SUPPORTED_VERSION_BITS = 0x40,
+                  FLG_INDEPENDENT_BLOCKS = 0x20, FLG_BLOCK_CHECKSUMS = 0x10, FLG_CONTENT_SIZE = 0x08,
+                  FLG_CONTENT_CHECKSUM = 0x04, FLG_DICTIONARY_ID = 0x01, BD_BLOCK_SIZE_MASK = 0x70,
+                  BD_RESERVED_MASK = 0x8F;
+constexpr uint32_t BLOCK_UNCOMPRESSED_SIZE_BIT = 0x80000000u, LZ4F_MAGIC_NUMBER = 0x184D2204u,
+                   LZ4F_LEGACY_MAGIC_NUMBER = 0x184C2102u;
+constexpr size_t MIN_FRAME_INFO_SIZE = 7, MAX_FRAME_INFO_SIZE = 19, WINDOW_SIZE = 64 * 1024;
+
+uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint64_t rd64(const uint8_t* p) { return (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32); }
+void wr32(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+void wr64(uint8_t* p, uint64_t v) { wr32(p, (uint32_t)v); wr32(p + 4, (uint32_t)(v >> 32)); }
+
+// BlockSize::get_size, header.rs:68-77
+size_t block_size_bytes(int code) {
+    switch (code) {
+        case 4: return 64u * 1024;
+        case 5: return 256u * 1024;
+        case 6: return 1024u * 1024;
+        case 7: return 4u * 1024 * 1024;
+        case 8: return 8u * 1024 * 1024;
+        default: return 0;
+    }
+}
+// BlockSize::from_buf_length, header.rs:57-67
+int block_size_from_buf_length(size_t n) { return n > 256u * 1024 ? 7 : (n > 64u * 1024 ? 5 : 4); }
+
+}  // namespace
+
+extern "C" {
+
+uint32_t lz4flex_xxh32(const uint8_t* data, size_t len, uint32_t seed) { return XxHash32::oneshot(seed, data, len); }
+
+// FrameInfo::write, header.rs:232-275
+int64_t lz4flex_frame_info_write(const lz4flex_frame_info* fi, uint8_t* out, size_t out_cap) {
+    if (!fi || !out) return -LZ4FLEX_E_INVALID_ARG;
+    const size_t write_size = MIN_FRAME_INFO_SIZE + (fi->has_content_size ? 8 : 0);
+    if (out_cap < write_size) return -LZ4FLEX_FE_IO;
+    uint8_t b[MAX_FRAME_INFO_SIZE] = {0};
+    wr32(b, LZ4F_MAGIC_NUMBER);
+    b[4] = FLG_SUPPORTED_VERSION_BITS;
+    if (fi->block_checksums) b[4] |= FLG_BLOCK_CHECKSUMS;
+    if (fi->content_checksum) b[4] |= FLG_CONTENT_CHECKSUM;
+    if (fi->block_mode == 0) b[4] |= FLG_INDEPENDENT_BLOCKS;
+    b[5] = (uint8_t)(fi->block_size << 4);
+    size_t off = 6;
+    if (fi->has_content_size) { b[4] |= FLG_CONTENT_SIZE; wr64(b + off, fi->content_size); off += 8; }
+    b[off] = (uint8_t)(XxHash32::oneshot(0, b + 4, off - 4) >> 8);
+    memcpy(out, b, write_size);
+    return (int64_t)write_size;
+}
+
+// FrameInfo::read, header.rs:277-373
+int64_t lz4flex_frame_info_read(const uint8_t* in, size_t in_len, lz4flex_frame_info* fi, lz4flex_err_detail* d) {
+    if (!in || !fi) return -LZ4FLEX_E_INVALID_ARG;
+    memset(fi, 0, sizeof *fi);
+    if (in_len < 4) return -LZ4FLEX_FE_IO;
+    const uint32_t magic = rd32(in);
+    size_t p = 4;
+    if (magic == LZ4F_LEGACY_MAGIC_NUMBER) { fi->block_size = 8; fi->legacy_frame = 1; return 4; }
+    if (magic >= 0x184D2A50u && magic <= 0x184D2A5Fu) {
+        if (in_len < 8) return -LZ4FLEX_FE_IO;
+        if (d) d->expected = rd32(in + 4);
+        return -LZ4FLEX_FE_SKIPPABLE_FRAME;
+    }
+    if (magic != LZ4F_MAGIC_NUMBER) return -LZ4FLEX_FE_WRONG_MAGIC;
+    if (in_len < p + 2) return -LZ4FLEX_FE_IO;
+    const uint8_t flg = in[p], bd = in[p + 1];
+    p += 2;
+    if ((flg & FLG_VERSION_MASK) != FLG_SUPPORTED_VERSION_BITS) {
+        if (d) d->expected = flg & FLG_VERSION_MASK;
+        return -LZ4FLEX_FE_UNSUPPORTED_VERSION;
+    }
+    if ((flg & FLG_RESERVED_MASK) || (bd & BD_RESERVED_MASK)) return -LZ4FLEX_FE_RESERVED_BITS;
+    fi->block_mode = (flg & FLG_INDEPENDENT_BLOCKS) ? 0 : 1;
+    fi->content_checksum = (flg & FLG_CONTENT_CHECKSUM) != 0;
+    fi->block_checksums = (flg & FLG_BLOCK_CHECKSUMS) != 0;
+    const int bs = (bd & BD_BLOCK_SIZE_MASK) >> 4;
+    if (bs <= 3) { if (d) d->expected = (uint64_t)bs; return -LZ4FLEX_FE_UNSUPPORTED_BLOCKSIZE; }
+    fi->block_size = bs;
+    if (flg & FLG_CONTENT_SIZE) {
+        if (in_len < p + 8) return -LZ4FLEX_FE_IO;
+        fi->has_content_size = 1; fi->content_size = rd64(in + p); p += 8;
+    }
+    bool has_dict = false;
+    if (flg & FLG_DICTIONARY_ID) { if (in_len < p + 4) return -LZ4FLEX_FE_IO; has_dict = true; p += 4; }
+    if (in_len < p + 1) return -LZ4FLEX_FE_IO;
+    if ((uint8_t)(XxHash32::oneshot(0, in + 4, p - 4) >> 8) != in[p]) return -LZ4FLEX_FE_HEADER_CHECKSUM;
+    p += 1;
+    if (has_dict) return -LZ4FLEX_FE_DICTIONARY_NOT_SUPPORTED;   // frame/decompress.rs:139-142
+    return (int64_t)p;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// FrameEncoder
+struct lz4flex_frame_encoder {
+    lz4flex_frame_info fi{};
+    lz4flex_write_fn w = nullptr;
+    void* user = nullptr;
+    std::vector<uint8_t> src;      // staged uncompressed bytes (whole blocks + a partial tail)
+    size_t src_len = 0;
+    std::vector<uint8_t> dst;      // compressed blocks at a fixed stride
+    std::vector<uint64_t> in_off, out_off;
+    std::vector<uint32_t> in_len, out_cap, out_len, flags;
+    std::vector<int32_t> status;
+    size_t batch_blocks = 0;       // blocks per kernel launch
+    size_t batch_bytes = 64u << 20;
+    uint64_t content_len = 0;
+    uint64_t src_stream_offset = 0;   // mirrors the reference field that decides the table state (N3)
+    XxHash32 content_hasher{0};
+    bool is_frame_open = false, data_to_frame_written = false;
+    int sticky_err = 0;
+
+    int emit(const uint8_t* p, size_t n) {
+        while (n) {
+            const int64_t k = w(user, p, n);
+            if (k <= 0) return -LZ4FLEX_FE_IO;     // io::ErrorKind::WriteZero / other
+            p += (size_t)k; n -= (size_t)k;
+        }
+        return 0;
+    }
+    // begin_frame, frame/compress.rs:234-257 (+ init :96-118)
+    int begin_frame(size_t buf_len) {
+        is_frame_open = true;
+        if (fi.block_size == 0) fi.block_size = block_size_from_buf_length(buf_len);
+        const size_t mbs = block_size_bytes(fi.block_size);
+        if (mbs == 0 || fi.block_size == 8) return -LZ4FLEX_E_INVALID_ARG;   // Max8MB is legacy-decode only (header.rs:287)
+        batch_blocks = std::max<size_t>(1, batch_bytes / mbs);
+        uint8_t hdr[MAX_FRAME_INFO_SIZE];
+        const int64_t n = lz4flex_frame_info_write(&fi, hdr, sizeof hdr);
+        if (n < 0) return (int)n;
+        int rc = emit(hdr, (size_t)n);
+        if (rc) return rc;
+        if (content_len != 0) {   // second or later frame of this encoder: reset compressor state
+            content_len = 0; src_stream_offset = 0; src_len = 0;
+            content_hasher.reset(0);
+        }
+        return 0;
+    }
+    // write_block (frame/compress.rs:261-371) for `nblk` staged blocks in one launch; the last may be partial
+    int write_blocks(size_t nblk) {
+        if (nblk == 0) return 0;
+        if (fi.block_mode != 0) return -LZ4FLEX_E_UNSUPPORTED;   // Linked: prefix/ext-dict encoder kernel not built yet
+        const size_t mbs = block_size_bytes(fi.block_size);
+        const size_t stride = (lz4flex_get_maximum_output_size(mbs) + 63) / 64 * 64;
+        if (dst.size() < stride * nblk) dst.resize(stride * nblk);
+        in_off.resize(nblk); out_off.resize(nblk); in_len.resize(nblk); out_cap.resize(nblk);
+        out_len.resize(nblk); flags.resize(nblk); status.resize(nblk);
+        uint64_t so = src_stream_offset;
+        size_t consumed = 0;
+        for (size_t i = 0; i < nblk; i++) {
+            const size_t len = std::min(mbs, src_len - i * mbs);
+            // reposition near 2 GiB (frame/compress.rs:266-271): the table collapses to "all zero, offset 0"
+            if (so + mbs + WINDOW_SIZE >= (uint64_t)(0xFFFFFFFFu / 2)) so = 0;
+            in_off[i] = i * mbs; in_len[i] = (uint32_t)len;
+            out_off[i] = i * stride; out_cap[i] = (uint32_t)stride;
+            flags[i] = so == 0 ? LZ4FLEX_BLOCK_FRAME_FIRST : LZ4FLEX_BLOCK_FRAME_CONTINUATION;
+            so += len;
+            consumed += len;
+        }
+        int rc = lz4flex_compress_batch(nullptr, src.data(), in_off.data(), in_len.data(), flags.data(), (uint32_t)nblk,
+                                        dst.data(), out_off.data(), out_cap.data(), out_len.data(), status.data(),
+                                        LZ4FLEX_MEM_HOST, nullptr);
+        if (rc) return rc;
+        for (size_t i = 0; i < nblk; i++) {
+            if (status[i] != 0) return -LZ4FLEX_FE_COMPRESSION;
+            const uint8_t* s = src.data() + in_off[i];
+            const size_t slen = in_len[i];
+            const uint8_t* block_data; size_t block_len; uint32_t info;
+            if (out_len[i] < slen) { block_data = dst.data() + out_off[i]; block_len = out_len[i]; info = out_len[i]; }   // :301-306
+            else { block_data = s; block_len = slen; info = (uint32_t)slen | BLOCK_UNCOMPRESSED_SIZE_BIT; }
+            uint8_t bi[4]; wr32(bi, info);
+            if ((rc = emit(bi, 4))) return rc;
+            if ((rc = emit(block_data, block_len))) return rc;
+            if (fi.block_checksums) {                                       // :313-316
+                uint8_t c[4]; wr32(c, XxHash32::oneshot(0, block_data, block_len));
+                if ((rc = emit(c, 4))) return rc;
+            }
+            if (fi.content_checksum) content_hasher.write(s, slen);         // :319-321
+            content_len += slen;
+        }
+        src_stream_offset = so;
+        // keep an unconsumed tail (never happens: callers pass every staged byte or whole blocks)
+        if (consumed < src_len) memmove(src.data(), src.data() + consumed, src_len - consumed);
+        src_len -= consumed;
+        return 0;
+    }
+    // io::Write::write, frame/compress.rs:375-396
+    int64_t write(const uint8_t* buf, size_t len) {
+        if (sticky_err) return sticky_err;
+        int rc;
+        if (!is_frame_open && len != 0) { if ((rc = begin_frame(len))) return sticky_err = rc; }
+        const size_t total = len;
+        const size_t mbs = block_size_bytes(fi.block_size);
+        while (len) {
+            const size_t cap = batch_blocks * mbs;
+            if (src.size() < cap) src.resize(cap);
+            if (src_len == cap) {   // staging full: make space by writing the staged blocks
+                if ((rc = write_blocks(batch_blocks))) return sticky_err = rc;
+                continue;
+            }
+            const size_t n = std::min(cap - src_len, len);
+            memcpy(src.data() + src_len, buf, n);
+            src_len += n; buf += n; len -= n;
+        }
+        return (int64_t)total;
+    }
+    // io::Write::flush, frame/compress.rs:398-403
+    int flush() {
+        if (sticky_err) return sticky_err;
+        if (src_len == 0) return 0;
+        const size_t mbs = block_size_bytes(fi.block_size);
+        const int rc = write_blocks((src_len + mbs - 1) / mbs);
+        return rc ? (sticky_err = rc) : 0;
+    }
+    // try_finish, frame/compress.rs:173-187 (+ end_frame :209-230)
+    int try_finish(lz4flex_err_detail* d) {
+        int rc = flush();
+        if (rc) return rc;
+        if (!is_frame_open && !data_to_frame_written) { if ((rc = begin_frame(0))) return rc; }
+        is_frame_open = false;
+        if (fi.has_content_size && fi.content_size != content_len) {
+            if (d) { d->expected = fi.content_size; d->actual = content_len; }
+            return -LZ4FLEX_FE_CONTENT_LENGTH;
+        }
+        uint8_t z[4] = {0, 0, 0, 0};
+        if ((rc = emit(z, 4))) return rc;
+        if (fi.content_checksum) {
+            uint8_t c[4]; wr32(c, content_hasher.finish());
+            if ((rc = emit(c, 4))) return rc;
+        }
+        data_to_frame_written = true;
+        return 0;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// FrameDecoder
+struct lz4flex_frame_decoder {
+    lz4flex_read_fn r = nullptr;
+    void* user = nullptr;
+    bool have_frame = false;
+    lz4flex_frame_info fi{};
+    XxHash32 content_hasher{0};
+    uint64_t content_len = 0;
+    size_t batch_bytes = 64u << 20;
+    // staged batch
+    std::vector<uint8_t> comp, out;
+    std::vector<uint64_t> in_off, out_off, detail;
+    std::vector<uint32_t> in_len, out_cap, out_len;
+    std::vector<int32_t> status;
+    struct Item { size_t off, len; };
+    std::vector<Item> ready;   // decoded pieces in stream order (len 0 = a block that decoded to nothing)
+    size_t ready_idx = 0, ready_pos = 0;
+    int pending_err = 0;       // surfaces after the pieces before it were delivered
+    lz4flex_err_detail pending_detail{};
+    bool pending_zero = false; // EndMark reached: one read() returns 0
+    // Linked-mode window (frame/decompress.rs:62-72): exact mirror of the reference's dst ring
+    std::vector<uint8_t> ldst;
+    size_t ext_dict_offset = 0, ext_dict_len = 0, dst_start = 0;
+
+    bool io_failed = false;    // the read callback itself reported an error (not a short read)
+    // read_exact; returns 0 ok, 1 clean EOF before any byte, -code on short read / error
+    int read_exact(uint8_t* p, size_t n, size_t* got_out = nullptr) {
+        size_t got = 0;
+        while (got < n) {
+            const int64_t k = r(user, p + got, n - got);
+            if (k < 0) { io_failed = true; return -LZ4FLEX_FE_IO; }
+            if (k == 0) break;
+            got += (size_t)k;
+        }
+        if (got_out) *got_out = got;
+        if (got == n) return 0;
+        return got == 0 ? 1 : -LZ4FLEX_FE_IO;
+    }
+    // read_frame_info, frame/decompress.rs:109-168. 1 = EOF (Ok(0)), 0 = frame opened, <0 error
+    int read_frame_info(lz4flex_err_detail* d) {
+        uint8_t b[MAX_FRAME_INFO_SIZE];
+        int rc = read_exact(b, 4);
+        if (rc) return rc;
+        size_t required;
+        const uint32_t magic = rd32(b);
+        if (magic == LZ4F_LEGACY_MAGIC_NUMBER) {
+            required = 4;
+        } else {
+            rc = read_exact(b + 4, MIN_FRAME_INFO_SIZE - 4);
+            if (rc) return rc;   // 1: r.read() returned 0 => Ok(0)
+            // FrameInfo::read_size, header.rs:194-219
+            if (magic >= 0x184D2A50u && magic <= 0x184D2A5Fu) required = 8;
+            else if (magic != LZ4F_MAGIC_NUMBER) return -LZ4FLEX_FE_WRONG_MAGIC;
+            else required = MIN_FRAME_INFO_SIZE + ((b[4] & FLG_CONTENT_SIZE) ? 8 : 0) + ((b[4] & FLG_DICTIONARY_ID) ? 4 : 0);
+            if (required != MIN_FRAME_INFO_SIZE) {
+                rc = read_exact(b + MIN_FRAME_INFO_SIZE, required - MIN_FRAME_INFO_SIZE);
+                if (rc) return rc == 1 ? -LZ4FLEX_FE_IO : rc;
+            }
+        }
+        const int64_t hs = lz4flex_frame_info_read(b, required, &fi, d);
+        if (hs < 0) return (int)hs;
+        have_frame = true;
+        content_hasher.reset(0);
+        content_len = 0;
+        ext_dict_len = 0; ext_dict_offset = 0; dst_start = 0;
+        if (fi.block_mode == 1) {
+            const size_t mbs = block_size_bytes(fi.block_size);
+            ldst.assign(mbs * 2 + WINDOW_SIZE, 0);
+        }
+        return 0;
+    }
+    void fail(int code, const lz4flex_err_detail* d = nullptr) {
+        pending_err = code;
+        if (d) pending_detail = *d; else memset(&pending_detail, 0, sizeof pending_detail);
+    }
+    // EndMark handling, frame/decompress.rs:313-332
+    void end_mark() {
+        if (fi.has_content_size && content_len != fi.content_size) {
+            lz4flex_err_detail d{}; d.expected = fi.content_size; d.actual = content_len;
+            fail(-LZ4FLEX_FE_CONTENT_LENGTH, &d);
+            return;
+        }
+        if (fi.content_checksum) {
+            uint8_t c[4];
+            if (read_exact(c, 4) != 0) { fail(-LZ4FLEX_FE_IO); return; }
+            if (content_hasher.finish() != rd32(c)) { fail(-LZ4FLEX_FE_CONTENT_CHECKSUM); return; }
+        }
+        have_frame = false;
+        pending_zero = true;
+    }
+
+    // Independent frames: gather blocks up to the batch size, decode them in one launch.
+    void read_blocks_independent() {
+        const size_t mbs = block_size_bytes(fi.block_size);
+        const size_t max_blocks = std::max<size_t>(1, batch_bytes / mbs);
+        comp.clear(); in_off.clear(); in_len.clear(); out_off.clear(); out_cap.clear();
+        ready.clear(); ready_idx = 0; ready_pos = 0;
+        struct Slot { bool raw; size_t out_at; size_t idx; size_t raw_len; };
+        std::vector<Slot> slots;
+        size_t out_need = 0;
+        bool saw_end = false;
+        while (slots.size() < max_blocks) {
+            uint8_t bi[4];
+            const int rc = read_exact(bi, 4);
+            if (rc != 0) {
+                if (io_failed) fail(-LZ4FLEX_FE_IO);
+                else pending_zero = true;   // UnexpectedEof on the block header => Ok(0), frame stays open (:231-238)
+                break;
+            }
+            const uint32_t size = rd32(bi);
+            if (size == 0) { saw_end = true; break; }   // EndMark: handled after the staged blocks are decoded
+            const bool raw = (size & BLOCK_UNCOMPRESSED_SIZE_BIT) != 0;
+            const size_t len = size & ~BLOCK_UNCOMPRESSED_SIZE_BIT;
+            if (len > mbs) { fail(-LZ4FLEX_FE_BLOCK_TOO_BIG); break; }
+            const size_t at = comp.size();
+            comp.resize(at + len);
+            if (len && read_exact(comp.data() + at, len) != 0) { comp.resize(at); fail(-LZ4FLEX_FE_IO); break; }
+            if (fi.block_checksums) {
+                uint8_t c[4];
+                if (read_exact(c, 4) != 0) { comp.resize(at); fail(-LZ4FLEX_FE_IO); break; }
+                if (XxHash32::oneshot(0, comp.data() + at, len) != rd32(c)) { comp.resize(at); fail(-LZ4FLEX_FE_BLOCK_CHECKSUM); break; }
+            }
+            Slot s{raw, out_need, in_off.size(), len};
+            if (!raw) { in_off.push_back(at); in_len.push_back((uint32_t)len); out_off.push_back(out_need); out_cap.push_back((uint32_t)mbs); out_need += mbs; }
+            else { s.idx = at; out_need += len; }
+            slots.push_back(s);
+        }
+        if (out.size() < out_need) out.resize(out_need);
+        const size_t nb = in_off.size();
+        out_len.assign(nb, 0); status.assign(nb, 0); detail.assign(2 * nb, 0);
+        if (nb) {
+            const int rc = lz4flex_decompress_batch(nullptr, comp.data(), in_off.data(), in_len.data(), (uint32_t)nb, out.data(),
+                                                    out_off.data(), out_cap.data(), out_len.data(), status.data(),
+                                                    detail.data(), LZ4FLEX_MEM_HOST, nullptr);
+            if (rc) { fail(rc); pending_zero = false; return; }
+        }
+        for (const Slot& s : slots) {
+            size_t plen;
+            if (s.raw) { memcpy(out.data() + s.out_at, comp.data() + s.idx, s.raw_len); plen = s.raw_len; }
+            else {
+                if (status[s.idx] != 0) {
+                    lz4flex_err_detail d{}; d.expected = detail[2 * s.idx]; d.actual = detail[2 * s.idx + 1]; d.inner = status[s.idx];
+                    fail(-LZ4FLEX_FE_DECOMPRESSION, &d);
+                    pending_zero = false;
+                    return;   // pieces before this one were queued; the error surfaces after them
+                }
+                plen = out_len[s.idx];
+            }
+            ready.push_back({s.out_at, plen});
+            content_len += plen;
+            if (fi.content_checksum) content_hasher.write(out.data() + s.out_at, plen);
+        }
+        if (pending_err) { pending_zero = false; return; }
+        if (saw_end && !pending_zero) end_mark();
+    }
+
+    // Linked frames: one block per launch, window handling exactly as frame/decompress.rs:195-222,280-306
+    void read_block_linked() {
+        const size_t mbs = block_size_bytes(fi.block_size);
+        ready.clear(); ready_idx = 0; ready_pos = 0;
+        if (dst_start + mbs > ldst.size()) {
+            ext_dict_offset = dst_start - WINDOW_SIZE; ext_dict_len = WINDOW_SIZE; dst_start = 0;
+        } else if (dst_start + ext_dict_len > WINDOW_SIZE) {
+            const size_t delta = std::min(ext_dict_len, dst_start + ext_dict_len - WINDOW_SIZE);
+            ext_dict_offset += delta; ext_dict_len -= delta;
+        }
+        uint8_t bi[4];
+        if (read_exact(bi, 4) != 0) { if (io_failed) fail(-LZ4FLEX_FE_IO); else pending_zero = true; return; }
+        const uint32_t size = rd32(bi);
+        if (size == 0) { end_mark(); return; }
+        const bool raw = (size & BLOCK_UNCOMPRESSED_SIZE_BIT) != 0;
+        const size_t len = size & ~BLOCK_UNCOMPRESSED_SIZE_BIT;
+        if (len > mbs) { fail(-LZ4FLEX_FE_BLOCK_TOO_BIG); return; }
+        size_t produced;
+        if (raw) {
+            if (len && read_exact(ldst.data() + dst_start, len) != 0) { fail(-LZ4FLEX_FE_IO); return; }
+            if (fi.block_checksums) {
+                uint8_t c[4];
+                if (read_exact(c, 4) != 0) { fail(-LZ4FLEX_FE_IO); return; }
+                if (XxHash32::oneshot(0, ldst.data() + dst_start, len) != rd32(c)) { fail(-LZ4FLEX_FE_BLOCK_CHECKSUM); return; }
+            }
+            produced = len;
+        } else {
+            comp.resize(len);
+            if (len && read_exact(comp.data(), len) != 0) { fail(-LZ4FLEX_FE_IO); return; }
+            if (fi.block_checksums) {
+                uint8_t c[4];
+                if (read_exact(c, 4) != 0) { fail(-LZ4FLEX_FE_IO); return; }
+                if (XxHash32::oneshot(0, comp.data(), len) != rd32(c)) { fail(-LZ4FLEX_FE_BLOCK_CHECKSUM); return; }
+            }
+            const bool with_dict = ext_dict_len != 0;
+            const uint64_t off0 = 0, doff = ext_dict_offset;
+            const uint32_t ilen = (uint32_t)len, pos = (uint32_t)dst_start, dlen = (uint32_t)ext_dict_len;
+            const uint32_t cap = (uint32_t)(with_dict ? ext_dict_offset : dst_start + mbs);
+            uint32_t olen = 0; int32_t st = 0; uint64_t det[2] = {0, 0};
+            lz4flex_decompress_ext ext{};
+            ext.out_pos = &pos;
+            if (with_dict) { ext.dict_base = ldst.data(); ext.dict_off = &doff; ext.dict_len = &dlen; }
+            const int rc = lz4flex_decompress_batch_ex(nullptr, comp.data(), &off0, &ilen, 1, ldst.data(), &off0, &cap, &olen, &st,
+                                                       det, &ext, LZ4FLEX_MEM_HOST, nullptr);
+            if (rc) { fail(rc); return; }
+            if (st) {
+                lz4flex_err_detail d{}; d.expected = det[0]; d.actual = det[1]; d.inner = st;
+                fail(-LZ4FLEX_FE_DECOMPRESSION, &d);
+                return;
+            }
+            produced = olen;
+        }
+        if (out.size() < produced) out.resize(produced);
+        memcpy(out.data(), ldst.data() + dst_start, produced);
+        ready.push_back({0, produced});
+        content_len += produced;
+        if (fi.content_checksum) content_hasher.write(out.data(), produced);
+        dst_start += produced;
+    }
+
+    // io::Read::read, frame/decompress.rs:353-367
+    int64_t read(uint8_t* buf, size_t len, lz4flex_err_detail* d) {
+        for (;;) {
+            while (ready_idx < ready.size()) {
+                const Item& it = ready[ready_idx];
+                if (it.len == 0) { ready_idx++; ready_pos = 0; return 0; }   // read_more() == 0
+                const size_t n = std::min(it.len - ready_pos, len);
+                if (n == 0) return 0;   // zero-length destination
+                memcpy(buf, out.data() + it.off + ready_pos, n);
+                ready_pos += n;
+                if (ready_pos == it.len) { ready_idx++; ready_pos = 0; }
+                return (int64_t)n;
+            }
+            if (pending_err) { if (d) *d = pending_detail; return pending_err; }
+            if (pending_zero) { pending_zero = false; return 0; }
+            if (!have_frame) {
+                lz4flex_err_detail hd{};
+                const int rc = read_frame_info(&hd);
+                if (rc == 1) return 0;
+                if (rc < 0) { if (d) *d = hd; return rc; }
+            }
+            if (fi.block_mode == 1) read_block_linked(); else read_blocks_independent();
+        }
+    }
+};
+
+extern "C" {
+
+lz4flex_frame_encoder* lz4flex_frame_encoder_new(const lz4flex_frame_info* info, lz4flex_write_fn w, void* user) {
+    if (!w) return nullptr;
+    lz4flex_frame_encoder* e = new (std::nothrow) lz4flex_frame_encoder();
+    if (!e) return nullptr;
+    if (info) e->fi = *info;
+    e->w = w; e->user = user;
+    return e;
+}
+int64_t lz4flex_frame_encoder_write(lz4flex_frame_encoder* e, const uint8_t* buf, size_t len) {
+    if (!e || (!buf && len)) return -LZ4FLEX_E_INVALID_ARG;
+    return e->write(buf, len);
+}
+int lz4flex_frame_encoder_flush(lz4flex_frame_encoder* e) { return e ? e->flush() : -LZ4FLEX_E_INVALID_ARG; }
+int lz4flex_frame_encoder_try_finish(lz4flex_frame_encoder* e, lz4flex_err_detail* d) {
+    if (d) memset(d, 0, sizeof *d);
+    return e ? e->try_finish(d) : -LZ4FLEX_E_INVALID_ARG;
+}
+void lz4flex_frame_encoder_frame_info(lz4flex_frame_encoder* e, lz4flex_frame_info* out) { if (e && out) *out = e->fi; }
+int lz4flex_frame_encoder_set_batch_bytes(lz4flex_frame_encoder* e, size_t bytes) {
+    if (!e || e->is_frame_open || bytes == 0) return -LZ4FLEX_E_INVALID_ARG;
+    e->batch_bytes = bytes;
+    return 0;
+}
+void lz4flex_frame_encoder_free(lz4flex_frame_encoder* e) { delete e; }
+
+lz4flex_frame_decoder* lz4flex_frame_decoder_new(lz4flex_read_fn r, void* user) {
+    if (!r) return nullptr;
+    lz4flex_frame_decoder* d = new (std::nothrow) lz4flex_frame_decoder();
+    if (!d) return nullptr;
+    d->r = r; d->user = user;
+    return d;
+}
+int64_t lz4flex_frame_decoder_read(lz4flex_frame_decoder* dcd, uint8_t* buf, size_t len, lz4flex_err_detail* d) {
+    if (!dcd || (!buf && len)) return -LZ4FLEX_E_INVALID_ARG;
+    if (d) memset(d, 0, sizeof *d);
+    return dcd->read(buf, len, d);
+}
+int lz4flex_frame_decoder_set_batch_bytes(lz4flex_frame_decoder* d, size_t bytes) {
+    if (!d || bytes == 0) return -LZ4FLEX_E_INVALID_ARG;
+    d->batch_bytes = bytes;
+    return 0;
+}
+void lz4flex_frame_decoder_free(lz4flex_frame_decoder* d) { delete d; }
+
+// ---- one-shot helpers over flat buffers -------------------------------------------------------
+namespace {
+struct FlatW { uint8_t* p; size_t pos, cap; bool full; };
+int64_t flat_write(void* u, const uint8_t* b, size_t n) {
+    FlatW* f = (FlatW*)u;
+    if (f->cap - f->pos < n) { f->full = true; return -1; }
+    memcpy(f->p + f->pos, b, n); f->pos += n;
+    return (int64_t)n;
+}
+struct FlatR { const uint8_t* p; size_t pos, len; };
+int64_t flat_read(void* u, uint8_t* b, size_t n) {
+    FlatR* f = (FlatR*)u;
+    const size_t k = std::min(n, f->len - f->pos);
+    memcpy(b, f->p + f->pos, k); f->pos += k;
+    return (int64_t)k;
+}
+}  // namespace
+
+size_t lz4flex_frame_compress_bound(size_t in_len, const lz4flex_frame_info* info) {
+    int bs = info ? info->block_size : 0;
+    if (bs == 0) bs = block_size_from_buf_length(in_len);
+    const size_t mbs = block_size_bytes(bs) ? block_size_bytes(bs) : 65536;
+    const size_t nblk = (in_len + mbs - 1) / mbs;
+    return MAX_FRAME_INFO_SIZE + in_len + nblk * 8 + 8;   // raw-stored worst case: 4 B header (+4 B checksum) per block
+}
+
+int64_t lz4flex_frame_compress(const uint8_t* in, size_t in_len, const lz4flex_frame_info* info, uint8_t* out,
+                               size_t out_cap, lz4flex_err_detail* detail) {
+    if ((!in && in_len) || !out) return -LZ4FLEX_E_INVALID_ARG;
+    if (detail) memset(detail, 0, sizeof *detail);
+    FlatW fw{out, 0, out_cap, false};
+    lz4flex_frame_encoder* e = lz4flex_frame_encoder_new(info, flat_write, &fw);
+    if (!e) return -LZ4FLEX_E_NOMEM;
+    int64_t rc = e->write(in, in_len);
+    if (rc >= 0) rc = e->try_finish(detail);
+    lz4flex_frame_encoder_free(e);
+    if (rc < 0) return fw.full ? -LZ4FLEX_FE_OUTPUT_FULL : rc;
+    return (int64_t)fw.pos;
+}
+
+int64_t lz4flex_frame_decompress(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, size_t* consumed,
+                                 lz4flex_err_detail* detail) {
+    if ((!in && in_len) || (!out && out_cap)) return -LZ4FLEX_E_INVALID_ARG;
+    if (detail) memset(detail, 0, sizeof *detail);
+    FlatR fr{in, 0, in_len};
+    lz4flex_frame_decoder* d = lz4flex_frame_decoder_new(flat_read, &fr);
+    if (!d) return -LZ4FLEX_E_NOMEM;
+    size_t pos = 0;
+    int64_t rc = 0;
+    uint8_t scratch[1];
+    for (;;) {   // read_to_end: until read() returns 0
+        if (pos == out_cap) {
+            // probe for more data without a destination
+            rc = d->read(scratch, 1, detail);
+            if (rc > 0) rc = -LZ4FLEX_FE_OUTPUT_FULL;
+            break;
+        }
+        rc = d->read(out + pos, out_cap - pos, detail);
+        if (rc <= 0) break;
+        pos += (size_t)rc;
+    }
+    if (consumed) *consumed = fr.pos;
+    lz4flex_frame_decoder_free(d);
+    return rc < 0 ? rc : (int64_t)pos;
+}
+
+}  // extern "C"

@@ -1,0 +1,301 @@
+// lz4_compress.hip -- batched LZ4 block encoder for MI355X (gfx950, wave64).
+//
+// Replaces the per-block call lz4_flex::block::compress_into / compress_internal (reference
+// src/block/compress.rs:318-489, table selection :554-568, hashes src/block/hashtable.rs:19-34)
+// for MANY independent blocks at once, and produces THE SAME BYTES as the reference encoder:
+// same hash, same 4096-entry direct-mapped table semantics (zero-initialised, last writer
+// wins), same skip schedule, same backward/forward extension, same end-of-block rules.
+//
+// Work decomposition (MI355X-first):
+//   * one GROUP of G lanes (G = 8 or 16: half / one DPP row of the wave) owns one block;
+//     a 64-thread workgroup (one wavefront) encodes 64/G blocks.
+//   * the block's 4096-entry hash table lives in LDS (u16 entries = 8 KiB for blocks
+//     <= 64 KiB, u32 = 16 KiB above); all table traffic is LDS traffic.  The table is the
+//     resource that bounds blocks in flight per CU (160 KiB LDS / 8 KiB).
+//   * the serial greedy probe loop is executed G probes at a time: probe i of a sequence sits
+//     at a position that depends only on i (skip schedule), so lane g evaluates probe i0+g;
+//     the first verified candidate (ballot + ctz) wins and only probes up to it update the
+//     table.  Two probes of one batch that fall in the same bucket are resolved exactly
+//     (DPP row shifts): a later probe sees the earlier probe's position as its candidate and
+//     only the last one is stored, which is what the serial loop does.
+//   * backward extension, forward extension (8 bytes per lane per step) and literal copies
+//     are lane-parallel; input is read straight from HBM/L2 (coalesced by construction: the
+//     G probes of a batch read adjacent positions), output bytes are written once.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lz4_device.h"
+
+namespace lz4flex_dev {
+
+#define LZ4_MFLIMIT 12u
+#define LZ4_END_OFFSET 6u
+#define LZ4_MIN_LENGTH 13u
+#define LZ4_MAX_DISTANCE 65535u
+
+__device__ __forceinline__ uint32_t cld32(const uint8_t* p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ uint64_t cld64(const uint8_t* p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ void cst32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
+// src/block/hashtable.rs:19-21, index = hash >> 4 (:52-53,78)
+__device__ __forceinline__ uint32_t hidx4(uint32_t x) { return ((x * 2654435761u) >> 16) >> 4; }
+// src/block/hashtable.rs:27-34 (little endian), index = hash >> 4
+__device__ __forceinline__ uint32_t hidx5(uint64_t x) { return (uint32_t)(((x << 24) * 889523592379ull) >> 52); }
+
+// src/block/compress.rs:588-590
+__device__ __forceinline__ uint64_t max_output_size(uint32_t n) { return 20ull + ((uint64_t)n * 110ull) / 100ull; }
+
+template <int N>
+__device__ __forceinline__ uint32_t row_shr(uint32_t v, uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x110 + N, 0xF, 0xF, false);
+}
+template <int N>
+__device__ __forceinline__ uint32_t row_shl(uint32_t v, uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x100 + N, 0xF, 0xF, false);
+}
+
+// position of probe `i` of a sequence whose probing started at `base`
+// (src/block/compress.rs:367-378: step = (32 + i) >> 5)
+__device__ __forceinline__ uint32_t probe_pos(uint32_t base, uint32_t i) {
+    const uint32_t q = 1u + (i >> 5), r = i & 31u;
+    return base + 16u * q * (q - 1u) + r * q;
+}
+
+template <int G>
+struct Grp {
+    uint32_t g;       // lane within group
+    uint32_t shift;   // first lane of the group within the wave
+    __device__ __forceinline__ uint32_t ballot(bool p) const {
+        return (uint32_t)(__ballot(p) >> shift) & ((G == 32) ? 0xFFFFFFFFu : ((1u << G) - 1u));
+    }
+    __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t src) const { return __shfl(v, (int)(shift + src)); }
+};
+
+// nearest EARLIER lane of the group with the same bucket: returns its distance (1..G-1) or 0
+template <int G, int N>
+struct FwdConflict {
+    static __device__ __forceinline__ uint32_t run(uint32_t idx, uint32_t g) {
+        const uint32_t far = FwdConflict<G, N + 1>::run(idx, g);
+        const uint32_t v = row_shr<N>(idx, 0xFFFFFFFFu);
+        return (g >= (uint32_t)N && v == idx) ? (uint32_t)N : far;   // nearer distance overrides
+    }
+};
+template <int G>
+struct FwdConflict<G, G> {
+    static __device__ __forceinline__ uint32_t run(uint32_t, uint32_t) { return 0u; }
+};
+// is there a LATER lane (distance 1..G-1, lane index <= last) with the same bucket?
+template <int G, int N>
+struct BwdConflict {
+    static __device__ __forceinline__ bool run(uint32_t idx, uint32_t g, uint32_t last) {
+        const uint32_t v = row_shl<N>(idx, 0xFFFFFFFFu);
+        const bool hit = (g + (uint32_t)N <= last) && ((g % G) + (uint32_t)N < (uint32_t)G) && v == idx;
+        return hit || BwdConflict<G, N + 1>::run(idx, g, last);
+    }
+};
+template <int G>
+struct BwdConflict<G, G> {
+    static __device__ __forceinline__ bool run(uint32_t, uint32_t, uint32_t) { return false; }
+};
+
+// group copy of literals: 4 bytes per lane per step, exact tail
+template <int G>
+__device__ __forceinline__ void lit_copy(uint8_t* dst, const uint8_t* src, uint32_t len, uint32_t g) {
+    for (uint32_t i = 4u * g; i < len; i += 4u * G) {
+        if (i + 4u <= len) cst32(dst + i, cld32(src + i));
+        else for (uint32_t k = i; k < len; ++k) dst[k] = src[k];
+    }
+}
+
+// token + literal-length extension + literals. Returns new output position. (compress.rs:463-478 / :237-247)
+template <int G>
+__device__ __forceinline__ uint32_t emit_literals(uint8_t* out, uint32_t o, const uint8_t* in, uint32_t lit_start,
+                                                  uint32_t lit_len, uint32_t token_low, uint32_t g) {
+    const uint32_t token = ((lit_len < 15u ? lit_len : 15u) << 4) | token_low;
+    if (g == 0u) out[o] = (uint8_t)token;
+    o += 1u;
+    if (lit_len >= 15u) {   // write_integer, compress.rs:224-233
+        uint32_t rem = lit_len - 15u;
+        const uint32_t n255 = rem / 255u;
+        for (uint32_t k = g; k < n255; k += G) out[o + k] = 0xFFu;
+        o += n255;
+        if (g == 0u) out[o] = (uint8_t)(rem - n255 * 255u);
+        o += 1u;
+    }
+    lit_copy<G>(out + o, in + lit_start, lit_len, g);
+    return o + lit_len;
+}
+
+template <int G, typename TblT>
+__device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, uint32_t n, uint8_t* __restrict__ out,
+                                                uint32_t cap, uint32_t flags, TblT* tbl, const Grp<G> grp,
+                                                uint32_t* produced) {
+    const uint32_t g = grp.g;
+    if ((uint64_t)cap < max_output_size(n)) return LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL;   // compress.rs:338-340
+    uint32_t o = 0u;
+    if (n < LZ4_MIN_LENGTH) {   // compress.rs:343-346
+        o = emit_literals<G>(out, o, in, 0u, n, 0u, g);
+        *produced = o;
+        return 0;
+    }
+    const bool frame_tbl = (flags & 2u) != 0u;        // FrameEncoder: HashTable4K + hash5 always
+    const bool continuation = (flags & 1u) != 0u;     // table holds only unreachable entries; pos 0 is probed
+    const bool use_h5 = frame_tbl || n >= 65535u;     // compress.rs:559-566
+    const uint32_t end_check = n - LZ4_MFLIMIT;       // compress.rs:349
+    // zero the table (HashTable::new / clear)
+    {
+        uint4* t4 = reinterpret_cast<uint4*>(tbl);
+        const uint32_t n16 = (4096u * (uint32_t)sizeof(TblT)) / 16u;
+        for (uint32_t k = g; k < n16; k += G) t4[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const uint32_t idx0 = use_h5 ? hidx5(cld64(in)) : hidx4(cld32(in));
+    // compress.rs:353-359: default mode seeds position 0 (a no-op store on a zeroed table) and starts at 1.
+    // continuation mode probes position 0 first: it can only miss (every entry is unreachable), stores
+    // 0 in its bucket and counts as probe #0 of the first sequence.
+    uint32_t lit_start = 0u;
+    uint32_t base = continuation ? 0u : 1u;   // probing origin of the current sequence
+    uint32_t i0 = continuation ? 1u : 0u;     // index of the first probe of the next batch
+    for (;;) {
+        // ------------------------------------------------------------------ probe batch
+        const uint32_t i = i0 + g;
+        const uint32_t p = probe_pos(base, i);
+        const bool valid = p <= end_check;                                    // compress.rs:381
+        uint32_t idx = 0xFFFF0000u + g;   // distinct sentinels for invalid lanes
+        uint32_t cand = 0u, cur4 = 0u;
+        bool cand_ok = false;
+        if (valid) {
+            if (use_h5) { const uint64_t x = cld64(in + p); idx = hidx5(x); cur4 = (uint32_t)x; }
+            else { cur4 = cld32(in + p); idx = hidx4(cur4); }
+            cand = (uint32_t)tbl[idx];
+            // a zero entry is "position 0": real in default mode, and in continuation
+            // mode only in the bucket position 0 was stored to
+            cand_ok = !continuation || cand != 0u || idx == idx0;
+        }
+        // same-bucket probes earlier in this batch supersede the table content
+        const uint32_t d = FwdConflict<G, 1>::run(idx, g);
+        if (d != 0u) { cand = probe_pos(base, i - d); cand_ok = true; }
+        bool is_match = false;
+        if (valid && cand_ok && (p - cand) <= LZ4_MAX_DISTANCE)                // compress.rs:403-405
+            is_match = cld32(in + cand) == cur4;                              // compress.rs:432-438
+        const uint32_t mm = grp.ballot(is_match);
+        const uint32_t vm = grp.ballot(valid);
+        const uint32_t last = mm ? (uint32_t)__builtin_ctz(mm) : (G - 1u);     // last probe that executes
+        // table stores of the executed probes (compress.rs:393), last writer per bucket only
+        if (valid && g <= last && !BwdConflict<G, 1>::run(idx, g, last)) tbl[idx] = (TblT)p;
+        if (mm == 0u) {
+            if (vm != (((G == 32) ? 0xFFFFFFFFu : ((1u << G) - 1u)))) break;   // ran past end_check: last literals
+            i0 += G;
+            continue;
+        }
+        uint32_t cur = grp.bcast(p, last);
+        uint32_t cnd = grp.bcast(cand, last);
+        const uint32_t offset = cur - cnd;                                    // compress.rs:409
+        // ------------------------------------------------------------------ backtrack (compress.rs:442-448)
+        for (;;) {
+            const bool ok = (cnd > g) && (cur > lit_start + g) && in[cur - 1u - g] == in[cnd - 1u - g];
+            const uint32_t okm = grp.ballot(ok);
+            const uint32_t nb = (uint32_t)__builtin_ctz(~okm);                // G..31 bits are 0 in okm => nb <= G
+            cur -= nb; cnd -= nb;
+            if (nb < (uint32_t)G) break;
+        }
+        const uint32_t lit_len = cur - lit_start;                             // compress.rs:451
+        // ------------------------------------------------------------------ forward (count_same_bytes :156-216)
+        cur += 4u; cnd += 4u;
+        const uint32_t limit = n - LZ4_END_OFFSET;                            // matches end 6 bytes before the end
+        uint32_t dl = 0u;
+        for (;;) {
+            const uint32_t a = cur + dl + 8u * g;
+            uint32_t c = 0u;                  // equal bytes seen by this lane (0..8)
+            if (a < limit) {
+                const uint32_t rem = limit - a;
+                const uint32_t b = cnd + dl + 8u * g;
+                if (rem >= 8u) {
+                    const uint64_t diff = cld64(in + a) ^ cld64(in + b);
+                    c = diff ? (uint32_t)(__builtin_ctzll(diff) >> 3) : 8u;
+                } else {
+                    while (c < rem && in[a + c] == in[b + c]) ++c;
+                }
+            }
+            const uint32_t part = grp.ballot(c != 8u);
+            if (part == 0u) { dl += 8u * G; continue; }
+            const uint32_t f = (uint32_t)__builtin_ctz(part);
+            dl += 8u * f + grp.bcast(c, f);
+            break;
+        }
+        cur += dl;
+        // ------------------------------------------------------------------ table: cur-2 (compress.rs:460-461)
+        if (g == 0u) {
+            const uint32_t q = cur - 2u;
+            const uint32_t qi = use_h5 ? hidx5(cld64(in + q)) : hidx4(cld32(in + q));
+            tbl[qi] = (TblT)q;
+        }
+        // ------------------------------------------------------------------ emit (compress.rs:463-486)
+        o = emit_literals<G>(out, o, in, lit_start, lit_len, dl < 15u ? dl : 15u, g);
+        if (g == 0u) { out[o] = (uint8_t)(offset & 0xFFu); out[o + 1u] = (uint8_t)(offset >> 8); }
+        o += 2u;
+        if (dl >= 15u) {
+            const uint32_t rem = dl - 15u;
+            const uint32_t n255 = rem / 255u;
+            for (uint32_t k = g; k < n255; k += G) out[o + k] = 0xFFu;
+            o += n255;
+            if (g == 0u) out[o] = (uint8_t)(rem - n255 * 255u);
+            o += 1u;
+        }
+        lit_start = cur;                                                      // compress.rs:487
+        base = cur;
+        i0 = 0u;
+    }
+    // handle_last_literals, compress.rs:237-247
+    o = emit_literals<G>(out, o, in, lit_start, n - lit_start, 0u, g);
+    *produced = o;
+    return 0;
+}
+
+template <int G, typename TblT>
+__global__ void __launch_bounds__(64) lz4_compress_blocks_kernel(CompressArgs a) {
+    constexpr int BPW = 64 / G;   // blocks per workgroup (one wave)
+    __shared__ __attribute__((aligned(16))) TblT tables[BPW][4096];
+    const uint32_t lane = threadIdx.x;
+    Grp<G> grp;
+    grp.g = lane % G;
+    grp.shift = (lane / G) * G;
+    const uint32_t b = blockIdx.x * BPW + lane / G;
+    if (b >= a.n) return;
+    const uint32_t n = a.in_len[b];
+    const uint32_t flags = a.flags ? a.flags[b] : 0u;
+    uint32_t produced = 0u;
+    const int32_t st = encode_block<G, TblT>(a.in_base + a.in_off[b], n, a.out_base + a.out_off[b], a.out_cap[b], flags,
+                                             &tables[lane / G][0], grp, &produced);
+    if (grp.g == 0u) {
+        a.status[b] = st;
+        a.out_len[b] = st == 0 ? produced : 0u;
+    }
+}
+
+template <int G, typename TblT>
+static hipError_t launch_c(const CompressArgs& a, hipStream_t s) {
+    constexpr uint32_t BPW = 64 / G;
+    const uint32_t grid = (a.n + BPW - 1u) / BPW;
+    hipLaunchKernelGGL((lz4_compress_blocks_kernel<G, TblT>), dim3(grid), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+// variant: bits 0..7 = lanes per block (8 or 16), bit 8 = blocks may exceed 64 KiB (u32 table)
+hipError_t launch_compress(const CompressArgs& a, int variant, hipStream_t s) {
+    if (a.n == 0u) return hipSuccess;
+    const int G = variant & 0xFF;
+    const bool big = (variant & 0x100) != 0;
+    if (G == 8) return big ? launch_c<8, uint32_t>(a, s) : launch_c<8, uint16_t>(a, s);
+    if (G == 16) return big ? launch_c<16, uint32_t>(a, s) : launch_c<16, uint16_t>(a, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace lz4flex_dev

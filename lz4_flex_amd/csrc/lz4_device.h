@@ -1,0 +1,49 @@
+// lz4_device.h -- kernel argument blocks and launch entry points shared by the HIP kernels
+// and the host C ABI (capi.cpp).  Device-side status codes mirror include/lz4flex_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL 1
+#define LZ4FLEX_DEV_E_LITERAL_OUT_OF_BOUNDS 2
+#define LZ4FLEX_DEV_E_EXPECTED_ANOTHER_BYTE 3
+#define LZ4FLEX_DEV_E_OFFSET_ZERO 4
+#define LZ4FLEX_DEV_E_OFFSET_OUT_OF_BOUNDS 5
+
+namespace lz4flex_dev {
+
+// All pointers are device pointers.
+struct DecompressArgs {
+    const uint8_t* in_base;
+    const uint64_t* in_off;
+    const uint32_t* in_len;
+    uint8_t* out_base;
+    const uint64_t* out_off;
+    const uint32_t* out_cap;
+    const uint32_t* out_pos;   // nullable: initial sink position (prefix mode of Linked frames)
+    const uint8_t* dict_base;  // nullable: external dictionaries
+    const uint64_t* dict_off;
+    const uint32_t* dict_len;
+    uint32_t* out_len;
+    int32_t* status;
+    uint64_t* detail;          // nullable: 2 per block (expected, actual)
+    uint32_t n;
+};
+
+struct CompressArgs {
+    const uint8_t* in_base;
+    const uint64_t* in_off;
+    const uint32_t* in_len;
+    const uint32_t* flags;     // nullable
+    uint8_t* out_base;
+    const uint64_t* out_off;
+    const uint32_t* out_cap;
+    uint32_t* out_len;
+    int32_t* status;
+    uint32_t n;
+};
+
+hipError_t launch_decompress(const DecompressArgs& a, int lanes_per_block, hipStream_t s);
+hipError_t launch_compress(const CompressArgs& a, int variant, hipStream_t s);
+
+}  // namespace lz4flex_dev

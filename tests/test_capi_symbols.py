@@ -1,0 +1,70 @@
+"""CPU test: the C-ABI shared library loads and exports every symbol include/lz4flex_amd.h declares,
+and fails loudly (no CPU fallback) when there is no GPU.  No compute calls."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "lz4flex_amd.h")
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from lz4_flex_amd import build
+    return build.build()   # hipcc cross-compiles gfx950 without a GPU
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lz4flex_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_entry_points():
+    names = declared_functions()
+    for must in ("lz4flex_compress_into", "lz4flex_decompress_into", "lz4flex_compress_batch", "lz4flex_decompress_batch",
+                 "lz4flex_frame_encoder_new", "lz4flex_frame_decoder_new", "lz4flex_get_maximum_output_size"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib_path]).decode()
+    exported = set(re.findall(r" T (lz4flex_[a-z0-9_]+)", out))
+    missing = [n for n in declared_functions() if n not in exported]
+    assert not missing, missing
+
+
+def test_ctypes_binding_covers_header(lib_path):
+    from lz4_flex_amd import _lib
+    lib = _lib.load()
+    for n in declared_functions():
+        assert n in _lib.SIGNATURES, n
+        assert getattr(lib, n) is not None
+
+
+def test_library_contains_gfx950_code_object(lib_path):
+    data = open(lib_path, "rb").read()
+    assert b"gfx950" in data
+    assert b"lz4_decompress_blocks_kernel" in data and b"lz4_compress_blocks_kernel" in data
+
+
+def test_host_logic_without_gpu(lib_path):
+    """pure host entry points work anywhere; compute entry points refuse to run without a device"""
+    import ctypes as C
+    from lz4_flex_amd import _lib, block, frame
+    lib = _lib.load()
+    assert block.get_maximum_output_size(65536) == 72109
+    assert frame.FrameInfo(block_size=frame.BlockSize.Max64KB).write() == bytes([0x04, 0x22, 0x4D, 0x18, 0x60, 0x40, 0x82])
+    assert frame.FrameInfo(block_size=frame.BlockSize.Max64KB, block_mode=frame.BlockMode.Linked).write()[-1] == 0xC0
+    fi = frame.FrameInfo.read(bytes([0x04, 0x22, 0x4D, 0x18, 0x40, 0x40, 0xC0]))
+    assert fi.block_mode == frame.BlockMode.Linked and fi.block_size == frame.BlockSize.Max64KB
+    with pytest.raises(frame.HeaderChecksumError):
+        frame.FrameInfo.read(bytes([0x04, 0x22, 0x4D, 0x18, 0x40, 0x40, 0xC1]))
+    assert lib.lz4flex_xxh32(b"", 0, 0) == 0x02CC5D05
+    if lib.lz4flex_device_count() == 0:
+        with pytest.raises(block.DeviceError):
+            block.compress(b"no gpu, no codec")
+        with pytest.raises(block.DeviceError):
+            block.decompress(bytes([0x10, 0x61]), 1)
