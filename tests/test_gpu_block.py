@@ -1,0 +1,285 @@
+"""GPU parity tests (-m gpu): the HIP block codec, called through the C ABI, against the oracle.
+Bit-exact: decoder output/byte count/error variant == oracle; encoder output bytes == oracle
+(== lz4_flex's own block bytes)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import corpus
+import oracle_api as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def blk():
+    from lz4_flex_amd import _lib, block
+    lib = _lib.load()
+    assert lib.lz4flex_device_count() >= 1, "GPU tests need a HIP device: " + _lib.last_error()
+    return block
+
+
+def _gpu_decode(blk, data, cap, dict_data=None):
+    out = bytearray(cap)
+    try:
+        n = blk.decompress_into(data, out) if dict_data is None else blk.decompress_into_with_dict(data, out, dict_data)
+    except blk.OutputTooSmall as e:
+        return "OutputTooSmall", (e.expected, e.actual)
+    except blk.DecompressError as e:
+        return type(e).__name__, (0, 0)
+    return "ok", bytes(out[:n])
+
+
+# ---------------------------------------------------------------- KATs: decompress.rs:534-622
+@pytest.mark.parametrize("kat", corpus.DECODER_KATS)
+def test_decoder_kats(blk, kat):
+    data, cap, d, (exp, payload) = kat
+    st, got = _gpu_decode(blk, data, cap, d)
+    assert st == exp
+    if exp == "ok":
+        assert got == payload
+    elif payload is not None:
+        assert got == payload
+
+
+@pytest.mark.parametrize("lanes", [8, 16, 32, 64])
+def test_decoder_kats_all_group_widths(blk, lanes):
+    from lz4_flex_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    ctx = C.c_void_p()
+    assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
+    assert lib.lz4flex_set_tuning(ctx, b"decompress_lanes", lanes) == 0
+    try:
+        for data, cap, d, (exp, payload) in corpus.DECODER_KATS:
+            if d is not None or len(data) == 0:
+                continue
+            inb = np.frombuffer(data, dtype=np.uint8)
+            out = np.zeros(max(cap, 1), dtype=np.uint8)
+            ol, st, det = blk.decompress_batch(inb, [0], [len(data)], out, [0], [cap], ctx=ctx)
+            name = "ok" if st[0] == 0 else O.ERR_NAMES[int(st[0])]
+            assert name == exp
+            if exp == "ok":
+                assert bytes(out[:ol[0]]) == payload
+            elif payload is not None:
+                assert (int(det[0][0]), int(det[0][1])) == payload
+    finally:
+        lib.lz4flex_ctx_destroy(ctx)
+
+
+# ---------------------------------------------------------------- fixtures
+@pytest.mark.parametrize("stem", corpus.FIXTURES)
+def test_fixture_decode_bit_exact(blk, stem):
+    m = O.manifest()[stem]
+    golden = O.golden_block(stem)
+    plain = blk.decompress(golden, m["plain_len"])
+    assert hashlib.md5(plain).hexdigest() == m["plain_md5"]
+    assert ("ok", plain) == O.decompress(golden, m["plain_len"])
+    # larger capacity is allowed (CHANGELOG.md:67-70) and yields the same bytes
+    assert blk.decompress(golden, m["plain_len"] + 1000) == plain
+    # C liblz4's encoding of the same fixture decodes to the same bytes
+    assert blk.decompress(O.c_compress(plain), len(plain)) == plain
+
+
+@pytest.mark.parametrize("stem", corpus.FIXTURES)
+def test_fixture_encode_bit_exact(blk, stem):
+    plain = O.fixture_plain(stem)
+    comp = blk.compress(plain)
+    assert comp == O.golden_block(stem) == O.compress(plain)
+    assert O.c_decompress(comp, len(plain)) == plain
+
+
+def test_config1_66k_json_single_block(blk):
+    """BASELINE configs[0]: the 66 675-byte JSON fixture as one block, compress + decompress, bit-exact"""
+    plain = O.fixture_plain("compression_66k_JSON")
+    comp = blk.compress(plain)
+    assert len(comp) == 15268
+    assert blk.decompress(comp, len(plain)) == plain
+    assert blk.decompress_size_prepended(blk.compress_prepend_size(plain)) == plain
+
+
+# ---------------------------------------------------------------- round trips: tests/tests.rs:78-147
+def _roundtrip(blk, data):
+    comp = blk.compress(data)
+    assert comp == O.compress(data)                                   # == reference encoder bytes
+    assert blk.decompress(comp, len(data)) == data
+    assert blk.decompress_size_prepended(blk.compress_prepend_size(data)) == data
+    assert O.c_decompress(comp, len(data)) == data                    # flex(GPU) -> C
+    if data:
+        assert blk.decompress(O.c_compress(data), len(data)) == data   # C -> flex(GPU)
+
+
+@pytest.mark.parametrize("i", range(len(corpus.roundtrip_inputs())))
+def test_roundtrip_corpus(blk, i):
+    _roundtrip(blk, corpus.roundtrip_inputs()[i])
+
+
+def test_roundtrip_generated(blk):
+    for seed, (alpha, run) in enumerate([(2, 1), (4, 8), (16, 3), (256, 1), (256, 64), (3, 300)]):
+        for n in (1, 12, 13, 14, 64, 1000, 65534, 65535, 65536):
+            _roundtrip(blk, corpus.lcg_bytes(n, seed * 1000 + n, alpha, run))
+
+
+def test_output_too_small_up_front(blk):   # compress.rs:338-340
+    out = bytearray(blk.get_maximum_output_size(11) - 1)
+    with pytest.raises(blk.CompressOutputTooSmall):
+        blk.compress_into(b"hello world", out)
+    assert out == bytearray(len(out))      # nothing written
+
+
+def test_conformant_last_block(blk):       # compress.rs:952-968
+    a = b"a" * 15
+    assert len(blk.compress(a[:12])) > 12
+    for n in (13, 14, 15):
+        assert len(blk.compress(a[:n])) <= n
+
+
+def test_no_panic_inputs_match_oracle(blk):   # tests/tests.rs:321-351, :497-526
+    for data in corpus.NO_PANIC_SIZE_PREPENDED:
+        size = int.from_bytes(data[:4], "little")
+        if size > 20_000_000:
+            continue
+        assert _gpu_decode(blk, data[4:], size) == _norm(O.decompress(data[4:], size))
+        assert _gpu_decode(blk, data[4:], size, data) == _norm(O.decompress(data[4:], size, dict_data=data))
+
+
+def _norm(r):
+    st, payload = r
+    if st not in ("ok", "OutputTooSmall"):
+        return st, (0, 0)
+    return st, payload
+
+
+def test_dict_decode(blk):   # compress.rs:884-949 (decode side), :991-998
+    inp = bytes([10, 12, 14, 16, 18] * 4)
+    comp = O.compress_with_dict(inp, inp)    # the dictionary-seeded ENCODER kernel is a later row; the oracle encodes
+    assert blk.decompress_with_dict(comp, len(inp), inp) == inp
+    big = b"a" * (1 << 20)
+    small = b"a" * 29
+    assert blk.decompress_with_dict(O.compress_with_dict(small, big), len(small), big[-65536:]) == small
+
+
+def test_truncated_and_corrupted_blocks_match_oracle(blk):
+    """every prefix / single-byte corruption of a real block: same outcome (bytes or error variant) as the oracle"""
+    plain = O.fixture_plain("compression_1k")
+    good = O.golden_block("compression_1k")
+    cases = [good[:k] for k in range(0, len(good), 7)]
+    for k in range(0, len(good), 11):
+        bad = bytearray(good); bad[k] ^= 0x5A
+        cases.append(bytes(bad))
+    n = len(cases)
+    inb = np.frombuffer(b"".join(cases), dtype=np.uint8)
+    in_len = np.array([len(c) for c in cases], dtype=np.uint32)
+    in_off = np.concatenate([[0], np.cumsum(in_len[:-1], dtype=np.uint64)]).astype(np.uint64)
+    cap = len(plain) + 64
+    out = np.full(n * cap, 0xEE, dtype=np.uint8)
+    ol, st, det = blk.decompress_batch(inb, in_off, in_len, out, np.arange(n, dtype=np.uint64) * cap, np.full(n, cap, np.uint32))
+    for i, c in enumerate(cases):
+        est, epay = O.decompress(c, cap)
+        if est == "ok":
+            assert st[i] == 0 and bytes(out[i * cap:i * cap + ol[i]]) == epay
+        else:
+            assert O.ERR_NAMES[int(st[i])] == est
+            if est == "OutputTooSmall":
+                assert (int(det[i][0]), int(det[i][1])) == epay
+
+
+def test_no_output_leak(blk):   # fuzz_decomp_no_output_leak.rs:16-44
+    for data in corpus.NO_PANIC_SIZE_PREPENDED + [O.golden_block("compression_1k")]:
+        res = []
+        for fill in (0, 1):
+            out = bytearray([fill]) * 4096
+            try:
+                n = blk.decompress_into(data, out)
+                res.append(("ok", bytes(out[:n])))
+            except blk.DecompressError as e:
+                res.append((type(e).__name__, None))
+        assert res[0] == res[1]
+
+
+# ---------------------------------------------------------------- batches
+def _tile(src, total, block):
+    reps = (total + len(src) - 1) // len(src) + 1
+    buf = (src * reps)[:total]
+    return buf
+
+
+@pytest.mark.parametrize("lanes", [8, 16])
+def test_compress_batch_bit_exact_vs_oracle(blk, lanes):
+    from lz4_flex_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    ctx = C.c_void_p()
+    assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
+    assert lib.lz4flex_set_tuning(ctx, b"compress_lanes", lanes) == 0
+    try:
+        srcs = [O.fixture_plain("compression_66k_JSON"), O.fixture_plain("compression_65k"), corpus.lcg_bytes(70000, 5, 4, 9),
+                bytes(70000), corpus.lcg_bytes(70000, 6, 256, 1)]
+        blocks = []
+        for s in srcs:
+            t = _tile(s, 6 * 65536 + 1234, 65536)
+            blocks += [t[i:i + 65536] for i in range(0, len(t), 65536)]
+        blocks += [b"", b"a", b"a" * 12, b"a" * 13, srcs[0][:65535], srcs[0][:65534], srcs[1][:100]]
+        n = len(blocks)
+        inb = np.frombuffer(b"".join(blocks), dtype=np.uint8)
+        in_len = np.array([len(b) for b in blocks], dtype=np.uint32)
+        in_off = np.concatenate([[0], np.cumsum(in_len[:-1], dtype=np.uint64)]).astype(np.uint64)
+        stride = 72128
+        out = np.zeros(n * stride, dtype=np.uint8)
+        for flags in (None, np.full(n, 2, np.uint32), np.full(n, 3, np.uint32)):
+            ol, st = blk.compress_batch(inb, in_off, in_len, out, np.arange(n, dtype=np.uint64) * stride,
+                                        np.full(n, stride, np.uint32), flags=flags, ctx=ctx)
+            assert (st == 0).all()
+            for i, b in enumerate(blocks):
+                got = bytes(out[i * stride:i * stride + ol[i]])
+                if flags is None:
+                    exp = O.compress(b)
+                else:
+                    exp = O.compress_frame_block(b, first_block=(flags[i] == 2))
+                assert got == exp, (i, len(b), lanes, None if flags is None else int(flags[i]))
+    finally:
+        lib.lz4flex_ctx_destroy(ctx)
+
+
+def test_compress_big_blocks_bit_exact(blk):
+    """blocks above 64 KiB take the u32-table kernel (config 4 uses 4 MiB blocks)"""
+    src = O.fixture_plain("compression_66k_JSON") + O.fixture_plain("compression_65k")
+    for n in (65537, 100000, 262144, 1 << 20):
+        data = _tile(src, n, n)
+        comp = blk.compress(data)
+        assert comp == O.compress(data)
+        assert blk.decompress(comp, n) == data
+
+
+@pytest.mark.parametrize("lanes", [8, 16, 32, 64])
+def test_decompress_batch_bit_exact_vs_oracle(blk, lanes):
+    from lz4_flex_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    ctx = C.c_void_p()
+    assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
+    assert lib.lz4flex_set_tuning(ctx, b"decompress_lanes", lanes) == 0
+    try:
+        srcs = [O.fixture_plain("compression_66k_JSON"), O.fixture_plain("compression_65k"), corpus.lcg_bytes(70000, 5, 4, 9),
+                bytes(70000), corpus.lcg_bytes(70000, 6, 256, 1), corpus.lcg_bytes(70000, 7, 3, 40)]
+        plains = []
+        for s in srcs:
+            t = _tile(s, 5 * 65536 + 777, 65536)
+            plains += [t[i:i + 65536] for i in range(0, len(t), 65536)]
+        plains += [b"", b"q", b"abc" * 5]
+        comps = [O.compress(p) for p in plains] + [O.c_compress(p) for p in plains if p]
+        plains = plains + [p for p in plains if p]
+        n = len(comps)
+        inb = np.frombuffer(b"".join(comps), dtype=np.uint8)
+        in_len = np.array([len(c) for c in comps], dtype=np.uint32)
+        in_off = np.concatenate([[0], np.cumsum(in_len[:-1], dtype=np.uint64)]).astype(np.uint64)
+        out_cap = np.array([len(p) for p in plains], dtype=np.uint32)
+        out_off = np.concatenate([[0], np.cumsum(out_cap[:-1], dtype=np.uint64)]).astype(np.uint64)
+        out = np.zeros(int(out_cap.sum()) + 1, dtype=np.uint8)
+        ol, st, det = blk.decompress_batch(inb, in_off, in_len, out, out_off, out_cap, ctx=ctx)
+        assert (st == 0).all(), st
+        assert (ol == out_cap).all()
+        assert bytes(out[:-1]) == b"".join(plains)
+    finally:
+        lib.lz4flex_ctx_destroy(ctx)

@@ -1,0 +1,175 @@
+"""GPU parity tests (-m gpu) for the frame layer: byte-identical frames vs the oracle's restatement of
+FrameEncoder, decode parity, C liblz4 (LZ4F) cross-compatibility, error variants."""
+import io
+
+import pytest
+
+import corpus
+import oracle_api as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fr():
+    from lz4_flex_amd import _lib, frame
+    assert _lib.load().lz4flex_device_count() >= 1
+    return frame
+
+
+def _enc(fr, data, chunks=None, **kw):
+    buf = io.BytesIO()
+    e = fr.FrameEncoder.with_frame_info(fr.FrameInfo(**kw), buf)
+    if chunks is None:
+        e.write_all(data)
+    else:
+        pos = 0
+        for c in chunks:
+            e.write(data[pos:pos + c]); pos += c
+        e.write(data[pos:])
+    e.finish()
+    return buf.getvalue()
+
+
+def _dec(fr, data):
+    return fr.FrameDecoder.new(io.BytesIO(data)).read_to_end()
+
+
+def test_header_goldens(fr):   # fuzz_decomp_corrupt_frame.rs:26-27
+    assert fr.FrameInfo(block_size=fr.BlockSize.Max64KB).write() == corpus.FRAME_HEADER_GOLDENS[0][1]
+    assert fr.FrameInfo(block_size=fr.BlockSize.Max64KB, block_mode=fr.BlockMode.Linked).write() == corpus.FRAME_HEADER_GOLDENS[1][1]
+
+
+@pytest.mark.parametrize("i", range(len(corpus.roundtrip_inputs())))
+def test_roundtrip_corpus_independent(fr, i):   # tests/tests.rs:96-104, :126-145
+    data = corpus.roundtrip_inputs()[i]
+    f = _enc(fr, data)
+    rc, exp = O.frame_compress(data)
+    assert rc == 0 and f == exp                       # byte-identical to the reference encoder's frame
+    assert _dec(fr, f) == data
+    assert O.c_frame_decompress(f, len(data)) == data               # flex(GPU) frame -> C
+    assert _dec(fr, O.c_frame_compress(data, independent=True)) == data   # C frame -> flex(GPU)
+
+
+@pytest.mark.parametrize("i", range(len(corpus.roundtrip_inputs())))
+def test_decode_linked_frames(fr, i):   # Linked DECODE on GPU (prefix + ext-dict window); Linked encode is a later row
+    data = corpus.roundtrip_inputs()[i]
+    assert _dec(fr, O.frame_compress(data, block_mode=1)[1]) == data
+    assert _dec(fr, O.c_frame_compress(data, independent=False)) == data
+
+
+@pytest.mark.parametrize("stem", corpus.FIXTURES)
+def test_fixtures(fr, stem):
+    data = O.fixture_plain(stem)
+    f = _enc(fr, data)
+    assert f == O.frame_compress(data)[1]
+    assert _dec(fr, f) == data
+    if stem in corpus.RATIO_FRAME:                    # tests/tests.rs:174-192
+        assert len(f) / len(data) < corpus.RATIO_FRAME[stem]
+
+
+def test_multi_block_options(fr):   # fuzz_roundtrip_frame.rs:14-80
+    data = O.fixture_plain("compression_66k_JSON") * 9 + O.fixture_plain("compression_65k") * 3
+    for bs in (fr.BlockSize.Max64KB, fr.BlockSize.Max256KB, fr.BlockSize.Max1MB, fr.BlockSize.Max4MB, fr.BlockSize.Auto):
+        for bc in (False, True):
+            for cc in (False, True):
+                f = _enc(fr, data, block_size=bs, block_checksums=bc, content_checksum=cc)
+                rc, exp = O.frame_compress(data, block_size=int(bs), block_checksums=bc, content_checksum=cc)
+                assert rc == 0 and f == exp, (bs, bc, cc)
+                assert _dec(fr, f) == data
+                assert O.c_frame_decompress(f, len(data)) == data
+    # chunked writes and small launch batches do not change the bytes
+    whole = _enc(fr, data, block_size=fr.BlockSize.Max64KB)
+    assert _enc(fr, data, chunks=[1, 7, 65535, 1, 65536, 100000, 13], block_size=fr.BlockSize.Max64KB) == whole
+    buf = io.BytesIO()
+    e = fr.FrameEncoder.with_frame_info(fr.FrameInfo(block_size=fr.BlockSize.Max64KB), buf)
+    e.set_batch_bytes(3 * 65536)
+    e.write_all(data); e.finish()
+    assert buf.getvalue() == whole
+    d = fr.FrameDecoder.new(io.BytesIO(whole)); d.set_batch_bytes(2 * 65536)
+    assert d.read_to_end() == data
+
+
+def test_linked_multi_block_decode(fr):
+    data = O.fixture_plain("compression_66k_JSON") * 9 + corpus.lcg_bytes(300000, 3, 8, 5)
+    for bs in (4, 5):
+        f = O.frame_compress(data, block_mode=1, block_size=bs)[1]
+        assert _dec(fr, f) == data
+    assert _dec(fr, O.c_frame_compress(data, independent=False)) == data
+
+
+def test_flush_makes_block_boundary(fr):
+    data = O.fixture_plain("compression_34k")
+    buf = io.BytesIO()
+    e = fr.FrameEncoder.new(buf)
+    e.write(data[:1000]); e.flush(); e.write(data[1000:]); e.finish()
+    assert _dec(fr, buf.getvalue()) == data
+    assert O.c_frame_decompress(buf.getvalue(), len(data)) == data
+
+
+def test_concatenated(fr):   # tests/tests.rs:633-647
+    a, b = O.fixture_plain("compression_1k"), O.fixture_plain("compression_34k")
+    buf = io.BytesIO()
+    e = fr.FrameEncoder.new(buf)
+    e.write_all(a); e.try_finish(); e.write_all(b); e.finish()
+    d = fr.FrameDecoder.new(io.BytesIO(buf.getvalue()))
+    assert d.read_to_end() == a
+    assert d.read_to_end() == b
+    assert d.read_to_end() == b""
+
+
+def test_checksums(fr):   # tests/tests.rs:650-684
+    for stem in ("compression_34k", "compression_66k_JSON"):
+        data = O.fixture_plain(stem)
+        f = bytearray(_enc(fr, data, block_checksums=True))
+        assert _dec(fr, bytes(f)) == data
+        f[-5] ^= 0xFF
+        with pytest.raises(fr.BlockChecksumError):
+            _dec(fr, bytes(f))
+        f = bytearray(_enc(fr, data, content_checksum=True))
+        assert _dec(fr, bytes(f)) == data
+        f[-1] ^= 0xFF
+        with pytest.raises(fr.ContentChecksumError):
+            _dec(fr, bytes(f))
+
+
+def test_content_size(fr):   # tests/tests.rs:712-737
+    data = O.fixture_plain("compression_1k")
+    f = bytearray(_enc(fr, data, content_size=len(data)))
+    assert _dec(fr, bytes(f)) == data
+    dummy = _enc(fr, b"123", content_size=3)
+    f[:15] = dummy[:15]
+    with pytest.raises(fr.ContentLengthError) as ei:
+        _dec(fr, bytes(f))
+    assert (ei.value.expected, ei.value.actual) == (3, 725)
+    with pytest.raises(fr.ContentLengthError):
+        _enc(fr, data, content_size=3)
+
+
+def test_errors(fr):
+    with pytest.raises(fr.WrongMagicNumber):
+        _dec(fr, b"\x00\x01\x02\x03\x04\x05\x06")
+    good = bytearray(_enc(fr, b"hello")); good[6] ^= 1
+    with pytest.raises(fr.HeaderChecksumError):
+        _dec(fr, bytes(good))
+    with pytest.raises(fr.SkippableFrame) as ei:
+        _dec(fr, (0x184D2A50).to_bytes(4, "little") + (5).to_bytes(4, "little") + b"abcde")
+    assert ei.value.length == 5
+    big = corpus.FRAME_HEADER_GOLDENS[0][1] + (70000).to_bytes(4, "little") + bytes(70000)
+    with pytest.raises(fr.BlockTooBig):
+        _dec(fr, big)
+    bad_block = corpus.FRAME_HEADER_GOLDENS[0][1] + (11).to_bytes(4, "little") + bytes([0x0E, 0, 0, 0x70, 0, 0, 0, 0, 0, 0, 0])
+    with pytest.raises(fr.DecompressionError) as ei:
+        _dec(fr, bad_block + bytes(4))
+    assert ei.value.inner == "OffsetZero"
+    legacy = (0x184C2102).to_bytes(4, "little")
+    blkb = O.compress(b"legacy frame payload " * 10)
+    assert _dec(fr, legacy + len(blkb).to_bytes(4, "little") + blkb) == b"legacy frame payload " * 10
+
+
+def test_one_shot_helpers(fr):
+    data = O.fixture_plain("compression_66k_JSON") * 3
+    f = fr.compress_frame(data)
+    assert f == O.frame_compress(data)[1]
+    out, used = fr.decompress_frame(f, len(data))
+    assert out == data and used == len(f)
