@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--decompress-lanes", type=int, default=0)
     ap.add_argument("--compress-lanes", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="kernel experiments only: skip the bit-exact check (never for reported numbers)")
+    ap.add_argument("--ablate", type=int, default=0, help="kernel timing ablations (wrong output; implies --no-verify)")
     ap.add_argument("--only", choices=["both", "compress", "decompress"], default="both",
                     help="profiling aid: run only one kernel in the timed steps (value then covers that kernel only)")
     args = ap.parse_args()
@@ -79,6 +81,8 @@ def main():
         assert lib.lz4flex_set_tuning(ctx, b"decompress_lanes", args.decompress_lanes) == 0
     if args.compress_lanes:
         assert lib.lz4flex_set_tuning(ctx, b"compress_lanes", args.compress_lanes) == 0
+    if args.ablate:
+        args.no_verify = True
 
     # ---- workload: buf[i] = json[(i + phase) mod 66 675], cut into 64 KiB blocks
     n = args.blocks
@@ -126,6 +130,8 @@ def main():
     do_compress()
     do_decompress()
     torch.cuda.synchronize()
+    if args.ablate:
+        assert lib.lz4flex_set_tuning(ctx, b"ablate", args.ablate) == 0
     for _ in range(args.warmup):
         if args.only in ("both", "compress"):
             do_compress()
@@ -155,9 +161,10 @@ def main():
         elapsed = float(te.item())
 
     # ---- verify after the timed loop
-    assert int((c_status != 0).sum().item()) == 0 and int((d_status != 0).sum().item()) == 0, "per-block status != 0"
-    assert int((back_len != BLOCK).sum().item()) == 0
-    assert torch.equal(back, src), "round trip mismatch"
+    if not args.no_verify:
+        assert int((c_status != 0).sum().item()) == 0 and int((d_status != 0).sum().item()) == 0, "per-block status != 0"
+        assert int((back_len != BLOCK).sum().item()) == 0
+        assert torch.equal(back, src), "round trip mismatch"
     comp_bytes = int(comp_len.to(torch.int64).sum().item())
     ratio = comp_bytes / total
 
@@ -218,7 +225,7 @@ def main():
         "decompress_MiB_per_s_per_gpu": kernels.get("decompress", {}).get("MiB_per_s"),
         "roofline": dict(kernels[dominant]["roofline"], kernel=kernels[dominant]["kernel"]),
         "kernels": kernels,
-        "verified": "round trip bit-exact on device; all per-block status 0",
+        "verified": "NOT VERIFIED (--no-verify)" if args.no_verify else "round trip bit-exact on device; all per-block status 0",
     }
 
     # ---- CPU baseline: the oracle (a C port of lz4_flex's block codec) on the host cores, bounded sample

@@ -116,7 +116,8 @@ int64_t lz4flex_decompress_size_prepended(const uint8_t *in, size_t in_len, uint
 /* Compress n independent blocks.  Block i reads in_base[in_off[i] .. +in_len[i]] and writes at
  * out_base[out_off[i] ..], capacity out_cap[i] (must be >= get_maximum_output_size(in_len[i]),
  * else status[i] = LZ4FLEX_E_OUTPUT_TOO_SMALL and nothing is written).  out_len[i] = bytes
- * written.  flags may be NULL.  hip_stream: a hipStream_t (NULL = the ctx stream).
+ * written.  flags may be NULL.  hip_stream: the hipStream_t a MEM_DEVICE batch is enqueued on (NULL = HIP's
+ * null stream); MEM_HOST batches ignore it and use the context's own stream.
  * Returns 0 or -code for call-level failures; per-block results are in status[]. */
 int lz4flex_compress_batch(lz4flex_ctx *ctx, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
                            const uint32_t *flags, uint32_t n, void *out_base, const uint64_t *out_off,
@@ -146,8 +147,9 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
                                 uint32_t *out_len, int32_t *status, uint64_t *detail,
                                 const lz4flex_decompress_ext *ext, int mem_kind, void *hip_stream);
 
-/* Tuning knobs for measurements: "decompress_lanes" (8/16/32/64), "compress_lanes" (8/16) = lanes
- * of a wavefront cooperating on one block. */
+/* Tuning knobs for measurements: "decompress_variant" (2 = LDS-staged decoder, default; 1 = decoder whose
+ * window lives in HBM/L2, also used for dictionary/prefix blocks), "decompress_lanes" (8/16/32/64, variant 1),
+ * "compress_lanes" (8/16) = lanes of a wavefront cooperating on one block. */
 int lz4flex_set_tuning(lz4flex_ctx *ctx, const char *key, int value);
 
 /* ---- frame (src/frame/) ------------------------------------------------------------------ */

@@ -40,6 +40,8 @@ struct lz4flex_ctx {
     size_t pin_cap = 0;
     int dec_lanes = 16;           // lanes per block, decode
     int comp_lanes = 8;           // lanes per block, encode
+    int ablate = 0;               // timing ablations (wrong output!), see lz4flex_set_tuning("ablate")
+    int dec_variant = 3;          // 1 = window in HBM/L2 (lz4_decompress.hip), 2 = LDS-staged generic loop, 3 = LDS-staged pipelined (lz4_decompress_lds.hip)
 };
 
 static int ensure_arena(lz4flex_ctx* c, size_t need) {
@@ -107,6 +109,12 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
     if (!strcmp(key, "decompress_lanes")) {
         if (value != 8 && value != 16 && value != 32 && value != 64) return -LZ4FLEX_E_INVALID_ARG;
         c->dec_lanes = value;
+        return 0;
+    }
+    if (!strcmp(key, "ablate")) { c->ablate = value; return 0; }
+    if (!strcmp(key, "decompress_variant")) {
+        if (value < 1 || value > 3) return -LZ4FLEX_E_INVALID_ARG;
+        c->dec_variant = value;
         return 0;
     }
     if (!strcmp(key, "compress_lanes")) {
@@ -236,7 +244,7 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
         a.dict_len = has_dict ? (const uint32_t*)(dd + at_dict_len) : nullptr;
         a.out_len = (uint32_t*)(dd + at_out_len); a.status = (int32_t*)(dd + at_status);
         a.detail = (uint64_t*)(dd + at_detail); a.n = n;
-        le = launch_decompress(a, c->dec_lanes, s);
+        le = (c->dec_variant >= 2 && !has_dict && !has_pos) ? (c->dec_variant == 3 ? launch_decompress_pipe(a, s, c->ablate) : launch_decompress_lds(a, s, c->ablate)) : launch_decompress(a, c->dec_lanes, s);
     }
     if (le != hipSuccess) return hip_fail(le, "kernel launch");
     HIP_TRY(hipMemcpyAsync(hp + at_out_len, dd + at_out_len, desc_bytes - at_out_len, hipMemcpyDeviceToHost, s));
@@ -276,7 +284,7 @@ static int run_device_batch(lz4flex_ctx* c, bool compress, const void* in_base, 
                             const uint32_t* in_len, const uint32_t* flags, uint32_t n, void* out_base,
                             const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len, int32_t* status,
                             uint64_t* detail, const lz4flex_decompress_ext_* ext, void* hip_stream, int big_hint) {
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    hipStream_t s = (hipStream_t)hip_stream;   // DEVICE batches run on the caller's stream (NULL = HIP's null stream)
     hipError_t le;
     if (compress) {
         CompressArgs a{};
@@ -293,7 +301,7 @@ static int run_device_batch(lz4flex_ctx* c, bool compress, const void* in_base, 
         a.dict_off = ext ? ext->dict_off : nullptr;
         a.dict_len = ext ? ext->dict_len : nullptr;
         a.out_len = out_len; a.status = status; a.detail = detail; a.n = n;
-        le = launch_decompress(a, c->dec_lanes, s);
+        le = (c->dec_variant >= 2 && !a.dict_base && !a.out_pos) ? (c->dec_variant == 3 ? launch_decompress_pipe(a, s, c->ablate) : launch_decompress_lds(a, s, c->ablate)) : launch_decompress(a, c->dec_lanes, s);
     }
     if (le != hipSuccess) return hip_fail(le, "kernel launch");
     return 0;
