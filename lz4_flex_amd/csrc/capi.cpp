@@ -40,6 +40,7 @@ struct lz4flex_ctx {
     size_t pin_cap = 0;
     int dec_lanes = 16;           // lanes per block, decode
     int comp_lanes = 8;           // lanes per block, encode
+    int comp_variant = 1;         // 1 = lz4_compress.hip (any block size, default), 2 = experimental LDS-staged lz4_compress_lds.hip (<= 64 KiB; bit-exact but measured slower in round 1: 44.7 vs 33.9 ms/GiB)
     int ablate = 0;               // timing ablations (wrong output!), see lz4flex_set_tuning("ablate")
     int dec_variant = 3;          // 1 = window in HBM/L2 (lz4_decompress.hip), 2 = LDS-staged generic loop, 3 = LDS-staged pipelined (lz4_decompress_lds.hip)
 };
@@ -115,6 +116,11 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
     if (!strcmp(key, "decompress_variant")) {
         if (value < 1 || value > 3) return -LZ4FLEX_E_INVALID_ARG;
         c->dec_variant = value;
+        return 0;
+    }
+    if (!strcmp(key, "compress_variant")) {
+        if (value != 1 && value != 2) return -LZ4FLEX_E_INVALID_ARG;
+        c->comp_variant = value;
         return 0;
     }
     if (!strcmp(key, "compress_lanes")) {
@@ -233,7 +239,7 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
         a.out_len = (uint32_t*)(dd + at_out_len); a.status = (int32_t*)(dd + at_status); a.n = n;
         bool big = false;
         for (uint32_t i = 0; i < n; i++) big |= in_len[i] > 65536u;
-        le = launch_compress(a, c->comp_lanes | (big ? 0x100 : 0), s);
+        le = (c->comp_variant == 2 && !big) ? launch_compress_lds(a, s) : launch_compress(a, c->comp_lanes | (big ? 0x100 : 0), s);
     } else {
         DecompressArgs a{};
         a.in_base = d + a_in; a.in_off = (const uint64_t*)(dd + at_in_off); a.in_len = (const uint32_t*)(dd + at_in_len);
@@ -291,7 +297,7 @@ static int run_device_batch(lz4flex_ctx* c, bool compress, const void* in_base, 
         a.in_base = (const uint8_t*)in_base; a.in_off = in_off; a.in_len = in_len; a.flags = flags;
         a.out_base = (uint8_t*)out_base; a.out_off = out_off; a.out_cap = out_cap; a.out_len = out_len;
         a.status = status; a.n = n;
-        le = launch_compress(a, c->comp_lanes | (big_hint ? 0x100 : 0), s);
+        le = (c->comp_variant == 2 && !big_hint) ? launch_compress_lds(a, s) : launch_compress(a, c->comp_lanes | (big_hint ? 0x100 : 0), s);
     } else {
         DecompressArgs a{};
         a.in_base = (const uint8_t*)in_base; a.in_off = in_off; a.in_len = in_len;

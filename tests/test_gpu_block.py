@@ -43,14 +43,18 @@ def test_decoder_kats(blk, kat):
         assert got == payload
 
 
-@pytest.mark.parametrize("lanes", [8, 16, 32, 64])
+@pytest.mark.parametrize("lanes", [8, 16, 32, 64, -2, -3])
 def test_decoder_kats_all_group_widths(blk, lanes):
     from lz4_flex_amd import _lib
     import ctypes as C
     lib = _lib.load()
     ctx = C.c_void_p()
     assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
-    assert lib.lz4flex_set_tuning(ctx, b"decompress_lanes", lanes) == 0
+    if lanes > 0:
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 1) == 0
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_lanes", lanes) == 0
+    else:
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", -lanes) == 0
     try:
         for data, cap, d, (exp, payload) in corpus.DECODER_KATS:
             if d is not None or len(data) == 0:
@@ -205,14 +209,18 @@ def _tile(src, total, block):
     return buf
 
 
-@pytest.mark.parametrize("lanes", [8, 16])
+@pytest.mark.parametrize("lanes", [8, 16, 0])
 def test_compress_batch_bit_exact_vs_oracle(blk, lanes):
+    """lanes 8/16: lz4_compress.hip group widths; lanes 0: the experimental LDS-staged encoder (variant 2)"""
     from lz4_flex_amd import _lib
     import ctypes as C
     lib = _lib.load()
     ctx = C.c_void_p()
     assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
-    assert lib.lz4flex_set_tuning(ctx, b"compress_lanes", lanes) == 0
+    if lanes:
+        assert lib.lz4flex_set_tuning(ctx, b"compress_lanes", lanes) == 0
+    else:
+        assert lib.lz4flex_set_tuning(ctx, b"compress_variant", 2) == 0
     try:
         srcs = [O.fixture_plain("compression_66k_JSON"), O.fixture_plain("compression_65k"), corpus.lcg_bytes(70000, 5, 4, 9),
                 bytes(70000), corpus.lcg_bytes(70000, 6, 256, 1)]
@@ -252,14 +260,19 @@ def test_compress_big_blocks_bit_exact(blk):
         assert blk.decompress(comp, n) == data
 
 
-@pytest.mark.parametrize("lanes", [8, 16, 32, 64])
+@pytest.mark.parametrize("lanes", [8, 16, 32, 64, -2, -3])
 def test_decompress_batch_bit_exact_vs_oracle(blk, lanes):
+    """lanes > 0: lz4_decompress.hip (variant 1) group widths; -2 / -3: LDS-staged generic / pipelined decoders"""
     from lz4_flex_amd import _lib
     import ctypes as C
     lib = _lib.load()
     ctx = C.c_void_p()
     assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
-    assert lib.lz4flex_set_tuning(ctx, b"decompress_lanes", lanes) == 0
+    if lanes > 0:
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 1) == 0
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_lanes", lanes) == 0
+    else:
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", -lanes) == 0
     try:
         srcs = [O.fixture_plain("compression_66k_JSON"), O.fixture_plain("compression_65k"), corpus.lcg_bytes(70000, 5, 4, 9),
                 bytes(70000), corpus.lcg_bytes(70000, 6, 256, 1), corpus.lcg_bytes(70000, 7, 3, 40)]
