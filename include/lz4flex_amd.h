@@ -124,6 +124,28 @@ int lz4flex_compress_batch(lz4flex_ctx *ctx, const void *in_base, const uint64_t
                            const uint32_t *out_cap, uint32_t *out_len, int32_t *status, int mem_kind,
                            void *hip_stream);
 
+/* Chains of DEPENDENT blocks: the full compress_internal signature (src/block/compress.rs:289-325) -- a
+ * prefix before in_pos, an external dictionary, a stream offset and ONE hash table that persists across
+ * the blocks of a chain (Linked frames, src/frame/compress.rs:280-299,327-356; compress_into_with_dict,
+ * :554-583).  Chains run in parallel, the blocks of a chain in order.  All offsets index in_base. */
+typedef struct lz4flex_chain_block {
+    uint64_t in_off;    /* start of `input` (prefix included) */
+    uint64_t dict_off;  /* start of ext_dict */
+    uint32_t in_len;    /* input.len() */
+    uint32_t in_pos;    /* input_pos: first byte to compress */
+    uint32_t dict_len;
+    uint32_t so;        /* input_stream_offset */
+    uint32_t repos;     /* HashTable4K::reposition(repos) before this block (hashtable.rs:113-117); 0 = none */
+    uint32_t flags;     /* bit0: 4-byte hash (the HashTable4KU16 case of compress.rs:559-562); bit1: clear the table and init_dict (:571-583) */
+} lz4flex_chain_block;
+/* blocks[chain_first[c] .. +chain_count[c]) form chain c; out_off/out_cap/out_len/status are per block.
+ * tbl_state (nullable): 4096 u32 per chain, read before the chain's first block and written back after its
+ * last one, so a chain can continue in a later call.  MEM_HOST or MEM_DEVICE as for the batches. */
+int lz4flex_compress_chains(lz4flex_ctx *ctx, const void *in_base, const lz4flex_chain_block *blocks, uint32_t n_blocks,
+                            const uint32_t *chain_first, const uint32_t *chain_count, uint32_t n_chains,
+                            void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
+                            int32_t *status, uint32_t *tbl_state, int mem_kind, void *hip_stream);
+
 /* Decompress n independent blocks.  out_cap[i] >= true size (larger allowed, as
  * decompress_into).  status[i] = 0 or a DecompressError code; detail (nullable, 2*n u64:
  * expected, actual) is filled for OutputTooSmall. */

@@ -386,9 +386,113 @@ int64_t lz4flex_compress_into(const uint8_t* in, size_t in_len, uint8_t* out, si
     return (int64_t)olen;
 }
 
-int64_t lz4flex_compress_into_with_dict(const uint8_t*, size_t, uint8_t*, size_t, const uint8_t*, size_t) {
-    g_last_error = "compress_into_with_dict: the dictionary-seeded encoder kernel is not built yet (SURVEY 8(f) f1)";
-    return -LZ4FLEX_E_UNSUPPORTED;
+int lz4flex_compress_chains(lz4flex_ctx* ctx, const void* in_base, const lz4flex_chain_block* blocks, uint32_t n_blocks,
+                            const uint32_t* chain_first, const uint32_t* chain_count, uint32_t n_chains, void* out_base,
+                            const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len, int32_t* status,
+                            uint32_t* tbl_state, int mem_kind, void* hip_stream) {
+    static_assert(sizeof(lz4flex_chain_block) == 40, "ChainBlock layout");
+    int rc;
+    if (!ctx && (rc = default_ctx(&ctx))) return rc;
+    if (n_chains == 0 || n_blocks == 0) return 0;
+    if (!blocks || !chain_first || !chain_count || !out_off || !out_cap || !out_len || !status) return -LZ4FLEX_E_INVALID_ARG;
+    if ((mem_kind & 0xFF) == LZ4FLEX_MEM_DEVICE) {
+        hipError_t le = launch_compress_chain((const uint8_t*)in_base, blocks, chain_first, chain_count, n_chains,
+                                              (uint8_t*)out_base, out_off, out_cap, out_len, status, tbl_state,
+                                              (hipStream_t)hip_stream);
+        return le == hipSuccess ? 0 : hip_fail(le, "chain kernel launch");
+    }
+    if (mem_kind != LZ4FLEX_MEM_HOST) return -LZ4FLEX_E_INVALID_ARG;
+    lz4flex_ctx* c = ctx;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    HIP_TRY(hipSetDevice(c->device));
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
+    // spans of the caller's buffers
+    uint64_t ilo = ~0ull, ihi = 0;
+    for (uint32_t i = 0; i < n_blocks; i++) {
+        ilo = std::min<uint64_t>(ilo, blocks[i].in_off);
+        ihi = std::max<uint64_t>(ihi, blocks[i].in_off + blocks[i].in_len);
+        if (blocks[i].dict_len) {
+            ilo = std::min<uint64_t>(ilo, blocks[i].dict_off);
+            ihi = std::max<uint64_t>(ihi, blocks[i].dict_off + blocks[i].dict_len);
+        }
+    }
+    if (ilo > ihi) { ilo = 0; ihi = 0; }
+    Span os = span_of(out_off, out_cap, n_blocks);
+    const size_t in_bytes = (size_t)(ihi - ilo), out_bytes = (size_t)(os.hi - os.lo);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 16); return at; };
+    const size_t at_blocks = take(sizeof(lz4flex_chain_block) * (size_t)n_blocks), at_first = take(4ull * n_chains),
+                 at_count = take(4ull * n_chains), at_out_off = take(8ull * n_blocks), at_out_cap = take(4ull * n_blocks);
+    const size_t desc_in = o;
+    const size_t at_out_len = take(4ull * n_blocks), at_status = take(4ull * n_blocks);
+    const size_t desc_bytes = o;
+    const size_t tbl_bytes = tbl_state ? 16384ull * n_chains : 0;
+    if ((rc = ensure_pin(c, desc_bytes))) return rc;
+    const size_t a_in = 0, a_out = align_up(in_bytes + 64, 256), a_desc = a_out + align_up(out_bytes + 64, 256),
+                 a_tbl = a_desc + align_up(desc_bytes + 64, 256);
+    if ((rc = ensure_arena(c, a_tbl + tbl_bytes + 256))) return rc;
+    uint8_t* hp = c->h_pin;
+    lz4flex_chain_block* hb = (lz4flex_chain_block*)(hp + at_blocks);
+    for (uint32_t i = 0; i < n_blocks; i++) {
+        hb[i] = blocks[i];
+        hb[i].in_off -= ilo;
+        hb[i].dict_off = blocks[i].dict_len ? blocks[i].dict_off - ilo : 0;
+        ((uint64_t*)(hp + at_out_off))[i] = out_off[i] - os.lo;
+        ((uint32_t*)(hp + at_out_cap))[i] = out_cap[i];
+    }
+    memcpy(hp + at_first, chain_first, 4ull * n_chains);
+    memcpy(hp + at_count, chain_count, 4ull * n_chains);
+    uint8_t* d = c->d_arena;
+    hipStream_t s = c->stream;
+    if (in_bytes) HIP_TRY(hipMemcpyAsync(d + a_in, (const uint8_t*)in_base + ilo, in_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + a_desc, hp, desc_in, hipMemcpyHostToDevice, s));
+    if (tbl_state) HIP_TRY(hipMemcpyAsync(d + a_tbl, tbl_state, tbl_bytes, hipMemcpyHostToDevice, s));
+    uint8_t* dd = d + a_desc;
+    hipError_t le = launch_compress_chain(d + a_in, dd + at_blocks, (const uint32_t*)(dd + at_first),
+                                          (const uint32_t*)(dd + at_count), n_chains, d + a_out,
+                                          (const uint64_t*)(dd + at_out_off), (const uint32_t*)(dd + at_out_cap),
+                                          (uint32_t*)(dd + at_out_len), (int32_t*)(dd + at_status),
+                                          tbl_state ? (uint32_t*)(d + a_tbl) : nullptr, s);
+    if (le != hipSuccess) return hip_fail(le, "chain kernel launch");
+    HIP_TRY(hipMemcpyAsync(hp + at_out_len, dd + at_out_len, desc_bytes - at_out_len, hipMemcpyDeviceToHost, s));
+    if (tbl_state) HIP_TRY(hipMemcpyAsync(tbl_state, d + a_tbl, tbl_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (uint32_t i = 0; i < n_blocks; i++) {
+        out_len[i] = ((const uint32_t*)(hp + at_out_len))[i];
+        status[i] = ((const int32_t*)(hp + at_status))[i];
+        if (status[i] == 0 && out_len[i])
+            HIP_TRY(hipMemcpyAsync((uint8_t*)out_base + out_off[i], d + a_out + (out_off[i] - os.lo), out_len[i],
+                                   hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int64_t lz4flex_compress_into_with_dict(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap,
+                                        const uint8_t* dict, size_t dict_len) {
+    if (in_len > 0x7FFFFFFFull) return -LZ4FLEX_E_INVALID_ARG;
+    if (out_cap < lz4flex_get_maximum_output_size(in_len)) return -LZ4FLEX_E_OUTPUT_TOO_SMALL;   // compress.rs:338-340
+    // compress_into_sink_with_dict, compress.rs:554-568: table kind from the UNtruncated dictionary length,
+    // then init_dict keeps the last 64 KiB (:572-574)
+    const bool h4 = dict_len + in_len < 65535u;
+    if (dict_len > 65536u) { dict += dict_len - 65536u; dict_len = 65536u; }
+    std::vector<uint8_t> buf(dict_len + in_len + 16);
+    if (dict_len) memcpy(buf.data(), dict, dict_len);
+    if (in_len) memcpy(buf.data() + dict_len, in, in_len);
+    lz4flex_chain_block b{};
+    b.in_off = dict_len; b.dict_off = 0; b.in_len = (uint32_t)in_len; b.in_pos = 0; b.dict_len = (uint32_t)dict_len;
+    b.so = (uint32_t)dict_len; b.repos = 0; b.flags = (h4 ? 1u : 0u) | 2u;
+    const uint32_t first = 0, count = 1;
+    const uint64_t off0 = 0;
+    const uint32_t cap = (uint32_t)std::min<size_t>(out_cap, 0xFFFFFFFFull);
+    uint32_t olen = 0;
+    int32_t st = 0;
+    int rc = lz4flex_compress_chains(nullptr, buf.data(), &b, 1, &first, &count, 1, out, &off0, &cap, &olen, &st, nullptr,
+                                     LZ4FLEX_MEM_HOST, nullptr);
+    if (rc) return rc;
+    if (st) return -(int64_t)st;
+    return (int64_t)olen;
 }
 
 int64_t lz4flex_compress_prepend_size(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap) {

@@ -132,6 +132,18 @@ struct lz4flex_frame_encoder {
     XxHash32 content_hasher{0};
     bool is_frame_open = false, data_to_frame_written = false;
     int sticky_err = 0;
+    // Linked mode (frame/compress.rs:62-93): the reference's src ring (prefix + ext_dict) expressed in
+    // stream coordinates; the dependent blocks of a batch run as ONE chain on the GPU.
+    std::vector<uint8_t> lstage;        // stream bytes [lbase, lbase + lstage_len)
+    size_t lstage_len = 0;
+    uint64_t lbase = 0;                 // stream position of lstage[0]
+    uint64_t proc_pos = 0;              // stream position of the first byte not yet compressed
+    uint64_t vbase = 0;                 // stream position of the reference's src[0]
+    uint64_t v_src_start = 0;           // == src_start == src_end between blocks
+    uint64_t dict_stream = 0;           // stream position of ext_dict[0]
+    uint32_t ext_dict_len = 0;
+    std::vector<uint32_t> tbl_state;    // the persistent HashTable4K
+    std::vector<lz4flex_chain_block> cblocks;
 
     int emit(const uint8_t* p, size_t n) {
         while (n) {
@@ -156,13 +168,107 @@ struct lz4flex_frame_encoder {
         if (content_len != 0) {   // second or later frame of this encoder: reset compressor state
             content_len = 0; src_stream_offset = 0; src_len = 0;
             content_hasher.reset(0);
+            ext_dict_len = 0; v_src_start = 0; vbase = proc_pos;
+            std::fill(tbl_state.begin(), tbl_state.end(), 0u);
+        }
+        if (fi.block_mode == 1 && tbl_state.empty()) tbl_state.assign(4096, 0u);
+        return 0;
+    }
+    // Linked mode: compress the stream bytes [proc_pos, proc_pos + total) as blocks of <= block_size, in order,
+    // with the reference's window bookkeeping (frame/compress.rs:261-371) done in stream coordinates.
+    int write_blocks_linked(size_t total) {
+        const size_t mbs = block_size_bytes(fi.block_size);
+        const size_t nblk = (total + mbs - 1) / mbs;
+        if (nblk == 0) return 0;
+        const size_t stride = (lz4flex_get_maximum_output_size(mbs) + 63) / 64 * 64;
+        if (dst.size() < stride * nblk) dst.resize(stride * nblk);
+        cblocks.resize(nblk); out_off.resize(nblk); out_cap.resize(nblk); out_len.resize(nblk); status.resize(nblk);
+        std::vector<uint64_t> bstart(nblk);
+        std::vector<uint32_t> blen(nblk);
+        size_t left = total;
+        uint64_t pos = proc_pos;
+        for (size_t i = 0; i < nblk; i++) {
+            const size_t len = std::min(mbs, left);
+            // :266-271 reposition near 2 GiB
+            uint32_t repos = 0;
+            if (src_stream_offset + mbs + WINDOW_SIZE >= (uint64_t)(0xFFFFFFFFu / 2)) {
+                repos = (uint32_t)(src_stream_offset - ext_dict_len);
+                src_stream_offset = ext_dict_len;
+            }
+            const uint64_t v_src_end = v_src_start + len;
+            lz4flex_chain_block& b = cblocks[i];
+            b.in_off = vbase - lbase;
+            b.in_len = (uint32_t)v_src_end;
+            b.in_pos = (uint32_t)v_src_start;
+            b.dict_off = ext_dict_len ? dict_stream - lbase : 0;
+            b.dict_len = ext_dict_len;
+            b.so = (uint32_t)src_stream_offset;
+            b.repos = repos;
+            b.flags = 0;
+            out_off[i] = i * stride; out_cap[i] = (uint32_t)stride;
+            bstart[i] = pos; blen[i] = (uint32_t)len;
+            // :324-356 buffer / offset maintenance
+            v_src_start += len;
+            if (v_src_start >= mbs + WINDOW_SIZE) {
+                dict_stream = vbase + v_src_end - WINDOW_SIZE;
+                ext_dict_len = (uint32_t)WINDOW_SIZE;
+                src_stream_offset += v_src_end;
+                vbase += v_src_end;
+                v_src_start = 0;
+            } else if (v_src_start + ext_dict_len > WINDOW_SIZE) {
+                const uint64_t delta = std::min<uint64_t>(ext_dict_len, v_src_start + ext_dict_len - WINDOW_SIZE);
+                dict_stream += delta;
+                ext_dict_len -= (uint32_t)delta;
+            }
+            pos += len; left -= len;
+        }
+        const uint32_t first = 0, count = (uint32_t)nblk;
+        int rc = lz4flex_compress_chains(nullptr, lstage.data(), cblocks.data(), (uint32_t)nblk, &first, &count, 1, dst.data(),
+                                         out_off.data(), out_cap.data(), out_len.data(), status.data(), tbl_state.data(),
+                                         LZ4FLEX_MEM_HOST, nullptr);
+        if (rc) return rc;
+        for (size_t i = 0; i < nblk; i++) {
+            if (status[i] != 0) return -LZ4FLEX_FE_COMPRESSION;
+            const uint8_t* s = lstage.data() + (bstart[i] - lbase);
+            const size_t slen = blen[i];
+            const uint8_t* block_data; size_t block_len; uint32_t info;
+            if (out_len[i] < slen) { block_data = dst.data() + out_off[i]; block_len = out_len[i]; info = out_len[i]; }
+            else { block_data = s; block_len = slen; info = (uint32_t)slen | BLOCK_UNCOMPRESSED_SIZE_BIT; }
+            uint8_t bi[4]; wr32(bi, info);
+            if ((rc = emit(bi, 4))) return rc;
+            if ((rc = emit(block_data, block_len))) return rc;
+            if (fi.block_checksums) { uint8_t c[4]; wr32(c, XxHash32::oneshot(0, block_data, block_len)); if ((rc = emit(c, 4))) return rc; }
+            if (fi.content_checksum) content_hasher.write(s, slen);
+            content_len += slen;
+        }
+        proc_pos += total;
+        // drop history the window can no longer reach
+        const uint64_t keep_from = ext_dict_len ? std::min(vbase, dict_stream) : vbase;
+        if (keep_from > lbase) {
+            const size_t drop = (size_t)(keep_from - lbase);
+            memmove(lstage.data(), lstage.data() + drop, lstage_len - drop);
+            lstage_len -= drop; lbase = keep_from;
         }
         return 0;
     }
+    int64_t write_linked(const uint8_t* buf, size_t len) {
+        const size_t mbs = block_size_bytes(fi.block_size);
+        const size_t per_launch = std::min<size_t>(batch_blocks, 64) * mbs;
+        const size_t total = len;
+        while (len) {
+            const size_t pending = (size_t)(lbase + lstage_len - proc_pos);
+            if (pending == per_launch) { int rc = write_blocks_linked(pending); if (rc) return sticky_err = rc; continue; }
+            const size_t n = std::min(per_launch - pending, len);
+            if (lstage.size() < lstage_len + n) lstage.resize(std::max(lstage.size() * 2, lstage_len + n));
+            memcpy(lstage.data() + lstage_len, buf, n);
+            lstage_len += n; buf += n; len -= n;
+        }
+        return (int64_t)total;
+    }
+
     // write_block (frame/compress.rs:261-371) for `nblk` staged blocks in one launch; the last may be partial
     int write_blocks(size_t nblk) {
         if (nblk == 0) return 0;
-        if (fi.block_mode != 0) return -LZ4FLEX_E_UNSUPPORTED;   // Linked: prefix/ext-dict encoder kernel not built yet
         const size_t mbs = block_size_bytes(fi.block_size);
         const size_t stride = (lz4flex_get_maximum_output_size(mbs) + 63) / 64 * 64;
         if (dst.size() < stride * nblk) dst.resize(stride * nblk);
@@ -212,6 +318,7 @@ struct lz4flex_frame_encoder {
         if (sticky_err) return sticky_err;
         int rc;
         if (!is_frame_open && len != 0) { if ((rc = begin_frame(len))) return sticky_err = rc; }
+        if (fi.block_mode == 1) return write_linked(buf, len);
         const size_t total = len;
         const size_t mbs = block_size_bytes(fi.block_size);
         while (len) {
@@ -230,6 +337,11 @@ struct lz4flex_frame_encoder {
     // io::Write::flush, frame/compress.rs:398-403
     int flush() {
         if (sticky_err) return sticky_err;
+        if (fi.block_mode == 1 && is_frame_open) {
+            const size_t pending = (size_t)(lbase + lstage_len - proc_pos);
+            const int rc = pending ? write_blocks_linked(pending) : 0;
+            return rc ? (sticky_err = rc) : 0;
+        }
         if (src_len == 0) return 0;
         const size_t mbs = block_size_bytes(fi.block_size);
         const int rc = write_blocks((src_len + mbs - 1) / mbs);

@@ -259,6 +259,196 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// General encoder: the full signature of compress_internal<T, USE_DICT> (src/block/compress.rs:318-489):
+// a prefix before input_pos, an external dictionary, a stream offset and a table that PERSISTS across the
+// blocks of a chain.  Used by block::compress_into_with_dict (init_dict, :571-583) and by Linked frames
+// (src/frame/compress.rs:280-299, :327-356), whose blocks depend on each other and therefore run one after
+// another inside one group (a "chain").  Table entries are u32 stream positions (HashTable4K semantics).
+struct ChainBlock {
+    uint64_t in_off;      // start of `input` (prefix included) in in_base
+    uint64_t dict_off;    // start of ext_dict in in_base
+    uint32_t in_len;      // input.len()
+    uint32_t in_pos;      // input_pos: first byte to compress
+    uint32_t dict_len;
+    uint32_t so;          // input_stream_offset
+    uint32_t repos;       // HashTable4K::reposition(repos) before this block (hashtable.rs:113-117); 0 = none
+    uint32_t flags;       // bit0: 4-byte hash (HashTable4KU16 path of compress_into_with_dict); bit1: clear table + init_dict
+};
+
+template <int G>
+__device__ __forceinline__ int32_t encode_general(const uint8_t* __restrict__ in, uint32_t n, uint32_t ipos,
+                                                  const uint8_t* __restrict__ dict, uint32_t dict_len, uint32_t so,
+                                                  bool use_h4, uint8_t* __restrict__ out, uint32_t cap, uint32_t* tbl,
+                                                  const Grp<G> grp, uint32_t* produced) {
+    const uint32_t g = grp.g;
+    const bool use_dict = dict_len != 0u;
+    if ((uint64_t)cap < max_output_size(n - ipos)) return LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL;   // :338-340
+    uint32_t o = 0u;
+    if (n - ipos < LZ4_MIN_LENGTH) {                                                       // :343-346
+        o = emit_literals<G>(out, o, in, ipos, n - ipos, 0u, g);
+        *produced = o;
+        return 0;
+    }
+    const uint32_t eds = so - dict_len;                // ext_dict_stream_offset, :348
+    const uint32_t end_check = n - LZ4_MFLIMIT;
+    uint32_t lit_start = ipos;
+    uint32_t base = ipos;
+    if (ipos == 0u && so == 0u) {                      // :353-359
+        if (g == 0u) tbl[use_h4 ? hidx4(cld32(in)) : hidx5(cld64(in))] = 0u;
+        base = 1u;
+    }
+    uint32_t i0 = 0u;
+    for (;;) {
+        const uint32_t i = i0 + g;
+        const uint32_t p = probe_pos(base, i);
+        const bool valid = p <= end_check;
+        uint32_t idx = 0xFFFF0000u + g;
+        uint32_t cs = 0u, cur4 = 0u;                   // candidate as a stream position
+        if (valid) {
+            if (use_h4) { cur4 = cld32(in + p); idx = hidx4(cur4); }
+            else { const uint64_t x = cld64(in + p); idx = hidx5(x); cur4 = (uint32_t)x; }
+            cs = tbl[idx];
+        }
+        const uint32_t d = FwdConflict<G, 1>::run(idx, g);
+        if (d != 0u) cs = probe_pos(base, i - d) + so;
+        const uint32_t ps = p + so;
+        const bool in_input = cs >= so;                                        // :407-411
+        const bool in_dict = !in_input && use_dict && cs >= eds;               // :412-421
+        const uint32_t cand = in_input ? cs - so : cs - eds;
+        const uint8_t* src = in_input ? in : dict;
+        bool is_match = false;
+        if (valid && (ps - cs) <= LZ4_MAX_DISTANCE && (in_input || in_dict))   // :403-405, :422-429
+            is_match = cld32(src + cand) == cur4;                              // :432-438
+        const uint32_t mm = grp.ballot(is_match);
+        const uint32_t vm = grp.ballot(valid);
+        const uint32_t last = mm ? (uint32_t)__builtin_ctz(mm) : (G - 1u);
+        if (valid && g <= last && !BwdConflict<G, 1>::run(idx, g, last)) tbl[idx] = ps;
+        if (mm == 0u) {
+            if (vm != ((1u << G) - 1u)) break;
+            i0 += G;
+            continue;
+        }
+        uint32_t cur = grp.bcast(p, last);
+        uint32_t cnd = grp.bcast(cand, last);
+        const bool m_in = grp.bcast(in_input ? 1u : 0u, last) != 0u;
+        const uint8_t* msrc = m_in ? in : dict;
+        const uint32_t msrc_len = m_in ? n : dict_len;
+        const uint32_t offset = (cur + so) - grp.bcast(cs, last);             // :409 / :419
+        for (;;) {                                                             // backtrack :442-448
+            const bool ok = (cnd > g) && (cur > lit_start + g) && in[cur - 1u - g] == msrc[cnd - 1u - g];
+            const uint32_t okm = grp.ballot(ok);
+            const uint32_t nb = (uint32_t)__builtin_ctz(~okm);
+            cur -= nb; cnd -= nb;
+            if (nb < (uint32_t)G) break;
+        }
+        const uint32_t lit_len = cur - lit_start;
+        cur += 4u; cnd += 4u;
+        // count_same_bytes :156-216: bounded by the input end - 6 and by the end of the candidate's buffer
+        const uint32_t max_in = n - LZ4_END_OFFSET > cur ? n - LZ4_END_OFFSET - cur : 0u;
+        const uint32_t max_c = msrc_len - cnd;
+        const uint32_t max_m = max_in < max_c ? max_in : max_c;
+        uint32_t dl = 0u;
+        for (;;) {
+            const uint32_t k = dl + 8u * g;
+            uint32_t c = 0u;
+            if (k < max_m) {
+                const uint32_t rem = max_m - k;
+                if (rem >= 8u) {
+                    const uint64_t diff = cld64(in + cur + k) ^ cld64(msrc + cnd + k);
+                    c = diff ? (uint32_t)(__builtin_ctzll(diff) >> 3) : 8u;
+                } else {
+                    while (c < rem && in[cur + k + c] == msrc[cnd + k + c]) ++c;
+                }
+            }
+            const uint32_t part = grp.ballot(c != 8u);
+            if (part == 0u) { dl += 8u * G; continue; }
+            const uint32_t f = (uint32_t)__builtin_ctz(part);
+            dl += 8u * f + grp.bcast(c, f);
+            break;
+        }
+        cur += dl;
+        if (g == 0u) {                                                         // :460-461
+            const uint32_t q = cur - 2u;
+            tbl[use_h4 ? hidx4(cld32(in + q)) : hidx5(cld64(in + q))] = q + so;
+        }
+        o = emit_literals<G>(out, o, in, lit_start, lit_len, dl < 15u ? dl : 15u, g);
+        if (g == 0u) { out[o] = (uint8_t)(offset & 0xFFu); out[o + 1u] = (uint8_t)(offset >> 8); }
+        o += 2u;
+        if (dl >= 15u) {
+            const uint32_t rem = dl - 15u;
+            const uint32_t n255 = rem / 255u;
+            for (uint32_t k = g; k < n255; k += G) out[o + k] = 0xFFu;
+            o += n255;
+            if (g == 0u) out[o] = (uint8_t)(rem - n255 * 255u);
+            o += 1u;
+        }
+        lit_start = cur;
+        base = cur;
+        i0 = 0u;
+    }
+    o = emit_literals<G>(out, o, in, lit_start, n - lit_start, 0u, g);
+    *produced = o;
+    return 0;
+}
+
+// One group per chain; the chain's blocks are encoded in order with one persistent u32 table in LDS.
+// tbl_state (nullable, 4096 u32 per chain): loaded before the first block unless it is cleared, saved at the end.
+__global__ void __launch_bounds__(64) lz4_compress_chain_kernel(const uint8_t* in_base, const ChainBlock* blocks,
+                                                               const uint32_t* chain_first, const uint32_t* chain_count,
+                                                               uint32_t n_chains, uint8_t* out_base, const uint64_t* out_off,
+                                                               const uint32_t* out_cap, uint32_t* out_len, int32_t* status,
+                                                               uint32_t* tbl_state) {
+    constexpr int G = 8;
+    __shared__ __attribute__((aligned(16))) uint32_t tables[64 / G][4096];
+    const uint32_t lane = threadIdx.x;
+    Grp<G> grp;
+    grp.g = lane % G;
+    grp.shift = (lane / G) * G;
+    const uint32_t c = blockIdx.x * (64 / G) + lane / G;
+    if (c >= n_chains) return;
+    uint32_t* tbl = &tables[lane / G][0];
+    const uint32_t first = chain_first[c], count = chain_count[c];
+    if (tbl_state) for (uint32_t k = grp.g; k < 4096u; k += G) tbl[k] = tbl_state[(size_t)c * 4096u + k];
+    else for (uint32_t k = grp.g; k < 4096u; k += G) tbl[k] = 0u;
+    for (uint32_t j = 0; j < count; ++j) {
+        const ChainBlock b = blocks[first + j];
+        const uint8_t* in = in_base + b.in_off;
+        const uint8_t* dict = in_base + b.dict_off;
+        const bool use_h4 = (b.flags & 1u) != 0u;
+        if (b.flags & 2u) {
+            for (uint32_t k = grp.g; k < 4096u; k += G) tbl[k] = 0u;
+            // init_dict (compress.rs:571-583): positions 0,3,6,... in order, later entries win
+            if (grp.g == 0u)
+                for (uint32_t i = 0u; i + 8u <= b.dict_len; i += 3u)
+                    tbl[use_h4 ? hidx4(cld32(dict + i)) : hidx5(cld64(dict + i))] = i;
+        }
+        if (b.repos != 0u)
+            for (uint32_t k = grp.g; k < 4096u; k += G) { const uint32_t v = tbl[k]; tbl[k] = v > b.repos ? v - b.repos : 0u; }
+        uint32_t produced = 0u;
+        const int32_t st = encode_general<G>(in, b.in_len, b.in_pos, dict, b.dict_len, b.so, use_h4,
+                                             out_base + out_off[first + j], out_cap[first + j], tbl, grp, &produced);
+        if (grp.g == 0u) {
+            status[first + j] = st;
+            out_len[first + j] = st == 0 ? produced : 0u;
+        }
+    }
+    if (tbl_state) for (uint32_t k = grp.g; k < 4096u; k += G) tbl_state[(size_t)c * 4096u + k] = tbl[k];
+}
+
+hipError_t launch_compress_chain(const uint8_t* in_base, const void* blocks, const uint32_t* chain_first,
+                                 const uint32_t* chain_count, uint32_t n_chains, uint8_t* out_base,
+                                 const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len, int32_t* status,
+                                 uint32_t* tbl_state, hipStream_t s) {
+    if (n_chains == 0u) return hipSuccess;
+    const uint32_t grid = (n_chains + 7u) / 8u;
+    hipLaunchKernelGGL(lz4_compress_chain_kernel, dim3(grid), dim3(64), 0, s, in_base,
+                       reinterpret_cast<const ChainBlock*>(blocks), chain_first, chain_count, n_chains, out_base, out_off,
+                       out_cap, out_len, status, tbl_state);
+    return hipGetLastError();
+}
+
 template <int G, typename TblT>
 __global__ void __launch_bounds__(64) lz4_compress_blocks_kernel(CompressArgs a) {
     constexpr int BPW = 64 / G;   // blocks per workgroup (one wave)

@@ -49,4 +49,11 @@ hipError_t launch_decompress_pipe(const DecompressArgs& a, hipStream_t s, int ab
 hipError_t launch_compress(const CompressArgs& a, int variant, hipStream_t s);
 hipError_t launch_compress_lds(const CompressArgs& a, hipStream_t s);   // LDS-staged encoder, blocks <= 64 KiB
 
+// chains of dependent blocks (dictionary / Linked frames); `blocks` is an array of the 40-byte ChainBlock
+// records laid out as {u64 in_off, u64 dict_off, u32 in_len, in_pos, dict_len, so, repos, flags}
+hipError_t launch_compress_chain(const uint8_t* in_base, const void* blocks, const uint32_t* chain_first,
+                                 const uint32_t* chain_count, uint32_t n_chains, uint8_t* out_base,
+                                 const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len, int32_t* status,
+                                 uint32_t* tbl_state, hipStream_t s);
+
 }  // namespace lz4flex_dev

@@ -155,13 +155,40 @@ def _norm(r):
     return st, payload
 
 
-def test_dict_decode(blk):   # compress.rs:884-949 (decode side), :991-998
+def test_dict(blk):   # compress.rs:884-949, :991-998
     inp = bytes([10, 12, 14, 16, 18] * 4)
-    comp = O.compress_with_dict(inp, inp)    # the dictionary-seeded ENCODER kernel is a later row; the oracle encodes
+    comp = blk.compress_with_dict(inp, inp)
+    assert comp == O.compress_with_dict(inp, inp)
+    assert len(comp) < len(blk.compress(inp))
     assert blk.decompress_with_dict(comp, len(inp), inp) == inp
+    blk.compress_with_dict(inp, bytes([10, 12, 14]))          # test_dict_no_panic
     big = b"a" * (1 << 20)
     small = b"a" * 29
-    assert blk.decompress_with_dict(O.compress_with_dict(small, big), len(small), big[-65536:]) == small
+    c = blk.compress_with_dict(small, big)                      # test_dict_size: 1 MiB dict -> last 64 KiB
+    assert c == O.compress_with_dict(small, big)
+    assert blk.decompress_with_dict(c, len(small), big[-65536:]) == small
+
+
+def test_dict_conformant_last_block(blk):   # compress.rs:970-987
+    a = b"a" * 15
+    assert len(blk.compress_with_dict(a[:11], a)) > 11
+    assert len(blk.compress_with_dict(a[:12], a)) > 12
+    for n in (13, 14, 15):
+        assert len(blk.compress_with_dict(a[:n], a)) <= n
+
+
+def test_dict_encode_bit_exact_generated(blk):
+    """compress_into_with_dict (init_dict + ext-dict matches + both table kinds) == oracle, and round trips"""
+    json = O.fixture_plain("compression_66k_JSON")
+    text = O.fixture_plain("compression_65k")
+    cases = [(json[:3000], json[3000:9000]), (json[:70000], json[100:30100]), (text[:100], text[50:20050]),
+             (corpus.lcg_bytes(5000, 1, 4, 6), corpus.lcg_bytes(20000, 2, 4, 6)), (json[:9], json[:5000]),
+             (json[:40000], json[20000:66675]), (text, text[:64000])]
+    for d, data in cases:
+        out = bytearray(blk.get_maximum_output_size(len(data)))
+        n = blk.compress_into_with_dict(data, out, d)
+        assert bytes(out[:n]) == O.compress_with_dict(data, d), (len(d), len(data))
+        assert blk.decompress_with_dict(bytes(out[:n]), len(data), d[-65536:]) == data
 
 
 def test_truncated_and_corrupted_blocks_match_oracle(blk):

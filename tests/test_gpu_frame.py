@@ -90,6 +90,39 @@ def test_multi_block_options(fr):   # fuzz_roundtrip_frame.rs:14-80
     assert d.read_to_end() == data
 
 
+@pytest.mark.parametrize("i", range(len(corpus.roundtrip_inputs())))
+def test_roundtrip_corpus_linked(fr, i):   # tests/tests.rs:96-104 with BlockMode::Linked
+    data = corpus.roundtrip_inputs()[i]
+    f = _enc(fr, data, block_mode=fr.BlockMode.Linked)
+    rc, exp = O.frame_compress(data, block_mode=1)
+    assert rc == 0 and f == exp
+    assert _dec(fr, f) == data
+    assert O.c_frame_decompress(f, len(data)) == data
+
+
+def test_linked_encode_multi_block_bit_exact(fr):
+    """Linked frames: blocks depend on each other (prefix + ext-dict window, persistent table): byte-identical to
+    the oracle's FrameEncoder restatement, incl. the ring wrap (several multiples of block_size + 64 KiB)"""
+    data = O.fixture_plain("compression_66k_JSON") * 7 + corpus.lcg_bytes(200000, 3, 8, 5) + O.fixture_plain("compression_65k") * 3
+    for bs in (fr.BlockSize.Max64KB, fr.BlockSize.Max256KB):
+        f = _enc(fr, data, block_mode=fr.BlockMode.Linked, block_size=bs)
+        rc, exp = O.frame_compress(data, block_mode=1, block_size=int(bs))
+        assert rc == 0 and f == exp, bs
+        assert _dec(fr, f) == data
+        assert O.c_frame_decompress(f, len(data)) == data
+    # chunked writes, flush points and small launch batches
+    whole = _enc(fr, data, block_mode=fr.BlockMode.Linked, block_size=fr.BlockSize.Max64KB)
+    assert _enc(fr, data, chunks=[1, 7, 65535, 1, 65536, 100000, 13], block_mode=fr.BlockMode.Linked,
+                block_size=fr.BlockSize.Max64KB) == whole
+    buf = io.BytesIO()
+    e = fr.FrameEncoder.with_frame_info(fr.FrameInfo(block_mode=fr.BlockMode.Linked, block_size=fr.BlockSize.Max64KB), buf)
+    e.set_batch_bytes(3 * 65536)
+    e.write_all(data); e.finish()
+    assert buf.getvalue() == whole
+    # a linked frame is smaller than the independent one on repetitive data (cross-block matches found)
+    assert len(whole) < len(_enc(fr, data, block_size=fr.BlockSize.Max64KB))
+
+
 def test_linked_multi_block_decode(fr):
     data = O.fixture_plain("compression_66k_JSON") * 9 + corpus.lcg_bytes(300000, 3, 8, 5)
     for bs in (4, 5):
