@@ -27,6 +27,11 @@ class FrameInfoC(C.Structure):
                 ("legacy_frame", C.c_int32)]
 
 
+class ChainBlock(C.Structure):
+    _fields_ = [("in_off", C.c_uint64), ("dict_off", C.c_uint64), ("in_len", C.c_uint32), ("in_pos", C.c_uint32),
+                ("dict_len", C.c_uint32), ("so", C.c_uint32), ("repos", C.c_uint32), ("flags", C.c_uint32)]
+
+
 class DecompressExt(C.Structure):
     _fields_ = [("dict_base", C.c_void_p), ("dict_off", C.c_void_p), ("dict_len", C.c_void_p), ("out_pos", C.c_void_p)]
 
@@ -51,6 +56,8 @@ SIGNATURES = {
     "lz4flex_uncompressed_size": (_I64, [_VP, _SZ]),
     "lz4flex_decompress_size_prepended": (_I64, [_VP, _SZ, _VP, _SZ, C.POINTER(ErrDetail)]),
     "lz4flex_compress_batch": (_I32, [_VP, _VP, _VP, _VP, _VP, _U32, _VP, _VP, _VP, _VP, _VP, _I32, _VP]),
+    "lz4flex_compress_chains": (_I32, [_VP, _VP, C.POINTER(ChainBlock), _U32, _VP, _VP, _U32, _VP, _VP, _VP, _VP, _VP, _VP,
+                                        _I32, _VP]),
     "lz4flex_decompress_batch": (_I32, [_VP, _VP, _VP, _VP, _U32, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _VP]),
     "lz4flex_decompress_batch_ex": (_I32, [_VP, _VP, _VP, _VP, _U32, _VP, _VP, _VP, _VP, _VP, _VP,
                                             C.POINTER(DecompressExt), _I32, _VP]),

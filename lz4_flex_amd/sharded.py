@@ -1,0 +1,275 @@
+"""Frame layer across ranks (BASELINE configs[3]): BlockMode::Independent frames shard
+naturally -- every rank owns a contiguous range of blocks, compresses them with the batched kernels, and the
+frame is reassembled with ONE exchange step: an all-gather of the per-rank segment sizes, an exclusive
+prefix sum, and a variable-size gather of the segments to the root (point-to-point sends over RCCL/xGMI;
+`ncclGather` needs equal counts).  The bytes are identical to what a single FrameEncoder produces
+(reference src/frame/compress.rs:261-371): block k>0 is compressed in the "continuation" table mode and the
+2 GiB reposition rule (:266-271) is a pure function of the global block index.
+
+Linked frames and `content_checksum` do not shard (each block / the running XXH32 depends on everything
+before it): replicas only.  torch.distributed is plumbing here: barrier-free, three collectives per frame.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from .frame import BlockMode, BlockSize, FrameInfo
+
+WINDOW_SIZE = 65536
+UNCOMPRESSED_BIT = 0x80000000
+
+
+def partition(n_blocks, world):
+    """contiguous block ranges [lo, hi) per rank, sizes differ by at most one"""
+    base, extra = divmod(n_blocks, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def block_flags(first_block, n_local, block_size):
+    """per-block table mode of a FrameEncoder that has already written `first_block` blocks of `block_size`:
+    FRAME_FIRST when src_stream_offset == 0 (block 0, and the first block after each reposition), else
+    FRAME_CONTINUATION (src/frame/compress.rs:266-271, :357-367)."""
+    flags = np.empty(n_local, dtype=np.uint32)
+    so = 0
+    # replay the offsets up to first_block (O(n) integer work, no data)
+    limit = 0xFFFFFFFF // 2
+    for k in range(first_block + n_local):
+        if so + block_size + WINDOW_SIZE >= limit:
+            so = 0
+        if k >= first_block:
+            flags[k - first_block] = L.BLOCK_FRAME_FIRST if so == 0 else L.BLOCK_FRAME_CONTINUATION
+        so += block_size
+    return flags
+
+
+# ---- batched block codec on device tensors (C ABI, LZ4FLEX_MEM_DEVICE) -------------------------------------
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def compress_blocks_device(src, block_size, flags):
+    """src: uint8 CUDA tensor; returns (comp, comp_off[i64], comp_len[i32]) on the same device"""
+    lib = L.load()
+    dev = src.device
+    total = src.numel()
+    n = (total + block_size - 1) // block_size
+    stride = (int(lib.lz4flex_get_maximum_output_size(block_size)) + 63) // 64 * 64
+    ar = torch.arange(n, dtype=torch.int64, device=dev)
+    in_off = ar * block_size
+    in_len = torch.full((n,), block_size, dtype=torch.int32, device=dev)
+    if total % block_size:
+        in_len[-1] = total % block_size
+    comp = torch.empty(n * stride, dtype=torch.uint8, device=dev)
+    comp_off = ar * stride
+    comp_cap = torch.full((n,), stride, dtype=torch.int32, device=dev)
+    comp_len = torch.zeros(n, dtype=torch.int32, device=dev)
+    status = torch.zeros(n, dtype=torch.int32, device=dev)
+    fl = torch.from_numpy(np.ascontiguousarray(flags, dtype=np.uint32).view(np.int32)).to(dev)
+    kind = L.MEM_DEVICE | (L.MEM_BIG_BLOCKS if block_size > 65536 else 0)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev):
+        rc = lib.lz4flex_compress_batch(None, _p(src), _p(in_off), _p(in_len), _p(fl), n, _p(comp), _p(comp_off), _p(comp_cap),
+                                        _p(comp_len), _p(status), kind, stream)
+    if rc:
+        raise RuntimeError("lz4flex_compress_batch: %d %s" % (rc, L.last_error()))
+    if int((status != 0).sum().item()):
+        raise RuntimeError("compress status != 0")
+    return comp, comp_off, comp_len, in_len
+
+
+def decompress_blocks_device(comp, comp_off, comp_len, out_len_expected, block_size):
+    """returns (out, out_len[i32], status[i32]); block i decodes into out[i*block_size : ...]"""
+    lib = L.load()
+    dev = comp.device
+    n = comp_off.numel()
+    out = torch.empty(n * block_size, dtype=torch.uint8, device=dev)
+    out_off = torch.arange(n, dtype=torch.int64, device=dev) * block_size
+    out_cap = torch.full((n,), block_size, dtype=torch.int32, device=dev)
+    out_len = torch.zeros(n, dtype=torch.int32, device=dev)
+    status = torch.zeros(n, dtype=torch.int32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev):
+        rc = lib.lz4flex_decompress_batch(None, _p(comp), _p(comp_off), _p(comp_len), n, _p(out), _p(out_off), _p(out_cap),
+                                          _p(out_len), _p(status), None, L.MEM_DEVICE, stream)
+    if rc:
+        raise RuntimeError("lz4flex_decompress_batch: %d %s" % (rc, L.last_error()))
+    return out, out_len, status
+
+
+# ---- segment assembly ------------------------------------------------------------------------------------
+def build_segment(src, comp, comp_off, comp_len, in_len, block_size):
+    """[4-byte block header | payload]* for this rank's blocks; store-raw rule of frame/compress.rs:301-306"""
+    dev = src.device
+    n = comp_len.numel()
+    clen = comp_len.to(torch.int64)
+    ilen = in_len.to(torch.int64)
+    raw = clen >= ilen
+    size = torch.where(raw, ilen, clen)
+    seg_off = torch.cumsum(size + 4, 0) - (size + 4)
+    total = int((size + 4).sum().item())
+    seg = torch.empty(total, dtype=torch.uint8, device=dev)
+    word = torch.where(raw, ilen | UNCOMPRESSED_BIT, clen)
+    hdr = torch.stack([(word >> s) & 0xFF for s in (0, 8, 16, 24)], dim=1).to(torch.uint8)
+    h_seg, h_size, h_raw, h_coff = seg_off.tolist(), size.tolist(), raw.tolist(), comp_off.tolist()
+    for i in range(n):
+        o = h_seg[i]
+        seg[o:o + 4] = hdr[i]
+        if h_raw[i]:
+            seg[o + 4:o + 4 + h_size[i]] = src[i * block_size:i * block_size + h_size[i]]
+        else:
+            seg[o + 4:o + 4 + h_size[i]] = comp[h_coff[i]:h_coff[i] + h_size[i]]
+    return seg
+
+
+def _world(group):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def compress_frame_sharded(local, first_block, frame_info, group=None, root=0, compress_blocks=compress_blocks_device):
+    """Every rank passes the bytes of its contiguous block range (`local`, uint8 tensor) and the global index
+    of its first block.  Returns the complete frame (uint8 tensor on the root's device) on `root`, None elsewhere.
+    `compress_blocks(src, block_size, flags) -> (comp, comp_off, comp_len, in_len)`."""
+    fi = frame_info
+    if fi.block_mode != BlockMode.Independent:
+        raise ValueError("Linked frames do not shard: every block depends on the previous 64 KiB (replicas only)")
+    if fi.content_checksum or fi.block_checksums:
+        raise ValueError("checksums: content XXH32 is serial over the stream, block XXH32 runs on the host; not sharded")
+    if fi.block_size == BlockSize.Auto or fi.content_size is not None:
+        raise ValueError("sharded frames need an explicit block_size and no content_size")
+    rank, world = _world(group)
+    bs = fi.block_size.get_size()
+    dev = local.device
+    n_local = (local.numel() + bs - 1) // bs
+    if n_local:
+        flags = block_flags(first_block, n_local, bs)
+        comp, comp_off, comp_len, in_len = compress_blocks(local, bs, flags)
+        seg = build_segment(local, comp, comp_off, comp_len, in_len, bs)
+    else:
+        seg = torch.empty(0, dtype=torch.uint8, device=dev)
+    # 1) all-gather of the segment sizes, 2) exclusive prefix sum
+    my = torch.tensor([seg.numel()], dtype=torch.int64, device=dev)
+    if world > 1:
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(sizes, my, group=group)
+        sizes = [int(s.item()) for s in sizes]
+    else:
+        sizes = [int(my.item())]
+    header = torch.frombuffer(bytearray(fi.write()), dtype=torch.uint8)
+    offs = [header.numel()]
+    for s in sizes[:-1]:
+        offs.append(offs[-1] + s)
+    total = offs[-1] + sizes[-1] + 4
+    # 3) variable-size gather to the root
+    if rank == root:
+        frame = torch.empty(total, dtype=torch.uint8, device=dev)
+        frame[:header.numel()] = header.to(dev)
+        frame[total - 4:] = 0                                   # EndMark, frame/compress.rs:222-224
+        reqs = []
+        for r in range(world):
+            view = frame[offs[r]:offs[r] + sizes[r]]
+            if r == rank:
+                view.copy_(seg)
+            elif sizes[r]:
+                reqs.append(dist.irecv(view, src=r, group=group))
+        for q in reqs:
+            q.wait()
+        return frame
+    if seg.numel():
+        dist.send(seg, dst=root, group=group)
+    return None
+
+
+def walk_blocks(frame_host, header_len):
+    """host-side block-header walk (frame/decompress.rs:231-241): returns [(payload_off, len, raw)], end offset"""
+    out, p = [], header_len
+    n = len(frame_host)
+    while True:
+        if p + 4 > n:
+            raise ValueError("truncated frame")
+        w = int.from_bytes(bytes(frame_host[p:p + 4]), "little")
+        p += 4
+        if w == 0:
+            return out, p
+        raw = bool(w & UNCOMPRESSED_BIT)
+        ln = w & ~UNCOMPRESSED_BIT
+        out.append((p, ln, raw))
+        p += ln
+
+
+def decompress_frame_sharded(frame, group=None, root=0, decompress_blocks=decompress_blocks_device, device=None):
+    """`frame` (uint8 tensor) is needed on the root only.  The root walks the block headers, every rank
+    receives and decodes a contiguous block range.  Returns (local_out tensor, (lo, hi) block range, FrameInfo)."""
+    rank, world = _world(group)
+    dev = frame.device if frame is not None else torch.device(device or "cpu")
+    meta = [None]
+    if rank == root:
+        host = frame.cpu().numpy()
+        hdr_len = 7 + (8 if host[4] & 0x08 else 0)
+        fi = FrameInfo.read(bytes(host[:hdr_len]))
+        if fi.block_mode != BlockMode.Independent or fi.content_checksum or fi.block_checksums:
+            raise ValueError("only Independent frames without checksums shard")
+        blocks, _end = walk_blocks(host, hdr_len)
+        meta = [(blocks, int(fi.block_size))]
+    if world > 1:
+        dist.broadcast_object_list(meta, src=root, group=group)
+    blocks, bs_code = meta[0]
+    bs = BlockSize(bs_code).get_size()
+    lo, hi = partition(len(blocks), world)[rank]
+    mine = blocks[lo:hi]
+    # the bytes of my range are contiguous in the frame: one transfer per rank
+    if mine:
+        a = mine[0][0]
+        b = mine[-1][0] + mine[-1][1]
+    else:
+        a = b = 0
+    if rank == root:
+        ranges = partition(len(blocks), world)
+        reqs = []
+        for r, (l2, h2) in enumerate(ranges):
+            if r == rank or l2 == h2:
+                continue
+            ra, rb = blocks[l2][0], blocks[h2 - 1][0] + blocks[h2 - 1][1]
+            reqs.append(dist.isend(frame[ra:rb].contiguous(), dst=r, group=group))
+        local = frame[a:b]
+        for q in reqs:
+            q.wait()
+    else:
+        local = torch.empty(b - a, dtype=torch.uint8, device=dev)
+        if b > a:
+            dist.recv(local, src=root, group=group)
+    n = len(mine)
+    out = torch.empty(n * bs, dtype=torch.uint8, device=dev)
+    produced = [0] * n
+    comp_idx = [i for i, m in enumerate(mine) if not m[2]]
+    if comp_idx:
+        coff = torch.tensor([mine[i][0] - a for i in comp_idx], dtype=torch.int64, device=dev)
+        clen = torch.tensor([mine[i][1] for i in comp_idx], dtype=torch.int32, device=dev)
+        dec, dlen, st = decompress_blocks(local, coff, clen, None, bs)
+        if int((st != 0).sum().item()):
+            raise RuntimeError("DecompressionError in a sharded block")
+        dl = dlen.tolist()
+        for k, i in enumerate(comp_idx):
+            out[i * bs:i * bs + dl[k]] = dec[k * bs:k * bs + dl[k]]
+            produced[i] = dl[k]
+    for i, m in enumerate(mine):
+        if m[2]:
+            out[i * bs:i * bs + m[1]] = local[m[0] - a:m[0] - a + m[1]]
+            produced[i] = m[1]
+    # blocks are full except possibly the frame's last one: compact view
+    total = sum(produced)
+    if n and any(p != bs for p in produced[:-1]):
+        pieces = [out[i * bs:i * bs + produced[i]] for i in range(n)]
+        out = torch.cat(pieces) if pieces else out[:0]
+    else:
+        out = out[:total]
+    return out, (lo, hi), FrameInfo(block_size=BlockSize(bs_code))
