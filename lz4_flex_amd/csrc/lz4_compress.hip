@@ -28,6 +28,20 @@
 
 namespace lz4flex_dev {
 
+// Phase timing (tools/phase_profile.py builds a private copy with -DLZ4FLEX_PROFILE_PHASES; the shipped
+// library has none of it): wave-level s_memtime deltas accumulated per code region.
+#ifdef LZ4FLEX_PROFILE_PHASES
+__device__ unsigned long long g_phase_cycles[8];
+__device__ unsigned long long g_phase_counts[8];
+#define PHASE_DECL unsigned long long _pt = __builtin_readcyclecounter(); unsigned long long _pacc[8] = {0,0,0,0,0,0,0,0}; unsigned _pcnt[8] = {0,0,0,0,0,0,0,0};
+#define PHASE_MARK(k) { const unsigned long long _n = __builtin_readcyclecounter(); _pacc[k] += _n - _pt; _pcnt[k]++; _pt = _n; }
+#define PHASE_FLUSH if (threadIdx.x == 0) { for (int _k = 0; _k < 8; ++_k) { atomicAdd(&g_phase_cycles[_k], _pacc[_k]); atomicAdd(&g_phase_counts[_k], (unsigned long long)_pcnt[_k]); } }
+#else
+#define PHASE_DECL
+#define PHASE_MARK(k)
+#define PHASE_FLUSH
+#endif
+
 #define LZ4_MFLIMIT 12u
 #define LZ4_END_OFFSET 6u
 #define LZ4_MIN_LENGTH 13u
@@ -163,7 +177,9 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
     uint32_t lit_start = 0u;
     uint32_t base = continuation ? 0u : 1u;   // probing origin of the current sequence
     uint32_t i0 = continuation ? 1u : 0u;     // index of the first probe of the next batch
+    PHASE_DECL
     for (;;) {
+        PHASE_MARK(0)   // loop overhead / previous emit tail
         // ------------------------------------------------------------------ probe batch
         const uint32_t i = i0 + g;
         const uint32_t p = probe_pos(base, i);
@@ -179,6 +195,7 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
             // mode only in the bucket position 0 was stored to
             cand_ok = !continuation || cand != 0u || idx == idx0;
         }
+        PHASE_MARK(1)   // probe bytes + hash + table read
         // same-bucket probes earlier in this batch supersede the table content
         const uint32_t d = FwdConflict<G, 1>::run(idx, g);
         if (d != 0u) { cand = probe_pos(base, i - d); cand_ok = true; }
@@ -186,6 +203,7 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
         if (valid && cand_ok && (p - cand) <= LZ4_MAX_DISTANCE)                // compress.rs:403-405
             is_match = cld32(in + cand) == cur4;                              // compress.rs:432-438
         const uint32_t mm = grp.ballot(is_match);
+        PHASE_MARK(2)   // conflict resolution + candidate load + verify
         const uint32_t vm = grp.ballot(valid);
         const uint32_t last = mm ? (uint32_t)__builtin_ctz(mm) : (G - 1u);     // last probe that executes
         // table stores of the executed probes (compress.rs:393), last writer per bucket only
@@ -195,28 +213,24 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
             i0 += G;
             continue;
         }
+        PHASE_MARK(3)   // table stores
         uint32_t cur = grp.bcast(p, last);
         uint32_t cnd = grp.bcast(cand, last);
         const uint32_t offset = cur - cnd;                                    // compress.rs:409
-        // ------------------------------------------------------------------ backtrack (compress.rs:442-448)
-        for (;;) {
-            const bool ok = (cnd > g) && (cur > lit_start + g) && in[cur - 1u - g] == in[cnd - 1u - g];
-            const uint32_t okm = grp.ballot(ok);
-            const uint32_t nb = (uint32_t)__builtin_ctz(~okm);                // G..31 bits are 0 in okm => nb <= G
-            cur -= nb; cnd -= nb;
-            if (nb < (uint32_t)G) break;
-        }
-        const uint32_t lit_len = cur - lit_start;                             // compress.rs:451
-        // ------------------------------------------------------------------ forward (count_same_bytes :156-216)
-        cur += 4u; cnd += 4u;
+        // ------------------------------------------------------------------ extension: ONE memory round trip for the
+        // first G bytes backwards and the first 8*G bytes forwards (the forward count starts at the verified
+        // position + 4 whatever the backtrack finds: the bytes in between are known equal)
         const uint32_t limit = n - LZ4_END_OFFSET;                            // matches end 6 bytes before the end
-        uint32_t dl = 0u;
-        for (;;) {
-            const uint32_t a = cur + dl + 8u * g;
-            uint32_t c = 0u;                  // equal bytes seen by this lane (0..8)
+        const uint32_t m4 = cur + 4u, c4 = cnd + 4u;
+        const bool bk_ok0 = (cnd > g) && (cur > lit_start + g);
+        uint32_t bka = 0u, bkb = 1u;
+        if (bk_ok0) { bka = in[cur - 1u - g]; bkb = in[cnd - 1u - g]; }
+        uint32_t c = 0u;                      // equal bytes seen by this lane in the first forward round (0..8)
+        {
+            const uint32_t a = m4 + 8u * g;
             if (a < limit) {
                 const uint32_t rem = limit - a;
-                const uint32_t b = cnd + dl + 8u * g;
+                const uint32_t b = c4 + 8u * g;
                 if (rem >= 8u) {
                     const uint64_t diff = cld64(in + a) ^ cld64(in + b);
                     c = diff ? (uint32_t)(__builtin_ctzll(diff) >> 3) : 8u;
@@ -224,21 +238,61 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
                     while (c < rem && in[a + c] == in[b + c]) ++c;
                 }
             }
-            const uint32_t part = grp.ballot(c != 8u);
-            if (part == 0u) { dl += 8u * G; continue; }
-            const uint32_t f = (uint32_t)__builtin_ctz(part);
-            dl += 8u * f + grp.bcast(c, f);
-            break;
         }
-        cur += dl;
+        // ---- backtrack (compress.rs:442-448)
+        {
+            const uint32_t okm = grp.ballot(bk_ok0 && bka == bkb);
+            uint32_t nb = (uint32_t)__builtin_ctz(~okm);                      // G..31 bits are 0 in okm => nb <= G
+            cur -= nb; cnd -= nb;
+            while (nb == (uint32_t)G) {                                       // rare: more than G bytes backwards
+                const bool ok = (cnd > g) && (cur > lit_start + g) && in[cur - 1u - g] == in[cnd - 1u - g];
+                const uint32_t okm2 = grp.ballot(ok);
+                nb = (uint32_t)__builtin_ctz(~okm2);
+                cur -= nb; cnd -= nb;
+            }
+        }
+        const uint32_t lit_len = cur - lit_start;                             // compress.rs:451
+        // ---- forward (count_same_bytes :156-216)
+        uint32_t dl = 0u;
+        {
+            uint32_t part = grp.ballot(c != 8u);
+            if (part != 0u) {
+                const uint32_t f = (uint32_t)__builtin_ctz(part);
+                dl = 8u * f + grp.bcast(c, f);
+            } else {
+                dl = 8u * G;
+                for (;;) {
+                    const uint32_t a = m4 + dl + 8u * g;
+                    uint32_t c2 = 0u;
+                    if (a < limit) {
+                        const uint32_t rem = limit - a;
+                        const uint32_t b = c4 + dl + 8u * g;
+                        if (rem >= 8u) {
+                            const uint64_t diff = cld64(in + a) ^ cld64(in + b);
+                            c2 = diff ? (uint32_t)(__builtin_ctzll(diff) >> 3) : 8u;
+                        } else {
+                            while (c2 < rem && in[a + c2] == in[b + c2]) ++c2;
+                        }
+                    }
+                    part = grp.ballot(c2 != 8u);
+                    if (part == 0u) { dl += 8u * G; continue; }
+                    const uint32_t f = (uint32_t)__builtin_ctz(part);
+                    dl += 8u * f + grp.bcast(c2, f);
+                    break;
+                }
+            }
+        }
+        const uint32_t cur_end = m4 + dl;
+        dl = cur_end - (cur + 4u);                                            // duplicate_length counts from the backtracked start + 4
+        cur = cur_end;
+        PHASE_MARK(4)   // backward + forward extension
         // ------------------------------------------------------------------ table: cur-2 (compress.rs:460-461)
-        if (g == 0u) {
-            const uint32_t q = cur - 2u;
-            const uint32_t qi = use_h5 ? hidx5(cld64(in + q)) : hidx4(cld32(in + q));
-            tbl[qi] = (TblT)q;
-        }
+        // (its input bytes are requested here, together with the literal bytes below: one round trip)
+        const uint32_t q = cur - 2u;
+        const uint64_t qx = use_h5 ? cld64(in + q) : (uint64_t)cld32(in + q);
         // ------------------------------------------------------------------ emit (compress.rs:463-486)
         o = emit_literals<G>(out, o, in, lit_start, lit_len, dl < 15u ? dl : 15u, g);
+        if (g == 0u) tbl[use_h5 ? hidx5(qx) : hidx4((uint32_t)qx)] = (TblT)q;
         if (g == 0u) { out[o] = (uint8_t)(offset & 0xFFu); out[o + 1u] = (uint8_t)(offset >> 8); }
         o += 2u;
         if (dl >= 15u) {
@@ -252,9 +306,11 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
         lit_start = cur;                                                      // compress.rs:487
         base = cur;
         i0 = 0u;
+        PHASE_MARK(5)   // cur-2 table update + emit
     }
     // handle_last_literals, compress.rs:237-247
     o = emit_literals<G>(out, o, in, lit_start, n - lit_start, 0u, g);
+    PHASE_FLUSH
     *produced = o;
     return 0;
 }
@@ -489,3 +545,18 @@ hipError_t launch_compress(const CompressArgs& a, int variant, hipStream_t s) {
 }
 
 }  // namespace lz4flex_dev
+
+#ifdef LZ4FLEX_PROFILE_PHASES
+extern "C" int lz4flex_debug_phase(unsigned long long* cycles, unsigned long long* counts, int reset) {
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(lz4flex_dev::g_phase_cycles), z, sizeof z);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(lz4flex_dev::g_phase_counts), z, sizeof z);
+        return 0;
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(cycles, HIP_SYMBOL(lz4flex_dev::g_phase_cycles), 64);
+    (void)hipMemcpyFromSymbol(counts, HIP_SYMBOL(lz4flex_dev::g_phase_counts), 64);
+    return 0;
+}
+#endif

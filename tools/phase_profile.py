@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of the encoder: builds a PRIVATE copy of the library with
+-DLZ4FLEX_PROFILE_PHASES (wave-level s_memtime deltas per code region), runs the bench workload once and
+prints cycles per region.  Diagnostic only; never part of the shipped .so."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    csrc = os.path.join(ROOT, "lz4_flex_amd", "csrc")
+    out = "/tmp/liblz4flex_prof.so"
+    srcs = ["lz4_decompress.hip", "lz4_decompress_lds.hip", "lz4_compress.hip", "lz4_compress_lds.hip", "capi.cpp", "frame.cpp"]
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLZ4FLEX_PROFILE_PHASES", "-x", "hip"] + \
+          [os.path.join(csrc, s) for s in srcs] + ["-o", out]
+    subprocess.check_call(cmd)
+    import torch
+    from lz4_flex_amd import _lib
+    _lib.LIB_PATH = out
+    lib = _lib.load()
+    from lz4_flex_amd import workloads as W, sharded
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api as O
+    plain = O.fixture_plain("compression_66k_JSON")
+    n = int(os.environ.get("BLOCKS", "16384"))
+    src = W.json_tiles(plain, n * 65536, device="cuda")
+    flags = np.zeros(n, dtype=np.uint32)
+    for _ in range(2):
+        comp, comp_off, comp_len, in_len = sharded.compress_blocks_device(src, 65536, flags)
+    torch.cuda.synchronize()
+    cyc = (C.c_ulonglong * 8)()
+    cnt = (C.c_ulonglong * 8)()
+    lib.lz4flex_debug_phase.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.lz4flex_debug_phase(None, None, 1)
+    comp, comp_off, comp_len, in_len = sharded.compress_blocks_device(src, 65536, flags)
+    lib.lz4flex_debug_phase(cyc, cnt, 0)
+    names = ["loop/emit tail", "probe+hash+table read", "conflict+cand load+verify", "table stores", "extension", "cur-2+emit", "-", "-"]
+    tot = sum(cyc)
+    for k in range(6):
+        print("%-28s cycles/visit %8.0f  visits %10d  share %5.1f%%" % (names[k], cyc[k] / max(cnt[k], 1), cnt[k], 100.0 * cyc[k] / max(tot, 1)))
+
+
+if __name__ == "__main__":
+    main()
