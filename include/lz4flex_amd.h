@@ -224,8 +224,12 @@ size_t lz4flex_frame_compress_bound(size_t in_len, const lz4flex_frame_info *inf
 int64_t lz4flex_frame_info_write(const lz4flex_frame_info *info, uint8_t *out, size_t out_cap);
 int64_t lz4flex_frame_info_read(const uint8_t *in, size_t in_len, lz4flex_frame_info *info,
                                 lz4flex_err_detail *detail);
-/* XXH32 as used by the frame format (twox-hash in the reference) */
+/* XXH32 as used by the frame format (twox-hash in the reference); host */
 uint32_t lz4flex_xxh32(const uint8_t *data, size_t len, uint32_t seed);
+/* batched XXH32 of n DEVICE-resident buffers base[off[i] .. +len[i]) -> out[i] (device), on hip_stream: the block
+ * checksums of src/frame/compress.rs:313-316 / src/frame/decompress.rs:178-187 for device-resident frames */
+int lz4flex_xxh32_batch_device(const void *base, const uint64_t *off, const uint32_t *len, uint32_t n, uint32_t seed,
+                               uint32_t *out, void *hip_stream);
 
 #ifdef __cplusplus
 }

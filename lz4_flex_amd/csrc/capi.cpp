@@ -540,6 +540,13 @@ int64_t lz4flex_decompress_into_with_dict(const uint8_t* in, size_t in_len, uint
     return decompress_common(in, in_len, out, out_cap, dict, dict_len, true, detail);
 }
 
+int lz4flex_xxh32_batch_device(const void* base, const uint64_t* off, const uint32_t* len, uint32_t n, uint32_t seed,
+                               uint32_t* out, void* hip_stream) {
+    if (n && (!base || !off || !len || !out)) return -LZ4FLEX_E_INVALID_ARG;
+    hipError_t le = launch_xxh32_batch((const uint8_t*)base, off, len, n, seed, out, (hipStream_t)hip_stream);
+    return le == hipSuccess ? 0 : hip_fail(le, "xxh32 kernel launch");
+}
+
 int64_t lz4flex_uncompressed_size(const uint8_t* in, size_t in_len) {
     if (in_len < 4) return -LZ4FLEX_E_EXPECTED_ANOTHER_BYTE;   // mod.rs:152
     return (int64_t)((uint32_t)in[0] | ((uint32_t)in[1] << 8) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 24));

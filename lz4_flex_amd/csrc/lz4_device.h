@@ -56,4 +56,7 @@ hipError_t launch_compress_chain(const uint8_t* in_base, const void* blocks, con
                                  const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len, int32_t* status,
                                  uint32_t* tbl_state, hipStream_t s);
 
+hipError_t launch_xxh32_batch(const uint8_t* base, const uint64_t* off, const uint32_t* len, uint32_t n, uint32_t seed,
+                              uint32_t* out, hipStream_t s);
+
 }  // namespace lz4flex_dev

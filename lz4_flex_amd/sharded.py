@@ -104,20 +104,41 @@ def decompress_blocks_device(comp, comp_off, comp_len, out_len_expected, block_s
     return out, out_len, status
 
 
+def xxh32_blocks_device(base, off, length, seed=0):
+    """XXH32 of base[off[i] : off[i]+length[i]] for every i, on the device (block checksums)"""
+    lib = L.load()
+    dev = base.device
+    n = off.numel()
+    out = torch.zeros(n, dtype=torch.int32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    o64 = off.to(torch.int64).contiguous()
+    l32 = length.to(torch.int32).contiguous()
+    with torch.cuda.device(dev):
+        rc = lib.lz4flex_xxh32_batch_device(_p(base), _p(o64), _p(l32), n, seed, _p(out), stream)
+    if rc:
+        raise RuntimeError("lz4flex_xxh32_batch_device: %d %s" % (rc, L.last_error()))
+    return out.to(torch.int64) & 0xFFFFFFFF
+
+
+def _le32(word):
+    return torch.stack([(word >> s) & 0xFF for s in (0, 8, 16, 24)], dim=1).to(torch.uint8)
+
+
 # ---- segment assembly ------------------------------------------------------------------------------------
-def build_segment(src, comp, comp_off, comp_len, in_len, block_size):
-    """[4-byte block header | payload]* for this rank's blocks; store-raw rule of frame/compress.rs:301-306"""
+def build_segment(src, comp, comp_off, comp_len, in_len, block_size, block_checksums=False, xxh32_blocks=None):
+    """[4-byte block header | payload | (XXH32 of the payload)]* for this rank's blocks; store-raw rule of
+    frame/compress.rs:301-306, block checksum :313-316"""
     dev = src.device
     n = comp_len.numel()
     clen = comp_len.to(torch.int64)
     ilen = in_len.to(torch.int64)
     raw = clen >= ilen
     size = torch.where(raw, ilen, clen)
-    seg_off = torch.cumsum(size + 4, 0) - (size + 4)
-    total = int((size + 4).sum().item())
+    per = size + 4 + (4 if block_checksums else 0)
+    seg_off = torch.cumsum(per, 0) - per
+    total = int(per.sum().item())
     seg = torch.empty(total, dtype=torch.uint8, device=dev)
-    word = torch.where(raw, ilen | UNCOMPRESSED_BIT, clen)
-    hdr = torch.stack([(word >> s) & 0xFF for s in (0, 8, 16, 24)], dim=1).to(torch.uint8)
+    hdr = _le32(torch.where(raw, ilen | UNCOMPRESSED_BIT, clen))
     h_seg, h_size, h_raw, h_coff = seg_off.tolist(), size.tolist(), raw.tolist(), comp_off.tolist()
     for i in range(n):
         o = h_seg[i]
@@ -126,6 +147,12 @@ def build_segment(src, comp, comp_off, comp_len, in_len, block_size):
             seg[o + 4:o + 4 + h_size[i]] = src[i * block_size:i * block_size + h_size[i]]
         else:
             seg[o + 4:o + 4 + h_size[i]] = comp[h_coff[i]:h_coff[i] + h_size[i]]
+    if block_checksums and n:
+        sums = (xxh32_blocks or xxh32_blocks_device)(seg, seg_off + 4, size)
+        cs = _le32(sums)
+        for i in range(n):
+            o = h_seg[i] + 4 + h_size[i]
+            seg[o:o + 4] = cs[i]
     return seg
 
 
@@ -135,15 +162,16 @@ def _world(group):
     return 0, 1
 
 
-def compress_frame_sharded(local, first_block, frame_info, group=None, root=0, compress_blocks=compress_blocks_device):
+def compress_frame_sharded(local, first_block, frame_info, group=None, root=0, compress_blocks=compress_blocks_device,
+                           xxh32_blocks=None):
     """Every rank passes the bytes of its contiguous block range (`local`, uint8 tensor) and the global index
     of its first block.  Returns the complete frame (uint8 tensor on the root's device) on `root`, None elsewhere.
     `compress_blocks(src, block_size, flags) -> (comp, comp_off, comp_len, in_len)`."""
     fi = frame_info
     if fi.block_mode != BlockMode.Independent:
         raise ValueError("Linked frames do not shard: every block depends on the previous 64 KiB (replicas only)")
-    if fi.content_checksum or fi.block_checksums:
-        raise ValueError("checksums: content XXH32 is serial over the stream, block XXH32 runs on the host; not sharded")
+    if fi.content_checksum:
+        raise ValueError("content_checksum: one XXH32 over the whole stream is serial (SURVEY H6); not sharded")
     if fi.block_size == BlockSize.Auto or fi.content_size is not None:
         raise ValueError("sharded frames need an explicit block_size and no content_size")
     rank, world = _world(group)
@@ -153,7 +181,7 @@ def compress_frame_sharded(local, first_block, frame_info, group=None, root=0, c
     if n_local:
         flags = block_flags(first_block, n_local, bs)
         comp, comp_off, comp_len, in_len = compress_blocks(local, bs, flags)
-        seg = build_segment(local, comp, comp_off, comp_len, in_len, bs)
+        seg = build_segment(local, comp, comp_off, comp_len, in_len, bs, fi.block_checksums, xxh32_blocks)
     else:
         seg = torch.empty(0, dtype=torch.uint8, device=dev)
     # 1) all-gather of the segment sizes, 2) exclusive prefix sum
@@ -189,7 +217,7 @@ def compress_frame_sharded(local, first_block, frame_info, group=None, root=0, c
     return None
 
 
-def walk_blocks(frame_host, header_len):
+def walk_blocks(frame_host, header_len, block_checksums=False):
     """host-side block-header walk (frame/decompress.rs:231-241): returns [(payload_off, len, raw)], end offset"""
     out, p = [], header_len
     n = len(frame_host)
@@ -203,10 +231,11 @@ def walk_blocks(frame_host, header_len):
         raw = bool(w & UNCOMPRESSED_BIT)
         ln = w & ~UNCOMPRESSED_BIT
         out.append((p, ln, raw))
-        p += ln
+        p += ln + (4 if block_checksums else 0)
 
 
-def decompress_frame_sharded(frame, group=None, root=0, decompress_blocks=decompress_blocks_device, device=None):
+def decompress_frame_sharded(frame, group=None, root=0, decompress_blocks=decompress_blocks_device, device=None,
+                             xxh32_blocks=None):
     """`frame` (uint8 tensor) is needed on the root only.  The root walks the block headers, every rank
     receives and decodes a contiguous block range.  Returns (local_out tensor, (lo, hi) block range, FrameInfo)."""
     rank, world = _world(group)
@@ -216,20 +245,21 @@ def decompress_frame_sharded(frame, group=None, root=0, decompress_blocks=decomp
         host = frame.cpu().numpy()
         hdr_len = 7 + (8 if host[4] & 0x08 else 0)
         fi = FrameInfo.read(bytes(host[:hdr_len]))
-        if fi.block_mode != BlockMode.Independent or fi.content_checksum or fi.block_checksums:
-            raise ValueError("only Independent frames without checksums shard")
-        blocks, _end = walk_blocks(host, hdr_len)
-        meta = [(blocks, int(fi.block_size))]
+        if fi.block_mode != BlockMode.Independent or fi.content_checksum:
+            raise ValueError("only Independent frames without a content checksum shard")
+        blocks, _end = walk_blocks(host, hdr_len, fi.block_checksums)
+        meta = [(blocks, int(fi.block_size), bool(fi.block_checksums))]
     if world > 1:
         dist.broadcast_object_list(meta, src=root, group=group)
-    blocks, bs_code = meta[0]
+    blocks, bs_code, has_bc = meta[0]
     bs = BlockSize(bs_code).get_size()
+    tail = 4 if has_bc else 0
     lo, hi = partition(len(blocks), world)[rank]
     mine = blocks[lo:hi]
     # the bytes of my range are contiguous in the frame: one transfer per rank
     if mine:
         a = mine[0][0]
-        b = mine[-1][0] + mine[-1][1]
+        b = mine[-1][0] + mine[-1][1] + tail
     else:
         a = b = 0
     if rank == root:
@@ -238,7 +268,7 @@ def decompress_frame_sharded(frame, group=None, root=0, decompress_blocks=decomp
         for r, (l2, h2) in enumerate(ranges):
             if r == rank or l2 == h2:
                 continue
-            ra, rb = blocks[l2][0], blocks[h2 - 1][0] + blocks[h2 - 1][1]
+            ra, rb = blocks[l2][0], blocks[h2 - 1][0] + blocks[h2 - 1][1] + tail
             reqs.append(dist.isend(frame[ra:rb].contiguous(), dst=r, group=group))
         local = frame[a:b]
         for q in reqs:
@@ -248,6 +278,14 @@ def decompress_frame_sharded(frame, group=None, root=0, decompress_blocks=decomp
         if b > a:
             dist.recv(local, src=root, group=group)
     n = len(mine)
+    if has_bc and n:   # verify the block checksums (frame/decompress.rs:255-261,275-278) before decoding
+        poff = torch.tensor([m[0] - a for m in mine], dtype=torch.int64, device=dev)
+        plen = torch.tensor([m[1] for m in mine], dtype=torch.int64, device=dev)
+        got = (xxh32_blocks or xxh32_blocks_device)(local, poff, plen)
+        idx = (poff + plen).unsqueeze(1) + torch.arange(4, device=dev).unsqueeze(0)
+        stored = (local[idx].to(torch.int64) << torch.tensor([0, 8, 16, 24], device=dev)).sum(dim=1)
+        if not torch.equal(got.cpu(), stored.cpu()):
+            raise RuntimeError("BlockChecksumError")
     out = torch.empty(n * bs, dtype=torch.uint8, device=dev)
     produced = [0] * n
     comp_idx = [i for i, m in enumerate(mine) if not m[2]]

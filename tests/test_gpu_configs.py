@@ -111,3 +111,28 @@ def test_big_blocks_device_batch(mods):
     h = src[:4 << 20].cpu().numpy().tobytes()
     got = comp[:int(comp_len[0].item())].cpu().numpy().tobytes()
     assert got == O.compress(h)
+
+
+def test_xxh32_batch_device_and_checksummed_sharded_frame(mods):
+    """device XXH32 (block checksums) == oracle XXH32; a block-checksummed frame built on device == oracle's bytes"""
+    block, frame, sharded, W = mods
+    data = W.log_stream(0, 128 * 20000, device="cuda")
+    lens = [0, 1, 3, 4, 15, 16, 17, 31, 32, 33, 100, 1000, 65536, 70001]
+    offs, o = [], 5
+    for n in lens:
+        offs.append(o); o += n + 3
+    got = sharded.xxh32_blocks_device(data, torch.tensor(offs, device="cuda"), torch.tensor(lens, device="cuda")).cpu().tolist()
+    host = data.cpu().numpy().tobytes()
+    assert got == [O.xxh32(host[a:a + n]) for a, n in zip(offs, lens)]
+    src = torch.cat([W.log_stream(0, 128 * 3000, device="cuda"),
+                     torch.frombuffer(bytearray(corpus.lcg_bytes(70000, 5, 256, 1)), dtype=torch.uint8).cuda()])
+    fi = frame.FrameInfo(block_size=frame.BlockSize.Max64KB, block_checksums=True)
+    fr = sharded.compress_frame_sharded(src, 0, fi)
+    h = src.cpu().numpy().tobytes()
+    rc, exp = O.frame_compress(h, block_size=4, block_checksums=True)
+    assert rc == 0 and fr.cpu().numpy().tobytes() == exp
+    out, _, _ = sharded.decompress_frame_sharded(fr)
+    assert torch.equal(out, src)
+    bad = fr.clone(); bad[-9] ^= 0x55          # corrupt the last block's checksum
+    with pytest.raises(RuntimeError, match="BlockChecksumError"):
+        sharded.decompress_frame_sharded(bad)

@@ -58,6 +58,13 @@ def oracle_decompress_blocks(comp, comp_off, comp_len, _unused, block_size):
     return out, torch.tensor(lens, dtype=torch.int32), torch.tensor(st, dtype=torch.int32)
 
 
+def oracle_xxh32_blocks(base, off, length, seed=0):
+    import oracle_api as O
+    raw = bytes(base.numpy().tobytes())
+    return torch.tensor([O.xxh32(raw[int(o):int(o) + int(l)], seed) for o, l in zip(off.tolist(), length.tolist())],
+                        dtype=torch.int64)
+
+
 def _stream(total):
     from lz4_flex_amd import workloads as W
     import oracle_api as O
@@ -68,7 +75,7 @@ def _stream(total):
     return torch.cat([log, rnd, js])      # the random part exercises the store-raw rule
 
 
-def _worker(rank, world, port, bs_code, total, q):
+def _worker(rank, world, port, bs_code, total, q, block_checksums=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -88,14 +95,15 @@ def _worker(rank, world, port, bs_code, total, q):
         n_blocks = (len(stream) + bs - 1) // bs
         lo, hi = S.partition(n_blocks, world)[rank]
         local = torch.frombuffer(bytearray(stream[lo * bs:hi * bs]), dtype=torch.uint8) if hi > lo else torch.empty(0, dtype=torch.uint8)
-        fi = FrameInfo(block_size=BlockSize(bs_code))
-        frame = S.compress_frame_sharded(local, lo, fi, compress_blocks=oracle_compress_blocks)
+        fi = FrameInfo(block_size=BlockSize(bs_code), block_checksums=block_checksums)
+        frame = S.compress_frame_sharded(local, lo, fi, compress_blocks=oracle_compress_blocks, xxh32_blocks=oracle_xxh32_blocks)
         if rank == 0:
             fb = bytes(frame.numpy().tobytes())
-            rc, exp = O.frame_compress(stream, block_size=bs_code)
+            rc, exp = O.frame_compress(stream, block_size=bs_code, block_checksums=block_checksums)
             assert rc == 0 and fb == exp, "sharded frame differs from the single-encoder frame"
             assert O.c_frame_decompress(fb, len(stream)) == stream
-        out, (l2, h2), _ = S.decompress_frame_sharded(frame if rank == 0 else None, decompress_blocks=oracle_decompress_blocks)
+        out, (l2, h2), _ = S.decompress_frame_sharded(frame if rank == 0 else None, decompress_blocks=oracle_decompress_blocks,
+                                                     xxh32_blocks=oracle_xxh32_blocks)
         assert (l2, h2) == (lo, hi)
         assert bytes(out.numpy().tobytes()) == stream[lo * bs:hi * bs]
         q.put((rank, "ok", hashlib.md5(bytes(frame.numpy().tobytes())).hexdigest() if rank == 0 else ""))
@@ -106,11 +114,11 @@ def _worker(rank, world, port, bs_code, total, q):
         dist.destroy_process_group()
 
 
-def _run(world, bs_code, total):
+def _run(world, bs_code, total, block_checksums=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, bs_code, total, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bs_code, total, q, block_checksums)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
@@ -146,8 +154,8 @@ def test_log_stream_is_pinned():
     assert torch.equal(y, x[128 * 1000:128 * 1050])
 
 
-@pytest.mark.parametrize("world,bs_code", [(2, 4), (4, 4), (2, 5)])
-def test_sharded_frame_matches_single_encoder(world, bs_code):
+@pytest.mark.parametrize("world,bs_code,bc", [(2, 4, False), (4, 4, False), (2, 5, False), (2, 4, True)])
+def test_sharded_frame_matches_single_encoder(world, bs_code, bc):
     total = 9 * 65536 + 12345 if bs_code == 4 else 5 * 262144 + 777
-    md5s = {w: _run(w, bs_code, total) for w in (1, world)}
+    md5s = {w: _run(w, bs_code, total, bc) for w in (1, world)}
     assert md5s[1] == md5s[world]
