@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=16384, help="64 KiB blocks per GPU (16384 = 1 GiB)")
     ap.add_argument("--decompress-lanes", type=int, default=0)
     ap.add_argument("--compress-lanes", type=int, default=0)
+    ap.add_argument("--compress-variant", type=int, default=0)
+    ap.add_argument("--decompress-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="kernel experiments only: skip the bit-exact check (never for reported numbers)")
     ap.add_argument("--ablate", type=int, default=0, help="kernel timing ablations (wrong output; implies --no-verify)")
@@ -87,6 +89,10 @@ def main():
         assert lib.lz4flex_set_tuning(ctx, b"decompress_lanes", args.decompress_lanes) == 0
     if args.compress_lanes:
         assert lib.lz4flex_set_tuning(ctx, b"compress_lanes", args.compress_lanes) == 0
+    if args.compress_variant:
+        assert lib.lz4flex_set_tuning(ctx, b"compress_variant", args.compress_variant) == 0
+    if args.decompress_variant:
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", args.decompress_variant) == 0
     if args.ablate:
         args.no_verify = True
 
@@ -190,7 +196,7 @@ def main():
         kernels["compress"] = {"kernel": "lz4_compress_blocks_kernel", "ms_per_launch": round(t_c * 1e3, 4),
                                "MiB_per_s": round(total / 1048576 / t_c, 1), "roofline": roof(t_c)}
     if args.only in ("both", "decompress"):
-        kernels["decompress"] = {"kernel": "lz4_decompress_blocks_kernel", "ms_per_launch": round(t_d * 1e3, 4),
+        kernels["decompress"] = {"kernel": "lz4_decompress_pipe_kernel", "ms_per_launch": round(t_d * 1e3, 4),
                                  "MiB_per_s": round(total / 1048576 / t_d, 1), "roofline": roof(t_d)}
     # measured HBM traffic per launch (rocprofv3 --pmc passes, corrected per MI355X_MICROARCH.md) if recorded
     tpath = os.path.join(ROOT, "profiles", "traffic.json")

@@ -87,6 +87,8 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
     lz4flex_ctx* c = new (std::nothrow) lz4flex_ctx();
     if (!c) return -LZ4FLEX_E_NOMEM;
     c->device = device;
+    if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v == 1 || v == 2) c->comp_variant = v; }
+    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v >= 1 && v <= 3) c->dec_variant = v; }
     int prev = 0;
     (void)hipGetDevice(&prev);
     e = hipSetDevice(device);

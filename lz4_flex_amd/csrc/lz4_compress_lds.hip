@@ -17,6 +17,17 @@
 #include "lz4_device.h"
 
 namespace lz4flex_dev {
+#ifdef LZ4FLEX_PROFILE_PHASES
+__device__ unsigned long long g2_phase_cycles[8];
+__device__ unsigned long long g2_phase_counts[8];
+#define C2_PHASE_DECL unsigned long long _pt = __builtin_readcyclecounter(); unsigned long long _pacc[8] = {0,0,0,0,0,0,0,0}; unsigned _pcnt[8] = {0,0,0,0,0,0,0,0};
+#define C2_PHASE_MARK(k) { const unsigned long long _n = __builtin_readcyclecounter(); _pacc[k] += _n - _pt; _pcnt[k]++; _pt = _n; }
+#define C2_PHASE_FLUSH if (threadIdx.x == 0) { for (int _k = 0; _k < 8; ++_k) { atomicAdd(&g2_phase_cycles[_k], _pacc[_k]); atomicAdd(&g2_phase_counts[_k], (unsigned long long)_pcnt[_k]); } }
+#else
+#define C2_PHASE_DECL
+#define C2_PHASE_MARK(k)
+#define C2_PHASE_FLUSH
+#endif
 namespace c2 {
 
 constexpr uint32_t G = 8;
@@ -200,209 +211,325 @@ struct Enc {
         if (lit_len != 0u) put_literals(ls, lit_len);
     }
 
+#ifdef LZ4FLEX_PROFILE_PHASES
+    unsigned long long facc[4] = {0, 0, 0, 0};
+    unsigned fcnt[4] = {0, 0, 0, 0};
+#endif
+    // ---- per-block state ----------------------------------------------------------------------------
+    uint32_t base, i0, lit_start;      // probing origin, index of the next probe, start of the pending literals
+    uint32_t end_check, limit, idx0;
+    uint32_t use_h5, continuation, done;
+    // a match whose forward extension continues over several steps
+    uint32_t ext, ecur, ecnd, e_mstart, e_offset;
+
+    __device__ __forceinline__ uint32_t hidx(uint64_t x) const { return use_h5 ? hidx5(x) : hidx4((uint32_t)x); }
+
+    // token, literals, offset, match-length extension of one sequence; then the cursor moves to cur_end
+    __device__ __forceinline__ void finalize(uint32_t mstart, uint32_t offset, uint32_t cur_end) {
+        const uint32_t dl = cur_end - (mstart + 4u);              // duplicate_length (compress.rs:456)
+        const uint32_t lit_len = mstart - lit_start;
+        // table: cur-2 (compress.rs:460-461); its 8 input bytes come from the window when it covers them
+        const uint32_t q = cur_end - 2u;
+        uint64_t qx;
+        if (q >= wlo && q + 8u <= wend) {
+            const uint8_t* wq = win + (q - wlo);
+            qx = ((uint64_t)ld32(wq + 4) << 32) | ld32(wq);
+        } else {
+            qx = rd64(q);
+        }
+        const uint32_t room = STG - (opos - obase);
+        if (lit_len <= 12u && dl < 270u && room >= 24u && lit_start >= wlo && mstart <= wend) {
+            // quick emit: <= 16 bytes, written straight into the stage (each later write overwrites the wild tail)
+            uint8_t* d = stg + (opos - obase);
+            const uint32_t token = (lit_len << 4) | (dl < 15u ? dl : 15u);
+            if (g == 0u) d[0] = (uint8_t)token;
+            if (4u * g < lit_len) st32(d + 1u + 4u * g, ld32(win + (lit_start - wlo) + 4u * g));
+            const uint32_t tail = offset | ((dl - 15u) << 16);   // offset LE, then the single extension byte (if any)
+            if (g == 0u) st32(d + 1u + lit_len, tail);
+            opos += 1u + lit_len + 2u + (dl >= 15u ? 1u : 0u);
+        } else {
+            emit_literals(lit_start, lit_len, dl < 15u ? dl : 15u);
+            stage_room(8u);
+            if (g == 0u) { stg[opos - obase] = (uint8_t)(offset & 0xFFu); stg[opos - obase + 1u] = (uint8_t)(offset >> 8); }
+            opos += 2u;
+            if (dl >= 15u) put_length_ext(dl - 15u);
+        }
+        if (g == 0u) tbl[hidx(qx)] = (uint16_t)q;
+        lit_start = cur_end;
+        base = cur_end;
+        i0 = 0u;
+        ext = 0u;
+    }
+    __device__ __forceinline__ void terminate() {   // handle_last_literals, compress.rs:237-247
+        emit_literals(lit_start, n - lit_start, 0u);
+        stage_flush(true);
+        done = 1u;
+    }
+
+    // generic continuation from a verified candidate (cur, cnd): any backward / forward length, from memory
+    __device__ __forceinline__ void finish_generic(uint32_t cur, uint32_t cnd) {
+        const uint32_t offset = cur - cnd;
+        const uint32_t m4 = cur + 4u, c4 = cnd + 4u;
+        for (;;) {                                                             // backtrack, compress.rs:442-448
+            const bool ok = (cnd > g) && (cur > lit_start + g) && in[cur - 1u - g] == in[cnd - 1u - g];
+            const uint32_t okm = ballot(ok);
+            const uint32_t k = (uint32_t)__builtin_ctz(~okm);
+            cur -= k; cnd -= k;
+            if (k < G) break;
+        }
+        uint32_t dl = 0u;
+        for (;;) {                                                             // count_same_bytes, :156-216
+            const uint32_t a = m4 + dl + 8u * g;
+            uint32_t c = 0u;
+            if (a < limit) {
+                const uint32_t rem = limit - a;
+                const uint32_t b = c4 + dl + 8u * g;
+                if (rem >= 8u) {
+                    const uint64_t diff = ld64(in + a) ^ ld64(in + b);
+                    c = diff ? (uint32_t)(__builtin_ctzll(diff) >> 3) : 8u;
+                } else {
+                    while (c < rem && in[a + c] == in[b + c]) ++c;
+                }
+            }
+            const uint32_t part = ballot(c != 8u);
+            if (part == 0u) { dl += 8u * G; continue; }
+            const uint32_t f = (uint32_t)__builtin_ctz(part);
+            dl += 8u * f + bcast(c, f);
+            break;
+        }
+        finalize(cur, offset, m4 + dl);
+    }
+
+    // one probe batch entirely from memory (block start, probing sparser than the window, tiny blocks)
+    __device__ __forceinline__ void generic_step() {
+        const uint32_t i = i0 + g;
+        const uint32_t p = probe_pos(base, i);
+        const bool valid = p <= end_check;
+        uint32_t idx = 0xFFFF0000u + g;
+        uint32_t cand = 0u, cur4 = 0u;
+        bool cand_ok = false;
+        if (valid) {
+            const uint64_t x = ld64(in + p);
+            idx = hidx(x);
+            cur4 = (uint32_t)x;
+            cand = (uint32_t)tbl[idx];
+            cand_ok = !continuation || cand != 0u || idx == idx0;
+        }
+        const uint32_t dconf = FwdConflict<1>::run(idx, g);
+        if (dconf != 0u) { cand = probe_pos(base, i - dconf); cand_ok = true; }
+        bool is_match = false;
+        if (valid && cand_ok) is_match = ld32(in + cand) == cur4;
+        const uint32_t mm = ballot(is_match);
+        const uint32_t vm = ballot(valid);
+        const uint32_t last = mm ? (uint32_t)__builtin_ctz(mm) : (G - 1u);
+        if (valid && g <= last && !BwdConflict<1>::run(idx, g, last)) tbl[idx] = (uint16_t)p;
+        if (mm == 0u) {
+            if (vm != 0xFFu) terminate(); else i0 += G;
+            return;
+        }
+        finish_generic(bcast(p, last), bcast(cand, last));
+    }
+
+    // ---- the fast step: window-resident probe batch / extension round, ONE memory round trip ---------------
+    __device__ __forceinline__ void fast_step() {
+#ifdef LZ4FLEX_PROFILE_PHASES
+        unsigned long long _t0 = __builtin_readcyclecounter();
+#define FS_MARK(k) { const unsigned long long _n = __builtin_readcyclecounter(); facc[k - 4] += _n - _t0; fcnt[k - 4]++; _t0 = _n; }
+#else
+#define FS_MARK(k)
+#endif
+        const bool ex = ext != 0u;
+        // cursor-side bytes: PROBE lane g looks at [p-8, p+40), EXT lane g at [ecur+16g, +16)
+        const uint32_t i = i0 + g;
+        const uint32_t p = probe_pos(base, i);
+        const bool valid = !ex && p <= end_check;
+        const uint32_t ea = ecur + 16u * g;
+        const uint32_t rb = (ex ? ea : p - 8u) - wlo;
+        const uint8_t* wp = win + rb;
+        uint32_t Cc[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Cc[k] = ld32(wp + 4 * k);
+        // ---- PROBE: hash, table, same-bucket forwarding
+        uint32_t idx = 0xFFFF0000u + g;
+        uint32_t cand = 0u;
+        bool cand_ok = false;
+        if (valid) {
+            idx = hidx(((uint64_t)Cc[3] << 32) | Cc[2]);
+            cand = (uint32_t)tbl[idx];
+            cand_ok = !continuation || cand != 0u || idx == idx0;
+        }
+        const uint32_t dconf = FwdConflict<1>::run(idx, g);
+        if (dconf != 0u) { cand = probe_pos(base, i - dconf); cand_ok = true; }
+        const bool want = valid && cand_ok;
+        FS_MARK(4)   // window reads + hash + table read + forward conflict
+        // later lanes of the batch that hit the same bucket (bit k-1: lane g+k)
+        uint32_t later = 0u;
+        {
+            const uint32_t v1 = row_shl<1>(idx, 0xFFFFFFFFu), v2 = row_shl<2>(idx, 0xFFFFFFFFu), v3 = row_shl<3>(idx, 0xFFFFFFFFu),
+                           v4 = row_shl<4>(idx, 0xFFFFFFFFu), v5 = row_shl<5>(idx, 0xFFFFFFFFu), v6 = row_shl<6>(idx, 0xFFFFFFFFu),
+                           v7 = row_shl<7>(idx, 0xFFFFFFFFu);
+            later = (v1 == idx ? 1u : 0u) | (v2 == idx ? 2u : 0u) | (v3 == idx ? 4u : 0u) | (v4 == idx ? 8u : 0u) |
+                    (v5 == idx ? 16u : 0u) | (v6 == idx ? 32u : 0u) | (v7 == idx ? 64u : 0u);
+            later &= (1u << (G - 1u - g)) - 1u;          // only lanes of this group
+        }
+        // ---- the one memory round trip: candidate bytes [cand-8, cand+40) (PROBE) / [ecnd+16g, +16) (EXT)
+        const uint32_t lo8 = cand >= 8u ? cand - 8u : 0u;
+        const uint32_t shc = cand - lo8;
+        const uint32_t ga = ex ? ecnd + 16u * g : lo8;
+        uint4 A = make_uint4(0u, 0u, 0u, 0u), Bq = A, Dq = A;
+        const bool a_fast = ga + 16u <= n;       // always true for PROBE lanes of blocks >= 128 B (lo8 + 16 <= n - 5)
+        if ((want || ex) && a_fast) A = ld128(in + ga);
+        if (want && lo8 + 32u <= n) Bq = ld128(in + lo8 + 16u);
+        if (want && lo8 + 48u <= n) Dq = ld128(in + lo8 + 32u);
+        if (ex && !a_fast) A = rd128(ga);        // block tail only
+        FS_MARK(5)   // backward-conflict masks + issue of the candidate loads
+        // ---- PROBE: verification dword = loaded bytes [shc, shc+4)
+        uint32_t c4;
+        {
+            const uint32_t wi = shc >> 2, sb = shc & 3u;
+            const uint32_t l0 = wi == 0u ? A.x : (wi == 1u ? A.y : A.z);
+            const uint32_t l1 = wi == 0u ? A.y : (wi == 1u ? A.z : A.w);
+            c4 = __builtin_amdgcn_alignbyte(l1, l0, sb);
+        }
+        const bool is_match = want && c4 == Cc[2];
+        // ---- speculative extension of THIS lane's candidate (exact when shc == 8)
+        uint32_t nb, common;
+        bool more, back_more;
+        {
+            const uint64_t ab = ((uint64_t)Cc[1] << 32) | Cc[0];
+            const uint64_t cb = ((uint64_t)A.y << 32) | A.x;
+            const uint64_t xd = ab ^ cb;
+            uint32_t maxb = p - lit_start;
+            if (maxb > cand) maxb = cand;
+            nb = xd ? (uint32_t)(__builtin_clzll(xd) >> 3) : 8u;
+            if (nb > maxb) nb = maxb;
+            back_more = nb == 8u && maxb > 8u;
+            const uint64_t x0 = (((uint64_t)Cc[4] << 32) | Cc[3]) ^ (((uint64_t)Bq.x << 32) | A.w);
+            const uint64_t x1 = (((uint64_t)Cc[6] << 32) | Cc[5]) ^ (((uint64_t)Bq.z << 32) | Bq.y);
+            const uint64_t x2 = (((uint64_t)Cc[8] << 32) | Cc[7]) ^ (((uint64_t)Dq.x << 32) | Bq.w);
+            const uint64_t x3 = (((uint64_t)Cc[10] << 32) | Cc[9]) ^ (((uint64_t)Dq.z << 32) | Dq.y);
+            const uint32_t x4 = Cc[11] ^ Dq.w;
+            common = x0 ? (uint32_t)(__builtin_ctzll(x0) >> 3)
+                        : (x1 ? 8u + (uint32_t)(__builtin_ctzll(x1) >> 3)
+                              : (x2 ? 16u + (uint32_t)(__builtin_ctzll(x2) >> 3)
+                                    : (x3 ? 24u + (uint32_t)(__builtin_ctzll(x3) >> 3)
+                                          : (x4 ? 32u + (uint32_t)(__builtin_ctz(x4) >> 3) : 36u))));
+            const uint32_t have_f = lo8 + 48u <= n ? 36u : (lo8 + 32u <= n ? 20u : 4u);
+            const uint32_t maxlen = limit - (p + 4u);               // p <= n-12 => >= 2
+            uint32_t lim = have_f < maxlen ? have_f : maxlen;
+            if (common > lim) common = lim;
+            more = common == lim && lim < maxlen;
+        }
+        // ---- EXT: equal bytes of this lane's 16
+        uint32_t ec;
+        {
+            const uint64_t y0 = (((uint64_t)Cc[1] << 32) | Cc[0]) ^ (((uint64_t)A.y << 32) | A.x);
+            const uint64_t y1 = (((uint64_t)Cc[3] << 32) | Cc[2]) ^ (((uint64_t)A.w << 32) | A.z);
+            ec = y0 ? (uint32_t)(__builtin_ctzll(y0) >> 3) : (y1 ? 8u + (uint32_t)(__builtin_ctzll(y1) >> 3) : 16u);
+            const uint32_t rem = ea < limit ? limit - ea : 0u;
+            if (ec > rem) ec = rem;
+        }
+        FS_MARK(6)   // wait for the candidate bytes + verification + speculative extension
+        if (ex) {
+            const uint32_t part = ballot(ec != 16u);
+            if (part == 0u) { ecur += 16u * G; ecnd += 16u * G; return; }
+            const uint32_t f = (uint32_t)__builtin_ctz(part);
+            finalize(e_mstart, e_offset, ecur + 16u * f + bcast(ec, f));
+            return;
+        }
+        const uint32_t mm = ballot(is_match);
+        const uint32_t vm = ballot(valid);
+        const uint32_t last = mm ? (uint32_t)__builtin_ctz(mm) : (G - 1u);
+        // table stores of the executed probes (compress.rs:393), last writer per bucket only
+        {
+            const uint32_t upto = last > g ? last - g : 0u;          // later lanes that execute: g+1 .. last
+            const bool superseded = (later & ((1u << upto) - 1u)) != 0u;
+            if (valid && g <= last && !superseded) tbl[idx] = (uint16_t)p;
+        }
+        if (mm == 0u) {
+            if (vm != 0xFFu) terminate(); else i0 += G;
+            return;
+        }
+        FS_MARK(7)   // ballots + table stores
+        const uint32_t pw = bcast(p, last), cw = bcast(cand, last);
+        const uint32_t pk = bcast(nb | (common << 8) | (more ? 0x10000u : 0u) | (back_more ? 0x20000u : 0u) |
+                                  (shc == 8u ? 0x40000u : 0u), last);
+        if ((pk & 0x40000u) == 0u || (pk & 0x20000u) != 0u) { finish_generic(pw, cw); return; }
+        const uint32_t mstart = pw - (pk & 0xFFu);
+        const uint32_t cm = (pk >> 8) & 0xFFu;
+        if (pk & 0x10000u) {           // every compared byte matched: keep extending, 128 bytes per step
+            ext = 1u; ecur = pw + 4u + cm; ecnd = cw + 4u + cm; e_mstart = mstart; e_offset = pw - cw;
+            return;
+        }
+        finalize(mstart, pw - cw, pw + 4u + cm);
+    }
+
     // ---- the block -----------------------------------------------------------------------------------
     __device__ __forceinline__ int32_t run(uint32_t cap, uint32_t flags, uint32_t* produced) {
         if ((uint64_t)cap < max_output_size(n)) return LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL;   // compress.rs:338-340
-        wlo = 0u; wend = 0u; obase = 0u; opos = 0u;
+        wlo = 0u; wend = 0u; obase = 0u; opos = 0u; done = 0u; ext = 0u;
+        ecur = ecnd = e_mstart = e_offset = 0u;
         if (n < 13u) {   // compress.rs:343-346
             emit_literals(0u, n, 0u);
             stage_flush(true);
             *produced = opos;
             return 0;
         }
-        const bool continuation = (flags & 1u) != 0u;
-        const bool use_h5 = (flags & 2u) != 0u || n >= 65535u;   // compress.rs:559-566; FrameEncoder: always hash5
-        const uint32_t end_check = n - 12u;
-        const uint32_t limit = n - 6u;
+        continuation = (flags & 1u) != 0u ? 1u : 0u;
+        use_h5 = ((flags & 2u) != 0u || n >= 65535u) ? 1u : 0u;   // compress.rs:559-566; FrameEncoder: always hash5
+        end_check = n - 12u;
+        limit = n - 6u;
         {
             uint4* t4 = reinterpret_cast<uint4*>(tbl);
             for (uint32_t k = g; k < TBL_BYTES / 16u; k += G) t4[k] = make_uint4(0u, 0u, 0u, 0u);
         }
-        window(0u, 64u < n ? 64u : n);
-        const uint32_t idx0 = use_h5 ? hidx5(win64(0u)) : hidx4((uint32_t)win64(0u));
-        uint32_t lit_start = 0u;
-        uint32_t base = continuation ? 0u : 1u;
-        uint32_t i0 = continuation ? 1u : 0u;
+        idx0 = hidx(ld64(in));
+        lit_start = 0u;
+        base = continuation ? 0u : 1u;      // compress.rs:353-359 (see lz4_compress.hip)
+        i0 = continuation ? 1u : 0u;
+        const bool big_enough = n >= 128u;
+        C2_PHASE_DECL
         for (;;) {
-            // ------------------------------------------------------------------ probe batch (compress.rs:373-439)
-            const uint32_t i = i0 + g;
-            const uint32_t p = probe_pos(base, i);
-            const bool valid = p <= end_check;
-            // window: 8 bytes of history before the first probe .. 48 bytes after the last valid probe
-            {
-                const uint32_t p0 = probe_pos(base, i0);
-                uint32_t pl = probe_pos(base, i0 + G - 1u);
-                if (pl > end_check) pl = end_check;
-                uint32_t lo = p0 >= 16u ? p0 - 16u : 0u;
-                if (lit_start < lo && p0 - lit_start <= 128u) lo = lit_start;
-                uint32_t hi = pl + 48u;
+            C2_PHASE_MARK(0)
+            // what the next step touches
+            bool slow = false, need = false;
+            uint32_t lo = 0u, hi = 0u;
+            if (!done) {
+                if (ext) { lo = ecur - 16u; hi = ecur + 16u * G + 48u; }   // ecur >= 20; keeps 16 bytes of history in the window
+                else {
+                    const uint32_t p0 = probe_pos(base, i0);
+                    uint32_t pl = probe_pos(base, i0 + G - 1u);
+                    if (pl > end_check) pl = end_check;
+                    slow = !big_enough || p0 < 16u;
+                    lo = p0 - 8u;
+                    if (lit_start < lo && p0 - lit_start <= 64u) lo = lit_start;
+                    hi = pl + 48u;
+                }
                 if (hi > n) hi = n;
-                if (hi - (lo & ~15u) <= WIN - 16u) window(lo, hi);
-                else window(p0 >= 16u ? p0 - 16u : 0u, (p0 + 400u) < n ? p0 + 400u : n);   // very sparse probing: see below
-            }
-            uint32_t idx = 0xFFFF0000u + g;
-            uint32_t cand = 0u, cur4 = 0u;
-            bool cand_ok = false;
-            if (valid) {
-                const uint64_t x = rd64(p);                                 // window, or memory when probing is sparser than the window
-                if (use_h5) idx = hidx5(x); else idx = hidx4((uint32_t)x);
-                cur4 = (uint32_t)x;
-                cand = (uint32_t)tbl[idx];
-                cand_ok = !continuation || cand != 0u || idx == idx0;
-            }
-            const uint32_t dconf = FwdConflict<1>::run(idx, g);
-            if (dconf != 0u) { cand = probe_pos(base, i - dconf); cand_ok = true; }
-            // ONE 32-byte load around the candidate: [cand-8, cand+24)
-            const bool want = valid && cand_ok;          // distance <= 65535 always holds for blocks <= 64 KiB
-            uint32_t lo8 = cand >= 8u ? cand - 8u : 0u;  // first loaded position
-            const uint32_t shc = cand - lo8;             // candidate's byte offset inside the loaded data (0..8)
-            uint4 ca = make_uint4(0u, 0u, 0u, 0u), cb = make_uint4(0u, 0u, 0u, 0u);
-            if (want) {
-                ca = rd128(lo8);
-                if (lo8 + 32u <= n) cb = ld128(in + lo8 + 16u);
-            }
-            // verification dword = loaded bytes [shc, shc+4)
-            uint32_t c4;
-            {
-                const uint32_t wi = shc >> 2, sb = shc & 3u;
-                const uint32_t l0 = wi == 0u ? ca.x : (wi == 1u ? ca.y : ca.z);
-                const uint32_t l1 = wi == 0u ? ca.y : (wi == 1u ? ca.z : ca.w);
-                c4 = __builtin_amdgcn_alignbyte(l1, l0, sb);
-            }
-            const bool is_match = want && c4 == cur4;
-            const uint32_t mm = ballot(is_match);
-            const uint32_t vm = ballot(valid);
-            const uint32_t last = mm ? (uint32_t)__builtin_ctz(mm) : (G - 1u);
-            if (valid && g <= last && !BwdConflict<1>::run(idx, g, last)) tbl[idx] = (uint16_t)p;
-            if (mm == 0u) {
-                if (vm != 0xFFu) break;        // ran past end_check: last literals
-                i0 += G;
-                continue;
-            }
-            // ------------------------------------------------------------------ the winning probe's data, group-wide
-            uint32_t cur = bcast(p, last);
-            uint32_t cnd = bcast(cand, last);
-            const uint32_t sc = bcast(shc, last);
-            uint32_t d0 = bcast(ca.x, last), d1 = bcast(ca.y, last), d2 = bcast(ca.z, last), d3 = bcast(ca.w, last);
-            uint32_t d4 = bcast(cb.x, last), d5 = bcast(cb.y, last), d6 = bcast(cb.z, last), d7 = bcast(cb.w, last);
-            const uint32_t have = ((cnd >= 8u ? cnd - 8u : 0u) + 32u <= n) ? 32u : 16u;   // loaded bytes
-            const uint32_t offset = cur - cnd;
-            // ------------------------------------------------------------------ backtrack (compress.rs:442-448)
-            {
-                // candidate side: loaded bytes [0, sc) are positions cnd-sc .. cnd-1 ; cursor side from the window
-                uint32_t maxb = cur - lit_start;
-                if (maxb > cnd) maxb = cnd;
-                uint32_t nb = 0u;
-                if (maxb != 0u) {
-                    const uint64_t lo64 = ((uint64_t)d1 << 32) | d0;     // loaded bytes 0..7
-                    // align so that byte 7 is position cnd-1: shift left by (8 - sc) bytes
-                    const uint64_t cb8 = sc == 8u ? lo64 : (sc == 0u ? 0ull : (lo64 << (8u * (8u - sc))));
-                    uint64_t ab8;
-                    if (cur >= 8u && cur - 8u >= wlo && cur <= wend) ab8 = win64(cur - 8u);
-                    else {   // fewer than 8 bytes of input before cur, or history left the window
-                        ab8 = 0ull;
-                        const uint32_t k0 = cur < 8u ? cur : 8u;
-                        for (uint32_t k = 1u; k <= k0; ++k) {
-                            const uint32_t q = cur - k;
-                            const uint32_t byte = (q >= wlo && q < wend) ? win[q - wlo] : in[q];
-                            ab8 |= (uint64_t)byte << (8u * (8u - k));
-                        }
-                    }
-                    const uint64_t xd = ab8 ^ cb8;
-                    nb = xd == 0ull ? 8u : (uint32_t)(__builtin_clzll(xd) >> 3);
-                    const uint32_t cap8 = maxb < 8u ? maxb : 8u;
-                    if (nb > cap8) nb = cap8;
-                    if (nb > sc) nb = sc;
-                    cur -= nb; cnd -= nb;
-                    if (nb == 8u && maxb > 8u) {
-                        // rare: more than 8 bytes of backward extension, continue byte-wise from memory
-                        for (;;) {
-                            const bool ok = (cnd > g) && (cur > lit_start + g) && in[cur - 1u - g] == in[cnd - 1u - g];
-                            const uint32_t okm = ballot(ok);
-                            const uint32_t k = (uint32_t)__builtin_ctz(~okm);
-                            cur -= k; cnd -= k;
-                            if (k < G) break;
-                        }
-                    }
+                if (!slow) {
+                    if (hi - (lo & ~15u) > WIN - 16u) slow = !ext;     // probing sparser than the window
+                    else need = lo < wlo || hi > wend || STG - (opos - obase) < 64u;
                 }
             }
-            const uint32_t lit_len = cur - lit_start;
-            const uint32_t mstart = cur;                              // match start after backtracking
-            // ------------------------------------------------------------------ forward (count_same_bytes :156-216)
-            // match start (after backtracking) + 4; the loaded candidate bytes from index sc+4 on are cnd0+4 ...
-            const uint32_t m4 = bcast(p, last) + 4u;                  // un-backtracked cursor + 4
-            uint32_t dl = 0u;
-            {
-                const uint32_t maxlen = limit > m4 ? limit - m4 : 0u;
-                const uint32_t fwd_have = have - (sc + 4u);          // candidate bytes available after the 4 verified ones
-                // candidate bytes [sc+4, ...) as up to three 64-bit pieces
-                const uint32_t wi = (sc + 4u) >> 2, sb = (sc + 4u) & 3u;     // wi in 1..3
-                const uint32_t e0 = wi == 1u ? d1 : (wi == 2u ? d2 : d3);
-                const uint32_t e1 = wi == 1u ? d2 : (wi == 2u ? d3 : d4);
-                const uint32_t e2 = wi == 1u ? d3 : (wi == 2u ? d4 : d5);
-                const uint32_t e3 = wi == 1u ? d4 : (wi == 2u ? d5 : d6);
-                const uint32_t e4 = wi == 1u ? d5 : (wi == 2u ? d6 : d7);
-                const uint32_t e5 = wi == 1u ? d6 : (wi == 2u ? d7 : 0u);
-                const uint32_t f0 = __builtin_amdgcn_alignbyte(e1, e0, sb), f1 = __builtin_amdgcn_alignbyte(e2, e1, sb);
-                const uint32_t f2 = __builtin_amdgcn_alignbyte(e3, e2, sb), f3 = __builtin_amdgcn_alignbyte(e4, e3, sb);
-                const uint32_t f4 = __builtin_amdgcn_alignbyte(e5, e4, sb);
-                const uint64_t a0 = rd64(m4), a1 = rd64(m4 + 8u);
-                const uint32_t a2 = (uint32_t)rd64(m4 + 16u);
-                const uint64_t x0 = a0 ^ (((uint64_t)f1 << 32) | f0);
-                const uint64_t x1 = a1 ^ (((uint64_t)f3 << 32) | f2);
-                const uint32_t x2 = a2 ^ f4;
-                uint32_t common = x0 ? (uint32_t)(__builtin_ctzll(x0) >> 3)
-                                     : (x1 ? 8u + (uint32_t)(__builtin_ctzll(x1) >> 3)
-                                           : (x2 ? 16u + (uint32_t)(__builtin_ctz(x2) >> 3) : 20u));
-                uint32_t lim = fwd_have < 20u ? fwd_have : 20u;
-                if (lim > maxlen) lim = maxlen;
-                if (common > lim) common = lim;
-                dl = common;
-                if (common == lim && lim < maxlen) {
-                    // every compared byte matched and more may follow: 8 bytes per lane per round trip
-                    const uint32_t c0 = bcast(cand, last) + 4u;       // un-backtracked candidate + 4
-                    for (;;) {
-                        const uint32_t a = m4 + dl + 8u * g;
-                        uint32_t c = 0u;
-                        if (a < limit) {
-                            const uint32_t rem = limit - a;
-                            const uint32_t b = c0 + dl + 8u * g;
-                            if (rem >= 8u) {
-                                const uint64_t diff = ld64(in + a) ^ ld64(in + b);
-                                c = diff ? (uint32_t)(__builtin_ctzll(diff) >> 3) : 8u;
-                            } else {
-                                while (c < rem && in[a + c] == in[b + c]) ++c;
-                            }
-                        }
-                        const uint32_t part = ballot(c != 8u);
-                        if (part == 0u) { dl += 8u * G; continue; }
-                        const uint32_t f = (uint32_t)__builtin_ctz(part);
-                        dl += 8u * f + bcast(c, f);
-                        break;
-                    }
+            // a refill / write-back costs a memory round trip for the whole wavefront: when one group needs it,
+            // every group that is at least half way through its window / stage does it in the same round trip
+            if (__any(need)) {
+                if (!done && !slow) {
+                    if (lo < wlo || hi > wend || hi + 192u > wend) window(lo, hi);
+                    if (STG - (opos - obase) < 192u) stage_flush(false);
                 }
             }
-            cur = m4 + dl;
-            dl = cur - (mstart + 4u);                                 // duplicate_length counts from the backtracked start + 4
-            // ------------------------------------------------------------------ table: cur-2 (compress.rs:460-461)
-            if (g == 0u) {
-                const uint32_t q = cur - 2u;
-                const uint64_t x = rd64(q);
-                const uint32_t qi = use_h5 ? hidx5(x) : hidx4((uint32_t)x);
-                tbl[qi] = (uint16_t)q;
-            }
-            // ------------------------------------------------------------------ emit (compress.rs:463-486)
-            emit_literals(lit_start, lit_len, dl < 15u ? dl : 15u);
-            stage_room(8u);
-            if (g == 0u) { stg[opos - obase] = (uint8_t)(offset & 0xFFu); stg[opos - obase + 1u] = (uint8_t)(offset >> 8); }
-            opos += 2u;
-            if (dl >= 15u) put_length_ext(dl - 15u);
-            lit_start = cur;
-            base = cur;
-            i0 = 0u;
+            C2_PHASE_MARK(1)   // window / stage maintenance
+            if (!done && slow) generic_step();
+            C2_PHASE_MARK(2)   // generic steps
+            if (!done && !slow) fast_step();
+            C2_PHASE_MARK(3)   // fast steps
+            if (done) break;
         }
-        emit_literals(lit_start, n - lit_start, 0u);   // handle_last_literals, compress.rs:237-247
-        stage_flush(true);
+        C2_PHASE_FLUSH
+#ifdef LZ4FLEX_PROFILE_PHASES
+        if (threadIdx.x == 0) for (int _k = 0; _k < 4; ++_k) { atomicAdd(&g2_phase_cycles[4 + _k], facc[_k]); atomicAdd(&g2_phase_counts[4 + _k], (unsigned long long)fcnt[_k]); }
+#endif
         *produced = opos;
         return 0;
     }
@@ -443,3 +570,18 @@ hipError_t launch_compress_lds(const CompressArgs& a, hipStream_t s) {
 }
 
 }  // namespace lz4flex_dev
+
+#ifdef LZ4FLEX_PROFILE_PHASES
+extern "C" int lz4flex_debug_phase2(unsigned long long* cycles, unsigned long long* counts, int reset) {
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(lz4flex_dev::g2_phase_cycles), z, sizeof z);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(lz4flex_dev::g2_phase_counts), z, sizeof z);
+        return 0;
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(cycles, HIP_SYMBOL(lz4flex_dev::g2_phase_cycles), 64);
+    (void)hipMemcpyFromSymbol(counts, HIP_SYMBOL(lz4flex_dev::g2_phase_counts), 64);
+    return 0;
+}
+#endif
