@@ -25,12 +25,23 @@
 #include "lz4_device.h"
 
 namespace lz4flex_dev {
+#ifdef LZ4FLEX_PROFILE_PHASES
+__device__ unsigned long long gd_phase_cycles[8];
+__device__ unsigned long long gd_phase_counts[8];
+#define D_PHASE_DECL unsigned long long _pt = __builtin_readcyclecounter(); unsigned long long _pacc[8] = {0,0,0,0,0,0,0,0}; unsigned _pcnt[8] = {0,0,0,0,0,0,0,0};
+#define D_PHASE_MARK(k) { const unsigned long long _n = __builtin_readcyclecounter(); _pacc[k] += _n - _pt; _pcnt[k]++; _pt = _n; }
+#define D_PHASE_FLUSH if (threadIdx.x == 0) { for (int _k = 0; _k < 8; ++_k) { atomicAdd(&gd_phase_cycles[_k], _pacc[_k]); atomicAdd(&gd_phase_counts[_k], (unsigned long long)_pcnt[_k]); } }
+#else
+#define D_PHASE_DECL
+#define D_PHASE_MARK(k)
+#define D_PHASE_FLUSH
+#endif
 namespace v2 {
 
 constexpr uint32_t G = 8;             // lanes per block
 constexpr uint32_t IN_CAP = 384;      // compressed-input window (bytes)
 constexpr uint32_t IN_PAD = 32;       // readable slack behind the window (16-byte parse window + alignment)
-constexpr uint32_t OUT_H = 1024;      // history kept in LDS after a write-back
+constexpr uint32_t OUT_H = 512;       // history kept in LDS after a write-back (older sources: pipelined HBM loads)
 constexpr uint32_t OUT_SLACK = 32;    // wild-copy slack
 constexpr uint32_t OUT_CAP = 2080;    // IN_CAP + IN_PAD + OUT_CAP = 2496 B per block
 constexpr uint32_t GROUP_LDS = IN_CAP + IN_PAD + OUT_CAP;
@@ -420,6 +431,7 @@ struct PipeDec : Dec<ABLATE_FAR> {
     }
 
     __device__ __forceinline__ void be_step(const Slot& s) {
+        // literal write strictly before the match read: a match may start inside the literals just written
         if (4u * g < s.lit_n) st32(lout + s.lit_dst + 4u * g, ld32(lin + s.lit_src + 4u * g));
         if (4u * g < s.m_n) {
             const uint32_t x = s.far ? s.v : ld32(lout + s.m_src + 4u * g);
@@ -431,7 +443,7 @@ struct PipeDec : Dec<ABLATE_FAR> {
     __device__ __forceinline__ void service(int32_t& status, uint64_t* det_expected) {
         if (done) return;
         if ((in_end - ip < 128u && in_end < ilen) || ip - in_lo >= 128u) B::refill(ip);
-        if (B::out_space() < 448u) B::flush_slide();
+        if (B::out_space() < 760u) B::flush_slide();
         int32_t r = 0;
         if (blocked == K_FINISH) {
             r = 1;
@@ -454,7 +466,9 @@ struct PipeDec : Dec<ABLATE_FAR> {
         B::refill(0u);
         int32_t status = 0;
         Slot s0, s1, s2, s3;
+        D_PHASE_DECL
         for (;;) {
+            D_PHASE_MARK(0)
             s1.lit_n = 0u; s1.m_n = 0u; s1.far = 0u; s1.v = 0u; s1.lit_src = s1.lit_dst = s1.m_src = s1.m_dst = 0u;
             s2 = s1; s3 = s1;
             do {
@@ -462,11 +476,15 @@ struct PipeDec : Dec<ABLATE_FAR> {
                 fe_step(s1); be_step(s2);
                 fe_step(s2); be_step(s3);
                 fe_step(s3); be_step(s0);
+                D_PHASE_MARK(1)   // one 4-step iteration of the steady loop
             } while (!__any(blocked != K_NONE));
             be_step(s1); be_step(s2); be_step(s3);
+            D_PHASE_MARK(2)       // drain
             service(status, det_expected);
+            D_PHASE_MARK(3)       // service
             if (done) break;
         }
+        D_PHASE_FLUSH
         return status;
     }
 };
@@ -547,3 +565,18 @@ hipError_t launch_decompress_lds(const DecompressArgs& a, hipStream_t s, int abl
 }
 
 }  // namespace lz4flex_dev
+
+#ifdef LZ4FLEX_PROFILE_PHASES
+extern "C" int lz4flex_debug_phase_dec(unsigned long long* cycles, unsigned long long* counts, int reset) {
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(lz4flex_dev::gd_phase_cycles), z, sizeof z);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(lz4flex_dev::gd_phase_counts), z, sizeof z);
+        return 0;
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(cycles, HIP_SYMBOL(lz4flex_dev::gd_phase_cycles), 64);
+    (void)hipMemcpyFromSymbol(counts, HIP_SYMBOL(lz4flex_dev::gd_phase_counts), 64);
+    return 0;
+}
+#endif

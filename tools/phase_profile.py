@@ -46,6 +46,18 @@ def main():
     dbg(None, None, 1)
     comp, comp_off, comp_len, in_len = sharded.compress_blocks_device(src, 65536, flags)
     dbg(cyc, cnt, 0)
+    if os.environ.get("DECODE"):
+        out, out_len, st = sharded.decompress_blocks_device(comp, comp_off, comp_len, None, 65536)
+        dbg = lib.lz4flex_debug_phase_dec
+        dbg.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        dbg(None, None, 1)
+        out, out_len, st = sharded.decompress_blocks_device(comp, comp_off, comp_len, None, 65536)
+        dbg(cyc, cnt, 0)
+        names = ["outer loop", "steady 4-step iteration", "drain (3 back-end steps)", "service", "-", "-", "-", "-"]
+        tot = sum(cyc)
+        for k in range(4):
+            print("%-28s cycles/visit %8.0f  visits %10d  share %5.1f%%" % (names[k], cyc[k] / max(cnt[k], 1), cnt[k], 100.0 * cyc[k] / max(tot, 1)))
+        return
     names = ["loop/emit tail", "probe+hash+table read", "conflict+cand load+verify", "table stores", "extension", "cur-2+emit", "-", "-"]
     if variant == 2:
         names = ["loop", "window/stage maintenance", "generic steps", "fast steps (all)", "fs: window reads+hash+table", "fs: conflict masks+load issue",
