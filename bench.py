@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=16384, help="64 KiB blocks per GPU (16384 = 1 GiB)")
     ap.add_argument("--decompress-lanes", type=int, default=0)
     ap.add_argument("--compress-lanes", type=int, default=0)
+    ap.add_argument("--in-pad", type=int, default=0, help="diagnostic: bytes of padding between input blocks (needs --no-verify)")
     ap.add_argument("--compress-variant", type=int, default=0)
     ap.add_argument("--decompress-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -110,6 +111,13 @@ def main():
     back = torch.empty(total, dtype=torch.uint8, device=dev)
     ar = torch.arange(n, dtype=torch.int64, device=dev)
     in_off = (ar * BLOCK).contiguous()            # u64 view of non-negative i64
+    if args.in_pad:                               # diagnostic layout: blocks no longer at 64 KiB multiples
+        istride = BLOCK + args.in_pad
+        src2 = torch.zeros(n * istride, dtype=torch.uint8, device=dev)
+        src2.view(n, istride)[:, :BLOCK] = src.view(n, BLOCK)
+        src = src2
+        back = torch.empty(n * istride, dtype=torch.uint8, device=dev)
+        in_off = (ar * istride).contiguous()
     comp_off = (ar * stride).contiguous()
     in_len = torch.full((n,), BLOCK, dtype=torch.int32, device=dev)
     comp_cap = torch.full((n,), stride, dtype=torch.int32, device=dev)

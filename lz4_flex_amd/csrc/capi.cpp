@@ -31,6 +31,9 @@ static int hip_fail(hipError_t e, const char* what) {
         if (_e != hipSuccess) return hip_fail(_e, #expr); \
     } while (0)
 
+// compress_variant -> launch_compress mode bits: 1 = LDS input ring, 3 = plain, 4 = plain + prefetch wave
+static inline int comp_mode_bits(int v) { return v == 1 ? 0x200 : (v == 4 ? 0x400 : 0); }
+
 struct lz4flex_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -40,7 +43,7 @@ struct lz4flex_ctx {
     size_t pin_cap = 0;
     int dec_lanes = 16;           // lanes per block, decode
     int comp_lanes = 8;           // lanes per block, encode
-    int comp_variant = 1;         // 1 = lz4_compress.hip (any block size, default), 2 = experimental LDS-staged lz4_compress_lds.hip (<= 64 KiB; bit-exact but measured slower in round 1: 44.7 vs 33.9 ms/GiB)
+    int comp_variant = 1;         // 1 = lz4_compress.hip with the LDS input ring (any block size, default), 2 = experimental fully LDS-staged lz4_compress_lds.hip (<= 64 KiB; bit-exact, slower), 3 = lz4_compress.hip without the ring
     int ablate = 0;               // timing ablations (wrong output!), see lz4flex_set_tuning("ablate")
     int dec_variant = 3;          // 1 = window in HBM/L2 (lz4_decompress.hip), 2 = LDS-staged generic loop, 3 = LDS-staged pipelined (lz4_decompress_lds.hip)
 };
@@ -87,7 +90,7 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
     lz4flex_ctx* c = new (std::nothrow) lz4flex_ctx();
     if (!c) return -LZ4FLEX_E_NOMEM;
     c->device = device;
-    if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v == 1 || v == 2) c->comp_variant = v; }
+    if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v >= 1 && v <= 4) c->comp_variant = v; }
     if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v >= 1 && v <= 3) c->dec_variant = v; }
     int prev = 0;
     (void)hipGetDevice(&prev);
@@ -121,7 +124,7 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "compress_variant")) {
-        if (value != 1 && value != 2) return -LZ4FLEX_E_INVALID_ARG;
+        if (value < 1 || value > 4) return -LZ4FLEX_E_INVALID_ARG;
         c->comp_variant = value;
         return 0;
     }
@@ -241,7 +244,7 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
         a.out_len = (uint32_t*)(dd + at_out_len); a.status = (int32_t*)(dd + at_status); a.n = n;
         bool big = false;
         for (uint32_t i = 0; i < n; i++) big |= in_len[i] > 65536u;
-        le = (c->comp_variant == 2 && !big) ? launch_compress_lds(a, s) : launch_compress(a, c->comp_lanes | (big ? 0x100 : 0), s);
+        le = (c->comp_variant == 2 && !big) ? launch_compress_lds(a, s) : launch_compress(a, c->comp_lanes | (big ? 0x100 : 0) | comp_mode_bits(c->comp_variant), s);
     } else {
         DecompressArgs a{};
         a.in_base = d + a_in; a.in_off = (const uint64_t*)(dd + at_in_off); a.in_len = (const uint32_t*)(dd + at_in_len);
@@ -299,7 +302,7 @@ static int run_device_batch(lz4flex_ctx* c, bool compress, const void* in_base, 
         a.in_base = (const uint8_t*)in_base; a.in_off = in_off; a.in_len = in_len; a.flags = flags;
         a.out_base = (uint8_t*)out_base; a.out_off = out_off; a.out_cap = out_cap; a.out_len = out_len;
         a.status = status; a.n = n;
-        le = (c->comp_variant == 2 && !big_hint) ? launch_compress_lds(a, s) : launch_compress(a, c->comp_lanes | (big_hint ? 0x100 : 0), s);
+        le = (c->comp_variant == 2 && !big_hint) ? launch_compress_lds(a, s) : launch_compress(a, c->comp_lanes | (big_hint ? 0x100 : 0) | comp_mode_bits(c->comp_variant), s);
     } else {
         DecompressArgs a{};
         a.in_base = (const uint8_t*)in_base; a.in_off = in_off; a.in_len = in_len;

@@ -151,7 +151,7 @@ __device__ __forceinline__ uint32_t emit_literals(uint8_t* out, uint32_t o, cons
 template <int G, typename TblT>
 __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, uint32_t n, uint8_t* __restrict__ out,
                                                 uint32_t cap, uint32_t flags, TblT* tbl, const Grp<G> grp,
-                                                uint32_t* produced) {
+                                                uint32_t* produced, volatile uint32_t* progress) {
     const uint32_t g = grp.g;
     if ((uint64_t)cap < max_output_size(n)) return LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL;   // compress.rs:338-340
     uint32_t o = 0u;
@@ -178,70 +178,82 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
     uint32_t base = continuation ? 0u : 1u;   // probing origin of the current sequence
     uint32_t i0 = continuation ? 1u : 0u;     // index of the first probe of the next batch
     PHASE_DECL
+    const uint32_t limit = n - LZ4_END_OFFSET;                                // matches end 6 bytes before the end
+    // The 8 input bytes at this lane's probe position are loaded one step AHEAD (at the end of the previous
+    // step, together with the bytes the cur-2 table update needs), so a step starts with its probe data
+    // in flight or already there.  p + 8 <= n - 4 for every valid probe, so the load is always 8 bytes.
+    uint64_t x = 0ull;
+    {
+        const uint32_t p0 = probe_pos(base, i0 + g);
+        x = cld64(in + (p0 <= end_check ? p0 : 0u));
+    }
     for (;;) {
-        PHASE_MARK(0)   // loop overhead / previous emit tail
         // ------------------------------------------------------------------ probe batch
         const uint32_t i = i0 + g;
         const uint32_t p = probe_pos(base, i);
         const bool valid = p <= end_check;                                    // compress.rs:381
         uint32_t idx = 0xFFFF0000u + g;   // distinct sentinels for invalid lanes
-        uint32_t cand = 0u, cur4 = 0u;
+        uint32_t cand = 0u;
+        const uint32_t cur4 = (uint32_t)x;
         bool cand_ok = false;
         if (valid) {
-            if (use_h5) { const uint64_t x = cld64(in + p); idx = hidx5(x); cur4 = (uint32_t)x; }
-            else { cur4 = cld32(in + p); idx = hidx4(cur4); }
+            idx = use_h5 ? hidx5(x) : hidx4(cur4);
             cand = (uint32_t)tbl[idx];
             // a zero entry is "position 0": real in default mode, and in continuation
             // mode only in the bucket position 0 was stored to
             cand_ok = !continuation || cand != 0u || idx == idx0;
         }
-        PHASE_MARK(1)   // probe bytes + hash + table read
+        PHASE_MARK(0)   // loop top: probe bytes wait + hash + table read issue
         // same-bucket probes earlier in this batch supersede the table content
         const uint32_t d = FwdConflict<G, 1>::run(idx, g);
         if (d != 0u) { cand = probe_pos(base, i - d); cand_ok = true; }
-        bool is_match = false;
-        if (valid && cand_ok && (p - cand) <= LZ4_MAX_DISTANCE)                // compress.rs:403-405
-            is_match = cld32(in + cand) == cur4;                              // compress.rs:432-438
+        PHASE_MARK(1)   // table read wait + conflict resolution
+        // every load of a step is issued unconditionally (lanes with nothing to read load position 0): a load
+        // inside a divergent branch is waited for inside it, which turns one round trip into several
+        const bool try_m = valid && cand_ok && (p - cand) <= LZ4_MAX_DISTANCE;  // compress.rs:403-405
+        const bool is_match = (cld32(in + (try_m ? cand : 0u)) == cur4) && try_m;   // compress.rs:432-438
         const uint32_t mm = grp.ballot(is_match);
-        PHASE_MARK(2)   // conflict resolution + candidate load + verify
+        PHASE_MARK(2)   // candidate round trip + verify
         const uint32_t vm = grp.ballot(valid);
         const uint32_t last = mm ? (uint32_t)__builtin_ctz(mm) : (G - 1u);     // last probe that executes
-        // table stores of the executed probes (compress.rs:393), last writer per bucket only
-        if (valid && g <= last && !BwdConflict<G, 1>::run(idx, g, last)) tbl[idx] = (TblT)p;
+        // table stores of the executed probes (compress.rs:393), last writer per bucket only.  A later lane
+        // with the same bucket exists only if some lane saw an earlier one (d != 0): skip the scan otherwise.
+        bool superseded = false;
+        if (__any(d != 0u)) superseded = BwdConflict<G, 1>::run(idx, g, last);
+        if (valid && g <= last && !superseded) tbl[idx] = (TblT)p;
         if (mm == 0u) {
             if (vm != (((G == 32) ? 0xFFFFFFFFu : ((1u << G) - 1u)))) break;   // ran past end_check: last literals
             i0 += G;
+            const uint32_t pn = probe_pos(base, i0 + g);
+            x = cld64(in + (pn <= end_check ? pn : 0u));
             continue;
         }
-        PHASE_MARK(3)   // table stores
         uint32_t cur = grp.bcast(p, last);
         uint32_t cnd = grp.bcast(cand, last);
         const uint32_t offset = cur - cnd;                                    // compress.rs:409
+        PHASE_MARK(3)   // table stores + winner broadcast
         // ------------------------------------------------------------------ extension: ONE memory round trip for the
         // first G bytes backwards and the first 8*G bytes forwards (the forward count starts at the verified
         // position + 4 whatever the backtrack finds: the bytes in between are known equal)
-        const uint32_t limit = n - LZ4_END_OFFSET;                            // matches end 6 bytes before the end
         const uint32_t m4 = cur + 4u, c4 = cnd + 4u;
         const bool bk_ok0 = (cnd > g) && (cur > lit_start + g);
-        uint32_t bka = 0u, bkb = 1u;
-        if (bk_ok0) { bka = in[cur - 1u - g]; bkb = in[cnd - 1u - g]; }
+        const uint32_t fa = m4 + 8u * g, fb = c4 + 8u * g;
+        const bool f8 = fa + 8u <= limit;                                     // a full 8-byte forward chunk
+        const uint32_t bka = in[bk_ok0 ? cur - 1u - g : 0u];
+        const uint32_t bkb = in[bk_ok0 ? cnd - 1u - g : 0u];
+        const uint64_t fdiff = cld64(in + (f8 ? fa : 0u)) ^ cld64(in + (f8 ? fb : 0u));
         uint32_t c = 0u;                      // equal bytes seen by this lane in the first forward round (0..8)
-        {
-            const uint32_t a = m4 + 8u * g;
-            if (a < limit) {
-                const uint32_t rem = limit - a;
-                const uint32_t b = c4 + 8u * g;
-                if (rem >= 8u) {
-                    const uint64_t diff = cld64(in + a) ^ cld64(in + b);
-                    c = diff ? (uint32_t)(__builtin_ctzll(diff) >> 3) : 8u;
-                } else {
-                    while (c < rem && in[a + c] == in[b + c]) ++c;
-                }
+        if (f8) c = fdiff ? (uint32_t)(__builtin_ctzll(fdiff) >> 3) : 8u;
+        if (__any(!f8 && fa < limit)) {       // rare: the last (< 8 byte) chunk before the end of the block
+            if (!f8 && fa < limit) {
+                const uint32_t rem = limit - fa;
+                while (c < rem && in[fa + c] == in[fb + c]) ++c;
             }
         }
         // ---- backtrack (compress.rs:442-448)
         {
             const uint32_t okm = grp.ballot(bk_ok0 && bka == bkb);
+        PHASE_MARK(4)   // extension round trip
             uint32_t nb = (uint32_t)__builtin_ctz(~okm);                      // G..31 bits are 0 in okm => nb <= G
             cur -= nb; cnd -= nb;
             while (nb == (uint32_t)G) {                                       // rare: more than G bytes backwards
@@ -284,29 +296,46 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
         }
         const uint32_t cur_end = m4 + dl;
         dl = cur_end - (cur + 4u);                                            // duplicate_length counts from the backtracked start + 4
-        cur = cur_end;
-        PHASE_MARK(4)   // backward + forward extension
-        // ------------------------------------------------------------------ table: cur-2 (compress.rs:460-461)
-        // (its input bytes are requested here, together with the literal bytes below: one round trip)
-        const uint32_t q = cur - 2u;
-        const uint64_t qx = use_h5 ? cld64(in + q) : (uint64_t)cld32(in + q);
+        PHASE_MARK(5)   // backtrack + forward resolution
+        // ------------------------------------------------------------------ requests for the NEXT step: the bytes of
+        // the cur-2 table update (compress.rs:460-461) and of the first probe batch after this match
+        const uint32_t q = cur_end - 2u;
+        const uint64_t qx = cld64(in + q);                                    // q + 8 <= n: matches end >= 6 bytes early
+        const uint64_t xn = cld64(in + (cur_end + g <= end_check ? cur_end + g : 0u));
+        PHASE_MARK(6)   // next-step requests issued
         // ------------------------------------------------------------------ emit (compress.rs:463-486)
-        o = emit_literals<G>(out, o, in, lit_start, lit_len, dl < 15u ? dl : 15u, g);
-        if (g == 0u) tbl[use_h5 ? hidx5(qx) : hidx4((uint32_t)qx)] = (TblT)q;
-        if (g == 0u) { out[o] = (uint8_t)(offset & 0xFFu); out[o + 1u] = (uint8_t)(offset >> 8); }
-        o += 2u;
-        if (dl >= 15u) {
-            const uint32_t rem = dl - 15u;
-            const uint32_t n255 = rem / 255u;
-            for (uint32_t k = g; k < n255; k += G) out[o + k] = 0xFFu;
-            o += n255;
-            if (g == 0u) out[o] = (uint8_t)(rem - n255 * 255u);
-            o += 1u;
+        if (i0 == 0u && base == lit_start && lit_len <= 7u && dl < 270u && o + 12u <= cap) {
+            // the match was found in the first batch: all (<= 7) literals sit in lane 0's probe bytes.
+            // token+literals as one 8-byte store, offset + length byte as one 4-byte store (bytes past the
+            // sequence are rewritten by the next one; the capacity check above keeps them inside `out`)
+            const uint32_t tk = (lit_len << 4) | (dl < 15u ? dl : 15u);
+            const uint64_t w0 = (uint64_t)tk | (x << 8);
+            const uint32_t w1 = offset | ((dl - 15u) << 16);
+            if (g == 0u) {
+                __builtin_memcpy(out + o, &w0, 8);
+                __builtin_memcpy(out + o + 1u + lit_len, &w1, 4);
+            }
+            o += 3u + lit_len + (dl >= 15u ? 1u : 0u);
+        } else {
+            o = emit_literals<G>(out, o, in, lit_start, lit_len, dl < 15u ? dl : 15u, g);
+            if (g == 0u) { out[o] = (uint8_t)(offset & 0xFFu); out[o + 1u] = (uint8_t)(offset >> 8); }
+            o += 2u;
+            if (dl >= 15u) {
+                const uint32_t rem = dl - 15u;
+                const uint32_t n255 = rem / 255u;
+                for (uint32_t k = g; k < n255; k += G) out[o + k] = 0xFFu;
+                o += n255;
+                if (g == 0u) out[o] = (uint8_t)(rem - n255 * 255u);
+                o += 1u;
+            }
         }
-        lit_start = cur;                                                      // compress.rs:487
-        base = cur;
+        if (g == 0u) tbl[use_h5 ? hidx5(qx) : hidx4((uint32_t)qx)] = (TblT)q;
+        lit_start = cur_end;                                                  // compress.rs:487
+        base = cur_end;
         i0 = 0u;
-        PHASE_MARK(5)   // cur-2 table update + emit
+        if (progress && g == 0u) *progress = cur_end;
+        x = xn;
+        PHASE_MARK(7)   // emit + cur-2 table update (waits for its bytes)
     }
     // handle_last_literals, compress.rs:237-247
     o = emit_literals<G>(out, o, in, lit_start, n - lit_start, 0u, g);
@@ -315,6 +344,253 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Windowed encoder (default for independent blocks).  Same algorithm and same bytes as encode_block; what
+// changes is where the CURRENT-side bytes come from.  A global load costs >= ~370 cycles on MI355X even when
+// it hits the CU's L1 (tools/ubench_mem.hip), an unaligned LDS read ~145, and the encoder is a serial chain
+// per block (at most 20 blocks fit a CU: the 8 KiB tables fill the LDS), so the chain length IS the
+// throughput.  Each block therefore keeps a small ring of its input around the probing position in LDS:
+//   * the ring is filled by coalesced 16 B/lane loads issued at the top of a step and written to LDS after
+//     the step's candidate round trip has been waited for anyway (in-order vmcnt: no extra wait);
+//   * probe bytes, the 8 bytes behind a match, the current side of the forward extension, the cur-2 table
+//     update and the next step's probe bytes are unaligned LDS reads; any read the ring does not cover
+//     (start-up, after a long match, tail of the block) falls back to the global load of encode_block;
+//   * the candidate side (verification, backward and forward bytes) stays in HBM/L2: 2 dependent global
+//     round trips per sequence instead of 3, and no literal load for sequences with <= 7 literals.
+#define LZ4_WIN 1024u       // ring bytes per block (power of two)
+#define LZ4_WIN_PAD 16u     // mirror of ring bytes [0,16): unaligned reads across the wrap
+#define LZ4_WIN_HIST 64u    // bytes kept behind the first probe of the current batch
+
+// LDS-typed views of the ring: a generic pointer would let the compiler fold "ring or memory" into one FLAT
+// load, which is as slow as the global load the ring exists to avoid
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef uint32_t __attribute__((address_space(3), aligned(1))) lds_u32_unaligned;
+typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+typedef u32x4 __attribute__((address_space(3))) lds_u128;
+
+struct Win {
+    const uint8_t* in;   // block input (global)
+    lds_u8* ring;        // LDS, LZ4_WIN + LZ4_WIN_PAD bytes, 16-aligned
+    uint32_t lo, hi;     // ring holds input positions [lo, hi) (hi - lo <= LZ4_WIN by construction)
+    __device__ __forceinline__ uint64_t lds64(uint32_t p) const {
+        lds_u8* a = ring + (p & (LZ4_WIN - 1u));
+        const uint32_t v0 = *reinterpret_cast<lds_u32_unaligned*>(a);
+        const uint32_t v1 = *reinterpret_cast<lds_u32_unaligned*>(a + 4);
+        return (uint64_t)v0 | ((uint64_t)v1 << 32);
+    }
+    // 8 input bytes at p (caller guarantees p + 8 <= n).  The ring read is unconditional (any address is
+    // inside the ring); memory is touched only by the lanes the ring does not cover.
+    __device__ __forceinline__ uint64_t rd64(uint32_t p) const {
+        uint64_t v = lds64(p);
+        if (!(p >= lo && p + 8u <= hi)) v = cld64(in + p);
+        return v;
+    }
+};
+
+template <int G, typename TblT>
+__device__ __forceinline__ int32_t encode_block_w(const uint8_t* __restrict__ in, uint32_t n, uint8_t* __restrict__ out,
+                                                  uint32_t cap, uint32_t flags, TblT* tbl, uint8_t* ring,
+                                                  const Grp<G> grp, uint32_t* produced) {
+    const uint32_t g = grp.g;
+    if ((uint64_t)cap < max_output_size(n)) return LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL;   // compress.rs:338-340
+    uint32_t o = 0u;
+    if (n < LZ4_MIN_LENGTH) {   // compress.rs:343-346
+        o = emit_literals<G>(out, o, in, 0u, n, 0u, g);
+        *produced = o;
+        return 0;
+    }
+    const bool frame_tbl = (flags & 2u) != 0u;        // FrameEncoder: HashTable4K + hash5 always
+    const bool continuation = (flags & 1u) != 0u;     // table holds only unreachable entries; pos 0 is probed
+    const bool use_h5 = frame_tbl || n >= 65535u;     // compress.rs:559-566
+    const uint32_t end_check = n - LZ4_MFLIMIT;       // compress.rs:349
+    const uint32_t limit = n - LZ4_END_OFFSET;        // matches end 6 bytes before the end
+    {   // zero the table (HashTable::new / clear)
+        uint4* t4 = reinterpret_cast<uint4*>(tbl);
+        const uint32_t n16 = (4096u * (uint32_t)sizeof(TblT)) / 16u;
+        for (uint32_t k = g; k < n16; k += G) t4[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const uint32_t idx0 = use_h5 ? hidx5(cld64(in)) : hidx4(cld32(in));
+    Win w;
+    w.in = in; w.ring = (lds_u8*)ring; w.lo = 0u; w.hi = 0u;
+    uint32_t lit_start = 0u;
+    uint32_t base = continuation ? 0u : 1u;   // probing origin of the current sequence (compress.rs:353-359)
+    uint32_t i0 = continuation ? 1u : 0u;     // index of the first probe of the next batch
+    uint64_t x = 0ull;                        // the 8 input bytes at this lane's probe position
+    {
+        const uint32_t p0 = probe_pos(base, i0 + g);
+        if (p0 <= end_check) x = cld64(in + p0);
+    }
+    for (;;) {
+        // ------------------------------------------------------------------ ring refill (request)
+        const uint32_t pfirst = probe_pos(base, i0);
+        if (pfirst >= w.hi) {   // the ring is entirely behind the probes (start, long match): restart it here
+            const uint32_t back = pfirst < LZ4_WIN_HIST ? pfirst : LZ4_WIN_HIST;
+            w.lo = w.hi = (pfirst - back) & ~15u;
+        }
+        const bool do_fill = (w.hi + 16u * G <= n) && (w.hi + 16u * G + LZ4_WIN_HIST <= pfirst + LZ4_WIN);
+        u32x4 fv = {0u, 0u, 0u, 0u};
+        if (do_fill) __builtin_memcpy(&fv, in + w.hi + 16u * g, 16);
+        // ------------------------------------------------------------------ probe batch
+        const uint32_t i = i0 + g;
+        const uint32_t p = probe_pos(base, i);
+        const bool valid = p <= end_check;                                    // compress.rs:381
+        uint32_t idx = 0xFFFF0000u + g;   // distinct sentinels for invalid lanes
+        uint32_t cand = 0u;
+        const uint32_t cur4 = (uint32_t)x;
+        bool cand_ok = false;
+        if (valid) {
+            idx = use_h5 ? hidx5(x) : hidx4(cur4);
+            cand = (uint32_t)tbl[idx];
+            cand_ok = !continuation || cand != 0u || idx == idx0;             // see encode_block
+        }
+        const uint32_t d = FwdConflict<G, 1>::run(idx, g);
+        if (d != 0u) { cand = probe_pos(base, i - d); cand_ok = true; }
+        bool is_match = false;
+        if (valid && cand_ok && (p - cand) <= LZ4_MAX_DISTANCE)                // compress.rs:403-405
+            is_match = cld32(in + cand) == cur4;                              // compress.rs:432-438
+        const uint32_t mm = grp.ballot(is_match);
+        // ------------------------------------------------------------------ ring refill (commit): the data arrived
+        // with the candidate bytes
+        if (do_fill) {
+            const uint32_t ro = (w.hi + 16u * g) & (LZ4_WIN - 1u);
+            *reinterpret_cast<lds_u128*>(w.ring + ro) = fv;
+            if (ro == 0u) *reinterpret_cast<lds_u128*>(w.ring + LZ4_WIN) = fv;
+            w.hi += 16u * G;
+        }
+        const uint32_t vm = grp.ballot(valid);
+        const uint32_t last = mm ? (uint32_t)__builtin_ctz(mm) : (G - 1u);     // last probe that executes
+        bool superseded = false;
+        if (__any(d != 0u)) superseded = BwdConflict<G, 1>::run(idx, g, last);
+        if (valid && g <= last && !superseded) tbl[idx] = (TblT)p;            // compress.rs:393
+        if (mm == 0u) {
+            if (vm != (((G == 32) ? 0xFFFFFFFFu : ((1u << G) - 1u)))) break;   // ran past end_check: last literals
+            i0 += G;
+            const uint32_t pn = probe_pos(base, i0 + g);
+            x = 0ull;
+            if (pn <= end_check) x = w.rd64(pn);
+            continue;
+        }
+        uint32_t cur = grp.bcast(p, last);
+        uint32_t cnd = grp.bcast(cand, last);
+        const uint32_t offset = cur - cnd;                                    // compress.rs:409
+        // ------------------------------------------------------------------ extension, one round trip: 8 bytes behind
+        // the match and 8*G bytes after it.  Current side from the ring, candidate side from memory.
+        const uint32_t m4 = cur + 4u, c4 = cnd + 4u;
+        const uint32_t nbmax = min(cur - lit_start, cnd);                     // compress.rs:442-448 bounds
+        const bool bk_fast = cur >= 8u && cnd >= 8u;
+        uint32_t eq = 0u;
+        if (bk_fast && nbmax != 0u) {
+            const uint64_t df = w.rd64(cur - 8u) ^ cld64(in + cnd - 8u);
+            eq = df ? (uint32_t)(__builtin_clzll(df) >> 3) : 8u;
+        }
+        uint32_t c = 0u;                      // equal bytes seen by this lane in the first forward round (0..8)
+        {
+            const uint32_t a = m4 + 8u * g;
+            if (a < limit) {
+                const uint32_t rem = limit - a;
+                const uint32_t b = c4 + 8u * g;
+                if (rem >= 8u) {
+                    const uint64_t diff = w.rd64(a) ^ cld64(in + b);
+                    c = diff ? (uint32_t)(__builtin_ctzll(diff) >> 3) : 8u;
+                } else {
+                    while (c < rem && in[a + c] == in[b + c]) ++c;
+                }
+            }
+        }
+        // ---- backtrack (compress.rs:442-448)
+        {
+            uint32_t nb = eq < nbmax ? eq : nbmax;
+            if (!bk_fast) nb = 0u;
+            cur -= nb; cnd -= nb;
+            // rare: block start (fewer than 8 bytes before either side) or more than 8 equal bytes
+            bool more = !bk_fast ? (nbmax != 0u) : (nb == 8u && nbmax > 8u);
+            while (__any(more)) {
+                if (more) {
+                    const bool ok = (cnd > g) && (cur > lit_start + g) && in[cur - 1u - g] == in[cnd - 1u - g];
+                    const uint32_t okm2 = grp.ballot(ok);
+                    const uint32_t nb2 = (uint32_t)__builtin_ctz(~okm2);
+                    cur -= nb2; cnd -= nb2;
+                    more = nb2 == (uint32_t)G;
+                }
+            }
+        }
+        const uint32_t lit_len = cur - lit_start;                             // compress.rs:451
+        // ---- forward (count_same_bytes :156-216)
+        uint32_t dl = 0u;
+        {
+            uint32_t part = grp.ballot(c != 8u);
+            if (part != 0u) {
+                const uint32_t f = (uint32_t)__builtin_ctz(part);
+                dl = 8u * f + grp.bcast(c, f);
+            } else {
+                dl = 8u * G;
+                for (;;) {
+                    const uint32_t a = m4 + dl + 8u * g;
+                    uint32_t c2 = 0u;
+                    if (a < limit) {
+                        const uint32_t rem = limit - a;
+                        const uint32_t b = c4 + dl + 8u * g;
+                        if (rem >= 8u) {
+                            const uint64_t diff = cld64(in + a) ^ cld64(in + b);
+                            c2 = diff ? (uint32_t)(__builtin_ctzll(diff) >> 3) : 8u;
+                        } else {
+                            while (c2 < rem && in[a + c2] == in[b + c2]) ++c2;
+                        }
+                    }
+                    part = grp.ballot(c2 != 8u);
+                    if (part == 0u) { dl += 8u * G; continue; }
+                    const uint32_t f = (uint32_t)__builtin_ctz(part);
+                    dl += 8u * f + grp.bcast(c2, f);
+                    break;
+                }
+            }
+        }
+        const uint32_t cur_end = m4 + dl;
+        dl = cur_end - (cur + 4u);                                            // duplicate_length counts from the backtracked start + 4
+        // ------------------------------------------------------------------ bytes for the cur-2 table update
+        // (compress.rs:460-461) and for the first probe batch after this match
+        const uint32_t q = cur_end - 2u;
+        const uint64_t qx = w.rd64(q);                                        // q + 8 <= n: matches end >= 6 bytes early
+        uint64_t xn = 0ull;
+        if (cur_end + g <= end_check) xn = w.rd64(cur_end + g);
+        // ------------------------------------------------------------------ emit (compress.rs:463-486)
+        if (i0 == 0u && base == lit_start && lit_len <= 7u && dl < 270u && o + 12u <= cap) {
+            // the match was found in the first batch: all (<= 7) literals sit in lane 0's probe bytes.
+            // token+literals as one 8-byte store, offset + length byte as one 4-byte store (bytes past the
+            // sequence are rewritten by the next one; the capacity check above keeps them inside `out`)
+            const uint32_t tk = (lit_len << 4) | (dl < 15u ? dl : 15u);
+            const uint64_t w0 = (uint64_t)tk | (x << 8);
+            const uint32_t w1 = offset | ((dl - 15u) << 16);
+            if (g == 0u) {
+                __builtin_memcpy(out + o, &w0, 8);
+                __builtin_memcpy(out + o + 1u + lit_len, &w1, 4);
+            }
+            o += 3u + lit_len + (dl >= 15u ? 1u : 0u);
+        } else {
+            o = emit_literals<G>(out, o, in, lit_start, lit_len, dl < 15u ? dl : 15u, g);
+            if (g == 0u) { out[o] = (uint8_t)(offset & 0xFFu); out[o + 1u] = (uint8_t)(offset >> 8); }
+            o += 2u;
+            if (dl >= 15u) {
+                const uint32_t rem = dl - 15u;
+                const uint32_t n255 = rem / 255u;
+                for (uint32_t k = g; k < n255; k += G) out[o + k] = 0xFFu;
+                o += n255;
+                if (g == 0u) out[o] = (uint8_t)(rem - n255 * 255u);
+                o += 1u;
+            }
+        }
+        if (g == 0u) tbl[use_h5 ? hidx5(qx) : hidx4((uint32_t)qx)] = (TblT)q;
+        lit_start = cur_end;                                                  // compress.rs:487
+        base = cur_end;
+        i0 = 0u;
+        x = xn;
+    }
+    // handle_last_literals, compress.rs:237-247
+    o = emit_literals<G>(out, o, in, lit_start, n - lit_start, 0u, g);
+    *produced = o;
+    return 0;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // General encoder: the full signature of compress_internal<T, USE_DICT> (src/block/compress.rs:318-489):
@@ -505,42 +781,96 @@ hipError_t launch_compress_chain(const uint8_t* in_base, const void* blocks, con
     return hipGetLastError();
 }
 
-template <int G, typename TblT>
-__global__ void __launch_bounds__(64) lz4_compress_blocks_kernel(CompressArgs a) {
-    constexpr int BPW = 64 / G;   // blocks per workgroup (one wave)
+// MODE 0: encode_block (everything read from HBM/L2).  MODE 1: encode_block_w (LDS input ring).
+// MODE 2: encode_block plus a second wavefront per workgroup that only walks ahead of the encoders and touches
+// the input lines they are about to need, so that the encoders' current-side loads hit L2 instead of paying
+// the first-touch HBM latency inside their serial chain (an in-order vmcnt makes self-prefetching useless:
+// a load behind a missing prefetch waits for it).
+#define LZ4_PF_AHEAD 2048u
+template <int G, typename TblT, int MODE>
+__global__ void __launch_bounds__(MODE == 2 ? 128 : 64) lz4_compress_blocks_kernel(CompressArgs a) {
+    constexpr int BPW = 64 / G;   // blocks per workgroup (one encoder wave)
+    constexpr bool WINDOW = MODE == 1;
     __shared__ __attribute__((aligned(16))) TblT tables[BPW][4096];
-    const uint32_t lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) uint8_t rings[WINDOW ? BPW : 1][WINDOW ? (LZ4_WIN + LZ4_WIN_PAD) : 16];
+    __shared__ uint32_t progress[BPW];
+    const uint32_t lane = threadIdx.x & 63u;
     Grp<G> grp;
     grp.g = lane % G;
     grp.shift = (lane / G) * G;
     const uint32_t b = blockIdx.x * BPW + lane / G;
-    if (b >= a.n) return;
+    if (MODE == 2) {
+        if (threadIdx.x < BPW) progress[threadIdx.x] = 0u;
+        __syncthreads();
+        if (threadIdx.x >= 64u) {
+            // ---- the prefetch wave: lane group j follows block j
+            const bool live = b < a.n;
+            const uint32_t n = live ? a.in_len[b] : 0u;
+            const uint8_t* in = a.in_base + (live ? a.in_off[b] : 0ull);
+            uint32_t pf = 0u, acc = 0u;
+            for (;;) {
+                const uint32_t pos = live ? *reinterpret_cast<volatile uint32_t*>(&progress[lane / G]) : 0xFFFFFFFFu;
+                const bool done = pos == 0xFFFFFFFFu;
+                if (!__any(!done)) break;
+                if (!done) {
+                    if (pf < pos) pf = pos & ~127u;
+                    if (pf < pos + LZ4_PF_AHEAD - 128u * G) {
+                        const uint32_t at = pf + 128u * grp.g;
+                        if (at + 4u <= n) acc += *reinterpret_cast<const volatile uint32_t*>(in + (at & ~3u));
+                        pf += 128u * G;
+                    }
+                }
+                __builtin_amdgcn_s_sleep(64);
+            }
+            if (acc == 0x9E3779B9u && live) progress[lane / G] = acc;   // keeps the loads alive
+            return;
+        }
+    }
+    if (b >= a.n) {
+        if (MODE == 2 && grp.g == 0u) progress[lane / G] = 0xFFFFFFFFu;
+        return;
+    }
     const uint32_t n = a.in_len[b];
     const uint32_t flags = a.flags ? a.flags[b] : 0u;
     uint32_t produced = 0u;
-    const int32_t st = encode_block<G, TblT>(a.in_base + a.in_off[b], n, a.out_base + a.out_off[b], a.out_cap[b], flags,
-                                             &tables[lane / G][0], grp, &produced);
+    int32_t st;
+    if (WINDOW)
+        st = encode_block_w<G, TblT>(a.in_base + a.in_off[b], n, a.out_base + a.out_off[b], a.out_cap[b], flags,
+                                     &tables[lane / G][0], &rings[WINDOW ? lane / G : 0][0], grp, &produced);
+    else
+        st = encode_block<G, TblT>(a.in_base + a.in_off[b], n, a.out_base + a.out_off[b], a.out_cap[b], flags,
+                                   &tables[lane / G][0], grp, &produced, MODE == 2 ? &progress[lane / G] : nullptr);
+    if (MODE == 2 && grp.g == 0u) *reinterpret_cast<volatile uint32_t*>(&progress[lane / G]) = 0xFFFFFFFFu;
     if (grp.g == 0u) {
         a.status[b] = st;
         a.out_len[b] = st == 0 ? produced : 0u;
     }
 }
 
-template <int G, typename TblT>
+template <int G, typename TblT, int MODE>
 static hipError_t launch_c(const CompressArgs& a, hipStream_t s) {
     constexpr uint32_t BPW = 64 / G;
     const uint32_t grid = (a.n + BPW - 1u) / BPW;
-    hipLaunchKernelGGL((lz4_compress_blocks_kernel<G, TblT>), dim3(grid), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((lz4_compress_blocks_kernel<G, TblT, MODE>), dim3(grid), dim3(MODE == 2 ? 128 : 64), 0, s, a);
     return hipGetLastError();
 }
 
-// variant: bits 0..7 = lanes per block (8 or 16), bit 8 = blocks may exceed 64 KiB (u32 table)
+template <int G, typename TblT>
+static hipError_t launch_m(const CompressArgs& a, int mode, hipStream_t s) {
+    if (mode == 1) return launch_c<G, TblT, 1>(a, s);
+    if (mode == 2) return launch_c<G, TblT, 2>(a, s);
+    return launch_c<G, TblT, 0>(a, s);
+}
+
+// variant: bits 0..7 = lanes per block (8 or 16), bit 8 = blocks may exceed 64 KiB (u32 table),
+// bits 9..10 = mode (0 encode_block, 1 LDS input ring, 2 encode_block + prefetch wave)
 hipError_t launch_compress(const CompressArgs& a, int variant, hipStream_t s) {
     if (a.n == 0u) return hipSuccess;
     const int G = variant & 0xFF;
     const bool big = (variant & 0x100) != 0;
-    if (G == 8) return big ? launch_c<8, uint32_t>(a, s) : launch_c<8, uint16_t>(a, s);
-    if (G == 16) return big ? launch_c<16, uint32_t>(a, s) : launch_c<16, uint16_t>(a, s);
+    const int mode = (variant >> 9) & 3;
+    if (G == 8) return big ? launch_m<8, uint32_t>(a, mode, s) : launch_m<8, uint16_t>(a, mode, s);
+    if (G == 16) return big ? launch_m<16, uint32_t>(a, mode, s) : launch_m<16, uint16_t>(a, mode, s);
     return hipErrorInvalidValue;
 }
 

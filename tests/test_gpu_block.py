@@ -236,16 +236,19 @@ def _tile(src, total, block):
     return buf
 
 
-@pytest.mark.parametrize("lanes", [8, 16, 0])
+@pytest.mark.parametrize("lanes", [8, 16, 0, -8, -16])
 def test_compress_batch_bit_exact_vs_oracle(blk, lanes):
-    """lanes 8/16: lz4_compress.hip group widths; lanes 0: the experimental LDS-staged encoder (variant 2)"""
+    """lanes 8/16: lz4_compress.hip group widths (default: with the LDS input ring; negative: without it,
+    variant 3); lanes 0: the experimental LDS-staged encoder (variant 2)"""
     from lz4_flex_amd import _lib
     import ctypes as C
     lib = _lib.load()
     ctx = C.c_void_p()
     assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
     if lanes:
-        assert lib.lz4flex_set_tuning(ctx, b"compress_lanes", lanes) == 0
+        assert lib.lz4flex_set_tuning(ctx, b"compress_lanes", abs(lanes)) == 0
+        if lanes < 0:
+            assert lib.lz4flex_set_tuning(ctx, b"compress_variant", 3) == 0
     else:
         assert lib.lz4flex_set_tuning(ctx, b"compress_variant", 2) == 0
     try:

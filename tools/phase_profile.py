@@ -41,7 +41,7 @@ def main():
     torch.cuda.synchronize()
     cyc = (C.c_ulonglong * 8)()
     cnt = (C.c_ulonglong * 8)()
-    dbg = lib.lz4flex_debug_phase2 if variant == 2 else lib.lz4flex_debug_phase
+    dbg = lib.lz4flex_debug_phase2 if variant == 2 else lib.lz4flex_debug_phase   # variant 3 = the instrumented plain encoder
     dbg.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     dbg(None, None, 1)
     comp, comp_off, comp_len, in_len = sharded.compress_blocks_device(src, 65536, flags)
@@ -58,7 +58,7 @@ def main():
         for k in range(4):
             print("%-28s cycles/visit %8.0f  visits %10d  share %5.1f%%" % (names[k], cyc[k] / max(cnt[k], 1), cnt[k], 100.0 * cyc[k] / max(tot, 1)))
         return
-    names = ["loop/emit tail", "probe+hash+table read", "conflict+cand load+verify", "table stores", "extension", "cur-2+emit", "-", "-"]
+    names = ["top: probe wait+hash+tbl issue", "tbl wait+conflict", "cand round trip+verify", "tbl stores+winner bcast", "extension round trip", "backtrack+forward math", "next requests issue", "emit+cur-2 update"]
     if variant == 2:
         names = ["loop", "window/stage maintenance", "generic steps", "fast steps (all)", "fs: window reads+hash+table", "fs: conflict masks+load issue",
                  "fs: wait+verify+extension math", "fs: ballots+table stores"]
