@@ -31,8 +31,9 @@ static int hip_fail(hipError_t e, const char* what) {
         if (_e != hipSuccess) return hip_fail(_e, #expr); \
     } while (0)
 
-// compress_variant -> launch_compress mode bits: 1 = LDS input ring, 3 = plain, 4 = plain + prefetch wave
-static inline int comp_mode_bits(int v) { return v == 1 ? 0x200 : (v == 4 ? 0x400 : 0); }
+// compress_variant -> launch_compress mode bits: 1 = encode_block + prefetch wave (default), 3 = encode_block alone,
+// 4 = LDS input ring + filler wave (experimental)
+static inline int comp_mode_bits(int v) { return (v == 1 ? 0x400 : (v == 4 ? 0x200 : 0)) | (getenv("LZ4FLEX_HALF") ? 0x800 : 0); }
 
 struct lz4flex_ctx {
     int device = 0;
@@ -43,7 +44,7 @@ struct lz4flex_ctx {
     size_t pin_cap = 0;
     int dec_lanes = 16;           // lanes per block, decode
     int comp_lanes = 8;           // lanes per block, encode
-    int comp_variant = 1;         // 1 = lz4_compress.hip with the LDS input ring (any block size, default), 2 = experimental fully LDS-staged lz4_compress_lds.hip (<= 64 KiB; bit-exact, slower), 3 = lz4_compress.hip without the ring
+    int comp_variant = 1;         // 1 = lz4_compress.hip encoder + prefetch wave (default), 3 = the same without the prefetch wave, 4 = with an LDS ring of the input fed by a filler wave (experimental, slower), 2 = experimental fully LDS-staged lz4_compress_lds.hip (<= 64 KiB, slower); all bit-exact
     int ablate = 0;               // timing ablations (wrong output!), see lz4flex_set_tuning("ablate")
     int dec_variant = 3;          // 1 = window in HBM/L2 (lz4_decompress.hip), 2 = LDS-staged generic loop, 3 = LDS-staged pipelined (lz4_decompress_lds.hip)
 };

@@ -23,6 +23,7 @@
 //     G probes of a batch read adjacent positions), output bytes are written once.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "lz4_device.h"
 
@@ -35,10 +36,14 @@ __device__ unsigned long long g_phase_cycles[8];
 __device__ unsigned long long g_phase_counts[8];
 #define PHASE_DECL unsigned long long _pt = __builtin_readcyclecounter(); unsigned long long _pacc[8] = {0,0,0,0,0,0,0,0}; unsigned _pcnt[8] = {0,0,0,0,0,0,0,0};
 #define PHASE_MARK(k) { const unsigned long long _n = __builtin_readcyclecounter(); _pacc[k] += _n - _pt; _pcnt[k]++; _pt = _n; }
+#define PHASE_COUNT(k) _pcnt[k]++;
+#define PHASE_WAIT_VM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #define PHASE_FLUSH if (threadIdx.x == 0) { for (int _k = 0; _k < 8; ++_k) { atomicAdd(&g_phase_cycles[_k], _pacc[_k]); atomicAdd(&g_phase_counts[_k], (unsigned long long)_pcnt[_k]); } }
 #else
 #define PHASE_DECL
 #define PHASE_MARK(k)
+#define PHASE_COUNT(k)
+#define PHASE_WAIT_VM
 #define PHASE_FLUSH
 #endif
 
@@ -79,8 +84,8 @@ __device__ __forceinline__ uint32_t row_shl(uint32_t v, uint32_t fill) {
 // position of probe `i` of a sequence whose probing started at `base`
 // (src/block/compress.rs:367-378: step = (32 + i) >> 5)
 __device__ __forceinline__ uint32_t probe_pos(uint32_t base, uint32_t i) {
-    const uint32_t q = 1u + (i >> 5), r = i & 31u;
-    return base + 16u * q * (q - 1u) + r * q;
+    const uint32_t q = 1u + (i >> 5), r = i & 31u;   // q < 2^15 for any block below 4 GiB: operands fit 24 bits, the products 32
+    return base + 16u * __umul24(q, q - 1u) + __umul24(r, q);
 }
 
 template <int G>
@@ -148,7 +153,8 @@ __device__ __forceinline__ uint32_t emit_literals(uint8_t* out, uint32_t o, cons
     return o + lit_len;
 }
 
-template <int G, typename TblT>
+// HM: hash selection known at compile time (0: 4-byte hash, 1: 5-byte hash) or per block at run time (2)
+template <int G, typename TblT, int HM>
 __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, uint32_t n, uint8_t* __restrict__ out,
                                                 uint32_t cap, uint32_t flags, TblT* tbl, const Grp<G> grp,
                                                 uint32_t* produced, volatile uint32_t* progress) {
@@ -162,7 +168,7 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
     }
     const bool frame_tbl = (flags & 2u) != 0u;        // FrameEncoder: HashTable4K + hash5 always
     const bool continuation = (flags & 1u) != 0u;     // table holds only unreachable entries; pos 0 is probed
-    const bool use_h5 = frame_tbl || n >= 65535u;     // compress.rs:559-566
+    const bool use_h5 = HM == 2 ? (frame_tbl || n >= 65535u) : (HM == 1);   // compress.rs:559-566
     const uint32_t end_check = n - LZ4_MFLIMIT;       // compress.rs:349
     // zero the table (HashTable::new / clear)
     {
@@ -187,8 +193,11 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
         const uint32_t p0 = probe_pos(base, i0 + g);
         x = cld64(in + (p0 <= end_check ? p0 : 0u));
     }
+    uint64_t x0 = 0ull;   // probe bytes of the FIRST batch of the current sequence: lanes 0 and 7 hold its first 15 literals
+    uint32_t x0_base = 0xFFFFFFFFu;   // position lane 0's x0 was read from
     for (;;) {
         // ------------------------------------------------------------------ probe batch
+        if (i0 == 0u) { x0 = x; x0_base = base; }
         const uint32_t i = i0 + g;
         const uint32_t p = probe_pos(base, i);
         const bool valid = p <= end_check;                                    // compress.rs:381
@@ -302,21 +311,26 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
         const uint32_t q = cur_end - 2u;
         const uint64_t qx = cld64(in + q);                                    // q + 8 <= n: matches end >= 6 bytes early
         const uint64_t xn = cld64(in + (cur_end + g <= end_check ? cur_end + g : 0u));
-        PHASE_MARK(6)   // next-step requests issued
         // ------------------------------------------------------------------ emit (compress.rs:463-486)
-        if (i0 == 0u && base == lit_start && lit_len <= 7u && dl < 270u && o + 12u <= cap) {
-            // the match was found in the first batch: all (<= 7) literals sit in lane 0's probe bytes.
-            // token+literals as one 8-byte store, offset + length byte as one 4-byte store (bytes past the
-            // sequence are rewritten by the next one; the capacity check above keeps them inside `out`)
+        if (x0_base == lit_start && lit_len <= 14u && dl < 270u && o + 20u <= cap) {
+            // short literal run: the literals sit in the first batch's probe bytes (lane 0: bytes 0..7 of the run,
+            // lane 7: bytes 7..14).  token+literals as 8-byte stores, then offset + length byte as one 4-byte
+            // store (bytes past the sequence are rewritten by the next one; the capacity check above keeps
+            // them inside `out`)
             const uint32_t tk = (lit_len << 4) | (dl < 15u ? dl : 15u);
-            const uint64_t w0 = (uint64_t)tk | (x << 8);
+            const uint64_t w0 = (uint64_t)tk | (x0 << 8);
             const uint32_t w1 = offset | ((dl - 15u) << 16);
-            if (g == 0u) {
-                __builtin_memcpy(out + o, &w0, 8);
-                __builtin_memcpy(out + o + 1u + lit_len, &w1, 4);
-            }
+#ifndef LZ4FLEX_ABL_NOSTORE
+            if (g == 0u) __builtin_memcpy(out + o, &w0, 8);
+            if (G >= 8 && g == 7u && lit_len > 7u) __builtin_memcpy(out + o + 8u, &x0, 8);
+            if (g == 0u) __builtin_memcpy(out + o + 1u + lit_len, &w1, 4);
+#endif
             o += 3u + lit_len + (dl >= 15u ? 1u : 0u);
+#ifdef LZ4FLEX_ABL_NOGENERIC
+        } else if (false) {
+#else
         } else {
+#endif
             o = emit_literals<G>(out, o, in, lit_start, lit_len, dl < 15u ? dl : 15u, g);
             if (g == 0u) { out[o] = (uint8_t)(offset & 0xFFu); out[o + 1u] = (uint8_t)(offset >> 8); }
             o += 2u;
@@ -329,13 +343,17 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
                 o += 1u;
             }
         }
+        PHASE_MARK(6)   // next-step requests + emit
+        PHASE_WAIT_VM
+        PHASE_MARK(7)   // what is left of the next-step round trip after the emit
+#ifndef LZ4FLEX_ABL_NOQ
         if (g == 0u) tbl[use_h5 ? hidx5(qx) : hidx4((uint32_t)qx)] = (TblT)q;
+#endif
         lit_start = cur_end;                                                  // compress.rs:487
         base = cur_end;
         i0 = 0u;
         if (progress && g == 0u) *progress = cur_end;
         x = xn;
-        PHASE_MARK(7)   // emit + cur-2 table update (waits for its bytes)
     }
     // handle_last_literals, compress.rs:237-247
     o = emit_literals<G>(out, o, in, lit_start, n - lit_start, 0u, g);
@@ -347,51 +365,102 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
 
 // ---------------------------------------------------------------------------------------------------
 // Windowed encoder (default for independent blocks).  Same algorithm and same bytes as encode_block; what
-// changes is where the CURRENT-side bytes come from.  A global load costs >= ~370 cycles on MI355X even when
-// it hits the CU's L1 (tools/ubench_mem.hip), an unaligned LDS read ~145, and the encoder is a serial chain
-// per block (at most 20 blocks fit a CU: the 8 KiB tables fill the LDS), so the chain length IS the
-// throughput.  Each block therefore keeps a small ring of its input around the probing position in LDS:
-//   * the ring is filled by coalesced 16 B/lane loads issued at the top of a step and written to LDS after
-//     the step's candidate round trip has been waited for anyway (in-order vmcnt: no extra wait);
+// changes is where the CURRENT-side bytes come from.  The encoder is a serial chain per block and at most
+// 16..20 blocks fit a CU (the 8 KiB tables fill the LDS), so the chain length IS the throughput; a global load
+// costs 350-1000 cycles in that chain (tools/ubench_mem.hip), an unaligned LDS read ~150.  Each block therefore
+// keeps a ring of its input around the probing position in LDS:
+//   * a second wavefront of the workgroup (the filler) walks ahead of the encoders and copies the input into
+//     the rings with coalesced 16 B/lane loads.  The encoder wave never issues those loads itself: the
+//     vmcnt counter is in order, so a refill that misses to HBM would stall every later load of the chain;
+//   * encoder and filler talk through three LDS words per block: `prog` (first probe position of the encoder's
+//     current step, written by the encoder) and {lo, hi} (the ring holds input positions [lo, hi), written
+//     by the filler AFTER the data, as one 8-byte store);
 //   * probe bytes, the 8 bytes behind a match, the current side of the forward extension, the cur-2 table
-//     update and the next step's probe bytes are unaligned LDS reads; any read the ring does not cover
+//     update and the next step's probe bytes are unaligned LDS reads; a read the ring does not cover
 //     (start-up, after a long match, tail of the block) falls back to the global load of encode_block;
 //   * the candidate side (verification, backward and forward bytes) stays in HBM/L2: 2 dependent global
-//     round trips per sequence instead of 3, and no literal load for sequences with <= 7 literals.
+//     round trips per sequence instead of 3.
 #define LZ4_WIN 1024u       // ring bytes per block (power of two)
 #define LZ4_WIN_PAD 16u     // mirror of ring bytes [0,16): unaligned reads across the wrap
-#define LZ4_WIN_HIST 64u    // bytes kept behind the first probe of the current batch
+#define LZ4_WIN_HIST 64u    // bytes kept behind the encoder's first probe
+#define LZ4_WIN_CHUNK 128u  // filler granularity: 8 lanes x 16 B
 
-// LDS-typed views of the ring: a generic pointer would let the compiler fold "ring or memory" into one FLAT
-// load, which is as slow as the global load the ring exists to avoid
+// LDS-typed views: a generic pointer would let the compiler fold "ring or memory" into one FLAT load, which
+// is as slow as the global load the ring exists to avoid
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef uint32_t __attribute__((address_space(3), aligned(1))) lds_u32_unaligned;
 typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
 typedef u32x4 __attribute__((address_space(3))) lds_u128;
 
+struct WinCtl {              // per block, in LDS
+    uint32_t lo, hi;         // filler -> encoder (8-byte aligned pair)
+    uint32_t prog;           // encoder -> filler; 0xFFFFFFFF = block finished
+    uint32_t pad;
+};
+typedef volatile uint32_t __attribute__((address_space(3))) lds_vu32;
+typedef volatile uint64_t __attribute__((address_space(3))) lds_vu64;
+// LDS-typed accessors of a block's control words (ctl = LDS address of its WinCtl)
+struct WinCtlRef {
+    lds_u8* p;
+    __device__ __forceinline__ uint32_t prog() const { return *reinterpret_cast<lds_vu32*>(p + 8); }
+    __device__ __forceinline__ void set_prog(uint32_t v) const { *reinterpret_cast<lds_vu32*>(p + 8) = v; }
+    __device__ __forceinline__ uint64_t window() const { return *reinterpret_cast<lds_vu64*>(p); }
+    __device__ __forceinline__ void set_window(uint32_t lo, uint32_t hi) const {
+        *reinterpret_cast<lds_vu64*>(p) = (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+};
+
 struct Win {
     const uint8_t* in;   // block input (global)
     lds_u8* ring;        // LDS, LZ4_WIN + LZ4_WIN_PAD bytes, 16-aligned
-    uint32_t lo, hi;     // ring holds input positions [lo, hi) (hi - lo <= LZ4_WIN by construction)
+    uint32_t lo, hi;     // snapshot of the filler's window for this step
     __device__ __forceinline__ uint64_t lds64(uint32_t p) const {
         lds_u8* a = ring + (p & (LZ4_WIN - 1u));
         const uint32_t v0 = *reinterpret_cast<lds_u32_unaligned*>(a);
         const uint32_t v1 = *reinterpret_cast<lds_u32_unaligned*>(a + 4);
         return (uint64_t)v0 | ((uint64_t)v1 << 32);
     }
-    // 8 input bytes at p (caller guarantees p + 8 <= n).  The ring read is unconditional (any address is
-    // inside the ring); memory is touched only by the lanes the ring does not cover.
-    __device__ __forceinline__ uint64_t rd64(uint32_t p) const {
-        uint64_t v = lds64(p);
-        if (!(p >= lo && p + 8u <= hi)) v = cld64(in + p);
-        return v;
-    }
+    __device__ __forceinline__ bool covers(uint32_t p) const { return p >= lo && p + 8u <= hi; }
 };
+
+// the filler wave: lane group j (8 lanes) serves block j of the workgroup
+__device__ __forceinline__ void ring_filler(const uint8_t* in, uint32_t n, bool live, lds_u8* ring, const WinCtlRef ctl,
+                                            uint32_t g8) {
+    const uint32_t n_fill = n & ~(LZ4_WIN_CHUNK - 1u);   // whole chunks only; the tail is read from memory
+    uint32_t lo = 0u, hi = 0u;
+    for (;;) {
+        const uint32_t p = live ? ctl.prog() : 0xFFFFFFFFu;
+        const bool done = p == 0xFFFFFFFFu;
+        if (!__any(!done)) break;
+        bool fill = false;
+        if (!done) {
+            if (p >= hi) {   // the ring is behind the encoder (start, long match): restart it around p
+                const uint32_t back = p < LZ4_WIN_HIST ? p : LZ4_WIN_HIST;
+                lo = hi = (p - back) & ~(LZ4_WIN_CHUNK - 1u);
+            }
+            fill = hi + LZ4_WIN_CHUNK <= n_fill && hi + LZ4_WIN_CHUNK + LZ4_WIN_HIST <= p + LZ4_WIN;
+        }
+        if (__any(fill)) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            __builtin_memcpy(&v, in + (fill ? hi + 16u * g8 : 0u), 16);
+            if (fill) {
+                const uint32_t ro = (hi + 16u * g8) & (LZ4_WIN - 1u);
+                *reinterpret_cast<lds_u128*>(ring + ro) = v;
+                if (ro == 0u) *reinterpret_cast<lds_u128*>(ring + LZ4_WIN) = v;
+                hi += LZ4_WIN_CHUNK;
+                if (hi - lo > LZ4_WIN) lo = hi - LZ4_WIN;
+                if (g8 == 0u) ctl.set_window(lo, hi);   // published after the data (a wave's LDS operations execute in order)
+            }
+        } else {
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+}
 
 template <int G, typename TblT>
 __device__ __forceinline__ int32_t encode_block_w(const uint8_t* __restrict__ in, uint32_t n, uint8_t* __restrict__ out,
-                                                  uint32_t cap, uint32_t flags, TblT* tbl, uint8_t* ring,
-                                                  const Grp<G> grp, uint32_t* produced) {
+                                                  uint32_t cap, uint32_t flags, TblT* tbl, uint8_t* ring_generic,
+                                                  const WinCtlRef ctl, const Grp<G> grp, uint32_t* produced) {
     const uint32_t g = grp.g;
     if ((uint64_t)cap < max_output_size(n)) return LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL;   // compress.rs:338-340
     uint32_t o = 0u;
@@ -412,25 +481,23 @@ __device__ __forceinline__ int32_t encode_block_w(const uint8_t* __restrict__ in
     }
     const uint32_t idx0 = use_h5 ? hidx5(cld64(in)) : hidx4(cld32(in));
     Win w;
-    w.in = in; w.ring = (lds_u8*)ring; w.lo = 0u; w.hi = 0u;
+    w.in = in; w.ring = (lds_u8*)ring_generic; w.lo = 0u; w.hi = 0u;
     uint32_t lit_start = 0u;
     uint32_t base = continuation ? 0u : 1u;   // probing origin of the current sequence (compress.rs:353-359)
     uint32_t i0 = continuation ? 1u : 0u;     // index of the first probe of the next batch
-    uint64_t x = 0ull;                        // the 8 input bytes at this lane's probe position
+    uint64_t x;                               // the 8 input bytes at this lane's probe position
     {
         const uint32_t p0 = probe_pos(base, i0 + g);
-        if (p0 <= end_check) x = cld64(in + p0);
+        x = cld64(in + (p0 <= end_check ? p0 : 0u));
     }
+    PHASE_DECL
     for (;;) {
-        // ------------------------------------------------------------------ ring refill (request)
-        const uint32_t pfirst = probe_pos(base, i0);
-        if (pfirst >= w.hi) {   // the ring is entirely behind the probes (start, long match): restart it here
-            const uint32_t back = pfirst < LZ4_WIN_HIST ? pfirst : LZ4_WIN_HIST;
-            w.lo = w.hi = (pfirst - back) & ~15u;
+        // ------------------------------------------------------------------ window snapshot for this step
+        {
+            const uint64_t snap = ctl.window();
+            w.lo = (uint32_t)snap;
+            w.hi = (uint32_t)(snap >> 32);
         }
-        const bool do_fill = (w.hi + 16u * G <= n) && (w.hi + 16u * G + LZ4_WIN_HIST <= pfirst + LZ4_WIN);
-        u32x4 fv = {0u, 0u, 0u, 0u};
-        if (do_fill) __builtin_memcpy(&fv, in + w.hi + 16u * g, 16);
         // ------------------------------------------------------------------ probe batch
         const uint32_t i = i0 + g;
         const uint32_t p = probe_pos(base, i);
@@ -444,20 +511,13 @@ __device__ __forceinline__ int32_t encode_block_w(const uint8_t* __restrict__ in
             cand = (uint32_t)tbl[idx];
             cand_ok = !continuation || cand != 0u || idx == idx0;             // see encode_block
         }
+        PHASE_MARK(0)   // top: snapshot + hash + table read
         const uint32_t d = FwdConflict<G, 1>::run(idx, g);
         if (d != 0u) { cand = probe_pos(base, i - d); cand_ok = true; }
-        bool is_match = false;
-        if (valid && cand_ok && (p - cand) <= LZ4_MAX_DISTANCE)                // compress.rs:403-405
-            is_match = cld32(in + cand) == cur4;                              // compress.rs:432-438
+        const bool try_m = valid && cand_ok && (p - cand) <= LZ4_MAX_DISTANCE;  // compress.rs:403-405
+        const bool is_match = (cld32(in + (try_m ? cand : 0u)) == cur4) && try_m;   // compress.rs:432-438
         const uint32_t mm = grp.ballot(is_match);
-        // ------------------------------------------------------------------ ring refill (commit): the data arrived
-        // with the candidate bytes
-        if (do_fill) {
-            const uint32_t ro = (w.hi + 16u * g) & (LZ4_WIN - 1u);
-            *reinterpret_cast<lds_u128*>(w.ring + ro) = fv;
-            if (ro == 0u) *reinterpret_cast<lds_u128*>(w.ring + LZ4_WIN) = fv;
-            w.hi += 16u * G;
-        }
+        PHASE_MARK(1)   // conflict + candidate round trip
         const uint32_t vm = grp.ballot(valid);
         const uint32_t last = mm ? (uint32_t)__builtin_ctz(mm) : (G - 1u);     // last probe that executes
         bool superseded = false;
@@ -466,36 +526,48 @@ __device__ __forceinline__ int32_t encode_block_w(const uint8_t* __restrict__ in
         if (mm == 0u) {
             if (vm != (((G == 32) ? 0xFFFFFFFFu : ((1u << G) - 1u)))) break;   // ran past end_check: last literals
             i0 += G;
+            const uint32_t pf = probe_pos(base, i0);
+            if (g == 0u) ctl.set_prog(pf);
             const uint32_t pn = probe_pos(base, i0 + g);
-            x = 0ull;
-            if (pn <= end_check) x = w.rd64(pn);
+            const bool pv = pn <= end_check;
+            x = w.lds64(pn);
+            if (__any(pv && !w.covers(pn))) x = (pv && !w.covers(pn)) ? cld64(in + pn) : x;
             continue;
         }
         uint32_t cur = grp.bcast(p, last);
         uint32_t cnd = grp.bcast(cand, last);
         const uint32_t offset = cur - cnd;                                    // compress.rs:409
+        PHASE_MARK(2)   // table stores + winner broadcast
         // ------------------------------------------------------------------ extension, one round trip: 8 bytes behind
         // the match and 8*G bytes after it.  Current side from the ring, candidate side from memory.
         const uint32_t m4 = cur + 4u, c4 = cnd + 4u;
         const uint32_t nbmax = min(cur - lit_start, cnd);                     // compress.rs:442-448 bounds
         const bool bk_fast = cur >= 8u && cnd >= 8u;
-        uint32_t eq = 0u;
-        if (bk_fast && nbmax != 0u) {
-            const uint64_t df = w.rd64(cur - 8u) ^ cld64(in + cnd - 8u);
-            eq = df ? (uint32_t)(__builtin_clzll(df) >> 3) : 8u;
+        const uint32_t fa = m4 + 8u * g, fb = c4 + 8u * g;
+        const bool f8 = fa + 8u <= limit;                                     // a full 8-byte forward chunk
+        const uint32_t pa = bk_fast ? cur - 8u : 0u;
+        uint64_t bk_a = w.lds64(pa);
+        uint64_t fw_a = w.lds64(fa);
+        const uint64_t bk_b = cld64(in + (bk_fast ? cnd - 8u : 0u));
+        const uint64_t fw_b = cld64(in + (f8 ? fb : 0u));
+        {   // current-side bytes the ring does not hold
+            const bool ma = bk_fast && !w.covers(pa), mf = f8 && !w.covers(fa);
+            if (__any(ma || mf)) {
+                PHASE_COUNT(7)
+                const uint64_t ga = cld64(in + (ma ? pa : 0u)), gf = cld64(in + (mf ? fa : 0u));
+                if (ma) bk_a = ga;
+                if (mf) fw_a = gf;
+            }
         }
+        uint32_t eq = 0u;
+        if (bk_fast) { const uint64_t df = bk_a ^ bk_b; eq = df ? (uint32_t)(__builtin_clzll(df) >> 3) : 8u; }
         uint32_t c = 0u;                      // equal bytes seen by this lane in the first forward round (0..8)
-        {
-            const uint32_t a = m4 + 8u * g;
-            if (a < limit) {
-                const uint32_t rem = limit - a;
-                const uint32_t b = c4 + 8u * g;
-                if (rem >= 8u) {
-                    const uint64_t diff = w.rd64(a) ^ cld64(in + b);
-                    c = diff ? (uint32_t)(__builtin_ctzll(diff) >> 3) : 8u;
-                } else {
-                    while (c < rem && in[a + c] == in[b + c]) ++c;
-                }
+        if (f8) { const uint64_t fd = fw_a ^ fw_b; c = fd ? (uint32_t)(__builtin_ctzll(fd) >> 3) : 8u; }
+        PHASE_MARK(3)   // extension round trip
+        if (__any(!f8 && fa < limit)) {       // rare: the last (< 8 byte) chunk before the end of the block
+            if (!f8 && fa < limit) {
+                const uint32_t rem = limit - fa;
+                while (c < rem && in[fa + c] == in[fb + c]) ++c;
             }
         }
         // ---- backtrack (compress.rs:442-448)
@@ -548,12 +620,24 @@ __device__ __forceinline__ int32_t encode_block_w(const uint8_t* __restrict__ in
         }
         const uint32_t cur_end = m4 + dl;
         dl = cur_end - (cur + 4u);                                            // duplicate_length counts from the backtracked start + 4
+        if (g == 0u) ctl.set_prog(cur_end);
+        PHASE_MARK(4)   // backtrack + forward math
         // ------------------------------------------------------------------ bytes for the cur-2 table update
         // (compress.rs:460-461) and for the first probe batch after this match
-        const uint32_t q = cur_end - 2u;
-        const uint64_t qx = w.rd64(q);                                        // q + 8 <= n: matches end >= 6 bytes early
-        uint64_t xn = 0ull;
-        if (cur_end + g <= end_check) xn = w.rd64(cur_end + g);
+        const uint32_t q = cur_end - 2u;                                      // q + 8 <= n: matches end >= 6 bytes early
+        const uint32_t pn = cur_end + g;
+        const bool pv = pn <= end_check;
+        uint64_t qx = w.lds64(q);
+        uint64_t xn = w.lds64(pn);
+        {
+            const bool mq = !w.covers(q), mx = pv && !w.covers(pn);
+            if (__any(mq || mx)) {
+                const uint64_t gq = cld64(in + (mq ? q : 0u)), gx = cld64(in + (mx ? pn : 0u));
+                if (mq) qx = gq;
+                if (mx) xn = gx;
+            }
+        }
+        PHASE_MARK(5)   // next-step bytes (ring or memory)
         // ------------------------------------------------------------------ emit (compress.rs:463-486)
         if (i0 == 0u && base == lit_start && lit_len <= 7u && dl < 270u && o + 12u <= cap) {
             // the match was found in the first batch: all (<= 7) literals sit in lane 0's probe bytes.
@@ -562,12 +646,18 @@ __device__ __forceinline__ int32_t encode_block_w(const uint8_t* __restrict__ in
             const uint32_t tk = (lit_len << 4) | (dl < 15u ? dl : 15u);
             const uint64_t w0 = (uint64_t)tk | (x << 8);
             const uint32_t w1 = offset | ((dl - 15u) << 16);
+#ifndef LZ4FLEX_ABL_NOSTORE
             if (g == 0u) {
                 __builtin_memcpy(out + o, &w0, 8);
                 __builtin_memcpy(out + o + 1u + lit_len, &w1, 4);
             }
+#endif
             o += 3u + lit_len + (dl >= 15u ? 1u : 0u);
+#ifdef LZ4FLEX_ABL_NOGENERIC
+        } else if (false) {
+#else
         } else {
+#endif
             o = emit_literals<G>(out, o, in, lit_start, lit_len, dl < 15u ? dl : 15u, g);
             if (g == 0u) { out[o] = (uint8_t)(offset & 0xFFu); out[o + 1u] = (uint8_t)(offset >> 8); }
             o += 2u;
@@ -580,6 +670,7 @@ __device__ __forceinline__ int32_t encode_block_w(const uint8_t* __restrict__ in
                 o += 1u;
             }
         }
+        PHASE_MARK(6)   // emit
         if (g == 0u) tbl[use_h5 ? hidx5(qx) : hidx4((uint32_t)qx)] = (TblT)q;
         lit_start = cur_end;                                                  // compress.rs:487
         base = cur_end;
@@ -588,6 +679,7 @@ __device__ __forceinline__ int32_t encode_block_w(const uint8_t* __restrict__ in
     }
     // handle_last_literals, compress.rs:237-247
     o = emit_literals<G>(out, o, in, lit_start, n - lit_start, 0u, g);
+    PHASE_FLUSH
     *produced = o;
     return 0;
 }
@@ -787,29 +879,49 @@ hipError_t launch_compress_chain(const uint8_t* in_base, const void* blocks, con
 // the first-touch HBM latency inside their serial chain (an in-order vmcnt makes self-prefetching useless:
 // a load behind a missing prefetch waits for it).
 #define LZ4_PF_AHEAD 2048u
-template <int G, typename TblT, int MODE>
-__global__ void __launch_bounds__(MODE == 2 ? 128 : 64) lz4_compress_blocks_kernel(CompressArgs a) {
-    constexpr int BPW = 64 / G;   // blocks per workgroup (one encoder wave)
+// BPW = blocks per workgroup: BPW * G <= 64 lanes of the encoder wave are used.  With u16 tables a CU's
+// 160 KiB of LDS hold 20 tables, i.e. five workgroups of four blocks; the encoder is a latency-bound serial chain
+// per block, so blocks in flight matter and half-empty waves do not.
+template <int G, typename TblT, int MODE, int BPW>
+__global__ void __launch_bounds__(MODE == 0 ? 64 : 128) lz4_compress_blocks_kernel(CompressArgs a) {
     constexpr bool WINDOW = MODE == 1;
-    __shared__ __attribute__((aligned(16))) TblT tables[BPW][4096];
-    __shared__ __attribute__((aligned(16))) uint8_t rings[WINDOW ? BPW : 1][WINDOW ? (LZ4_WIN + LZ4_WIN_PAD) : 16];
-    __shared__ uint32_t progress[BPW];
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
+    TblT* tables = reinterpret_cast<TblT*>(dyn_lds);                                        // [BPW][4096]
+    uint8_t* rings = dyn_lds + (size_t)BPW * 4096u * sizeof(TblT);                          // [BPW][LZ4_WIN + LZ4_WIN_PAD] (MODE 1)
+    WinCtl* ctls = reinterpret_cast<WinCtl*>(rings + (WINDOW ? (size_t)BPW * (LZ4_WIN + LZ4_WIN_PAD) : 0u));   // [BPW] (MODE 1)
+    uint32_t* progress = reinterpret_cast<uint32_t*>(rings);                                // [BPW] (MODE 2)
     const uint32_t lane = threadIdx.x & 63u;
     Grp<G> grp;
     grp.g = lane % G;
     grp.shift = (lane / G) * G;
-    const uint32_t b = blockIdx.x * BPW + lane / G;
+    const uint32_t j = lane / G;                                                            // block slot of this lane group
+    const uint32_t b = blockIdx.x * BPW + j;
+    if (MODE == 1) {
+        // the filler wave works in groups of 8 lanes whatever G is
+        const uint32_t j8 = lane / 8u, b8 = blockIdx.x * BPW + j8;
+        if (threadIdx.x < BPW) {
+            const bool live = blockIdx.x * BPW + threadIdx.x < a.n;
+            ctls[threadIdx.x].lo = 0u; ctls[threadIdx.x].hi = 0u; ctls[threadIdx.x].prog = live ? 0u : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        if (threadIdx.x >= 64u) {
+            const bool live = j8 < BPW && b8 < a.n;
+            ring_filler(a.in_base + (live ? a.in_off[b8] : 0ull), live ? a.in_len[b8] : 0u, live,
+                        (lds_u8*)(rings + (size_t)(live ? j8 : 0u) * (LZ4_WIN + LZ4_WIN_PAD)), WinCtlRef{(lds_u8*)&ctls[live ? j8 : 0u]}, lane % 8u);
+            return;
+        }
+    }
     if (MODE == 2) {
         if (threadIdx.x < BPW) progress[threadIdx.x] = 0u;
         __syncthreads();
         if (threadIdx.x >= 64u) {
             // ---- the prefetch wave: lane group j follows block j
-            const bool live = b < a.n;
+            const bool live = j < BPW && b < a.n;
             const uint32_t n = live ? a.in_len[b] : 0u;
             const uint8_t* in = a.in_base + (live ? a.in_off[b] : 0ull);
             uint32_t pf = 0u, acc = 0u;
             for (;;) {
-                const uint32_t pos = live ? *reinterpret_cast<volatile uint32_t*>(&progress[lane / G]) : 0xFFFFFFFFu;
+                const uint32_t pos = live ? *reinterpret_cast<volatile uint32_t*>(&progress[j]) : 0xFFFFFFFFu;
                 const bool done = pos == 0xFFFFFFFFu;
                 if (!__any(!done)) break;
                 if (!done) {
@@ -822,12 +934,13 @@ __global__ void __launch_bounds__(MODE == 2 ? 128 : 64) lz4_compress_blocks_kern
                 }
                 __builtin_amdgcn_s_sleep(64);
             }
-            if (acc == 0x9E3779B9u && live) progress[lane / G] = acc;   // keeps the loads alive
+            if (acc == 0x9E3779B9u && live) progress[j] = acc;   // keeps the loads alive
             return;
         }
     }
+    if (j >= BPW) return;
     if (b >= a.n) {
-        if (MODE == 2 && grp.g == 0u) progress[lane / G] = 0xFFFFFFFFu;
+        if (MODE == 2 && grp.g == 0u) progress[j] = 0xFFFFFFFFu;
         return;
     }
     const uint32_t n = a.in_len[b];
@@ -836,41 +949,73 @@ __global__ void __launch_bounds__(MODE == 2 ? 128 : 64) lz4_compress_blocks_kern
     int32_t st;
     if (WINDOW)
         st = encode_block_w<G, TblT>(a.in_base + a.in_off[b], n, a.out_base + a.out_off[b], a.out_cap[b], flags,
-                                     &tables[lane / G][0], &rings[WINDOW ? lane / G : 0][0], grp, &produced);
-    else
-        st = encode_block<G, TblT>(a.in_base + a.in_off[b], n, a.out_base + a.out_off[b], a.out_cap[b], flags,
-                                   &tables[lane / G][0], grp, &produced, MODE == 2 ? &progress[lane / G] : nullptr);
-    if (MODE == 2 && grp.g == 0u) *reinterpret_cast<volatile uint32_t*>(&progress[lane / G]) = 0xFFFFFFFFu;
+                                     tables + (size_t)j * 4096u, rings + (size_t)j * (LZ4_WIN + LZ4_WIN_PAD), WinCtlRef{(lds_u8*)&ctls[j]}, grp,
+                                     &produced);
+    else {
+        // the hash choice (compress.rs:559-566) is the same for every block of a typical batch: pick the
+        // specialised loop when the whole wave agrees
+        const bool h5 = (flags & 2u) != 0u || n >= 65535u;
+        const uint8_t* in = a.in_base + a.in_off[b];
+        uint8_t* out = a.out_base + a.out_off[b];
+        TblT* tbl = tables + (size_t)j * 4096u;
+        volatile uint32_t* pg = MODE == 2 ? &progress[j] : nullptr;
+        if (__all(h5)) st = encode_block<G, TblT, 1>(in, n, out, a.out_cap[b], flags, tbl, grp, &produced, pg);
+        else if (__all(!h5)) st = encode_block<G, TblT, 0>(in, n, out, a.out_cap[b], flags, tbl, grp, &produced, pg);
+        else st = encode_block<G, TblT, 2>(in, n, out, a.out_cap[b], flags, tbl, grp, &produced, pg);
+    }
+    if (MODE == 1 && grp.g == 0u) WinCtlRef{(lds_u8*)&ctls[j]}.set_prog(0xFFFFFFFFu);
+    if (MODE == 2 && grp.g == 0u) *reinterpret_cast<volatile uint32_t*>(&progress[j]) = 0xFFFFFFFFu;
     if (grp.g == 0u) {
         a.status[b] = st;
         a.out_len[b] = st == 0 ? produced : 0u;
     }
 }
 
-template <int G, typename TblT, int MODE>
+template <int G, typename TblT, int MODE, int BPW>
 static hipError_t launch_c(const CompressArgs& a, hipStream_t s) {
-    constexpr uint32_t BPW = 64 / G;
+    static_assert(BPW * G <= 64 && BPW <= 8, "one encoder wave per workgroup; the filler wave serves 8 blocks");
     const uint32_t grid = (a.n + BPW - 1u) / BPW;
-    hipLaunchKernelGGL((lz4_compress_blocks_kernel<G, TblT, MODE>), dim3(grid), dim3(MODE == 2 ? 128 : 64), 0, s, a);
+    const size_t lds = (size_t)BPW * 4096u * sizeof(TblT) +
+                       (MODE == 1 ? (size_t)BPW * (LZ4_WIN + LZ4_WIN_PAD + sizeof(WinCtl)) : (MODE == 2 ? 64u : 0u));
+    auto kern = lz4_compress_blocks_kernel<G, TblT, MODE, BPW>;
+    static bool attr_set = false;   // per instantiation
+    if (!attr_set && lds > 65536u) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MODE == 0 ? 64 : 128), lds, s, a);
     return hipGetLastError();
 }
 
-template <int G, typename TblT>
+template <int G, typename TblT, int BPW>
 static hipError_t launch_m(const CompressArgs& a, int mode, hipStream_t s) {
-    if (mode == 1) return launch_c<G, TblT, 1>(a, s);
-    if (mode == 2) return launch_c<G, TblT, 2>(a, s);
-    return launch_c<G, TblT, 0>(a, s);
+    if (mode == 1) return launch_c<G, TblT, 1, BPW>(a, s);
+    if (mode == 2) return launch_c<G, TblT, 2, BPW>(a, s);
+    return launch_c<G, TblT, 0, BPW>(a, s);
 }
 
 // variant: bits 0..7 = lanes per block (8 or 16), bit 8 = blocks may exceed 64 KiB (u32 table),
-// bits 9..10 = mode (0 encode_block, 1 LDS input ring, 2 encode_block + prefetch wave)
+// bits 9..10 = mode (0 encode_block, 1 LDS input ring, 2 encode_block + prefetch wave),
+// bit 11 = half-filled waves (4 blocks of 8 lanes per workgroup: 20 instead of 16 u16 tables per CU)
 hipError_t launch_compress(const CompressArgs& a, int variant, hipStream_t s) {
     if (a.n == 0u) return hipSuccess;
     const int G = variant & 0xFF;
     const bool big = (variant & 0x100) != 0;
     const int mode = (variant >> 9) & 3;
-    if (G == 8) return big ? launch_m<8, uint32_t>(a, mode, s) : launch_m<8, uint16_t>(a, mode, s);
-    if (G == 16) return big ? launch_m<16, uint32_t>(a, mode, s) : launch_m<16, uint16_t>(a, mode, s);
+    const bool half = (variant & 0x800) != 0;
+    if (G == 8) {
+        if (!big) {   // experiment hook: blocks per workgroup
+            static const int bpw = getenv("LZ4FLEX_BPW") ? atoi(getenv("LZ4FLEX_BPW")) : 0;
+            if (bpw == 2) return launch_m<8, uint16_t, 2>(a, mode, s);
+            if (bpw == 3) return launch_m<8, uint16_t, 3>(a, mode, s);
+            if (bpw == 5) return launch_m<8, uint16_t, 5>(a, mode, s);
+            if (bpw == 6) return launch_m<8, uint16_t, 6>(a, mode, s);
+        }
+        if (half) return big ? launch_m<8, uint32_t, 4>(a, mode, s) : launch_m<8, uint16_t, 4>(a, mode, s);
+        return big ? launch_m<8, uint32_t, 8>(a, mode, s) : launch_m<8, uint16_t, 8>(a, mode, s);
+    }
+    if (G == 16) return big ? launch_m<16, uint32_t, 4>(a, mode, s) : launch_m<16, uint16_t, 4>(a, mode, s);
     return hipErrorInvalidValue;
 }
 

@@ -236,21 +236,16 @@ def _tile(src, total, block):
     return buf
 
 
-@pytest.mark.parametrize("lanes", [8, 16, 0, -8, -16])
-def test_compress_batch_bit_exact_vs_oracle(blk, lanes):
-    """lanes 8/16: lz4_compress.hip group widths (default: with the LDS input ring; negative: without it,
-    variant 3); lanes 0: the experimental LDS-staged encoder (variant 2)"""
+@pytest.mark.parametrize("lanes,variant", [(8, 1), (16, 1), (8, 3), (16, 3), (8, 4), (16, 4), (8, 2)])
+def test_compress_batch_bit_exact_vs_oracle(blk, lanes, variant):
+    """every encoder variant (see lz4flex_set_tuning) and both group widths produce the reference's bytes"""
     from lz4_flex_amd import _lib
     import ctypes as C
     lib = _lib.load()
     ctx = C.c_void_p()
     assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
-    if lanes:
-        assert lib.lz4flex_set_tuning(ctx, b"compress_lanes", abs(lanes)) == 0
-        if lanes < 0:
-            assert lib.lz4flex_set_tuning(ctx, b"compress_variant", 3) == 0
-    else:
-        assert lib.lz4flex_set_tuning(ctx, b"compress_variant", 2) == 0
+    assert lib.lz4flex_set_tuning(ctx, b"compress_lanes", lanes) == 0
+    assert lib.lz4flex_set_tuning(ctx, b"compress_variant", variant) == 0
     try:
         srcs = [O.fixture_plain("compression_66k_JSON"), O.fixture_plain("compression_65k"), corpus.lcg_bytes(70000, 5, 4, 9),
                 bytes(70000), corpus.lcg_bytes(70000, 6, 256, 1)]
@@ -275,7 +270,7 @@ def test_compress_batch_bit_exact_vs_oracle(blk, lanes):
                     exp = O.compress(b)
                 else:
                     exp = O.compress_frame_block(b, first_block=(flags[i] == 2))
-                assert got == exp, (i, len(b), lanes, None if flags is None else int(flags[i]))
+                assert got == exp, (i, len(b), lanes, variant, None if flags is None else int(flags[i]))
     finally:
         lib.lz4flex_ctx_destroy(ctx)
 
