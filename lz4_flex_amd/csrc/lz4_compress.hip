@@ -153,19 +153,64 @@ __device__ __forceinline__ uint32_t emit_literals(uint8_t* out, uint32_t o, cons
     return o + lit_len;
 }
 
+// LDS-typed views: a generic pointer would make every access a FLAT instruction, which is as slow as a global one
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef uint32_t __attribute__((address_space(3), aligned(1))) lds_u32_unaligned;
+typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+typedef u32x4 __attribute__((address_space(3))) lds_u128;
+typedef volatile u32x4 __attribute__((address_space(3))) lds_vu128;
+typedef volatile uint32_t __attribute__((address_space(3))) lds_vu32;
+typedef volatile uint64_t __attribute__((address_space(3))) lds_vu64;
+
+// Sequence queue between the encoder wave and the emitter wave of a workgroup (one per block, in LDS).
+// The encoder's chain is probe -> verify -> extend -> next probe; writing the sequence out (token, literals,
+// offset, length bytes: compress.rs:463-486) is not on that chain, but every global store the encoder wave
+// issues costs it ~80 issue cycles and its acknowledgement is waited for by the next load (one in-order
+// vmcnt).  So the encoder only pushes {lit_start, lit_len, offset, match_len - 4} records; a second wavefront
+// pops them and does all the output formatting and all the stores.
+#define LZ4_PF_AHEAD 2048u          // bytes of input kept warm ahead of the encoder
+#define LZ4_EQ_DEPTH 16u
+#define LZ4_EQ_FINAL 0xFFFFFFFFu     // record.offset: "last literals" record, the block ends after it
+#define LZ4_EQ_SELF 0xFFFFFFFFu      // head value: the encoder wrote the block's output and status itself
+struct EmitQ {                       // LDS layout per block: 16 records of 16 B, then head, tail, prog, pad
+    lds_u8* p;
+    __device__ __forceinline__ uint32_t head() const { return *reinterpret_cast<lds_vu32*>(p + 16u * LZ4_EQ_DEPTH); }
+    __device__ __forceinline__ void set_head(uint32_t v) const { *reinterpret_cast<lds_vu32*>(p + 16u * LZ4_EQ_DEPTH) = v; }
+    __device__ __forceinline__ uint32_t tail() const { return *reinterpret_cast<lds_vu32*>(p + 16u * LZ4_EQ_DEPTH + 4u); }
+    __device__ __forceinline__ void set_tail(uint32_t v) const { *reinterpret_cast<lds_vu32*>(p + 16u * LZ4_EQ_DEPTH + 4u) = v; }
+    __device__ __forceinline__ uint32_t prog() const { return *reinterpret_cast<lds_vu32*>(p + 16u * LZ4_EQ_DEPTH + 8u); }
+    __device__ __forceinline__ void set_prog(uint32_t v) const { *reinterpret_cast<lds_vu32*>(p + 16u * LZ4_EQ_DEPTH + 8u) = v; }
+    __device__ __forceinline__ void put(uint32_t slot, uint32_t a, uint32_t b, uint32_t c, uint32_t d) const {
+        const u32x4 v = {a, b, c, d};
+        *reinterpret_cast<lds_vu128*>(p + 16u * (slot & (LZ4_EQ_DEPTH - 1u))) = v;
+    }
+    __device__ __forceinline__ u32x4 get(uint32_t slot) const {
+        return *reinterpret_cast<lds_vu128*>(p + 16u * (slot & (LZ4_EQ_DEPTH - 1u)));
+    }
+};
+#define LZ4_EQ_BYTES (16u * LZ4_EQ_DEPTH + 16u)
+
 // HM: hash selection known at compile time (0: 4-byte hash, 1: 5-byte hash) or per block at run time (2)
-template <int G, typename TblT, int HM>
+// EQ: sequences are pushed to the block's EmitQ (an emitter wave writes the output and the block's status)
+// instead of being written here; the return value is then LZ4FLEX_DEV_QUEUED unless the block was handled inline.
+#define LZ4FLEX_DEV_QUEUED 0x7FFFFFFF
+template <int G, typename TblT, int HM, bool EQ>
 __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, uint32_t n, uint8_t* __restrict__ out,
                                                 uint32_t cap, uint32_t flags, TblT* tbl, const Grp<G> grp,
-                                                uint32_t* produced, volatile uint32_t* progress) {
+                                                uint32_t* produced, volatile uint32_t* progress, const EmitQ eq) {
     const uint32_t g = grp.g;
-    if ((uint64_t)cap < max_output_size(n)) return LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL;   // compress.rs:338-340
+    if ((uint64_t)cap < max_output_size(n)) {   // compress.rs:338-340
+        if (EQ && g == 0u) eq.set_head(LZ4_EQ_SELF);
+        return LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL;
+    }
     uint32_t o = 0u;
     if (n < LZ4_MIN_LENGTH) {   // compress.rs:343-346
         o = emit_literals<G>(out, o, in, 0u, n, 0u, g);
         *produced = o;
+        if (EQ && g == 0u) eq.set_head(LZ4_EQ_SELF);
         return 0;
     }
+    uint32_t q_head = 0u;
     const bool frame_tbl = (flags & 2u) != 0u;        // FrameEncoder: HashTable4K + hash5 always
     const bool continuation = (flags & 1u) != 0u;     // table holds only unreachable entries; pos 0 is probed
     const bool use_h5 = HM == 2 ? (frame_tbl || n >= 65535u) : (HM == 1);   // compress.rs:559-566
@@ -311,36 +356,47 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
         const uint32_t q = cur_end - 2u;
         const uint64_t qx = cld64(in + q);                                    // q + 8 <= n: matches end >= 6 bytes early
         const uint64_t xn = cld64(in + (cur_end + g <= end_check ? cur_end + g : 0u));
-        // ------------------------------------------------------------------ emit (compress.rs:463-486)
-        if (x0_base == lit_start && lit_len <= 14u && dl < 270u && o + 20u <= cap) {
-            // short literal run: the literals sit in the first batch's probe bytes (lane 0: bytes 0..7 of the run,
-            // lane 7: bytes 7..14).  token+literals as 8-byte stores, then offset + length byte as one 4-byte
-            // store (bytes past the sequence are rewritten by the next one; the capacity check above keeps
-            // them inside `out`)
-            const uint32_t tk = (lit_len << 4) | (dl < 15u ? dl : 15u);
-            const uint64_t w0 = (uint64_t)tk | (x0 << 8);
-            const uint32_t w1 = offset | ((dl - 15u) << 16);
-#ifndef LZ4FLEX_ABL_NOSTORE
-            if (g == 0u) __builtin_memcpy(out + o, &w0, 8);
-            if (G >= 8 && g == 7u && lit_len > 7u) __builtin_memcpy(out + o + 8u, &x0, 8);
-            if (g == 0u) __builtin_memcpy(out + o + 1u + lit_len, &w1, 4);
-#endif
-            o += 3u + lit_len + (dl >= 15u ? 1u : 0u);
-#ifdef LZ4FLEX_ABL_NOGENERIC
-        } else if (false) {
-#else
+        if (EQ) {
+            // ---- hand the sequence to the emitter wave (compress.rs:463-486 happen there)
+            while (__any(q_head - eq.tail() >= LZ4_EQ_DEPTH)) __builtin_amdgcn_s_sleep(1);   // queue full: rare
+            if (g == 0u) {
+                eq.put(q_head, lit_start, lit_len, offset, dl);
+                eq.set_head(q_head + 1u);
+                eq.set_prog(cur_end);
+            }
+            q_head += 1u;
         } else {
+            // ------------------------------------------------------------------ emit (compress.rs:463-486)
+            if (x0_base == lit_start && lit_len <= 14u && dl < 270u && o + 20u <= cap) {
+                // short literal run: the literals sit in the first batch's probe bytes (lane 0: bytes 0..7 of the run,
+                // lane 7: bytes 7..14).  token+literals as 8-byte stores, then offset + length byte as one 4-byte
+                // store (bytes past the sequence are rewritten by the next one; the capacity check above keeps
+                // them inside `out`)
+                const uint32_t tk = (lit_len << 4) | (dl < 15u ? dl : 15u);
+                const uint64_t w0 = (uint64_t)tk | (x0 << 8);
+                const uint32_t w1 = offset | ((dl - 15u) << 16);
+#ifndef LZ4FLEX_ABL_NOSTORE
+                if (g == 0u) __builtin_memcpy(out + o, &w0, 8);
+                if (G >= 8 && g == 7u && lit_len > 7u) __builtin_memcpy(out + o + 8u, &x0, 8);
+                if (g == 0u) __builtin_memcpy(out + o + 1u + lit_len, &w1, 4);
 #endif
-            o = emit_literals<G>(out, o, in, lit_start, lit_len, dl < 15u ? dl : 15u, g);
-            if (g == 0u) { out[o] = (uint8_t)(offset & 0xFFu); out[o + 1u] = (uint8_t)(offset >> 8); }
-            o += 2u;
-            if (dl >= 15u) {
-                const uint32_t rem = dl - 15u;
-                const uint32_t n255 = rem / 255u;
-                for (uint32_t k = g; k < n255; k += G) out[o + k] = 0xFFu;
-                o += n255;
-                if (g == 0u) out[o] = (uint8_t)(rem - n255 * 255u);
-                o += 1u;
+                o += 3u + lit_len + (dl >= 15u ? 1u : 0u);
+#ifdef LZ4FLEX_ABL_NOGENERIC
+            } else if (false) {
+#else
+            } else {
+#endif
+                o = emit_literals<G>(out, o, in, lit_start, lit_len, dl < 15u ? dl : 15u, g);
+                if (g == 0u) { out[o] = (uint8_t)(offset & 0xFFu); out[o + 1u] = (uint8_t)(offset >> 8); }
+                o += 2u;
+                if (dl >= 15u) {
+                    const uint32_t rem = dl - 15u;
+                    const uint32_t n255 = rem / 255u;
+                    for (uint32_t k = g; k < n255; k += G) out[o + k] = 0xFFu;
+                    o += n255;
+                    if (g == 0u) out[o] = (uint8_t)(rem - n255 * 255u);
+                    o += 1u;
+                }
             }
         }
         PHASE_MARK(6)   // next-step requests + emit
@@ -356,10 +412,75 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
         x = xn;
     }
     // handle_last_literals, compress.rs:237-247
+    if (EQ) {
+        while (__any(q_head - eq.tail() >= LZ4_EQ_DEPTH)) __builtin_amdgcn_s_sleep(1);
+        if (g == 0u) {
+            eq.put(q_head, lit_start, n - lit_start, LZ4_EQ_FINAL, 0u);
+            eq.set_head(q_head + 1u);
+        }
+        PHASE_FLUSH
+        return LZ4FLEX_DEV_QUEUED;
+    }
     o = emit_literals<G>(out, o, in, lit_start, n - lit_start, 0u, g);
     PHASE_FLUSH
     *produced = o;
     return 0;
+}
+
+// The emitter wave: lane group j pops block j's sequence records and writes the compressed block
+// (compress.rs:463-486, :237-247), then the block's length and status.  It also walks ahead of the encoder
+// touching the input lines it is about to read (see MODE 2 below).
+template <int G>
+__device__ __forceinline__ void emitter_wave(const CompressArgs& a, uint32_t b, bool live, const EmitQ eq, const Grp<G> grp) {
+    const uint32_t g = grp.g;
+    const uint8_t* in = a.in_base + (live ? a.in_off[b] : 0ull);
+    uint8_t* out = a.out_base + (live ? a.out_off[b] : 0ull);
+    const uint32_t n = live ? a.in_len[b] : 0u;
+    uint32_t o = 0u, tail = 0u, pf = 0u, acc = 0u;
+    bool done = !live;
+    for (;;) {
+        if (!__any(!done)) break;
+        bool worked = false;
+        if (!done) {
+            const uint32_t head = eq.head();
+            if (head == LZ4_EQ_SELF) {
+                done = true;
+            } else if (tail != head) {
+                const u32x4 r = eq.get(tail);
+                const uint32_t lit_start = r.x, lit_len = r.y, offset = r.z, dl = r.w;
+                if (offset == LZ4_EQ_FINAL) {
+                    o = emit_literals<G>(out, o, in, lit_start, lit_len, 0u, g);
+                    if (g == 0u) { a.status[b] = 0; a.out_len[b] = o; }
+                    done = true;
+                } else {
+                    o = emit_literals<G>(out, o, in, lit_start, lit_len, dl < 15u ? dl : 15u, g);
+                    if (g == 0u) { out[o] = (uint8_t)(offset & 0xFFu); out[o + 1u] = (uint8_t)(offset >> 8); }
+                    o += 2u;
+                    if (dl >= 15u) {   // write_integer, compress.rs:224-233
+                        const uint32_t rem = dl - 15u;
+                        const uint32_t n255 = rem / 255u;
+                        for (uint32_t k = g; k < n255; k += G) out[o + k] = 0xFFu;
+                        o += n255;
+                        if (g == 0u) out[o] = (uint8_t)(rem - n255 * 255u);
+                        o += 1u;
+                    }
+                }
+                tail += 1u;
+                if (g == 0u) eq.set_tail(tail);
+                worked = true;
+            }
+            // stream prefetch: keep the lines [pos, pos + LZ4_PF_AHEAD) of the input on their way into L2
+            const uint32_t pos = eq.prog();
+            if (pf < pos) pf = pos & ~127u;
+            if (!done && pf + 128u * G < pos + LZ4_PF_AHEAD) {
+                const uint32_t at = pf + 128u * g;
+                if (at + 4u <= n) acc += *reinterpret_cast<const volatile uint32_t*>(in + (at & ~3u));
+                pf += 128u * G;
+            }
+        }
+        if (!__any(worked)) __builtin_amdgcn_s_sleep(8);
+    }
+    if (acc == 0x9E3779B9u && live) eq.set_prog(acc);   // keeps the prefetch loads alive
 }
 
 
@@ -385,20 +506,12 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
 #define LZ4_WIN_HIST 64u    // bytes kept behind the encoder's first probe
 #define LZ4_WIN_CHUNK 128u  // filler granularity: 8 lanes x 16 B
 
-// LDS-typed views: a generic pointer would let the compiler fold "ring or memory" into one FLAT load, which
-// is as slow as the global load the ring exists to avoid
-typedef __attribute__((address_space(3))) uint8_t lds_u8;
-typedef uint32_t __attribute__((address_space(3), aligned(1))) lds_u32_unaligned;
-typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
-typedef u32x4 __attribute__((address_space(3))) lds_u128;
 
 struct WinCtl {              // per block, in LDS
     uint32_t lo, hi;         // filler -> encoder (8-byte aligned pair)
     uint32_t prog;           // encoder -> filler; 0xFFFFFFFF = block finished
     uint32_t pad;
 };
-typedef volatile uint32_t __attribute__((address_space(3))) lds_vu32;
-typedef volatile uint64_t __attribute__((address_space(3))) lds_vu64;
 // LDS-typed accessors of a block's control words (ctl = LDS address of its WinCtl)
 struct WinCtlRef {
     lds_u8* p;
@@ -878,13 +991,13 @@ hipError_t launch_compress_chain(const uint8_t* in_base, const void* blocks, con
 // the input lines they are about to need, so that the encoders' current-side loads hit L2 instead of paying
 // the first-touch HBM latency inside their serial chain (an in-order vmcnt makes self-prefetching useless:
 // a load behind a missing prefetch waits for it).
-#define LZ4_PF_AHEAD 2048u
 // BPW = blocks per workgroup: BPW * G <= 64 lanes of the encoder wave are used.  With u16 tables a CU's
 // 160 KiB of LDS hold 20 tables, i.e. five workgroups of four blocks; the encoder is a latency-bound serial chain
 // per block, so blocks in flight matter and half-empty waves do not.
 template <int G, typename TblT, int MODE, int BPW>
 __global__ void __launch_bounds__(MODE == 0 ? 64 : 128) lz4_compress_blocks_kernel(CompressArgs a) {
     constexpr bool WINDOW = MODE == 1;
+    constexpr bool EQ = MODE == 3;
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     TblT* tables = reinterpret_cast<TblT*>(dyn_lds);                                        // [BPW][4096]
     uint8_t* rings = dyn_lds + (size_t)BPW * 4096u * sizeof(TblT);                          // [BPW][LZ4_WIN + LZ4_WIN_PAD] (MODE 1)
@@ -908,6 +1021,19 @@ __global__ void __launch_bounds__(MODE == 0 ? 64 : 128) lz4_compress_blocks_kern
             const bool live = j8 < BPW && b8 < a.n;
             ring_filler(a.in_base + (live ? a.in_off[b8] : 0ull), live ? a.in_len[b8] : 0u, live,
                         (lds_u8*)(rings + (size_t)(live ? j8 : 0u) * (LZ4_WIN + LZ4_WIN_PAD)), WinCtlRef{(lds_u8*)&ctls[live ? j8 : 0u]}, lane % 8u);
+            return;
+        }
+    }
+    if (MODE == 3) {
+        // sequence queues live where MODE 1 keeps its rings; the second wave is the emitter (+ stream prefetch)
+        if (threadIdx.x < BPW) {
+            const EmitQ q0{(lds_u8*)(rings + (size_t)threadIdx.x * LZ4_EQ_BYTES)};
+            q0.set_head(0u); q0.set_tail(0u); q0.set_prog(0u);
+        }
+        __syncthreads();
+        if (threadIdx.x >= 64u) {
+            const bool live = j < BPW && b < a.n;
+            emitter_wave<G>(a, b, live, EmitQ{(lds_u8*)(rings + (size_t)(live ? j : 0u) * LZ4_EQ_BYTES)}, grp);
             return;
         }
     }
@@ -959,13 +1085,14 @@ __global__ void __launch_bounds__(MODE == 0 ? 64 : 128) lz4_compress_blocks_kern
         uint8_t* out = a.out_base + a.out_off[b];
         TblT* tbl = tables + (size_t)j * 4096u;
         volatile uint32_t* pg = MODE == 2 ? &progress[j] : nullptr;
-        if (__all(h5)) st = encode_block<G, TblT, 1>(in, n, out, a.out_cap[b], flags, tbl, grp, &produced, pg);
-        else if (__all(!h5)) st = encode_block<G, TblT, 0>(in, n, out, a.out_cap[b], flags, tbl, grp, &produced, pg);
-        else st = encode_block<G, TblT, 2>(in, n, out, a.out_cap[b], flags, tbl, grp, &produced, pg);
+        const EmitQ eq{(lds_u8*)(rings + (size_t)(EQ ? j : 0u) * LZ4_EQ_BYTES)};
+        if (__all(h5)) st = encode_block<G, TblT, 1, EQ>(in, n, out, a.out_cap[b], flags, tbl, grp, &produced, pg, eq);
+        else if (__all(!h5)) st = encode_block<G, TblT, 0, EQ>(in, n, out, a.out_cap[b], flags, tbl, grp, &produced, pg, eq);
+        else st = encode_block<G, TblT, 2, EQ>(in, n, out, a.out_cap[b], flags, tbl, grp, &produced, pg, eq);
     }
     if (MODE == 1 && grp.g == 0u) WinCtlRef{(lds_u8*)&ctls[j]}.set_prog(0xFFFFFFFFu);
     if (MODE == 2 && grp.g == 0u) *reinterpret_cast<volatile uint32_t*>(&progress[j]) = 0xFFFFFFFFu;
-    if (grp.g == 0u) {
+    if (grp.g == 0u && st != LZ4FLEX_DEV_QUEUED) {   // a queued block's length and status come from the emitter wave
         a.status[b] = st;
         a.out_len[b] = st == 0 ? produced : 0u;
     }
@@ -976,7 +1103,7 @@ static hipError_t launch_c(const CompressArgs& a, hipStream_t s) {
     static_assert(BPW * G <= 64 && BPW <= 8, "one encoder wave per workgroup; the filler wave serves 8 blocks");
     const uint32_t grid = (a.n + BPW - 1u) / BPW;
     const size_t lds = (size_t)BPW * 4096u * sizeof(TblT) +
-                       (MODE == 1 ? (size_t)BPW * (LZ4_WIN + LZ4_WIN_PAD + sizeof(WinCtl)) : (MODE == 2 ? 64u : 0u));
+                       (MODE == 1 ? (size_t)BPW * (LZ4_WIN + LZ4_WIN_PAD + sizeof(WinCtl)) : (MODE == 2 ? 64u : (MODE == 3 ? (size_t)BPW * LZ4_EQ_BYTES : 0u)));
     auto kern = lz4_compress_blocks_kernel<G, TblT, MODE, BPW>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set && lds > 65536u) {
@@ -992,11 +1119,12 @@ template <int G, typename TblT, int BPW>
 static hipError_t launch_m(const CompressArgs& a, int mode, hipStream_t s) {
     if (mode == 1) return launch_c<G, TblT, 1, BPW>(a, s);
     if (mode == 2) return launch_c<G, TblT, 2, BPW>(a, s);
+    if (mode == 3) return launch_c<G, TblT, 3, BPW>(a, s);
     return launch_c<G, TblT, 0, BPW>(a, s);
 }
 
 // variant: bits 0..7 = lanes per block (8 or 16), bit 8 = blocks may exceed 64 KiB (u32 table),
-// bits 9..10 = mode (0 encode_block, 1 LDS input ring, 2 encode_block + prefetch wave),
+// bits 9..10 = mode (0 encode_block, 1 LDS input ring, 2 encode_block + prefetch wave, 3 encode_block + emitter wave),
 // bit 11 = half-filled waves (4 blocks of 8 lanes per workgroup: 20 instead of 16 u16 tables per CU)
 hipError_t launch_compress(const CompressArgs& a, int variant, hipStream_t s) {
     if (a.n == 0u) return hipSuccess;
