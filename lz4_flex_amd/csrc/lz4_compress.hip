@@ -168,7 +168,12 @@ typedef volatile uint64_t __attribute__((address_space(3))) lds_vu64;
 // issues costs it ~80 issue cycles and its acknowledgement is waited for by the next load (one in-order
 // vmcnt).  So the encoder only pushes {lit_start, lit_len, offset, match_len - 4} records; a second wavefront
 // pops them and does all the output formatting and all the stores.
+#ifndef LZ4_PF_AHEAD
 #define LZ4_PF_AHEAD 2048u          // bytes of input kept warm ahead of the encoder
+#endif
+#ifndef LZ4_EM_SLEEP
+#define LZ4_EM_SLEEP 8
+#endif
 #define LZ4_EQ_DEPTH 16u
 #define LZ4_EQ_FINAL 0xFFFFFFFFu     // record.offset: "last literals" record, the block ends after it
 #define LZ4_EQ_SELF 0xFFFFFFFFu      // head value: the encoder wrote the block's output and status itself
@@ -210,7 +215,7 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
         if (EQ && g == 0u) eq.set_head(LZ4_EQ_SELF);
         return 0;
     }
-    uint32_t q_head = 0u;
+    uint32_t q_head = 0u, q_tail = 0u;   // q_tail: last value read of the emitter's tail (it only grows)
     const bool frame_tbl = (flags & 2u) != 0u;        // FrameEncoder: HashTable4K + hash5 always
     const bool continuation = (flags & 1u) != 0u;     // table holds only unreachable entries; pos 0 is probed
     const bool use_h5 = HM == 2 ? (frame_tbl || n >= 65535u) : (HM == 1);   // compress.rs:559-566
@@ -258,14 +263,26 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
             cand_ok = !continuation || cand != 0u || idx == idx0;
         }
         PHASE_MARK(0)   // loop top: probe bytes wait + hash + table read issue
-        // same-bucket probes earlier in this batch supersede the table content
+        // The candidate's 4 bytes are requested straight from the table value.  Every load of a step is issued
+        // unconditionally (lanes with nothing to read load position 0): a load inside a divergent branch is
+        // waited for inside it, which turns one round trip into several.
+        bool try_m = valid && cand_ok && (p - cand) <= LZ4_MAX_DISTANCE;        // compress.rs:403-405
+        uint32_t cand4 = cld32(in + (try_m ? cand : 0u));
+        // Same-bucket probes earlier in this batch supersede the table content (the serial loop would have stored
+        // them first).  Resolved while the load is in flight; the superseding candidate is a probe position of
+        // this very batch, so its 4 bytes are that lane's probe bytes - no second load.
         const uint32_t d = FwdConflict<G, 1>::run(idx, g);
-        if (d != 0u) { cand = probe_pos(base, i - d); cand_ok = true; }
+        const bool anyd = __any(d != 0u);
         PHASE_MARK(1)   // table read wait + conflict resolution
-        // every load of a step is issued unconditionally (lanes with nothing to read load position 0): a load
-        // inside a divergent branch is waited for inside it, which turns one round trip into several
-        const bool try_m = valid && cand_ok && (p - cand) <= LZ4_MAX_DISTANCE;  // compress.rs:403-405
-        const bool is_match = (cld32(in + (try_m ? cand : 0u)) == cur4) && try_m;   // compress.rs:432-438
+        if (anyd) {
+            const uint32_t src4 = grp.bcast(cur4, g - d);                     // lanes with d == 0 read themselves
+            if (d != 0u) {
+                cand = probe_pos(base, i - d);
+                try_m = (p - cand) <= LZ4_MAX_DISTANCE;
+                cand4 = src4;
+            }
+        }
+        const bool is_match = (cand4 == cur4) && try_m;                         // compress.rs:432-438
         const uint32_t mm = grp.ballot(is_match);
         PHASE_MARK(2)   // candidate round trip + verify
         const uint32_t vm = grp.ballot(valid);
@@ -273,7 +290,7 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
         // table stores of the executed probes (compress.rs:393), last writer per bucket only.  A later lane
         // with the same bucket exists only if some lane saw an earlier one (d != 0): skip the scan otherwise.
         bool superseded = false;
-        if (__any(d != 0u)) superseded = BwdConflict<G, 1>::run(idx, g, last);
+        if (anyd) superseded = BwdConflict<G, 1>::run(idx, g, last);
         if (valid && g <= last && !superseded) tbl[idx] = (TblT)p;
         if (mm == 0u) {
             if (vm != (((G == 32) ? 0xFFFFFFFFu : ((1u << G) - 1u)))) break;   // ran past end_check: last literals
@@ -358,7 +375,11 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
         const uint64_t xn = cld64(in + (cur_end + g <= end_check ? cur_end + g : 0u));
         if (EQ) {
             // ---- hand the sequence to the emitter wave (compress.rs:463-486 happen there)
-            while (__any(q_head - eq.tail() >= LZ4_EQ_DEPTH)) __builtin_amdgcn_s_sleep(1);   // queue full: rare
+            while (__any(q_head - q_tail >= LZ4_EQ_DEPTH)) {   // looks full: refresh the tail, wait if it really is (rare)
+                const uint32_t t = eq.tail();
+                if (t == q_tail) __builtin_amdgcn_s_sleep(1);
+                q_tail = t;
+            }
             if (g == 0u) {
                 eq.put(q_head, lit_start, lit_len, offset, dl);
                 eq.set_head(q_head + 1u);
@@ -413,7 +434,11 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
     }
     // handle_last_literals, compress.rs:237-247
     if (EQ) {
-        while (__any(q_head - eq.tail() >= LZ4_EQ_DEPTH)) __builtin_amdgcn_s_sleep(1);
+        while (__any(q_head - q_tail >= LZ4_EQ_DEPTH)) {
+            const uint32_t t = eq.tail();
+            if (t == q_tail) __builtin_amdgcn_s_sleep(1);
+            q_tail = t;
+        }
         if (g == 0u) {
             eq.put(q_head, lit_start, n - lit_start, LZ4_EQ_FINAL, 0u);
             eq.set_head(q_head + 1u);
@@ -478,7 +503,7 @@ __device__ __forceinline__ void emitter_wave(const CompressArgs& a, uint32_t b, 
                 pf += 128u * G;
             }
         }
-        if (!__any(worked)) __builtin_amdgcn_s_sleep(8);
+        if (!__any(worked)) __builtin_amdgcn_s_sleep(LZ4_EM_SLEEP);
     }
     if (acc == 0x9E3779B9u && live) eq.set_prog(acc);   // keeps the prefetch loads alive
 }

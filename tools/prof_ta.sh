@@ -11,7 +11,7 @@ for set in "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE" "TA_ADDR_STALLED_BY_TC_C
            "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TOTAL_READ_sum" "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_sum" \
            "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum"; do
   k=$((k+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$k -o p -- $CMD > $OUT/p$k.log 2>&1
+  timeout 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$k -o p -- $CMD > $OUT/p$k.log 2>&1
 done
 python - <<PY
 import csv, glob, collections
