@@ -321,20 +321,8 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
                 while (c < rem && in[fa + c] == in[fb + c]) ++c;
             }
         }
-        // ---- backtrack (compress.rs:442-448)
-        {
-            const uint32_t okm = grp.ballot(bk_ok0 && bka == bkb);
+        const uint32_t okm = grp.ballot(bk_ok0 && bka == bkb);
         PHASE_MARK(4)   // extension round trip
-            uint32_t nb = (uint32_t)__builtin_ctz(~okm);                      // G..31 bits are 0 in okm => nb <= G
-            cur -= nb; cnd -= nb;
-            while (nb == (uint32_t)G) {                                       // rare: more than G bytes backwards
-                const bool ok = (cnd > g) && (cur > lit_start + g) && in[cur - 1u - g] == in[cnd - 1u - g];
-                const uint32_t okm2 = grp.ballot(ok);
-                nb = (uint32_t)__builtin_ctz(~okm2);
-                cur -= nb; cnd -= nb;
-            }
-        }
-        const uint32_t lit_len = cur - lit_start;                             // compress.rs:451
         // ---- forward (count_same_bytes :156-216)
         uint32_t dl = 0u;
         {
@@ -365,14 +353,25 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
                 }
             }
         }
-        const uint32_t cur_end = m4 + dl;
-        dl = cur_end - (cur + 4u);                                            // duplicate_length counts from the backtracked start + 4
-        PHASE_MARK(5)   // backtrack + forward resolution
+        const uint32_t cur_end = m4 + dl;     // the forward count starts at the verified position + 4 whatever the backtrack finds
         // ------------------------------------------------------------------ requests for the NEXT step: the bytes of
         // the cur-2 table update (compress.rs:460-461) and of the first probe batch after this match
         const uint32_t q = cur_end - 2u;
         const uint64_t qx = cld64(in + q);                                    // q + 8 <= n: matches end >= 6 bytes early
         const uint64_t xn = cld64(in + (cur_end + g <= end_check ? cur_end + g : 0u));
+        // ---- backtrack (compress.rs:442-448), off the critical path: the next step only needs cur_end
+        {
+            uint32_t nb = (uint32_t)__builtin_ctz(~okm);                      // G..31 bits are 0 in okm => nb <= G
+            cur -= nb; cnd -= nb;
+            while (nb == (uint32_t)G) {                                       // rare: more than G bytes backwards
+                const bool ok = (cnd > g) && (cur > lit_start + g) && in[cur - 1u - g] == in[cnd - 1u - g];
+                const uint32_t okm2 = grp.ballot(ok);
+                nb = (uint32_t)__builtin_ctz(~okm2);
+                cur -= nb; cnd -= nb;
+            }
+        }
+        const uint32_t lit_len = cur - lit_start;                             // compress.rs:451
+        dl = cur_end - (cur + 4u);                                            // duplicate_length counts from the backtracked start + 4
         if (EQ) {
             // ---- hand the sequence to the emitter wave (compress.rs:463-486 happen there)
             while (__any(q_head - q_tail >= LZ4_EQ_DEPTH)) {   // looks full: refresh the tail, wait if it really is (rare)
