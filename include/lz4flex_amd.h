@@ -173,8 +173,8 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  * window lives in HBM/L2, also used for dictionary/prefix blocks), "decompress_lanes" (8/16/32/64, variant 1),
  * "compress_lanes" (8/16) = lanes of a wavefront cooperating on one block, "compress_variant" (1 = default:
  * the group encoder pushes sequences to a second wavefront that writes the output; 3 = the group encoder alone;
- * 5 = group encoder + a wavefront that only prefetches the input; 4 = group encoder reading its current-side
- * bytes from an LDS ring fed by a filler wavefront; 2 = fully LDS-staged encoder.  2 and 4 are experiments that
+ * 5 = group encoder + a wavefront that only prefetches the input; 6 = variant 1 with the current-side bytes read
+ * from an LDS ring fed by the second wavefront; 2 = fully LDS-staged encoder.  2 and 6 are experiments that
  * measured slower; every variant produces the reference's bytes). */
 int lz4flex_set_tuning(lz4flex_ctx *ctx, const char *key, int value);
 

@@ -32,8 +32,8 @@ static int hip_fail(hipError_t e, const char* what) {
     } while (0)
 
 // compress_variant -> launch_compress mode bits: 1 = encode_block + emitter wave (default), 3 = encode_block alone,
-// 5 = encode_block + prefetch-only wave, 4 = LDS input ring + filler wave (experimental)
-static inline int comp_mode_bits(int v) { return (v == 1 ? 0x600 : (v == 4 ? 0x200 : (v == 5 ? 0x400 : 0))) | (getenv("LZ4FLEX_HALF") ? 0x800 : 0); }
+// 5 = encode_block + prefetch-only wave, 6 = emitter wave + LDS input ring (experimental)
+static inline int comp_mode_bits(int v) { return (v == 1 ? 0x600 : (v == 5 ? 0x400 : (v == 6 ? 0x1000 : 0))) | (getenv("LZ4FLEX_HALF") ? 0x800 : 0); }
 
 struct lz4flex_ctx {
     int device = 0;
@@ -44,7 +44,7 @@ struct lz4flex_ctx {
     size_t pin_cap = 0;
     int dec_lanes = 16;           // lanes per block, decode
     int comp_lanes = 8;           // lanes per block, encode
-    int comp_variant = 1;         // 1 = group encoder + emitter wave (default), 3 = group encoder alone, 5 = group encoder + prefetch-only wave, 4 = group encoder + LDS input ring fed by a filler wave (slower), 2 = fully LDS-staged lz4_compress_lds.hip (<= 64 KiB, slower); all bit-exact
+    int comp_variant = 1;         // 1 = group encoder + emitter wave (default), 3 = group encoder alone, 5 = group encoder + prefetch-only wave, 6 = emitter wave that also feeds an LDS input ring (slower), 2 = fully LDS-staged lz4_compress_lds.hip (<= 64 KiB, slower); all bit-exact
     int ablate = 0;               // timing ablations (wrong output!), see lz4flex_set_tuning("ablate")
     int dec_variant = 3;          // 1 = window in HBM/L2 (lz4_decompress.hip), 2 = LDS-staged generic loop, 3 = LDS-staged pipelined (lz4_decompress_lds.hip)
 };
@@ -91,7 +91,7 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
     lz4flex_ctx* c = new (std::nothrow) lz4flex_ctx();
     if (!c) return -LZ4FLEX_E_NOMEM;
     c->device = device;
-    if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v >= 1 && v <= 5) c->comp_variant = v; }
+    if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v >= 1 && v <= 6 && v != 4) c->comp_variant = v; }
     if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v >= 1 && v <= 3) c->dec_variant = v; }
     int prev = 0;
     (void)hipGetDevice(&prev);
@@ -125,7 +125,7 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "compress_variant")) {
-        if (value < 1 || value > 5) return -LZ4FLEX_E_INVALID_ARG;
+        if (value < 1 || value > 6 || value == 4) return -LZ4FLEX_E_INVALID_ARG;
         c->comp_variant = value;
         return 0;
     }

@@ -194,12 +194,42 @@ struct EmitQ {                       // LDS layout per block: 16 records of 16 B
     }
 };
 #define LZ4_EQ_BYTES (16u * LZ4_EQ_DEPTH + 16u)
+// MODE 4 adds, behind the queue, an LDS ring of the block's input around the encoder's position, written by the
+// emitter wave (which then doubles as the "filler"): {lo, hi} (8 B, + 8 B pad) and RING + RING_PAD bytes.
+#define LZ4_RG_SIZE 1024u       // ring bytes per block (power of two)
+#define LZ4_RG_PAD 16u          // mirror of ring bytes [0,16): unaligned reads across the wrap
+#define LZ4_RG_HIST 64u         // bytes kept behind the encoder's first probe
+#define LZ4_RG_CHUNK 128u       // filler granularity: 8 lanes x 16 B
+#define LZ4_EQ_BYTES_RING (LZ4_EQ_BYTES + 16u + LZ4_RG_SIZE + LZ4_RG_PAD)
+struct InRing {                      // encoder-side view
+    lds_u8* ctl;                     // {lo, hi}
+    lds_u8* ring;
+    __device__ __forceinline__ uint64_t window() const { return *reinterpret_cast<lds_vu64*>(ctl); }
+    __device__ __forceinline__ void set_window(uint32_t lo, uint32_t hi) const {
+        *reinterpret_cast<lds_vu64*>(ctl) = (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+    // 8 bytes at any byte position: three ALIGNED dwords + two byte-funnel shifts (a misaligned ds_read stalls
+    // the LDS pipe for much longer than that; the mirror pad keeps the third dword inside the allocation)
+    __device__ __forceinline__ uint64_t ld64(uint32_t pos) const {
+        const uint32_t o = pos & (LZ4_RG_SIZE - 1u);
+        typedef uint32_t __attribute__((address_space(3))) lds_u32a;
+        lds_u32a* a = reinterpret_cast<lds_u32a*>(ring + (o & ~3u));
+        const uint32_t d0 = a[0], d1 = a[1], d2 = a[2];
+        const uint32_t sh = o & 3u;
+        const uint32_t v0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+        const uint32_t v1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        return (uint64_t)v0 | ((uint64_t)v1 << 32);
+    }
+    __device__ __forceinline__ uint32_t ld8(uint32_t pos) const { return ring[pos & (LZ4_RG_SIZE - 1u)]; }
+};
+__device__ __forceinline__ InRing in_ring_of(const EmitQ& q) { return InRing{q.p + LZ4_EQ_BYTES, q.p + LZ4_EQ_BYTES + 16u}; }
 
 // HM: hash selection known at compile time (0: 4-byte hash, 1: 5-byte hash) or per block at run time (2)
 // EQ: sequences are pushed to the block's EmitQ (an emitter wave writes the output and the block's status)
 // instead of being written here; the return value is then LZ4FLEX_DEV_QUEUED unless the block was handled inline.
 #define LZ4FLEX_DEV_QUEUED 0x7FFFFFFF
-template <int G, typename TblT, int HM, bool EQ>
+// RG (with EQ): current-side bytes come from the block's LDS input ring whenever the whole wave's reads are covered
+template <int G, typename TblT, int HM, bool EQ, bool RG>
 __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, uint32_t n, uint8_t* __restrict__ out,
                                                 uint32_t cap, uint32_t flags, TblT* tbl, const Grp<G> grp,
                                                 uint32_t* produced, volatile uint32_t* progress, const EmitQ eq) {
@@ -216,6 +246,8 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
         return 0;
     }
     uint32_t q_head = 0u, q_tail = 0u;   // q_tail: last value read of the emitter's tail (it only grows)
+    const InRing rg = in_ring_of(eq);
+    uint32_t rg_lo = 0u, rg_hi = 0u;     // last window read from the filler (the real one only moves forward)
     const bool frame_tbl = (flags & 2u) != 0u;        // FrameEncoder: HashTable4K + hash5 always
     const bool continuation = (flags & 1u) != 0u;     // table holds only unreachable entries; pos 0 is probed
     const bool use_h5 = HM == 2 ? (frame_tbl || n >= 65535u) : (HM == 1);   // compress.rs:559-566
@@ -246,6 +278,21 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
     uint64_t x0 = 0ull;   // probe bytes of the FIRST batch of the current sequence: lanes 0 and 7 hold its first 15 literals
     uint32_t x0_base = 0xFFFFFFFFu;   // position lane 0's x0 was read from
     for (;;) {
+        // ------------------------------------------------------------------ may this step read the ring?  (wave-uniform)
+        bool fast = false;
+        if (RG) {
+            const uint32_t pfirst = probe_pos(base, i0);
+            if (g == 0u) eq.set_prog(pfirst);
+            // consecutive probe positions (i < 32) and every current-side read of the step inside [lo, hi)
+            bool ok = i0 + G <= 32u && pfirst + (10u * G + 16u) <= rg_hi && (rg_lo == 0u || rg_lo + 8u <= pfirst);
+            if (!__all(ok)) {
+                const uint64_t snap = rg.window();
+                rg_lo = (uint32_t)snap; rg_hi = (uint32_t)(snap >> 32);
+                ok = i0 + G <= 32u && pfirst + (10u * G + 16u) <= rg_hi && (rg_lo == 0u || rg_lo + 8u <= pfirst);
+            }
+            fast = __all(ok);
+            if (fast) { PHASE_COUNT(5) }
+        }
         // ------------------------------------------------------------------ probe batch
         if (i0 == 0u) { x0 = x; x0_base = base; }
         const uint32_t i = i0 + g;
@@ -296,7 +343,8 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
             if (vm != (((G == 32) ? 0xFFFFFFFFu : ((1u << G) - 1u)))) break;   // ran past end_check: last literals
             i0 += G;
             const uint32_t pn = probe_pos(base, i0 + g);
-            x = cld64(in + (pn <= end_check ? pn : 0u));
+            if (RG && fast && i0 + G <= 32u && __all(probe_pos(base, i0) + G + 8u <= rg_hi)) x = rg.ld64(pn);
+            else x = cld64(in + (pn <= end_check ? pn : 0u));
             continue;
         }
         uint32_t cur = grp.bcast(p, last);
@@ -310,9 +358,17 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
         const bool bk_ok0 = (cnd > g) && (cur > lit_start + g);
         const uint32_t fa = m4 + 8u * g, fb = c4 + 8u * g;
         const bool f8 = fa + 8u <= limit;                                     // a full 8-byte forward chunk
-        const uint32_t bka = in[bk_ok0 ? cur - 1u - g : 0u];
+        uint32_t bka;
+        uint64_t fwa;
+        if (RG && fast) {                     // current side from the ring (lanes with nothing to read re-read cur)
+            bka = rg.ld8(bk_ok0 ? cur - 1u - g : cur);
+            fwa = rg.ld64(f8 ? fa : cur);
+        } else {
+            bka = in[bk_ok0 ? cur - 1u - g : 0u];
+            fwa = cld64(in + (f8 ? fa : 0u));
+        }
         const uint32_t bkb = in[bk_ok0 ? cnd - 1u - g : 0u];
-        const uint64_t fdiff = cld64(in + (f8 ? fa : 0u)) ^ cld64(in + (f8 ? fb : 0u));
+        const uint64_t fdiff = fwa ^ cld64(in + (f8 ? fb : 0u));
         uint32_t c = 0u;                      // equal bytes seen by this lane in the first forward round (0..8)
         if (f8) c = fdiff ? (uint32_t)(__builtin_ctzll(fdiff) >> 3) : 8u;
         if (__any(!f8 && fa < limit)) {       // rare: the last (< 8 byte) chunk before the end of the block
@@ -357,8 +413,17 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
         // ------------------------------------------------------------------ requests for the NEXT step: the bytes of
         // the cur-2 table update (compress.rs:460-461) and of the first probe batch after this match
         const uint32_t q = cur_end - 2u;
-        const uint64_t qx = cld64(in + q);                                    // q + 8 <= n: matches end >= 6 bytes early
-        const uint64_t xn = cld64(in + (cur_end + g <= end_check ? cur_end + g : 0u));
+        uint64_t qx, xn;                                                      // q + 8 <= n: matches end >= 6 bytes early
+        {
+            const bool pv = cur_end + g <= end_check;
+            if (RG && fast && __all(cur_end + G + 8u <= rg_hi)) {
+                qx = rg.ld64(q);
+                xn = rg.ld64(pv ? cur_end + g : q);
+            } else {
+                qx = cld64(in + q);
+                xn = cld64(in + (pv ? cur_end + g : 0u));
+            }
+        }
         // ---- backtrack (compress.rs:442-448), off the critical path: the next step only needs cur_end
         {
             uint32_t nb = (uint32_t)__builtin_ctz(~okm);                      // G..31 bits are 0 in okm => nb <= G
@@ -382,7 +447,7 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
             if (g == 0u) {
                 eq.put(q_head, lit_start, lit_len, offset, dl);
                 eq.set_head(q_head + 1u);
-                eq.set_prog(cur_end);
+                if (!RG) eq.set_prog(cur_end);
             }
             q_head += 1u;
         } else {
@@ -454,13 +519,16 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
 // The emitter wave: lane group j pops block j's sequence records and writes the compressed block
 // (compress.rs:463-486, :237-247), then the block's length and status.  It also walks ahead of the encoder
 // touching the input lines it is about to read (see MODE 2 below).
-template <int G>
+template <int G, bool RG>
 __device__ __forceinline__ void emitter_wave(const CompressArgs& a, uint32_t b, bool live, const EmitQ eq, const Grp<G> grp) {
     const uint32_t g = grp.g;
     const uint8_t* in = a.in_base + (live ? a.in_off[b] : 0ull);
     uint8_t* out = a.out_base + (live ? a.out_off[b] : 0ull);
     const uint32_t n = live ? a.in_len[b] : 0u;
     uint32_t o = 0u, tail = 0u, pf = 0u, acc = 0u;
+    const InRing rg = in_ring_of(eq);
+    const uint32_t n_fill = n & ~(LZ4_RG_CHUNK - 1u);   // whole chunks only; the encoder reads the tail from memory
+    uint32_t rlo = 0u, rhi = 0u;                       // the ring holds input positions [rlo, rhi)
     bool done = !live;
     for (;;) {
         if (!__any(!done)) break;
@@ -493,13 +561,45 @@ __device__ __forceinline__ void emitter_wave(const CompressArgs& a, uint32_t b, 
                 if (g == 0u) eq.set_tail(tail);
                 worked = true;
             }
-            // stream prefetch: keep the lines [pos, pos + LZ4_PF_AHEAD) of the input on their way into L2
             const uint32_t pos = eq.prog();
-            if (pf < pos) pf = pos & ~127u;
-            if (!done && pf + 128u * G < pos + LZ4_PF_AHEAD) {
-                const uint32_t at = pf + 128u * g;
-                if (at + 4u <= n) acc += *reinterpret_cast<const volatile uint32_t*>(in + (at & ~3u));
-                pf += 128u * G;
+            if (!RG) {
+                // stream prefetch: keep the lines [pos, pos + LZ4_PF_AHEAD) of the input on their way into L2
+                if (pf < pos) pf = pos & ~127u;
+                if (!done && pf + 128u * G < pos + LZ4_PF_AHEAD) {
+                    const uint32_t at = pf + 128u * g;
+                    if (at + 4u <= n) acc += *reinterpret_cast<const volatile uint32_t*>(in + (at & ~3u));
+                    pf += 128u * G;
+                }
+            }
+        }
+        if (RG) {
+            // ---- input ring: one 128-byte chunk per block and iteration, lanes 0..7 of the group 16 B each.
+            // The chunk [rhi, rhi+128) may overwrite ring positions below prog - HIST only; {lo, hi} are published
+            // after the data (a wave's LDS operations execute in order).
+            bool fill = false;
+            if (!done) {
+                const uint32_t pos = eq.prog();
+                if (pos >= rhi) {   // the ring is behind the encoder (start, long match): restart it around pos
+                    const uint32_t back = pos < LZ4_RG_HIST ? pos : LZ4_RG_HIST;
+                    rlo = rhi = (pos - back) & ~(LZ4_RG_CHUNK - 1u);
+                }
+                fill = rhi + LZ4_RG_CHUNK <= n_fill && rhi + LZ4_RG_CHUNK + LZ4_RG_HIST <= pos + LZ4_RG_SIZE;
+            }
+            if (__any(fill)) {
+                const bool mine = fill && g < 8u;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                __builtin_memcpy(&v, in + (mine ? rhi + 16u * g : 0u), 16);
+                if (mine) {
+                    const uint32_t ro = (rhi + 16u * g) & (LZ4_RG_SIZE - 1u);
+                    *reinterpret_cast<lds_u128*>(rg.ring + ro) = v;
+                    if (ro == 0u) *reinterpret_cast<lds_u128*>(rg.ring + LZ4_RG_SIZE) = v;
+                }
+                if (fill) {
+                    rhi += LZ4_RG_CHUNK;
+                    if (rhi - rlo > LZ4_RG_SIZE) rlo = rhi - LZ4_RG_SIZE;
+                    if (g == 0u) rg.set_window(rlo, rhi);
+                    worked = true;
+                }
             }
         }
         if (!__any(worked)) __builtin_amdgcn_s_sleep(LZ4_EM_SLEEP);
@@ -507,319 +607,6 @@ __device__ __forceinline__ void emitter_wave(const CompressArgs& a, uint32_t b, 
     if (acc == 0x9E3779B9u && live) eq.set_prog(acc);   // keeps the prefetch loads alive
 }
 
-
-// ---------------------------------------------------------------------------------------------------
-// Windowed encoder (default for independent blocks).  Same algorithm and same bytes as encode_block; what
-// changes is where the CURRENT-side bytes come from.  The encoder is a serial chain per block and at most
-// 16..20 blocks fit a CU (the 8 KiB tables fill the LDS), so the chain length IS the throughput; a global load
-// costs 350-1000 cycles in that chain (tools/ubench_mem.hip), an unaligned LDS read ~150.  Each block therefore
-// keeps a ring of its input around the probing position in LDS:
-//   * a second wavefront of the workgroup (the filler) walks ahead of the encoders and copies the input into
-//     the rings with coalesced 16 B/lane loads.  The encoder wave never issues those loads itself: the
-//     vmcnt counter is in order, so a refill that misses to HBM would stall every later load of the chain;
-//   * encoder and filler talk through three LDS words per block: `prog` (first probe position of the encoder's
-//     current step, written by the encoder) and {lo, hi} (the ring holds input positions [lo, hi), written
-//     by the filler AFTER the data, as one 8-byte store);
-//   * probe bytes, the 8 bytes behind a match, the current side of the forward extension, the cur-2 table
-//     update and the next step's probe bytes are unaligned LDS reads; a read the ring does not cover
-//     (start-up, after a long match, tail of the block) falls back to the global load of encode_block;
-//   * the candidate side (verification, backward and forward bytes) stays in HBM/L2: 2 dependent global
-//     round trips per sequence instead of 3.
-#define LZ4_WIN 1024u       // ring bytes per block (power of two)
-#define LZ4_WIN_PAD 16u     // mirror of ring bytes [0,16): unaligned reads across the wrap
-#define LZ4_WIN_HIST 64u    // bytes kept behind the encoder's first probe
-#define LZ4_WIN_CHUNK 128u  // filler granularity: 8 lanes x 16 B
-
-
-struct WinCtl {              // per block, in LDS
-    uint32_t lo, hi;         // filler -> encoder (8-byte aligned pair)
-    uint32_t prog;           // encoder -> filler; 0xFFFFFFFF = block finished
-    uint32_t pad;
-};
-// LDS-typed accessors of a block's control words (ctl = LDS address of its WinCtl)
-struct WinCtlRef {
-    lds_u8* p;
-    __device__ __forceinline__ uint32_t prog() const { return *reinterpret_cast<lds_vu32*>(p + 8); }
-    __device__ __forceinline__ void set_prog(uint32_t v) const { *reinterpret_cast<lds_vu32*>(p + 8) = v; }
-    __device__ __forceinline__ uint64_t window() const { return *reinterpret_cast<lds_vu64*>(p); }
-    __device__ __forceinline__ void set_window(uint32_t lo, uint32_t hi) const {
-        *reinterpret_cast<lds_vu64*>(p) = (uint64_t)lo | ((uint64_t)hi << 32);
-    }
-};
-
-struct Win {
-    const uint8_t* in;   // block input (global)
-    lds_u8* ring;        // LDS, LZ4_WIN + LZ4_WIN_PAD bytes, 16-aligned
-    uint32_t lo, hi;     // snapshot of the filler's window for this step
-    __device__ __forceinline__ uint64_t lds64(uint32_t p) const {
-        lds_u8* a = ring + (p & (LZ4_WIN - 1u));
-        const uint32_t v0 = *reinterpret_cast<lds_u32_unaligned*>(a);
-        const uint32_t v1 = *reinterpret_cast<lds_u32_unaligned*>(a + 4);
-        return (uint64_t)v0 | ((uint64_t)v1 << 32);
-    }
-    __device__ __forceinline__ bool covers(uint32_t p) const { return p >= lo && p + 8u <= hi; }
-};
-
-// the filler wave: lane group j (8 lanes) serves block j of the workgroup
-__device__ __forceinline__ void ring_filler(const uint8_t* in, uint32_t n, bool live, lds_u8* ring, const WinCtlRef ctl,
-                                            uint32_t g8) {
-    const uint32_t n_fill = n & ~(LZ4_WIN_CHUNK - 1u);   // whole chunks only; the tail is read from memory
-    uint32_t lo = 0u, hi = 0u;
-    for (;;) {
-        const uint32_t p = live ? ctl.prog() : 0xFFFFFFFFu;
-        const bool done = p == 0xFFFFFFFFu;
-        if (!__any(!done)) break;
-        bool fill = false;
-        if (!done) {
-            if (p >= hi) {   // the ring is behind the encoder (start, long match): restart it around p
-                const uint32_t back = p < LZ4_WIN_HIST ? p : LZ4_WIN_HIST;
-                lo = hi = (p - back) & ~(LZ4_WIN_CHUNK - 1u);
-            }
-            fill = hi + LZ4_WIN_CHUNK <= n_fill && hi + LZ4_WIN_CHUNK + LZ4_WIN_HIST <= p + LZ4_WIN;
-        }
-        if (__any(fill)) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            __builtin_memcpy(&v, in + (fill ? hi + 16u * g8 : 0u), 16);
-            if (fill) {
-                const uint32_t ro = (hi + 16u * g8) & (LZ4_WIN - 1u);
-                *reinterpret_cast<lds_u128*>(ring + ro) = v;
-                if (ro == 0u) *reinterpret_cast<lds_u128*>(ring + LZ4_WIN) = v;
-                hi += LZ4_WIN_CHUNK;
-                if (hi - lo > LZ4_WIN) lo = hi - LZ4_WIN;
-                if (g8 == 0u) ctl.set_window(lo, hi);   // published after the data (a wave's LDS operations execute in order)
-            }
-        } else {
-            __builtin_amdgcn_s_sleep(4);
-        }
-    }
-}
-
-template <int G, typename TblT>
-__device__ __forceinline__ int32_t encode_block_w(const uint8_t* __restrict__ in, uint32_t n, uint8_t* __restrict__ out,
-                                                  uint32_t cap, uint32_t flags, TblT* tbl, uint8_t* ring_generic,
-                                                  const WinCtlRef ctl, const Grp<G> grp, uint32_t* produced) {
-    const uint32_t g = grp.g;
-    if ((uint64_t)cap < max_output_size(n)) return LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL;   // compress.rs:338-340
-    uint32_t o = 0u;
-    if (n < LZ4_MIN_LENGTH) {   // compress.rs:343-346
-        o = emit_literals<G>(out, o, in, 0u, n, 0u, g);
-        *produced = o;
-        return 0;
-    }
-    const bool frame_tbl = (flags & 2u) != 0u;        // FrameEncoder: HashTable4K + hash5 always
-    const bool continuation = (flags & 1u) != 0u;     // table holds only unreachable entries; pos 0 is probed
-    const bool use_h5 = frame_tbl || n >= 65535u;     // compress.rs:559-566
-    const uint32_t end_check = n - LZ4_MFLIMIT;       // compress.rs:349
-    const uint32_t limit = n - LZ4_END_OFFSET;        // matches end 6 bytes before the end
-    {   // zero the table (HashTable::new / clear)
-        uint4* t4 = reinterpret_cast<uint4*>(tbl);
-        const uint32_t n16 = (4096u * (uint32_t)sizeof(TblT)) / 16u;
-        for (uint32_t k = g; k < n16; k += G) t4[k] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    const uint32_t idx0 = use_h5 ? hidx5(cld64(in)) : hidx4(cld32(in));
-    Win w;
-    w.in = in; w.ring = (lds_u8*)ring_generic; w.lo = 0u; w.hi = 0u;
-    uint32_t lit_start = 0u;
-    uint32_t base = continuation ? 0u : 1u;   // probing origin of the current sequence (compress.rs:353-359)
-    uint32_t i0 = continuation ? 1u : 0u;     // index of the first probe of the next batch
-    uint64_t x;                               // the 8 input bytes at this lane's probe position
-    {
-        const uint32_t p0 = probe_pos(base, i0 + g);
-        x = cld64(in + (p0 <= end_check ? p0 : 0u));
-    }
-    PHASE_DECL
-    for (;;) {
-        // ------------------------------------------------------------------ window snapshot for this step
-        {
-            const uint64_t snap = ctl.window();
-            w.lo = (uint32_t)snap;
-            w.hi = (uint32_t)(snap >> 32);
-        }
-        // ------------------------------------------------------------------ probe batch
-        const uint32_t i = i0 + g;
-        const uint32_t p = probe_pos(base, i);
-        const bool valid = p <= end_check;                                    // compress.rs:381
-        uint32_t idx = 0xFFFF0000u + g;   // distinct sentinels for invalid lanes
-        uint32_t cand = 0u;
-        const uint32_t cur4 = (uint32_t)x;
-        bool cand_ok = false;
-        if (valid) {
-            idx = use_h5 ? hidx5(x) : hidx4(cur4);
-            cand = (uint32_t)tbl[idx];
-            cand_ok = !continuation || cand != 0u || idx == idx0;             // see encode_block
-        }
-        PHASE_MARK(0)   // top: snapshot + hash + table read
-        const uint32_t d = FwdConflict<G, 1>::run(idx, g);
-        if (d != 0u) { cand = probe_pos(base, i - d); cand_ok = true; }
-        const bool try_m = valid && cand_ok && (p - cand) <= LZ4_MAX_DISTANCE;  // compress.rs:403-405
-        const bool is_match = (cld32(in + (try_m ? cand : 0u)) == cur4) && try_m;   // compress.rs:432-438
-        const uint32_t mm = grp.ballot(is_match);
-        PHASE_MARK(1)   // conflict + candidate round trip
-        const uint32_t vm = grp.ballot(valid);
-        const uint32_t last = mm ? (uint32_t)__builtin_ctz(mm) : (G - 1u);     // last probe that executes
-        bool superseded = false;
-        if (__any(d != 0u)) superseded = BwdConflict<G, 1>::run(idx, g, last);
-        if (valid && g <= last && !superseded) tbl[idx] = (TblT)p;            // compress.rs:393
-        if (mm == 0u) {
-            if (vm != (((G == 32) ? 0xFFFFFFFFu : ((1u << G) - 1u)))) break;   // ran past end_check: last literals
-            i0 += G;
-            const uint32_t pf = probe_pos(base, i0);
-            if (g == 0u) ctl.set_prog(pf);
-            const uint32_t pn = probe_pos(base, i0 + g);
-            const bool pv = pn <= end_check;
-            x = w.lds64(pn);
-            if (__any(pv && !w.covers(pn))) x = (pv && !w.covers(pn)) ? cld64(in + pn) : x;
-            continue;
-        }
-        uint32_t cur = grp.bcast(p, last);
-        uint32_t cnd = grp.bcast(cand, last);
-        const uint32_t offset = cur - cnd;                                    // compress.rs:409
-        PHASE_MARK(2)   // table stores + winner broadcast
-        // ------------------------------------------------------------------ extension, one round trip: 8 bytes behind
-        // the match and 8*G bytes after it.  Current side from the ring, candidate side from memory.
-        const uint32_t m4 = cur + 4u, c4 = cnd + 4u;
-        const uint32_t nbmax = min(cur - lit_start, cnd);                     // compress.rs:442-448 bounds
-        const bool bk_fast = cur >= 8u && cnd >= 8u;
-        const uint32_t fa = m4 + 8u * g, fb = c4 + 8u * g;
-        const bool f8 = fa + 8u <= limit;                                     // a full 8-byte forward chunk
-        const uint32_t pa = bk_fast ? cur - 8u : 0u;
-        uint64_t bk_a = w.lds64(pa);
-        uint64_t fw_a = w.lds64(fa);
-        const uint64_t bk_b = cld64(in + (bk_fast ? cnd - 8u : 0u));
-        const uint64_t fw_b = cld64(in + (f8 ? fb : 0u));
-        {   // current-side bytes the ring does not hold
-            const bool ma = bk_fast && !w.covers(pa), mf = f8 && !w.covers(fa);
-            if (__any(ma || mf)) {
-                PHASE_COUNT(7)
-                const uint64_t ga = cld64(in + (ma ? pa : 0u)), gf = cld64(in + (mf ? fa : 0u));
-                if (ma) bk_a = ga;
-                if (mf) fw_a = gf;
-            }
-        }
-        uint32_t eq = 0u;
-        if (bk_fast) { const uint64_t df = bk_a ^ bk_b; eq = df ? (uint32_t)(__builtin_clzll(df) >> 3) : 8u; }
-        uint32_t c = 0u;                      // equal bytes seen by this lane in the first forward round (0..8)
-        if (f8) { const uint64_t fd = fw_a ^ fw_b; c = fd ? (uint32_t)(__builtin_ctzll(fd) >> 3) : 8u; }
-        PHASE_MARK(3)   // extension round trip
-        if (__any(!f8 && fa < limit)) {       // rare: the last (< 8 byte) chunk before the end of the block
-            if (!f8 && fa < limit) {
-                const uint32_t rem = limit - fa;
-                while (c < rem && in[fa + c] == in[fb + c]) ++c;
-            }
-        }
-        // ---- backtrack (compress.rs:442-448)
-        {
-            uint32_t nb = eq < nbmax ? eq : nbmax;
-            if (!bk_fast) nb = 0u;
-            cur -= nb; cnd -= nb;
-            // rare: block start (fewer than 8 bytes before either side) or more than 8 equal bytes
-            bool more = !bk_fast ? (nbmax != 0u) : (nb == 8u && nbmax > 8u);
-            while (__any(more)) {
-                if (more) {
-                    const bool ok = (cnd > g) && (cur > lit_start + g) && in[cur - 1u - g] == in[cnd - 1u - g];
-                    const uint32_t okm2 = grp.ballot(ok);
-                    const uint32_t nb2 = (uint32_t)__builtin_ctz(~okm2);
-                    cur -= nb2; cnd -= nb2;
-                    more = nb2 == (uint32_t)G;
-                }
-            }
-        }
-        const uint32_t lit_len = cur - lit_start;                             // compress.rs:451
-        // ---- forward (count_same_bytes :156-216)
-        uint32_t dl = 0u;
-        {
-            uint32_t part = grp.ballot(c != 8u);
-            if (part != 0u) {
-                const uint32_t f = (uint32_t)__builtin_ctz(part);
-                dl = 8u * f + grp.bcast(c, f);
-            } else {
-                dl = 8u * G;
-                for (;;) {
-                    const uint32_t a = m4 + dl + 8u * g;
-                    uint32_t c2 = 0u;
-                    if (a < limit) {
-                        const uint32_t rem = limit - a;
-                        const uint32_t b = c4 + dl + 8u * g;
-                        if (rem >= 8u) {
-                            const uint64_t diff = cld64(in + a) ^ cld64(in + b);
-                            c2 = diff ? (uint32_t)(__builtin_ctzll(diff) >> 3) : 8u;
-                        } else {
-                            while (c2 < rem && in[a + c2] == in[b + c2]) ++c2;
-                        }
-                    }
-                    part = grp.ballot(c2 != 8u);
-                    if (part == 0u) { dl += 8u * G; continue; }
-                    const uint32_t f = (uint32_t)__builtin_ctz(part);
-                    dl += 8u * f + grp.bcast(c2, f);
-                    break;
-                }
-            }
-        }
-        const uint32_t cur_end = m4 + dl;
-        dl = cur_end - (cur + 4u);                                            // duplicate_length counts from the backtracked start + 4
-        if (g == 0u) ctl.set_prog(cur_end);
-        PHASE_MARK(4)   // backtrack + forward math
-        // ------------------------------------------------------------------ bytes for the cur-2 table update
-        // (compress.rs:460-461) and for the first probe batch after this match
-        const uint32_t q = cur_end - 2u;                                      // q + 8 <= n: matches end >= 6 bytes early
-        const uint32_t pn = cur_end + g;
-        const bool pv = pn <= end_check;
-        uint64_t qx = w.lds64(q);
-        uint64_t xn = w.lds64(pn);
-        {
-            const bool mq = !w.covers(q), mx = pv && !w.covers(pn);
-            if (__any(mq || mx)) {
-                const uint64_t gq = cld64(in + (mq ? q : 0u)), gx = cld64(in + (mx ? pn : 0u));
-                if (mq) qx = gq;
-                if (mx) xn = gx;
-            }
-        }
-        PHASE_MARK(5)   // next-step bytes (ring or memory)
-        // ------------------------------------------------------------------ emit (compress.rs:463-486)
-        if (i0 == 0u && base == lit_start && lit_len <= 7u && dl < 270u && o + 12u <= cap) {
-            // the match was found in the first batch: all (<= 7) literals sit in lane 0's probe bytes.
-            // token+literals as one 8-byte store, offset + length byte as one 4-byte store (bytes past the
-            // sequence are rewritten by the next one; the capacity check above keeps them inside `out`)
-            const uint32_t tk = (lit_len << 4) | (dl < 15u ? dl : 15u);
-            const uint64_t w0 = (uint64_t)tk | (x << 8);
-            const uint32_t w1 = offset | ((dl - 15u) << 16);
-#ifndef LZ4FLEX_ABL_NOSTORE
-            if (g == 0u) {
-                __builtin_memcpy(out + o, &w0, 8);
-                __builtin_memcpy(out + o + 1u + lit_len, &w1, 4);
-            }
-#endif
-            o += 3u + lit_len + (dl >= 15u ? 1u : 0u);
-#ifdef LZ4FLEX_ABL_NOGENERIC
-        } else if (false) {
-#else
-        } else {
-#endif
-            o = emit_literals<G>(out, o, in, lit_start, lit_len, dl < 15u ? dl : 15u, g);
-            if (g == 0u) { out[o] = (uint8_t)(offset & 0xFFu); out[o + 1u] = (uint8_t)(offset >> 8); }
-            o += 2u;
-            if (dl >= 15u) {
-                const uint32_t rem = dl - 15u;
-                const uint32_t n255 = rem / 255u;
-                for (uint32_t k = g; k < n255; k += G) out[o + k] = 0xFFu;
-                o += n255;
-                if (g == 0u) out[o] = (uint8_t)(rem - n255 * 255u);
-                o += 1u;
-            }
-        }
-        PHASE_MARK(6)   // emit
-        if (g == 0u) tbl[use_h5 ? hidx5(qx) : hidx4((uint32_t)qx)] = (TblT)q;
-        lit_start = cur_end;                                                  // compress.rs:487
-        base = cur_end;
-        i0 = 0u;
-        x = xn;
-    }
-    // handle_last_literals, compress.rs:237-247
-    o = emit_literals<G>(out, o, in, lit_start, n - lit_start, 0u, g);
-    PHASE_FLUSH
-    *produced = o;
-    return 0;
-}
 
 // ---------------------------------------------------------------------------------------------------
 // General encoder: the full signature of compress_internal<T, USE_DICT> (src/block/compress.rs:318-489):
@@ -1010,22 +797,27 @@ hipError_t launch_compress_chain(const uint8_t* in_base, const void* blocks, con
     return hipGetLastError();
 }
 
-// MODE 0: encode_block (everything read from HBM/L2).  MODE 1: encode_block_w (LDS input ring).
-// MODE 2: encode_block plus a second wavefront per workgroup that only walks ahead of the encoders and touches
-// the input lines they are about to need, so that the encoders' current-side loads hit L2 instead of paying
-// the first-touch HBM latency inside their serial chain (an in-order vmcnt makes self-prefetching useless:
-// a load behind a missing prefetch waits for it).
+// MODE 0: the encoder wavefront alone (everything read from HBM/L2, output written inline).
+// MODE 2: plus a second wavefront per workgroup that only walks ahead of the encoders and touches the input
+//         lines they are about to need, so that the encoders' current-side loads hit L2 instead of paying the
+//         first-touch HBM latency inside their serial chain (an in-order vmcnt makes self-prefetching useless:
+//         a load behind a missing prefetch waits for it).
+// MODE 3: (default) the second wavefront is the EMITTER: it pops the sequence records the encoders push into
+//         their LDS queues, writes the compressed blocks and their status, and does MODE 2's prefetch.
+// MODE 4: MODE 3 + the emitter also copies the input into an LDS ring per block that serves the encoders'
+//         current-side reads (experiment; measured slower than MODE 3).
 // BPW = blocks per workgroup: BPW * G <= 64 lanes of the encoder wave are used.  With u16 tables a CU's
-// 160 KiB of LDS hold 20 tables, i.e. five workgroups of four blocks; the encoder is a latency-bound serial chain
-// per block, so blocks in flight matter and half-empty waves do not.
+// 160 KiB of LDS hold two workgroups of eight blocks (or four of five: 20 tables, but 16 384 blocks then
+// still need 4 rounds); the encoder is a latency-bound serial chain per block, so blocks in flight matter and
+// half-empty waves do not.
 template <int G, typename TblT, int MODE, int BPW>
 __global__ void __launch_bounds__(MODE == 0 ? 64 : 128) lz4_compress_blocks_kernel(CompressArgs a) {
-    constexpr bool WINDOW = MODE == 1;
-    constexpr bool EQ = MODE == 3;
+    constexpr bool EQ = MODE == 3 || MODE == 4;
+    constexpr bool RG = MODE == 4;
+    constexpr uint32_t EQB = RG ? LZ4_EQ_BYTES_RING : LZ4_EQ_BYTES;
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     TblT* tables = reinterpret_cast<TblT*>(dyn_lds);                                        // [BPW][4096]
-    uint8_t* rings = dyn_lds + (size_t)BPW * 4096u * sizeof(TblT);                          // [BPW][LZ4_WIN + LZ4_WIN_PAD] (MODE 1)
-    WinCtl* ctls = reinterpret_cast<WinCtl*>(rings + (WINDOW ? (size_t)BPW * (LZ4_WIN + LZ4_WIN_PAD) : 0u));   // [BPW] (MODE 1)
+    uint8_t* rings = dyn_lds + (size_t)BPW * 4096u * sizeof(TblT);                          // per-block side structures (MODE 2..4)
     uint32_t* progress = reinterpret_cast<uint32_t*>(rings);                                // [BPW] (MODE 2)
     const uint32_t lane = threadIdx.x & 63u;
     Grp<G> grp;
@@ -1033,31 +825,17 @@ __global__ void __launch_bounds__(MODE == 0 ? 64 : 128) lz4_compress_blocks_kern
     grp.shift = (lane / G) * G;
     const uint32_t j = lane / G;                                                            // block slot of this lane group
     const uint32_t b = blockIdx.x * BPW + j;
-    if (MODE == 1) {
-        // the filler wave works in groups of 8 lanes whatever G is
-        const uint32_t j8 = lane / 8u, b8 = blockIdx.x * BPW + j8;
+    if (EQ) {
+        // sequence queues (+ input rings, MODE 4) behind the tables; the second wave is the emitter
         if (threadIdx.x < BPW) {
-            const bool live = blockIdx.x * BPW + threadIdx.x < a.n;
-            ctls[threadIdx.x].lo = 0u; ctls[threadIdx.x].hi = 0u; ctls[threadIdx.x].prog = live ? 0u : 0xFFFFFFFFu;
-        }
-        __syncthreads();
-        if (threadIdx.x >= 64u) {
-            const bool live = j8 < BPW && b8 < a.n;
-            ring_filler(a.in_base + (live ? a.in_off[b8] : 0ull), live ? a.in_len[b8] : 0u, live,
-                        (lds_u8*)(rings + (size_t)(live ? j8 : 0u) * (LZ4_WIN + LZ4_WIN_PAD)), WinCtlRef{(lds_u8*)&ctls[live ? j8 : 0u]}, lane % 8u);
-            return;
-        }
-    }
-    if (MODE == 3) {
-        // sequence queues live where MODE 1 keeps its rings; the second wave is the emitter (+ stream prefetch)
-        if (threadIdx.x < BPW) {
-            const EmitQ q0{(lds_u8*)(rings + (size_t)threadIdx.x * LZ4_EQ_BYTES)};
+            const EmitQ q0{(lds_u8*)(rings + (size_t)threadIdx.x * EQB)};
             q0.set_head(0u); q0.set_tail(0u); q0.set_prog(0u);
+            if (RG) in_ring_of(q0).set_window(0u, 0u);
         }
         __syncthreads();
         if (threadIdx.x >= 64u) {
             const bool live = j < BPW && b < a.n;
-            emitter_wave<G>(a, b, live, EmitQ{(lds_u8*)(rings + (size_t)(live ? j : 0u) * LZ4_EQ_BYTES)}, grp);
+            emitter_wave<G, RG>(a, b, live, EmitQ{(lds_u8*)(rings + (size_t)(live ? j : 0u) * EQB)}, grp);
             return;
         }
     }
@@ -1097,11 +875,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 64 : 128) lz4_compress_blocks_kern
     const uint32_t flags = a.flags ? a.flags[b] : 0u;
     uint32_t produced = 0u;
     int32_t st;
-    if (WINDOW)
-        st = encode_block_w<G, TblT>(a.in_base + a.in_off[b], n, a.out_base + a.out_off[b], a.out_cap[b], flags,
-                                     tables + (size_t)j * 4096u, rings + (size_t)j * (LZ4_WIN + LZ4_WIN_PAD), WinCtlRef{(lds_u8*)&ctls[j]}, grp,
-                                     &produced);
-    else {
+    {
         // the hash choice (compress.rs:559-566) is the same for every block of a typical batch: pick the
         // specialised loop when the whole wave agrees
         const bool h5 = (flags & 2u) != 0u || n >= 65535u;
@@ -1109,12 +883,11 @@ __global__ void __launch_bounds__(MODE == 0 ? 64 : 128) lz4_compress_blocks_kern
         uint8_t* out = a.out_base + a.out_off[b];
         TblT* tbl = tables + (size_t)j * 4096u;
         volatile uint32_t* pg = MODE == 2 ? &progress[j] : nullptr;
-        const EmitQ eq{(lds_u8*)(rings + (size_t)(EQ ? j : 0u) * LZ4_EQ_BYTES)};
-        if (__all(h5)) st = encode_block<G, TblT, 1, EQ>(in, n, out, a.out_cap[b], flags, tbl, grp, &produced, pg, eq);
-        else if (__all(!h5)) st = encode_block<G, TblT, 0, EQ>(in, n, out, a.out_cap[b], flags, tbl, grp, &produced, pg, eq);
-        else st = encode_block<G, TblT, 2, EQ>(in, n, out, a.out_cap[b], flags, tbl, grp, &produced, pg, eq);
+        const EmitQ eq{(lds_u8*)(rings + (size_t)(EQ ? j : 0u) * EQB)};
+        if (__all(h5)) st = encode_block<G, TblT, 1, EQ, RG>(in, n, out, a.out_cap[b], flags, tbl, grp, &produced, pg, eq);
+        else if (__all(!h5)) st = encode_block<G, TblT, 0, EQ, RG>(in, n, out, a.out_cap[b], flags, tbl, grp, &produced, pg, eq);
+        else st = encode_block<G, TblT, 2, EQ, RG>(in, n, out, a.out_cap[b], flags, tbl, grp, &produced, pg, eq);
     }
-    if (MODE == 1 && grp.g == 0u) WinCtlRef{(lds_u8*)&ctls[j]}.set_prog(0xFFFFFFFFu);
     if (MODE == 2 && grp.g == 0u) *reinterpret_cast<volatile uint32_t*>(&progress[j]) = 0xFFFFFFFFu;
     if (grp.g == 0u && st != LZ4FLEX_DEV_QUEUED) {   // a queued block's length and status come from the emitter wave
         a.status[b] = st;
@@ -1124,10 +897,10 @@ __global__ void __launch_bounds__(MODE == 0 ? 64 : 128) lz4_compress_blocks_kern
 
 template <int G, typename TblT, int MODE, int BPW>
 static hipError_t launch_c(const CompressArgs& a, hipStream_t s) {
-    static_assert(BPW * G <= 64 && BPW <= 8, "one encoder wave per workgroup; the filler wave serves 8 blocks");
+    static_assert(BPW * G <= 64 && BPW <= 8, "one encoder wave per workgroup");
     const uint32_t grid = (a.n + BPW - 1u) / BPW;
     const size_t lds = (size_t)BPW * 4096u * sizeof(TblT) +
-                       (MODE == 1 ? (size_t)BPW * (LZ4_WIN + LZ4_WIN_PAD + sizeof(WinCtl)) : (MODE == 2 ? 64u : (MODE == 3 ? (size_t)BPW * LZ4_EQ_BYTES : 0u)));
+                       (MODE == 2 ? 64u : (MODE == 3 ? (size_t)BPW * LZ4_EQ_BYTES : (MODE == 4 ? (size_t)BPW * LZ4_EQ_BYTES_RING : 0u)));
     auto kern = lz4_compress_blocks_kernel<G, TblT, MODE, BPW>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set && lds > 65536u) {
@@ -1141,20 +914,20 @@ static hipError_t launch_c(const CompressArgs& a, hipStream_t s) {
 
 template <int G, typename TblT, int BPW>
 static hipError_t launch_m(const CompressArgs& a, int mode, hipStream_t s) {
-    if (mode == 1) return launch_c<G, TblT, 1, BPW>(a, s);
     if (mode == 2) return launch_c<G, TblT, 2, BPW>(a, s);
     if (mode == 3) return launch_c<G, TblT, 3, BPW>(a, s);
+    if (mode == 4) return launch_c<G, TblT, 4, BPW>(a, s);
     return launch_c<G, TblT, 0, BPW>(a, s);
 }
 
 // variant: bits 0..7 = lanes per block (8 or 16), bit 8 = blocks may exceed 64 KiB (u32 table),
-// bits 9..10 = mode (0 encode_block, 1 LDS input ring, 2 encode_block + prefetch wave, 3 encode_block + emitter wave),
+// bits 9..10 + bit 12 = MODE of lz4_compress_blocks_kernel (0, 2, 3; bit 12: 4),
 // bit 11 = half-filled waves (4 blocks of 8 lanes per workgroup: 20 instead of 16 u16 tables per CU)
 hipError_t launch_compress(const CompressArgs& a, int variant, hipStream_t s) {
     if (a.n == 0u) return hipSuccess;
     const int G = variant & 0xFF;
     const bool big = (variant & 0x100) != 0;
-    const int mode = (variant >> 9) & 3;
+    const int mode = ((variant >> 9) & 3) | ((variant & 0x1000) ? 4 : 0);
     const bool half = (variant & 0x800) != 0;
     if (G == 8) {
         if (!big) {   // experiment hook: blocks per workgroup

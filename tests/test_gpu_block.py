@@ -236,7 +236,7 @@ def _tile(src, total, block):
     return buf
 
 
-@pytest.mark.parametrize("lanes,variant", [(8, 1), (16, 1), (8, 3), (16, 3), (8, 4), (16, 4), (8, 5), (16, 5), (8, 2)])
+@pytest.mark.parametrize("lanes,variant", [(8, 1), (16, 1), (8, 3), (16, 3), (8, 5), (16, 5), (8, 6), (16, 6), (8, 2)])
 def test_compress_batch_bit_exact_vs_oracle(blk, lanes, variant):
     """every encoder variant (see lz4flex_set_tuning) and both group widths produce the reference's bytes"""
     from lz4_flex_amd import _lib

@@ -59,9 +59,6 @@ def main():
             print("%-28s cycles/visit %8.0f  visits %10d  share %5.1f%%" % (names[k], cyc[k] / max(cnt[k], 1), cnt[k], 100.0 * cyc[k] / max(tot, 1)))
         return
     names = ["top: probe wait+hash+tbl issue", "tbl wait+conflict", "cand round trip+verify", "tbl stores+winner bcast", "extension round trip", "backtrack+forward math", "next requests + emit", "rest of next-step round trip"]
-    if variant == 4:
-        names = ["top: snapshot+hash+tbl read", "conflict+cand round trip", "tbl stores+winner bcast", "extension round trip", "backtrack+forward math",
-                 "next-step bytes", "emit", "(count) ext fallback to memory"]
     if variant == 2:
         names = ["loop", "window/stage maintenance", "generic steps", "fast steps (all)", "fs: window reads+hash+table", "fs: conflict masks+load issue",
                  "fs: wait+verify+extension math", "fs: ballots+table stores"]
