@@ -33,7 +33,7 @@ static int hip_fail(hipError_t e, const char* what) {
 
 // compress_variant -> launch_compress mode bits: 1 = encode_block + emitter wave (default), 3 = encode_block alone,
 // 5 = encode_block + prefetch-only wave, 6 = emitter wave + LDS input ring (experimental)
-static inline int comp_mode_bits(int v) { return (v == 1 ? 0x600 : (v == 5 ? 0x400 : (v == 6 ? 0x1000 : 0))) | (getenv("LZ4FLEX_HALF") ? 0x800 : 0); }
+static inline int comp_mode_bits(int v) { return (v == 1 ? 0x600 : (v == 5 ? 0x400 : (v == 6 ? 0x1000 : 0))); }
 
 struct lz4flex_ctx {
     int device = 0;

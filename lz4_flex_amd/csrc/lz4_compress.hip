@@ -23,7 +23,6 @@
 //     G probes of a batch read adjacent positions), output bytes are written once.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "lz4_device.h"
 
@@ -806,10 +805,9 @@ hipError_t launch_compress_chain(const uint8_t* in_base, const void* blocks, con
 //         their LDS queues, writes the compressed blocks and their status, and does MODE 2's prefetch.
 // MODE 4: MODE 3 + the emitter also copies the input into an LDS ring per block that serves the encoders'
 //         current-side reads (experiment; measured slower than MODE 3).
-// BPW = blocks per workgroup: BPW * G <= 64 lanes of the encoder wave are used.  With u16 tables a CU's
-// 160 KiB of LDS hold two workgroups of eight blocks (or four of five: 20 tables, but 16 384 blocks then
-// still need 4 rounds); the encoder is a latency-bound serial chain per block, so blocks in flight matter and
-// half-empty waves do not.
+// BPW = blocks per workgroup = 64 / G.  With u16 tables a CU's 160 KiB of LDS hold two workgroups of eight
+// blocks.  (Measured with smaller workgroups: four workgroups of five blocks = 20 tables do fit, five of four
+// do not, and 16 384 blocks need 4 rounds either way; half-filled waves of four blocks are as fast as full ones.)
 template <int G, typename TblT, int MODE, int BPW>
 __global__ void __launch_bounds__(MODE == 0 ? 64 : 128) lz4_compress_blocks_kernel(CompressArgs a) {
     constexpr bool EQ = MODE == 3 || MODE == 4;
@@ -921,25 +919,13 @@ static hipError_t launch_m(const CompressArgs& a, int mode, hipStream_t s) {
 }
 
 // variant: bits 0..7 = lanes per block (8 or 16), bit 8 = blocks may exceed 64 KiB (u32 table),
-// bits 9..10 + bit 12 = MODE of lz4_compress_blocks_kernel (0, 2, 3; bit 12: 4),
-// bit 11 = half-filled waves (4 blocks of 8 lanes per workgroup: 20 instead of 16 u16 tables per CU)
+// bits 9..10 + bit 12 = MODE of lz4_compress_blocks_kernel (0, 2, 3; bit 12: 4)
 hipError_t launch_compress(const CompressArgs& a, int variant, hipStream_t s) {
     if (a.n == 0u) return hipSuccess;
     const int G = variant & 0xFF;
     const bool big = (variant & 0x100) != 0;
     const int mode = ((variant >> 9) & 3) | ((variant & 0x1000) ? 4 : 0);
-    const bool half = (variant & 0x800) != 0;
-    if (G == 8) {
-        if (!big) {   // experiment hook: blocks per workgroup
-            static const int bpw = getenv("LZ4FLEX_BPW") ? atoi(getenv("LZ4FLEX_BPW")) : 0;
-            if (bpw == 2) return launch_m<8, uint16_t, 2>(a, mode, s);
-            if (bpw == 3) return launch_m<8, uint16_t, 3>(a, mode, s);
-            if (bpw == 5) return launch_m<8, uint16_t, 5>(a, mode, s);
-            if (bpw == 6) return launch_m<8, uint16_t, 6>(a, mode, s);
-        }
-        if (half) return big ? launch_m<8, uint32_t, 4>(a, mode, s) : launch_m<8, uint16_t, 4>(a, mode, s);
-        return big ? launch_m<8, uint32_t, 8>(a, mode, s) : launch_m<8, uint16_t, 8>(a, mode, s);
-    }
+    if (G == 8) return big ? launch_m<8, uint32_t, 8>(a, mode, s) : launch_m<8, uint16_t, 8>(a, mode, s);
     if (G == 16) return big ? launch_m<16, uint32_t, 4>(a, mode, s) : launch_m<16, uint16_t, 4>(a, mode, s);
     return hipErrorInvalidValue;
 }
