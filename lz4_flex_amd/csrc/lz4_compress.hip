@@ -900,11 +900,16 @@ static hipError_t launch_c(const CompressArgs& a, hipStream_t s) {
     const size_t lds = (size_t)BPW * 4096u * sizeof(TblT) +
                        (MODE == 2 ? 64u : (MODE == 3 ? (size_t)BPW * LZ4_EQ_BYTES : (MODE == 4 ? (size_t)BPW * LZ4_EQ_BYTES_RING : 0u)));
     auto kern = lz4_compress_blocks_kernel<G, TblT, MODE, BPW>;
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set && lds > 65536u) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
+    if (lds > 65536u) {   // the attribute is per device: remember which devices have it (per instantiation)
+        static unsigned long long have = 0ull;   // benign race: setting it twice is harmless
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(have & bit)) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            have |= bit;
+        }
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MODE == 0 ? 64 : 128), lds, s, a);
     return hipGetLastError();
