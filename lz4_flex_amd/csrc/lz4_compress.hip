@@ -7,20 +7,23 @@
 // wins), same skip schedule, same backward/forward extension, same end-of-block rules.
 //
 // Work decomposition (MI355X-first):
-//   * one GROUP of G lanes (G = 8 or 16: half / one DPP row of the wave) owns one block;
-//     a 64-thread workgroup (one wavefront) encodes 64/G blocks.
-//   * the block's 4096-entry hash table lives in LDS (u16 entries = 8 KiB for blocks
-//     <= 64 KiB, u32 = 16 KiB above); all table traffic is LDS traffic.  The table is the
-//     resource that bounds blocks in flight per CU (160 KiB LDS / 8 KiB).
-//   * the serial greedy probe loop is executed G probes at a time: probe i of a sequence sits
-//     at a position that depends only on i (skip schedule), so lane g evaluates probe i0+g;
-//     the first verified candidate (ballot + ctz) wins and only probes up to it update the
-//     table.  Two probes of one batch that fall in the same bucket are resolved exactly
-//     (DPP row shifts): a later probe sees the earlier probe's position as its candidate and
-//     only the last one is stored, which is what the serial loop does.
-//   * backward extension, forward extension (8 bytes per lane per step) and literal copies
-//     are lane-parallel; input is read straight from HBM/L2 (coalesced by construction: the
-//     G probes of a batch read adjacent positions), output bytes are written once.
+//   * one GROUP of G lanes (G = 8 or 16: half / one DPP row of the wave) owns one block; the ENCODER
+//     wavefront of a workgroup holds 64/G blocks.
+//   * the block's 4096-entry hash table lives in LDS (u16 entries = 8 KiB for blocks <= 64 KiB, u32 = 16 KiB
+//     above); all table traffic is LDS traffic.  The table is the resource that bounds blocks in flight per
+//     CU (160 KiB LDS / 8 KiB, 16 in practice), and a block is a serial chain of ~3 500 steps: the kernel is
+//     bound by the length of one step's dependency chain, not by bandwidth.
+//   * the serial greedy probe loop is executed G probes at a time: probe i of a sequence sits at a position
+//     that depends only on i (skip schedule), so lane g evaluates probe i0+g; the first verified candidate
+//     (ballot + ctz) wins and only probes up to it update the table.  Two probes of one batch that fall in the
+//     same bucket are resolved exactly (DPP row shifts): a later probe sees the earlier probe's position as
+//     its candidate and only the last one is stored, which is what the serial loop does.
+//   * a step is three memory round trips (candidate bytes; 8 bytes behind + 8*G bytes after the match on both
+//     sides; the next step's probe bytes + the cur-2 update's bytes), every load issued unconditionally with a
+//     clamped address and as early as its address is known.
+//   * the encoder wavefront issues no stores: sequences go through an LDS queue to the EMITTER wavefront of the
+//     workgroup, which writes tokens, literals, offsets, the block's length and status, and prefetches the
+//     input stream ahead of the encoders (see EmitQ / emitter_wave / the MODE list below).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
