@@ -1,5 +1,7 @@
 #!/bin/bash
 # rocprofv3 TA/TCP counter passes (run on the GPU box through gpurun). usage: prof_ta.sh <tag> <bench args...>
+# NOTE: the second counter set (TA_*_STALLED_BY_TC) aborted rocprofv3 and hung until the time limit in round 1;
+# every pass is wrapped in `timeout`, but only the first set (TA_TA_BUSY_sum TA_BUSY_avr) has produced data so far.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=$1; shift
 OUT=gpurun_out/ta_$tag
