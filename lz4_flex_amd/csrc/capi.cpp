@@ -42,6 +42,8 @@ struct lz4flex_ctx {
     size_t arena_cap = 0;
     uint8_t* h_pin = nullptr;     // pinned host staging for descriptor / result arrays
     size_t pin_cap = 0;
+    uint8_t* h_pay = nullptr;     // pinned host staging for compacted results of MEM_HOST compress batches
+    size_t pay_cap = 0;
     int dec_lanes = 16;           // lanes per block, decode
     int comp_lanes = 8;           // lanes per block, encode
     int comp_variant = 1;         // 1 = group encoder + emitter wave (default), 3 = group encoder alone, 5 = group encoder + prefetch-only wave, 6 = emitter wave that also feeds an LDS input ring (slower), 2 = fully LDS-staged lz4_compress_lds.hip (<= 64 KiB, slower); all bit-exact
@@ -64,6 +66,28 @@ static int ensure_pin(lz4flex_ctx* c, size_t need) {
     HIP_TRY(hipHostMalloc((void**)&c->h_pin, cap, hipHostMallocDefault));
     c->pin_cap = cap;
     return 0;
+}
+
+static int ensure_pay(lz4flex_ctx* c, size_t need) {
+    if (need <= c->pay_cap) return 0;
+    if (c->h_pay) { (void)hipHostFree(c->h_pay); c->h_pay = nullptr; c->pay_cap = 0; }
+    size_t cap = std::max<size_t>(need + need / 4, 1u << 20);
+    HIP_TRY(hipHostMalloc((void**)&c->h_pay, cap, hipHostMallocDefault));
+    c->pay_cap = cap;
+    return 0;
+}
+
+// MEM_HOST batches whose results are sparse in the output span (compress: ~15 KB used of every 72 KB stride):
+// pack the produced bytes densely on the device so that ONE transfer brings them to the host.
+__global__ void __launch_bounds__(256) lz4flex_pack_results_kernel(const uint8_t* src, const uint64_t* src_off, const uint32_t* len,
+                                                                   const int32_t* status, const uint64_t* dst_off, uint8_t* dst,
+                                                                   uint32_t n) {
+    const uint32_t b = blockIdx.x;
+    if (b >= n || status[b] != 0) return;
+    const uint8_t* s = src + src_off[b];
+    uint8_t* d = dst + dst_off[b];
+    const uint32_t m = len[b];
+    for (uint32_t i = threadIdx.x; i < m; i += 256u) d[i] = s[i];
 }
 
 extern "C" {
@@ -107,6 +131,7 @@ void lz4flex_ctx_destroy(lz4flex_ctx* c) {
     if (!c) return;
     if (c->d_arena) (void)hipFree(c->d_arena);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_pay) (void)hipHostFree(c->h_pay);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -281,6 +306,29 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
             HIP_TRY(hipStreamSynchronize(s));
             return 0;
         }
+    }
+    // sparse results, many blocks: pack them on the device into the (now free) input region, one transfer to pinned
+    // memory, scatter on the host.  A per-block hipMemcpy to pageable memory costs ~10 us each.
+    if (!has_pos && n >= 16u && produced != 0 && produced <= (uint64_t)align_up(in_bytes + 64, 256) &&
+        ensure_pay(c, (size_t)produced) == 0) {
+        uint64_t* h_dense = (uint64_t*)(hp + at_detail);          // reuse the detail slot (16 B per block >= 8 B)
+        uint64_t at = 0;
+        for (uint32_t i = 0; i < n; i++) { h_dense[i] = at; if (r_st[i] == 0) at += r_len[i]; }
+        uint64_t* d_dense = (uint64_t*)(dd + at_detail);
+        HIP_TRY(hipMemcpyAsync(d_dense, h_dense, 8ull * n, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(lz4flex_pack_results_kernel, dim3(n), dim3(256), 0, s, d + a_out,
+                           (const uint64_t*)(dd + at_out_off), (const uint32_t*)(dd + at_out_len),
+                           (const int32_t*)(dd + at_status), d_dense, d + a_in, n);
+        if (hipGetLastError() != hipSuccess) return hip_fail(hipGetLastError(), "pack kernel launch");
+        HIP_TRY(hipMemcpyAsync(c->h_pay, d + a_in, (size_t)produced, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        at = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            if (r_st[i] != 0 || r_len[i] == 0) continue;
+            memcpy(out_base + out_off[i], c->h_pay + at, r_len[i]);
+            at += r_len[i];
+        }
+        return 0;
     }
     for (uint32_t i = 0; i < n; i++) {
         if (r_st[i] != 0 || r_len[i] == 0) continue;
