@@ -115,6 +115,15 @@ int64_t lz4flex_frame_info_read(const uint8_t* in, size_t in_len, lz4flex_frame_
 
 // ------------------------------------------------------------------------------------------
 // FrameEncoder
+// Blocks gathered per kernel launch.  A block is one serial chain on the device (a 4 MiB block takes 64x as long as
+// a 64 KiB one), so throughput needs MANY blocks in flight: by default at least 256 blocks per launch (one per
+// CU), capped at 1 GiB of staged input; an explicit set_batch_bytes is honoured exactly.
+static size_t blocks_per_launch(size_t batch_bytes, size_t mbs, bool automatic) {
+    size_t nb = std::max<size_t>(1, batch_bytes / mbs);
+    if (automatic) nb = std::max<size_t>(nb, std::min<size_t>(256, ((size_t)1 << 30) / mbs));
+    return nb;
+}
+
 struct lz4flex_frame_encoder {
     lz4flex_frame_info fi{};
     lz4flex_write_fn w = nullptr;
@@ -127,6 +136,7 @@ struct lz4flex_frame_encoder {
     std::vector<int32_t> status;
     size_t batch_blocks = 0;       // blocks per kernel launch
     size_t batch_bytes = 64u << 20;
+    bool batch_auto = true;        // no explicit set_batch_bytes: big blocks get enough blocks per launch to fill the GPU
     uint64_t content_len = 0;
     uint64_t src_stream_offset = 0;   // mirrors the reference field that decides the table state (N3)
     XxHash32 content_hasher{0};
@@ -159,7 +169,7 @@ struct lz4flex_frame_encoder {
         if (fi.block_size == 0) fi.block_size = block_size_from_buf_length(buf_len);
         const size_t mbs = block_size_bytes(fi.block_size);
         if (mbs == 0 || fi.block_size == 8) return -LZ4FLEX_E_INVALID_ARG;   // Max8MB is legacy-decode only (header.rs:287)
-        batch_blocks = std::max<size_t>(1, batch_bytes / mbs);
+        batch_blocks = blocks_per_launch(batch_bytes, mbs, batch_auto);
         uint8_t hdr[MAX_FRAME_INFO_SIZE];
         const int64_t n = lz4flex_frame_info_write(&fi, hdr, sizeof hdr);
         if (n < 0) return (int)n;
@@ -323,12 +333,12 @@ struct lz4flex_frame_encoder {
         const size_t mbs = block_size_bytes(fi.block_size);
         while (len) {
             const size_t cap = batch_blocks * mbs;
-            if (src.size() < cap) src.resize(cap);
             if (src_len == cap) {   // staging full: make space by writing the staged blocks
                 if ((rc = write_blocks(batch_blocks))) return sticky_err = rc;
                 continue;
             }
             const size_t n = std::min(cap - src_len, len);
+            if (src.size() < src_len + n) src.resize(std::min(cap, std::max(src.size() * 2, src_len + n)));   // grows with the data
             memcpy(src.data() + src_len, buf, n);
             src_len += n; buf += n; len -= n;
         }
@@ -378,6 +388,7 @@ struct lz4flex_frame_decoder {
     XxHash32 content_hasher{0};
     uint64_t content_len = 0;
     size_t batch_bytes = 64u << 20;
+    bool batch_auto = true;
     // staged batch
     std::vector<uint8_t> comp, out;
     std::vector<uint64_t> in_off, out_off, detail;
@@ -463,7 +474,7 @@ struct lz4flex_frame_decoder {
     // Independent frames: gather blocks up to the batch size, decode them in one launch.
     void read_blocks_independent() {
         const size_t mbs = block_size_bytes(fi.block_size);
-        const size_t max_blocks = std::max<size_t>(1, batch_bytes / mbs);
+        const size_t max_blocks = blocks_per_launch(batch_bytes, mbs, batch_auto);
         comp.clear(); in_off.clear(); in_len.clear(); out_off.clear(); out_cap.clear();
         ready.clear(); ready_idx = 0; ready_pos = 0;
         struct Slot { bool raw; size_t out_at; size_t idx; size_t raw_len; };
@@ -634,6 +645,7 @@ void lz4flex_frame_encoder_frame_info(lz4flex_frame_encoder* e, lz4flex_frame_in
 int lz4flex_frame_encoder_set_batch_bytes(lz4flex_frame_encoder* e, size_t bytes) {
     if (!e || e->is_frame_open || bytes == 0) return -LZ4FLEX_E_INVALID_ARG;
     e->batch_bytes = bytes;
+    e->batch_auto = false;
     return 0;
 }
 void lz4flex_frame_encoder_free(lz4flex_frame_encoder* e) { delete e; }
@@ -653,6 +665,7 @@ int64_t lz4flex_frame_decoder_read(lz4flex_frame_decoder* dcd, uint8_t* buf, siz
 int lz4flex_frame_decoder_set_batch_bytes(lz4flex_frame_decoder* d, size_t bytes) {
     if (!d || bytes == 0) return -LZ4FLEX_E_INVALID_ARG;
     d->batch_bytes = bytes;
+    d->batch_auto = false;
     return 0;
 }
 void lz4flex_frame_decoder_free(lz4flex_frame_decoder* d) { delete d; }
