@@ -334,7 +334,7 @@ def compress_frame(data, frame_info=None):
     r = lib.lz4flex_frame_compress(C.cast(inp, C.c_void_p), len(b), C.byref(fi), C.cast(out, C.c_void_p), cap, C.byref(d))
     if r < 0:
         raise _frame_error(int(-r), d)
-    return bytes(out[:r])
+    return C.string_at(out, r)
 
 
 def decompress_frame(data, max_size):
@@ -349,4 +349,4 @@ def decompress_frame(data, max_size):
                                      C.byref(consumed), C.byref(d))
     if r < 0:
         raise _frame_error(int(-r), d)
-    return bytes(out[:r]), int(consumed.value)
+    return C.string_at(out, r), int(consumed.value)
