@@ -95,10 +95,11 @@ def load():
         raise ImportError(
             "lz4_flex_amd: %s is missing. Build it with `python -m lz4_flex_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
-    try:
-        import torch  # noqa: F401  (HIP runtime unification; plumbing only)
-    except Exception:
-        pass
+    if not os.environ.get("LZ4FLEX_NO_TORCH"):   # torch-free tools (tools/dec_geometry.py) load libamdhip64 themselves
+        try:
+            import torch  # noqa: F401  (HIP runtime unification; plumbing only)
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

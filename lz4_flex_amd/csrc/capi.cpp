@@ -48,6 +48,7 @@ struct lz4flex_ctx {
     int comp_lanes = 8;           // lanes per block, encode
     int comp_variant = 1;         // 1 = group encoder + emitter wave (default), 3 = group encoder alone, 5 = group encoder + prefetch-only wave, 6 = emitter wave that also feeds an LDS input ring (slower), 2 = fully LDS-staged lz4_compress_lds.hip (<= 64 KiB, slower); all bit-exact
     int ablate = 0;               // timing ablations (wrong output!), see lz4flex_set_tuning("ablate")
+    int dec_geometry = -1;        // pipelined decoder geometry (lz4_decompress_lds.hip launch_decompress_pipe): -1 by batch size, 0 = 8 lanes x 4 B, 1 = 4 lanes x 8 B
     int dec_variant = 3;          // 1 = window in HBM/L2 (lz4_decompress.hip), 2 = LDS-staged generic loop, 3 = LDS-staged pipelined (lz4_decompress_lds.hip)
 };
 
@@ -117,6 +118,7 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
     c->device = device;
     if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v >= 1 && v <= 6 && v != 4) c->comp_variant = v; }
     if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v >= 1 && v <= 3) c->dec_variant = v; }
+    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_GEOMETRY")) { const int v = atoi(e); if (v >= -1 && v <= 1) c->dec_geometry = v; }
     int prev = 0;
     (void)hipGetDevice(&prev);
     e = hipSetDevice(device);
@@ -147,6 +149,11 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
     if (!strcmp(key, "decompress_variant")) {
         if (value < 1 || value > 3) return -LZ4FLEX_E_INVALID_ARG;
         c->dec_variant = value;
+        return 0;
+    }
+    if (!strcmp(key, "decompress_geometry")) {
+        if (value < -1 || value > 1) return -LZ4FLEX_E_INVALID_ARG;
+        c->dec_geometry = value;
         return 0;
     }
     if (!strcmp(key, "compress_variant")) {
@@ -281,7 +288,7 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
         a.dict_len = has_dict ? (const uint32_t*)(dd + at_dict_len) : nullptr;
         a.out_len = (uint32_t*)(dd + at_out_len); a.status = (int32_t*)(dd + at_status);
         a.detail = (uint64_t*)(dd + at_detail); a.n = n;
-        le = (c->dec_variant >= 2 && !has_dict && !has_pos) ? (c->dec_variant == 3 ? launch_decompress_pipe(a, s, c->ablate) : launch_decompress_lds(a, s, c->ablate)) : launch_decompress(a, c->dec_lanes, s);
+        le = (c->dec_variant >= 2 && !has_dict && !has_pos) ? (c->dec_variant == 3 ? launch_decompress_pipe(a, s, c->ablate, c->dec_geometry) : launch_decompress_lds(a, s, c->ablate)) : launch_decompress(a, c->dec_lanes, s);
     }
     if (le != hipSuccess) return hip_fail(le, "kernel launch");
     HIP_TRY(hipMemcpyAsync(hp + at_out_len, dd + at_out_len, desc_bytes - at_out_len, hipMemcpyDeviceToHost, s));
@@ -361,7 +368,7 @@ static int run_device_batch(lz4flex_ctx* c, bool compress, const void* in_base, 
         a.dict_off = ext ? ext->dict_off : nullptr;
         a.dict_len = ext ? ext->dict_len : nullptr;
         a.out_len = out_len; a.status = status; a.detail = detail; a.n = n;
-        le = (c->dec_variant >= 2 && !a.dict_base && !a.out_pos) ? (c->dec_variant == 3 ? launch_decompress_pipe(a, s, c->ablate) : launch_decompress_lds(a, s, c->ablate)) : launch_decompress(a, c->dec_lanes, s);
+        le = (c->dec_variant >= 2 && !a.dict_base && !a.out_pos) ? (c->dec_variant == 3 ? launch_decompress_pipe(a, s, c->ablate, c->dec_geometry) : launch_decompress_lds(a, s, c->ablate)) : launch_decompress(a, c->dec_lanes, s);
     }
     if (le != hipSuccess) return hip_fail(le, "kernel launch");
     return 0;

@@ -38,22 +38,55 @@ __device__ unsigned long long gd_phase_counts[8];
 #endif
 namespace v2 {
 
-constexpr uint32_t G = 8;             // lanes per block
-constexpr uint32_t IN_CAP = 384;      // compressed-input window (bytes)
-constexpr uint32_t IN_PAD = 32;       // readable slack behind the window (16-byte parse window + alignment)
-constexpr uint32_t OUT_H = 512;       // history kept in LDS after a write-back (older sources: pipelined HBM loads)
-constexpr uint32_t OUT_SLACK = 32;    // wild-copy slack
-constexpr uint32_t OUT_CAP = 2080;    // IN_CAP + IN_PAD + OUT_CAP = 2496 B per block
-constexpr uint32_t GROUP_LDS = IN_CAP + IN_PAD + OUT_CAP;
-static_assert(GROUP_LDS == 2496 && GROUP_LDS % 16 == 0, "LDS budget per block");
+// Geometry of one decoder flavour.  G lanes own a block and copy WB bytes each per piece (a piece is
+// G*WB bytes); the per-block LDS is IN_CAP + IN_PAD (compressed-input window) + OUT_CAP (output buffer
+// holding OUT_H bytes of history after a write-back plus the bytes not yet written back).
+template <uint32_t G_, uint32_t WB_, uint32_t IN_CAP_, uint32_t OUT_H_, uint32_t OUT_CAP_>
+struct Geometry {
+    static constexpr uint32_t G = G_;                 // lanes per block
+    static constexpr uint32_t WB = WB_;               // bytes per lane and piece in the pipelined decoder (4 or 8)
+    static constexpr uint32_t PIECE = G_ * WB_;
+    static constexpr uint32_t IN_CAP = IN_CAP_;       // compressed-input window (bytes)
+    static constexpr uint32_t IN_PAD = 32;            // readable slack behind the window (parse window + wild copies)
+    static constexpr uint32_t OUT_H = OUT_H_;         // history kept in LDS after a write-back (older sources: pipelined HBM loads)
+    static constexpr uint32_t OUT_SLACK = 32;         // wild-copy slack
+    static constexpr uint32_t OUT_CAP = OUT_CAP_;
+    static constexpr uint32_t GROUP_LDS = IN_CAP + IN_PAD + OUT_CAP;
+    static constexpr uint32_t IN_SLIDE = IN_CAP / 3;                              // slide the window once this much is consumed
+    static constexpr uint32_t FLUSH_AT = (OUT_CAP - OUT_SLACK - OUT_H) / 2 - 8;   // service: write back below this much space
+    static constexpr uint32_t SLOW_FLUSH_AT = FLUSH_AT < 320u ? FLUSH_AT : 320u;
+    static_assert(GROUP_LDS % 16 == 0 && OUT_H % 16 == 0 && IN_CAP % 16 == 0, "16-byte pieces");
+    static_assert(OUT_H >= 2 * PIECE + 32, "a far piece must lie entirely in the written-back part");
+    static_assert((64 / G) * GROUP_LDS <= 65536, "static LDS per workgroup");
+};
+// Measured on the configs[1] workload (tools/dec_geometry.py): a batch of n blocks puts n*G/64 wavefronts on 1 024
+// SIMDs, and two wavefronts per SIMD are needed to cover each other's LDS / issue latency (a lone wavefront needs
+// 1 760 cycles per step, two share a SIMD at 1 460 cycles per step each).  16 384 blocks: Geo8 2.93 ms, Geo4s
+// 3.67 ms (one wavefront per SIMD); 32 768 blocks: Geo8 5.80 ms (two rounds), Geo4s 4.18 ms.  Tried and dropped:
+// 4 lanes x 4 B (16-byte pieces: 40 % more steps, 3.88 ms), 4 x 8 B with 2 496 B of LDS (never more than one
+// wavefront per SIMD: 3.63 / 7.26 ms), 8 x 8 B (64-byte pieces: 16 % fewer steps but no faster, 2.99 ms).
+using Geo8 = Geometry<8, 4, 384, 512, 2080>;      // 8 blocks per wavefront, 2 496 B per block: 8 wavefronts per CU hold 64 blocks
+using Geo4s = Geometry<4, 8, 192, 256, 1024>;     // 16 blocks per wavefront, 1 248 B per block: 8 wavefronts per CU hold 128 blocks
+static_assert(Geo8::GROUP_LDS == 2496 && Geo8::FLUSH_AT == 760 && Geo8::IN_SLIDE == 128, "round-1 geometry");
+static_assert(Geo4s::GROUP_LDS == 1248, "LDS budget per block");
 
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ void st32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 __device__ __forceinline__ uint4 ld128(const uint8_t* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 __device__ __forceinline__ void st128(uint8_t* p, uint4 v) { __builtin_memcpy(p, &v, 16); }
+// the WB-byte word one lane moves per piece
+template <uint32_t WB> struct Word;
+template <> struct Word<4> { using type = uint32_t; };
+template <> struct Word<8> { using type = uint2; };
+template <uint32_t WB> __device__ __forceinline__ typename Word<WB>::type ldw(const uint8_t* p) {
+    typename Word<WB>::type v; __builtin_memcpy(&v, p, WB); return v;
+}
+template <uint32_t WB> __device__ __forceinline__ void stw(uint8_t* p, typename Word<WB>::type v) { __builtin_memcpy(p, &v, WB); }
 
-template <bool ABLATE_FAR>   // timing ablation only: far sources read garbage from LDS instead of HBM (wrong bytes)
+template <class GEO, bool ABLATE_FAR>   // ABLATE_FAR: timing ablation only, far sources read garbage from LDS instead of HBM (wrong bytes)
 struct Dec {
+    static constexpr uint32_t G = GEO::G, IN_CAP = GEO::IN_CAP, OUT_H = GEO::OUT_H, OUT_CAP = GEO::OUT_CAP,
+                              OUT_SLACK = GEO::OUT_SLACK;
     const uint8_t* gin;   // compressed block (global)
     uint8_t* gout;        // output block (global)
     uint8_t* lin;         // LDS: input window
@@ -185,8 +218,8 @@ struct Dec {
     // refill / write-back the fast path asked for.  Returns: 0 continue, 1 block finished, <0 -error code.
     __device__ __forceinline__ int32_t slow_step(uint64_t* det_expected) {
         // keep >= 24 bytes of lookahead while the input lasts; slide when 128 bytes are consumed
-        if ((in_end - ip < 24u && in_end < ilen) || ip - in_lo >= 128u) refill(ip);
-        if (out_space() < 320u) flush_slide();
+        if ((in_end - ip < 24u && in_end < ilen) || ip - in_lo >= GEO::IN_SLIDE) refill(ip);
+        if (out_space() < GEO::SLOW_FLUSH_AT) flush_slide();
         const uint32_t avail = in_end - ip;
         const uint32_t rel = ip - in_lo;
         const uint32_t* lw = reinterpret_cast<const uint32_t*>(lin + (rel & ~3u));
@@ -324,13 +357,15 @@ struct Dec {
 //   * anything else (errors, 255-chains, offsets < 4, block tail, window refill, write-back) blocks
 //     the group; once per 4-step iteration the wave checks for blocked groups, drains the pipeline
 //     and runs the generic code above for them (and window/write-back maintenance for every group).
-template <bool ABLATE_FAR>
-struct PipeDec : Dec<ABLATE_FAR> {
-    using B = Dec<ABLATE_FAR>;
+template <class GEO, bool ABLATE_FAR>
+struct PipeDec : Dec<GEO, ABLATE_FAR> {
+    using B = Dec<GEO, ABLATE_FAR>;
+    static constexpr uint32_t G = GEO::G, WB = GEO::WB, PIECE = GEO::PIECE;
+    using word_t = typename Word<WB>::type;
     using B::gin; using B::gout; using B::lin; using B::lout; using B::g; using B::ilen; using B::cap;
     using B::ip; using B::op; using B::in_lo; using B::in_end; using B::L0; using B::F;
 
-    struct Slot { uint32_t lit_n, lit_src, lit_dst, m_n, m_src, m_dst, far, v; };
+    struct Slot { uint32_t lit_n, lit_src, lit_dst, m_n, m_src, m_dst, far; word_t v; };
     enum : uint32_t { K_NONE = 0, K_MAINT = 1, K_RARE_TOKEN = 2, K_RARE_OFFSET = 3, K_FINISH = 4 };
 
     uint32_t lit_rem, ml_rem, moff, mlc_saved;
@@ -378,7 +413,7 @@ struct PipeDec : Dec<ABLATE_FAR> {
         const bool ext = mlc == 15u;
         const uint32_t ml = 4u + mlc + (ext ? e : 0u);
         const uint32_t mstart = op + lit_s;
-        const bool rare_o = (ext && e == 0xFFu) || offset < 4u || offset > mstart || ml > cap - mstart;
+        const bool rare_o = (ext && e == 0xFFu) || offset < WB || offset > mstart || ml > cap - mstart;
         // ---- what this group does in this step
         const bool tok = active && space_ok && boundary;
         const bool win_ok = avail >= 20u;
@@ -399,12 +434,12 @@ struct PipeDec : Dec<ABLATE_FAR> {
         // ---- one piece: a long-literal piece, else a match piece
         const bool go = active && space_ok && !rare && !maint;
         const bool lpiece = go && lit_rem1 != 0u;
-        const uint32_t ln = lit_rem1 < 4u * G ? lit_rem1 : 4u * G;
+        const uint32_t ln = lit_rem1 < PIECE ? lit_rem1 : PIECE;
         const bool l_in_ok = in_end - ip1 >= ln;
         const bool do_l = lpiece && l_in_ok;
         maint = maint || (lpiece && !l_in_ok);
         const bool do_m = go && lit_rem1 == 0u && ml_rem1 != 0u;
-        const uint32_t pm = moff >= 4u * G ? 4u * G : (moff & ~3u);
+        const uint32_t pm = moff >= PIECE ? PIECE : (moff & ~(WB - 1u));
         const uint32_t mn = ml_rem1 < pm ? ml_rem1 : pm;
         const uint32_t msrc = op1 - moff;
         const bool far = do_m && msrc < L0;
@@ -416,7 +451,7 @@ struct PipeDec : Dec<ABLATE_FAR> {
         s.m_dst = op1 - L0;
         s.m_src = msrc - L0;
         s.far = far ? 1u : 0u;
-        const uint8_t* ld_addr = far ? gout + msrc + 4u * g : dummy;   // msrc + 32 <= L0 + 31 < F: written back
+        const uint8_t* ld_addr = far ? gout + msrc + WB * g : dummy;   // msrc + PIECE <= L0 + PIECE - 1 < F: written back
         // ---- advance
         ip = do_l ? ip1 + ln : ip1;
         op = do_l ? op1 + ln : (do_m ? op1 + mn : op1);
@@ -427,23 +462,24 @@ struct PipeDec : Dec<ABLATE_FAR> {
         blocked = finish ? (uint32_t)K_FINISH
                          : (rare ? (need ? (uint32_t)K_RARE_OFFSET : (uint32_t)K_RARE_TOKEN)
                                  : (maint ? (uint32_t)K_MAINT : blocked));
-        s.v = ABLATE_FAR ? 0u : ld32(ld_addr);   // exactly one HBM load per step and lane: exact vmcnt bookkeeping
+        if (ABLATE_FAR) s.v = word_t{}; else s.v = ldw<WB>(ld_addr);   // exactly one HBM load per step and lane: exact vmcnt bookkeeping
     }
 
     __device__ __forceinline__ void be_step(const Slot& s) {
         // literal write strictly before the match read: a match may start inside the literals just written
-        if (4u * g < s.lit_n) st32(lout + s.lit_dst + 4u * g, ld32(lin + s.lit_src + 4u * g));
-        if (4u * g < s.m_n) {
-            const uint32_t x = s.far ? s.v : ld32(lout + s.m_src + 4u * g);
-            st32(lout + s.m_dst + 4u * g, x);
+        if (WB * g < s.lit_n) stw<WB>(lout + s.lit_dst + WB * g, ldw<WB>(lin + s.lit_src + WB * g));
+        if (WB * g < s.m_n) {
+            word_t x = s.v;
+            if (!s.far) x = ldw<WB>(lout + s.m_src + WB * g);
+            stw<WB>(lout + s.m_dst + WB * g, x);
         }
     }
 
     // generic handling for blocked groups + window / write-back maintenance for every live group
     __device__ __forceinline__ void service(int32_t& status, uint64_t* det_expected) {
         if (done) return;
-        if ((in_end - ip < 128u && in_end < ilen) || ip - in_lo >= 128u) B::refill(ip);
-        if (B::out_space() < 760u) B::flush_slide();
+        if ((in_end - ip < GEO::IN_SLIDE && in_end < ilen) || ip - in_lo >= GEO::IN_SLIDE) B::refill(ip);
+        if (B::out_space() < GEO::FLUSH_AT) B::flush_slide();
         int32_t r = 0;
         if (blocked == K_FINISH) {
             r = 1;
@@ -469,7 +505,7 @@ struct PipeDec : Dec<ABLATE_FAR> {
         D_PHASE_DECL
         for (;;) {
             D_PHASE_MARK(0)
-            s1.lit_n = 0u; s1.m_n = 0u; s1.far = 0u; s1.v = 0u; s1.lit_src = s1.lit_dst = s1.m_src = s1.m_dst = 0u;
+            s1.lit_n = 0u; s1.m_n = 0u; s1.far = 0u; s1.v = word_t{}; s1.lit_src = s1.lit_dst = s1.m_src = s1.m_dst = 0u;
             s2 = s1; s3 = s1;
             do {
                 fe_step(s0); be_step(s1);
@@ -489,13 +525,14 @@ struct PipeDec : Dec<ABLATE_FAR> {
     }
 };
 
-template <bool ABLATE_FAR>
+template <class GEO, bool ABLATE_FAR>
 __global__ void __launch_bounds__(64) lz4_decompress_pipe_kernel(DecompressArgs a) {
+    constexpr uint32_t G = GEO::G, GROUP_LDS = GEO::GROUP_LDS, IN_CAP = GEO::IN_CAP, IN_PAD = GEO::IN_PAD;
     __shared__ __attribute__((aligned(16))) uint8_t lds[(64 / G) * GROUP_LDS];
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x * (64u / G) + lane / G;
     if (b >= a.n) return;
-    PipeDec<ABLATE_FAR> d;
+    PipeDec<GEO, ABLATE_FAR> d;
     d.g = lane % G;
     d.gin = a.in_base + a.in_off[b];
     d.gout = a.out_base + a.out_off[b];
@@ -503,7 +540,7 @@ __global__ void __launch_bounds__(64) lz4_decompress_pipe_kernel(DecompressArgs 
     d.lout = d.lin + IN_CAP + IN_PAD;
     d.ilen = a.in_len[b];
     d.cap = a.out_cap[b];
-    d.dummy = reinterpret_cast<const uint8_t*>(a.in_len);
+    d.dummy = reinterpret_cast<const uint8_t*>(a.in_off);   // always readable, >= 8 bytes
     uint64_t expected = 0u;
     const int32_t st = d.run(&expected);
     if (d.g == 0u) {
@@ -518,11 +555,13 @@ __global__ void __launch_bounds__(64) lz4_decompress_pipe_kernel(DecompressArgs 
 
 template <bool ABLATE_FAR>
 __global__ void __launch_bounds__(64) lz4_decompress_lds_kernel(DecompressArgs a) {
+    using GEO = Geo8;
+    constexpr uint32_t G = GEO::G, GROUP_LDS = GEO::GROUP_LDS, IN_CAP = GEO::IN_CAP, IN_PAD = GEO::IN_PAD;
     __shared__ __attribute__((aligned(16))) uint8_t lds[(64 / G) * GROUP_LDS];
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x * (64u / G) + lane / G;
     if (b >= a.n) return;
-    Dec<ABLATE_FAR> d;
+    Dec<GEO, ABLATE_FAR> d;
     d.g = lane % G;
     d.gin = a.in_base + a.in_off[b];
     d.gout = a.out_base + a.out_off[b];
@@ -544,20 +583,31 @@ __global__ void __launch_bounds__(64) lz4_decompress_lds_kernel(DecompressArgs a
 
 }  // namespace v2
 
-hipError_t launch_decompress_pipe(const DecompressArgs& a, hipStream_t s, int ablate) {
+template <class GEO, bool ABLATE_FAR>
+static hipError_t launch_pipe_geo(const DecompressArgs& a, hipStream_t s) {
+    const uint32_t per_wg = 64u / GEO::G;
+    const uint32_t grid = (a.n + per_wg - 1u) / per_wg;
+    hipLaunchKernelGGL((v2::lz4_decompress_pipe_kernel<GEO, ABLATE_FAR>), dim3(grid), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+// geometry: 0 = 8 lanes x 4 B per block (Geo8), 1 = 4 lanes x 8 B with 1 248 B of LDS per block (Geo4s),
+// -1 = by batch size: Geo4s once the batch is large enough to give it two wavefronts per SIMD
+hipError_t launch_decompress_pipe(const DecompressArgs& a, hipStream_t s, int ablate, int geometry) {
     if (a.n == 0u) return hipSuccess;
     if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;
-    const uint32_t per_wg = 64u / v2::G;
-    const uint32_t grid = (a.n + per_wg - 1u) / per_wg;
-    if (ablate & 1) hipLaunchKernelGGL(v2::lz4_decompress_pipe_kernel<true>, dim3(grid), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(v2::lz4_decompress_pipe_kernel<false>, dim3(grid), dim3(64), 0, s, a);
-    return hipGetLastError();
+    if (geometry < 0) geometry = a.n > 20480u ? 1 : 0;
+    switch (geometry) {
+        case 0: return (ablate & 1) ? launch_pipe_geo<v2::Geo8, true>(a, s) : launch_pipe_geo<v2::Geo8, false>(a, s);
+        case 1: return launch_pipe_geo<v2::Geo4s, false>(a, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_decompress_lds(const DecompressArgs& a, hipStream_t s, int ablate) {
     if (a.n == 0u) return hipSuccess;
     if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;   // dictionary / prefix: v1 kernel
-    const uint32_t per_wg = 64u / v2::G;
+    const uint32_t per_wg = 64u / v2::Geo8::G;
     const uint32_t grid = (a.n + per_wg - 1u) / per_wg;
     if (ablate & 1) hipLaunchKernelGGL(v2::lz4_decompress_lds_kernel<true>, dim3(grid), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(v2::lz4_decompress_lds_kernel<false>, dim3(grid), dim3(64), 0, s, a);

@@ -31,6 +31,22 @@ def _gpu_decode(blk, data, cap, dict_data=None):
     return "ok", bytes(out[:n])
 
 
+# every decoder kernel behind lz4flex_decompress_batch: lanes > 0 = lz4_decompress.hip (variant 1) group widths,
+# -2 = LDS-staged generic loop, -30 / -31 = pipelined decoder with 8 lanes x 4 B / 4 lanes x 8 B per block
+DECODERS = [8, 16, 32, 64, -2, -30, -31]
+
+
+def _select_decoder(lib, ctx, lanes):
+    if lanes > 0:
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 1) == 0
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_lanes", lanes) == 0
+    elif lanes <= -30:
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 3) == 0
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_geometry", -lanes - 30) == 0
+    else:
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", -lanes) == 0
+
+
 # ---------------------------------------------------------------- KATs: decompress.rs:534-622
 @pytest.mark.parametrize("kat", corpus.DECODER_KATS)
 def test_decoder_kats(blk, kat):
@@ -43,18 +59,14 @@ def test_decoder_kats(blk, kat):
         assert got == payload
 
 
-@pytest.mark.parametrize("lanes", [8, 16, 32, 64, -2, -3])
+@pytest.mark.parametrize("lanes", DECODERS)
 def test_decoder_kats_all_group_widths(blk, lanes):
     from lz4_flex_amd import _lib
     import ctypes as C
     lib = _lib.load()
     ctx = C.c_void_p()
     assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
-    if lanes > 0:
-        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 1) == 0
-        assert lib.lz4flex_set_tuning(ctx, b"decompress_lanes", lanes) == 0
-    else:
-        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", -lanes) == 0
+    _select_decoder(lib, ctx, lanes)
     try:
         for data, cap, d, (exp, payload) in corpus.DECODER_KATS:
             if d is not None or len(data) == 0:
@@ -285,19 +297,15 @@ def test_compress_big_blocks_bit_exact(blk):
         assert blk.decompress(comp, n) == data
 
 
-@pytest.mark.parametrize("lanes", [8, 16, 32, 64, -2, -3])
+@pytest.mark.parametrize("lanes", DECODERS)
 def test_decompress_batch_bit_exact_vs_oracle(blk, lanes):
-    """lanes > 0: lz4_decompress.hip (variant 1) group widths; -2 / -3: LDS-staged generic / pipelined decoders"""
+    """every decoder kernel (DECODERS) on a mixed batch, byte-exact against the oracle"""
     from lz4_flex_amd import _lib
     import ctypes as C
     lib = _lib.load()
     ctx = C.c_void_p()
     assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
-    if lanes > 0:
-        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 1) == 0
-        assert lib.lz4flex_set_tuning(ctx, b"decompress_lanes", lanes) == 0
-    else:
-        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", -lanes) == 0
+    _select_decoder(lib, ctx, lanes)
     try:
         srcs = [O.fixture_plain("compression_66k_JSON"), O.fixture_plain("compression_65k"), corpus.lcg_bytes(70000, 5, 4, 9),
                 bytes(70000), corpus.lcg_bytes(70000, 6, 256, 1), corpus.lcg_bytes(70000, 7, 3, 40)]
