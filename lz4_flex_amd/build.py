@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblz4flex_amd.so")
-SOURCES = ["lz4_decompress.hip", "lz4_decompress_lds.hip", "lz4_compress.hip", "lz4_compress_lds.hip", "xxh32_kernel.hip", "capi.cpp", "frame.cpp"]
+SOURCES = ["lz4_decompress.hip", "lz4_decompress_lds.hip", "lz4_decompress_split.hip", "lz4_compress.hip", "lz4_compress_lds.hip", "xxh32_kernel.hip", "capi.cpp", "frame.cpp"]
 DEPS = SOURCES + ["lz4_device.h", "xxh32.h", os.path.join("..", "..", "include", "lz4flex_amd.h")]
 
 

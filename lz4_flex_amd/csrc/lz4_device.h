@@ -46,6 +46,7 @@ struct CompressArgs {
 hipError_t launch_decompress(const DecompressArgs& a, int lanes_per_block, hipStream_t s);
 hipError_t launch_decompress_lds(const DecompressArgs& a, hipStream_t s, int ablate = 0);   // LDS-staged variant, no dict/prefix
 hipError_t launch_decompress_pipe(const DecompressArgs& a, hipStream_t s, int ablate = 0, int geometry = -1);  // pipelined LDS variant
+hipError_t launch_decompress_split(const DecompressArgs& a, hipStream_t s, int blocks_per_wg = 0);   // parser / copier wavefronts, no dict/prefix
 hipError_t launch_compress(const CompressArgs& a, int variant, hipStream_t s);
 hipError_t launch_compress_lds(const CompressArgs& a, hipStream_t s);   // LDS-staged encoder, blocks <= 64 KiB
 

@@ -83,21 +83,23 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--blocks", type=int, default=16384)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--geometries", default="0,1")
+    ap.add_argument("--geometries", default="0,1", help="pipelined decoder (variant 3) geometries")
+    ap.add_argument("--split", default="", help="split decoder (variant 4): blocks per workgroup, e.g. 64,32")
     ap.add_argument("--encoders", default="1")
     ap.add_argument("--block-size", type=int, default=65536)
     ap.add_argument("--lib", default=None, help="private build of the library (e.g. -DLZ4FLEX_PROFILE_PHASES; see --build-prof)")
     ap.add_argument("--build-prof", action="store_true", help="build lz4_flex_amd/build/liblz4flex_prof.so (run this where hipcc is) and exit")
+    ap.add_argument("--defs", default="-DLZ4FLEX_PROFILE_PHASES", help="extra -D flags of --build-prof")
     ap.add_argument("--phases", action="store_true", help="with --lib <profiling build>: print the decoder's per-phase cycle shares")
     a = ap.parse_args()
     if a.build_prof:
         import subprocess
         csrc = os.path.join(ROOT, "lz4_flex_amd", "csrc")
-        srcs = ["lz4_decompress.hip", "lz4_decompress_lds.hip", "lz4_compress.hip", "lz4_compress_lds.hip", "xxh32_kernel.hip",
+        srcs = ["lz4_decompress.hip", "lz4_decompress_lds.hip", "lz4_decompress_split.hip", "lz4_compress.hip", "lz4_compress_lds.hip", "xxh32_kernel.hip",
                 "capi.cpp", "frame.cpp"]
         out = os.path.join(ROOT, "lz4_flex_amd", "build", "liblz4flex_prof.so")
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLZ4FLEX_PROFILE_PHASES",
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + a.defs.split() + [
                                "-x", "hip"] + [os.path.join(csrc, f) for f in srcs] + ["-o", out])
         print(out)
         return
@@ -128,6 +130,8 @@ def main():
     d_comp_len = dev_array(np.zeros(n, dtype=np.uint32))
     d_status = dev_array(np.zeros(n, dtype=np.int32))
     d_out_len = dev_array(np.zeros(n, dtype=np.uint32))
+    d_detail = dev_array(np.zeros(2 * n, dtype=np.uint64))
+    detail = np.zeros(2 * n, dtype=np.uint64)
     t = Timer()
     comp_len = np.zeros(n, dtype=np.uint32)
     status = np.zeros(n, dtype=np.int32)
@@ -139,7 +143,7 @@ def main():
 
     def decompress():
         r = lib.lz4flex_decompress_batch(ctx, d_comp, d_comp_off, d_comp_len, n, d_out, d_in_off, d_in_len, d_out_len,
-                                         d_status, None, _lib.MEM_DEVICE, None)
+                                         d_status, d_detail, _lib.MEM_DEVICE, None)
         assert r == 0, _lib.last_error()
 
     first = True
@@ -171,11 +175,14 @@ def main():
     d2h(comp_len, d_comp_len)
     out = np.empty(total, dtype=np.uint8)
     out_len = np.zeros(n, dtype=np.uint32)
-    for g in [int(x) for x in a.geometries.split(",") if x != ""]:
-        assert lib.lz4flex_set_tuning(ctx, b"decompress_geometry", g) == 0, "geometry %d rejected" % g
+    runs = [(3, int(x)) for x in a.geometries.split(",") if x != ""] + [(4, int(x)) for x in a.split.split(",") if x != ""]
+    for variant, g in runs:
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", variant) == 0
+        key = b"decompress_geometry" if variant == 3 else b"decompress_blocks_per_wg"
+        assert lib.lz4flex_set_tuning(ctx, key, g) == 0, "%s %d rejected" % (key, g)
         chk(_hip().hipMemset(d_out, 0xA5, C.c_size_t(total)))
         decompress()
-        chk(_hip().hipDeviceSynchronize(), "decode geometry %d" % g)
+        chk(_hip().hipDeviceSynchronize(), "decode %d/%d" % (variant, g))
         d2h(out, d_out)
         d2h(status, d_status)
         d2h(out_len, d_out_len)
@@ -186,9 +193,9 @@ def main():
             decompress()
             best = min(best, t.stop_ms())
         alg = (total + int(comp_len.sum())) / 1e9
-        print("DEC geometry %d: %8.3f ms  (%7.1f GiB/s out, %6.1f GB/s algorithmic = %.2f%% of 8 TB/s)  exact=%s" %
-              (g, best, total / 2**30 / (best / 1e3), alg / (best / 1e3), alg / (best / 1e3) / 80.0, ok), flush=True)
-        if a.phases:
+        print("DEC variant %d/%d: %8.3f ms  (%7.1f GiB/s out, %6.1f GB/s algorithmic = %.2f%% of 8 TB/s)  exact=%s" %
+              (variant, g, best, total / 2**30 / (best / 1e3), alg / (best / 1e3), alg / (best / 1e3) / 80.0, ok), flush=True)
+        if a.phases and variant == 3:
             cyc = (C.c_ulonglong * 8)()
             cnt = (C.c_ulonglong * 8)()
             dbg = lib.lz4flex_debug_phase_dec
@@ -205,6 +212,15 @@ def main():
         if not ok:
             bad = np.nonzero(status != 0)[0]
             print("   failing status blocks:", bad[:8], status[bad[:8]] if len(bad) else "", flush=True)
+            d2h(detail, d_detail)
+            for b in bad[:8]:
+                print("     block %d: comp_len %d detail %x %x" % (b, comp_len[b], detail[2 * b], detail[2 * b + 1]))
+                dip = int(detail[2 * b]) >> 32
+                if dip < comp_len[b]:
+                    buf = np.zeros(stride, dtype=np.uint8)
+                    chk(_hip().hipMemcpy(C.c_void_p(buf.ctypes.data), C.c_void_p(d_comp.value + int(b) * stride), C.c_size_t(stride), 2))
+                    print("       bytes at ip %d:" % dip, buf[dip:dip + 24].tobytes().hex(), " oracle:",
+                          O.compress(src[int(b) * bs:(int(b) + 1) * bs].tobytes())[dip:dip + 24].hex())
             if not len(bad):
                 diff = np.nonzero(out != src)[0]
                 print("   first diffs at", diff[:8], "block", diff[:1] // bs, "count", len(diff), flush=True)

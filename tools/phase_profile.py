@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 def main():
     csrc = os.path.join(ROOT, "lz4_flex_amd", "csrc")
     out = "/tmp/liblz4flex_prof.so"
-    srcs = ["lz4_decompress.hip", "lz4_decompress_lds.hip", "lz4_compress.hip", "lz4_compress_lds.hip", "xxh32_kernel.hip", "capi.cpp", "frame.cpp"]
+    srcs = ["lz4_decompress.hip", "lz4_decompress_lds.hip", "lz4_decompress_split.hip", "lz4_compress.hip", "lz4_compress_lds.hip", "xxh32_kernel.hip", "capi.cpp", "frame.cpp"]
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLZ4FLEX_PROFILE_PHASES", "-x", "hip"] + \
           [os.path.join(csrc, s) for s in srcs] + ["-o", out]
     subprocess.check_call(cmd)
