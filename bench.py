@@ -204,7 +204,9 @@ def main():
         kernels["compress"] = {"kernel": "lz4_compress_blocks_kernel", "ms_per_launch": round(t_c * 1e3, 4),
                                "MiB_per_s": round(total / 1048576 / t_c, 1), "roofline": roof(t_c)}
     if args.only in ("both", "decompress"):
-        kernels["decompress"] = {"kernel": "lz4_decompress_pipe_kernel", "ms_per_launch": round(t_d * 1e3, 4),
+        dv = args.decompress_variant or (3 if n > 20480 else 4)   # capi.cpp launch_decompress_fast's choice by batch size
+        kernels["decompress"] = {"kernel": {4: "lz4_decompress_split_kernel", 3: "lz4_decompress_pipe_kernel", 2: "lz4_decompress_lds_kernel",
+                                            1: "lz4_decompress_blocks_kernel"}[dv], "ms_per_launch": round(t_d * 1e3, 4),
                                  "MiB_per_s": round(total / 1048576 / t_d, 1), "roofline": roof(t_d)}
     # measured HBM traffic per launch (rocprofv3 --pmc passes, corrected per MI355X_MICROARCH.md) if recorded
     tpath = os.path.join(ROOT, "profiles", "traffic.json")

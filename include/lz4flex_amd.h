@@ -169,8 +169,11 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
                                 uint32_t *out_len, int32_t *status, uint64_t *detail,
                                 const lz4flex_decompress_ext *ext, int mem_kind, void *hip_stream);
 
-/* Tuning knobs for measurements: "decompress_variant" (2 = LDS-staged decoder, default; 1 = decoder whose
- * window lives in HBM/L2, also used for dictionary/prefix blocks), "decompress_lanes" (8/16/32/64, variant 1),
+/* Tuning knobs for measurements: "decompress_variant" (0 = default: by batch size; 4 = parser / copier split decoder;
+ * 3 = pipelined LDS-staged decoder, with "decompress_geometry" -1 / 0 / 1 = by batch size / 8 lanes x 4 B / 4 lanes
+ * x 8 B per block; 2 = LDS-staged decoder with the generic loop; 1 = decoder whose window lives in HBM/L2, always
+ * used for dictionary/prefix blocks), "decompress_blocks_per_wg" (variant 4: 0 = by batch size, 8/16/32/64),
+ * "decompress_lanes" (8/16/32/64, variant 1),
  * "compress_lanes" (8/16) = lanes of a wavefront cooperating on one block, "compress_variant" (1 = default:
  * the group encoder pushes sequences to a second wavefront that writes the output; 3 = the group encoder alone;
  * 5 = group encoder + a wavefront that only prefetches the input; 6 = variant 1 with the current-side bytes read

@@ -50,13 +50,17 @@ struct lz4flex_ctx {
     int ablate = 0;               // timing ablations (wrong output!), see lz4flex_set_tuning("ablate")
     int dec_blocks_per_wg = 0;    // split decoder: blocks per workgroup (8/16/32/64), 0 = by batch size
     int dec_geometry = -1;        // pipelined decoder geometry (lz4_decompress_lds.hip launch_decompress_pipe): -1 by batch size, 0 = 8 lanes x 4 B, 1 = 4 lanes x 8 B
-    int dec_variant = 3;          // 1 = window in HBM/L2 (lz4_decompress.hip), 2 = LDS-staged generic loop, 3 = LDS-staged pipelined (lz4_decompress_lds.hip), 4 = parser / copier split (lz4_decompress_split.hip)
+    int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 2 = LDS-staged generic loop, 3 = LDS-staged pipelined (lz4_decompress_lds.hip), 4 = parser / copier split (lz4_decompress_split.hip)
 };
 
 // the decoders for blocks without dictionary / prefix
 static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressArgs& a, hipStream_t s) {
-    if (c->dec_variant == 4) return launch_decompress_split(a, s, c->dec_blocks_per_wg);
-    if (c->dec_variant == 3) return launch_decompress_pipe(a, s, c->ablate, c->dec_geometry);
+    // 0: by batch size (tools/dec_geometry.py on the configs[1] workload: split 1.69 / 1.80 / 2.36 ms for 1 024 / 8 192 /
+    // 16 384 blocks against 2.39 / 2.55 / 2.93 ms pipelined; above one split round per CU the 4-lane pipelined geometry
+    // holds twice the blocks per CU: 32 768 blocks 4.19 ms against 4.60 ms)
+    const int v = c->dec_variant != 0 ? c->dec_variant : (a.n > 20480u ? 3 : 4);
+    if (v == 4) return launch_decompress_split(a, s, c->dec_blocks_per_wg);
+    if (v == 3) return launch_decompress_pipe(a, s, c->ablate, c->dec_geometry);
     return launch_decompress_lds(a, s, c->ablate);
 }
 
@@ -125,7 +129,7 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
     if (!c) return -LZ4FLEX_E_NOMEM;
     c->device = device;
     if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v >= 1 && v <= 6 && v != 4) c->comp_variant = v; }
-    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v >= 1 && v <= 4) c->dec_variant = v; }
+    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v >= 0 && v <= 4) c->dec_variant = v; }
     if (const char* e = getenv("LZ4FLEX_DECOMPRESS_GEOMETRY")) { const int v = atoi(e); if (v >= -1 && v <= 1) c->dec_geometry = v; }
     int prev = 0;
     (void)hipGetDevice(&prev);
@@ -160,7 +164,7 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "decompress_variant")) {
-        if (value < 1 || value > 4) return -LZ4FLEX_E_INVALID_ARG;
+        if (value < 0 || value > 4) return -LZ4FLEX_E_INVALID_ARG;
         c->dec_variant = value;
         return 0;
     }
@@ -301,7 +305,7 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
         a.dict_len = has_dict ? (const uint32_t*)(dd + at_dict_len) : nullptr;
         a.out_len = (uint32_t*)(dd + at_out_len); a.status = (int32_t*)(dd + at_status);
         a.detail = (uint64_t*)(dd + at_detail); a.n = n;
-        le = (c->dec_variant >= 2 && !has_dict && !has_pos) ? launch_decompress_fast(c, a, s) : launch_decompress(a, c->dec_lanes, s);
+        le = (c->dec_variant != 1 && !has_dict && !has_pos) ? launch_decompress_fast(c, a, s) : launch_decompress(a, c->dec_lanes, s);
     }
     if (le != hipSuccess) return hip_fail(le, "kernel launch");
     HIP_TRY(hipMemcpyAsync(hp + at_out_len, dd + at_out_len, desc_bytes - at_out_len, hipMemcpyDeviceToHost, s));
@@ -381,7 +385,7 @@ static int run_device_batch(lz4flex_ctx* c, bool compress, const void* in_base, 
         a.dict_off = ext ? ext->dict_off : nullptr;
         a.dict_len = ext ? ext->dict_len : nullptr;
         a.out_len = out_len; a.status = status; a.detail = detail; a.n = n;
-        le = (c->dec_variant >= 2 && !a.dict_base && !a.out_pos) ? launch_decompress_fast(c, a, s) : launch_decompress(a, c->dec_lanes, s);
+        le = (c->dec_variant != 1 && !a.dict_base && !a.out_pos) ? launch_decompress_fast(c, a, s) : launch_decompress(a, c->dec_lanes, s);
     }
     if (le != hipSuccess) return hip_fail(le, "kernel launch");
     return 0;

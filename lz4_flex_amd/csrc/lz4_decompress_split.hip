@@ -20,8 +20,8 @@
 //     are needed, near matches are LDS -> LDS.  Steps without a load touch the compressed stream ahead of the
 //     parser (one 128-byte line per step), which keeps the parser's chunk loads out of HBM latency.
 //
-// LDS per block: 2 080 B output buffer + 16 x 16 B queue + 16 B head/tail + 80 B tail copy = 2 432 B;
-// 64 blocks = 152 KiB of the CU's 160 KiB.
+// LDS per block: 2 080 B output buffer + 16 x 16 B queue + 16 B head/tail + 80 B tail copy + 16 B sink = 2 448 B;
+// 64 blocks = 153 KiB of the CU's 160 KiB.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -29,12 +29,27 @@
 #include "lz4_split_parser.h"
 
 namespace lz4flex_dev {
+#ifdef LZ4FLEX_PROFILE_PHASES
+// [0] parser wave cycles, [1] parser wave-steps, [2..6] lane sums: live steps, queue-full, window bubbles, exact path, records
+// [8] copier wave cycles, [9] copier wave 4-step iterations, [10] service visits, [11] group-steps with a piece,
+// [12] group-steps idle on an empty queue, [13] group-steps blocked/done, [14] cycles in service
+__device__ unsigned long long g_split_prof[16];
+#define SP_ADD(k, v) atomicAdd(&g_split_prof[k], (unsigned long long)(v))
+#endif
 namespace v5 {
 
 // =====================================================================================================
 // COPIER: G lanes = one block
 // =====================================================================================================
+template <uint32_t WB> struct Word;
+template <> struct Word<4> { using type = uint32_t; };
+template <> struct Word<8> { using type = uint2; };
+
+// G lanes per block, WB bytes per lane and piece
+template <uint32_t G, uint32_t WB>
 struct Copier {
+    static constexpr uint32_t PIECE = G * WB;
+    using word_t = typename Word<WB>::type;
     const uint8_t* gin;
     uint8_t* gout;
     lds_u8* lout;         // the block's LDS output buffer
@@ -43,11 +58,20 @@ struct Copier {
     uint32_t ilen;
     uint32_t op, L0, F;   // LDS output holds positions [L0, op); [0, F) is written back
     uint32_t lit_src, lit_rem, ml_rem, moff;
-    uint32_t head;
-    uint32_t pf_next;     // next compressed position whose line has not been touched yet
+    const uint8_t* gin_ld;   // bases of the per-step load: gin / gout, or g_pad when the block is too small to read 4 bytes from
+    const uint8_t* gout_ld;
+    uint32_t ilen_w;         // ilen - WB (0 with gin_ld = g_pad): the last position a literal load may start at
+    uint32_t head, head_pub, snap;
+    u32x4 e;                 // the record at `head` (complete iff head != snap)
+    uint32_t pf_next;        // next compressed position whose line has not been touched yet
+    uint32_t pf_v, pf_acc;
     uint32_t blocked, done;
-    enum : uint32_t { K_NONE = 0, K_MAINT = 1, K_RARE = 2, K_CAREFUL = 3, K_FINISH = 4 };
-    struct Slot { uint32_t n, dst, msrc, glob, v; };
+#ifdef LZ4FLEX_PROFILE_PHASES
+    uint32_t pr_piece, pr_idle, pr_blocked;
+#endif
+    enum : uint32_t { K_NONE = 0, K_MAINT = 1, K_RARE = R_RARE, K_CAREFUL = R_CAREFUL, K_FINISH = R_FINISH };
+    struct Slot { uint32_t n, dst, msrc, glob; word_t v; };
+    static __device__ __forceinline__ word_t ldw(const uint8_t* p) { word_t v; __builtin_memcpy(&v, p, WB); return v; }
 
     __device__ __forceinline__ uint32_t out_space() const { return L0 + OUT_CAP - OUT_SLACK - op; }
     __device__ __forceinline__ void st32l(uint32_t off, uint32_t v) const { __builtin_memcpy((void*)(lout + off), &v, 4); }
@@ -135,64 +159,69 @@ struct Copier {
         }
     }
 
+    // Once per 4-step iteration: snapshot the queue's tail (records below it are complete), publish the head, make
+    // sure four pieces fit into the output buffer, touch the next line of the compressed stream ahead of the parser.
+    __device__ __forceinline__ void iteration_begin() {
+        snap = q.tail();
+        e = q.get(head);   // re-read AFTER the snapshot: the copy fetched at the end of the last step may predate the record
+        if (g == 0u && head != head_pub) q.set_head(head);
+        head_pub = head;
+        if ((done | blocked) == 0u && out_space() < 4u * PIECE + 64u) blocked = K_MAINT;
+        pf_acc += pf_v;                                   // the touch issued one iteration ago (long complete)
+        const bool pf = pf_next < lit_src + PF_AHEAD;
+        const uint32_t pos = pf_next + (128u / G) * g;
+        pf_v = ld32(gin_ld + (pos < ilen_w ? pos : ilen_w));
+        pf_next = pf ? pf_next + 128u : pf_next;
+    }
     // Front end: pop a record when the current one is finished, cut one piece, issue its global load.
     __device__ __forceinline__ void fe_step(Slot& s) {
-        const bool active = (done | blocked) == 0u;
-        const uint32_t qt = q.tail();
-        const u32x4 e = q.get(head);
-        const bool boundary = (lit_rem | ml_rem) == 0u;
-        const bool pop = active && boundary && qt != head;
+        const bool ok = (done | blocked) == 0u;
+        const bool pop = ok && (lit_rem | ml_rem) == 0u && head != snap;
         lit_src = pop ? e.x : lit_src;
         lit_rem = pop ? e.y : lit_rem;
         ml_rem = pop ? e.z : ml_rem;
         moff = pop ? (e.w & 0xFFFFu) : moff;
+        const uint32_t kind = pop ? e.w >> 16 : 0u;      // R_RARE / R_CAREFUL / R_FINISH == K_*: generic code in service()
+        blocked |= kind;
         head = pop ? head + 1u : head;
-        if (pop && g == 0u) q.set_head(head);
-        const bool special = pop && (e.w & (F_FIN | F_CAREFUL)) != 0u;
-        const uint32_t special_kind = (e.w & F_FIN) ? (uint32_t)K_FINISH : (uint32_t)K_CAREFUL;
-        const bool space_ok = out_space() >= 64u;
-        const bool go = active && !special;
-        const bool want_l = go && lit_rem != 0u;
-        const bool want_m = go && lit_rem == 0u && ml_rem != 0u;
-        const bool do_l = want_l && space_ok;
-        const bool rare = want_m && space_ok && moff < 4u;
-        const bool do_m = want_m && space_ok && moff >= 4u;
-        const bool maint = (want_l || want_m) && !space_ok;
-        const uint32_t ln = lit_rem < PIECE ? lit_rem : PIECE;
-        const uint32_t pm = moff >= PIECE ? PIECE : (moff & ~3u);
-        const uint32_t mn = ml_rem < pm ? ml_rem : pm;
-        const uint32_t n = do_l ? ln : (do_m ? mn : 0u);
+        e = q.get(head);                                  // next record (complete iff head != snap); its latency overlaps this step
+        const bool go = ok && kind == 0u;
+        const bool isl = lit_rem != 0u;
+        const uint32_t pm = moff >= PIECE ? PIECE : (moff & ~(WB - 1u));
+        const uint32_t rem = isl ? lit_rem : ml_rem;
+        const uint32_t lim = isl ? PIECE : pm;
+        const uint32_t n = go ? (rem < lim ? rem : lim) : 0u;
         const uint32_t msrc = op - moff;
-        const bool far = do_m && msrc < L0;
-        const bool glob = do_l || far;
-        // a step without a load touches the next line of the compressed stream ahead of the parser
-        const uint32_t pf_pos = pf_next + 16u * g;
-        const bool pf = !glob && pf_next < lit_src + PF_AHEAD && pf_pos + 4u <= ilen;
-        const bool lane_in = 4u * g < n;   // a literal piece never reads behind lit_end + 3 (<= ilen for plain records)
-        const uint8_t* addr = (do_l && lane_in) ? gin + lit_src + 4u * g : (far ? gout + msrc + 4u * g : (pf ? gin + pf_pos : g_pad));
-        s.v = ld32(addr);   // exactly one load per step and lane: exact vmcnt bookkeeping
-        pf_next = (!glob && pf_next < lit_src + PF_AHEAD) ? pf_next + 16u * G : pf_next;
+        const bool far = !isl && msrc < L0;
+        // one load per step and lane: literal bytes, far match bytes (already written back: msrc + PIECE <= L0 + PIECE - 1 < F),
+        // or nothing useful (position 0).  Literal positions are clamped so that no lane reads behind the block.
+        const uint32_t lpos = lit_src + WB * g;
+        const uint32_t off = isl ? (lpos < ilen_w ? lpos : ilen_w) : (far ? msrc + WB * g : 0u);
+        s.v = ldw((isl ? gin_ld : gout_ld) + off);
         s.n = n;
         s.dst = op - L0;
-        s.msrc = msrc - L0;
-        s.glob = glob ? 1u : 0u;
-        lit_src = do_l ? lit_src + ln : lit_src;
-        lit_rem = do_l ? lit_rem - ln : lit_rem;
-        ml_rem = do_m ? ml_rem - mn : ml_rem;
+        s.msrc = far ? 0u : msrc - L0;                    // LDS source (always read; 0 when unused)
+        s.glob = (isl || far) ? 1u : 0u;
+        lit_src = isl ? lit_src + n : lit_src;
+        lit_rem = isl ? lit_rem - n : lit_rem;
+        ml_rem = isl ? ml_rem : ml_rem - n;
         op += n;
-        blocked = special ? special_kind : (rare ? (uint32_t)K_RARE : (maint ? (uint32_t)K_MAINT : blocked));
+#ifdef LZ4FLEX_PROFILE_PHASES
+        pr_piece += n != 0u; pr_idle += ok && !pop && n == 0u; pr_blocked += !ok;
+#endif
     }
     __device__ __forceinline__ void be_step(const Slot& s) {
-        if (4u * g < s.n) {
-            uint32_t x = s.v;
-            if (!s.glob) x = ld32o(s.msrc + 4u * g);
-            st32l(s.dst + 4u * g, x);
-        }
+        word_t x;
+        __builtin_memcpy(&x, (const void*)(lout + (s.glob ? 0u : s.msrc) + WB * g), WB);
+        if (s.glob) x = s.v;
+        if (WB * g < s.n) __builtin_memcpy((void*)(lout + s.dst + WB * g), &x, WB);
     }
     __device__ __forceinline__ void service() {
         if (done) return;
         if (out_space() < FLUSH_AT) flush_slide();
-        if (blocked == K_RARE) {
+        if (blocked == K_RARE) {   // a periodic match; the record's literals (if any) go first
+            generic_literals(lit_src, lit_rem);
+            lit_rem = 0u;
             generic_match(moff, ml_rem);
             ml_rem = 0u;
         } else if (blocked == K_CAREFUL || blocked == K_FINISH) {
@@ -204,30 +233,62 @@ struct Copier {
     }
     __device__ __forceinline__ void run() {
         Slot s0, s1, s2, s3;
+#ifdef LZ4FLEX_PROFILE_PHASES
+        pr_piece = pr_idle = pr_blocked = 0u;
+        const unsigned long long t_begin = __builtin_readcyclecounter();
+        unsigned long long t_service = 0ull;
+        uint32_t iters = 0u, services = 0u;
+#endif
+        if (__all(done != 0u)) return;   // a wavefront without blocks (batch tail)
         for (;;) {
-            s1.n = 0u; s1.dst = 0u; s1.msrc = 0u; s1.glob = 0u; s1.v = 0u;
+            s1.n = 0u; s1.dst = 0u; s1.msrc = 0u; s1.glob = 0u; s1.v = word_t{};
             s2 = s1; s3 = s1;
             do {
                 const uint32_t before = head + op;
+                iteration_begin();
                 fe_step(s0); be_step(s1);
                 fe_step(s1); be_step(s2);
                 fe_step(s2); be_step(s3);
                 fe_step(s3); be_step(s0);
                 if (!__any(head + op != before)) __builtin_amdgcn_s_sleep(2);   // nothing to do in the whole wave: yield issue slots
+#ifdef LZ4FLEX_PROFILE_PHASES
+                iters++;
+#endif
             } while (!__any(blocked != K_NONE));
             be_step(s1); be_step(s2); be_step(s3);
+#ifdef LZ4FLEX_PROFILE_PHASES
+            const unsigned long long ts = __builtin_readcyclecounter();
+#endif
             service();
+#ifdef LZ4FLEX_PROFILE_PHASES
+            t_service += __builtin_readcyclecounter() - ts;
+            services++;
+#endif
             if (__all(done != 0u)) break;
         }
+        if (g == 0u && head != head_pub) q.set_head(head);
+        if (pf_acc + pf_v == 0x9E3779B9u && ilen == 0xFFFFFFFFu) gout[0] = 1;   // keeps the touch loads alive; never true
+#ifdef LZ4FLEX_PROFILE_PHASES
+        if (g == 0u) { SP_ADD(11, pr_piece); SP_ADD(12, pr_idle); SP_ADD(13, pr_blocked); }
+        if (threadIdx.x % 64u == 0u) {
+            SP_ADD(8, __builtin_readcyclecounter() - t_begin); SP_ADD(9, iters); SP_ADD(10, services); SP_ADD(14, t_service);
+        }
+#endif
     }
 };
 
-// NB blocks per workgroup: NB/8 copier wavefronts followed by the parser wavefront (NB lanes in use)
-template <uint32_t NB>
-__global__ void __launch_bounds__(64 * (NB / 8 + 1)) lz4_decompress_split_kernel(DecompressArgs a) {
+// NB blocks per workgroup: NB*G/64 copier wavefronts followed by the parser wavefront (NB lanes in use).  G copier lanes
+// per block move WB bytes each per piece.
+// Measured on the configs[1] workload (tools/dec_geometry.py --split, 16 384 blocks): G = 8 x 4 B 2.36 ms; G = 4 x 8 B
+// (half the copier wavefronts, each alone on its SIMD) 4.35 ms; two or four blocks per parser lane (independent
+// chains in one instruction stream) 2.94 / 14.4 ms: the compiler serialises them and the wider parser starves the
+// copiers that share its SIMD.  Only G = 8, WB = 4 is instantiated.
+template <uint32_t NB, uint32_t G, uint32_t WB>
+__global__ void __launch_bounds__(64 * (NB * G / 64 + 1)) lz4_decompress_split_kernel(DecompressArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
     constexpr uint32_t CW = NB * G / 64u;
+    static_assert(NB <= 64 && (NB * G) % 64 == 0, "geometry");
     const uint32_t wave = threadIdx.x / 64u;
     const uint32_t lane = threadIdx.x % 64u;
     const uint32_t first = blockIdx.x * NB;
@@ -236,7 +297,7 @@ __global__ void __launch_bounds__(64 * (NB / 8 + 1)) lz4_decompress_split_kernel
         const uint32_t j = wave * (64u / G) + lane / G;
         const uint32_t b = first + j;
         const bool valid = b < a.n;
-        Copier c;
+        Copier<G, WB> c;
         c.g = lane % G;
         c.lout = lds + j * BLK_LDS;
         c.q.blk = c.lout;
@@ -247,8 +308,12 @@ __global__ void __launch_bounds__(64 * (NB / 8 + 1)) lz4_decompress_split_kernel
         for (uint32_t i = c.g; i < TAIL_BUF; i += G) c.lout[TAIL_OFF + i] = (tstart + i < c.ilen) ? c.gin[tstart + i] : (uint8_t)0;
         if (c.g == 0u) { c.q.set_head(0u); c.q.set_tail(0u); }
         c.op = 0u; c.L0 = 0u; c.F = 0u;
-        c.lit_src = 0u; c.lit_rem = 0u; c.ml_rem = 0u; c.moff = 0u; c.head = 0u; c.pf_next = 0u;
-        c.blocked = Copier::K_NONE;
+        c.lit_src = 0u; c.lit_rem = 0u; c.ml_rem = 0u; c.moff = 0u; c.head = 0u; c.head_pub = 0u; c.snap = 0u; c.pf_next = 0u;
+        c.pf_v = 0u; c.pf_acc = 0u;
+        c.gin_ld = c.ilen >= WB ? c.gin : g_pad;
+        c.ilen_w = c.ilen >= WB ? c.ilen - WB : 0u;
+        c.gout_ld = (valid && a.out_cap[b] >= WB) ? c.gout : g_pad;
+        c.blocked = Copier<G, WB>::K_NONE;
         c.done = valid ? 0u : 1u;
         __syncthreads();
         c.run();
@@ -259,16 +324,12 @@ __global__ void __launch_bounds__(64 * (NB / 8 + 1)) lz4_decompress_split_kernel
         const bool valid = j < NB && b < a.n;
         Parser p;
         p.q.blk = lds + (j < NB ? j : 0u) * BLK_LDS;
-        p.gin = valid ? a.in_base + a.in_off[b] : g_pad;
-        p.A = (uint32_t)(reinterpret_cast<uintptr_t>(p.gin) & 3u);
-        p.gal = p.gin - p.A;
-        p.ilen = valid ? a.in_len[b] : 0u;
+        p.init_window(valid ? a.in_base + a.in_off[b] : g_pad, valid ? a.in_len[b] : 0u);
+        p.rare_below = WB;
         p.cap = valid ? a.out_cap[b] : 0u;
-        p.tstart = p.ilen > TAILB ? p.ilen - TAILB : 0u;
-        p.ip = 0u; p.op = 0u; p.need_off = 0u; p.mlc_saved = 0u; p.qtail = 0u;
+        p.ip = 0u; p.op = 0u; p.tok_over = 0u; p.qtail = 0u;
         p.status = 0; p.expected = 0u;
         p.done = valid ? 0u : 1u;
-        p.base = 0u;
 #ifdef LZ4FLEX_SPLIT_DEBUG
         p.dbg_ip = 0xFFFFFFFFu; p.dbg_w0 = 0u; p.dbg_w1 = 0u; p.dbg_kb = 0u;
 #endif
@@ -277,9 +338,20 @@ __global__ void __launch_bounds__(64 * (NB / 8 + 1)) lz4_decompress_split_kernel
         p.C2 = *reinterpret_cast<const u32x4*>(p.chunk_addr(32u));
         p.N = *reinterpret_cast<const u32x4*>(p.chunk_addr(48u));
         __syncthreads();
+        // the token chain is the critical path of the workgroup: the parser wavefront issues ahead of the copiers on its SIMD
+        // (priority 0: 2.80 ms instead of 2.36 ms)
         __builtin_amdgcn_s_setprio(3);
         if (valid && p.ilen == 0u) p.fail(LZ4FLEX_DEV_E_EXPECTED_ANOTHER_BYTE);   // :207-209
+#ifdef LZ4FLEX_PROFILE_PHASES
+        p.pr_steps = p.pr_noroom = p.pr_bubble = p.pr_slow = p.pr_pushed = 0u;
+        const unsigned long long t_begin = __builtin_readcyclecounter();
+        uint32_t wsteps = 0u;
+        while (!__all(p.done != 0u)) { p.step(); wsteps++; }
+        if (lane == 0u) { SP_ADD(0, __builtin_readcyclecounter() - t_begin); SP_ADD(1, wsteps); }
+        SP_ADD(2, p.pr_steps); SP_ADD(3, p.pr_noroom); SP_ADD(4, p.pr_bubble); SP_ADD(5, p.pr_slow); SP_ADD(6, p.pr_pushed);
+#else
         while (!__all(p.done != 0u)) p.step();
+#endif
         if (valid) {
             a.status[b] = p.status;
             a.out_len[b] = p.status == 0 ? p.op : 0u;
@@ -296,11 +368,11 @@ __global__ void __launch_bounds__(64 * (NB / 8 + 1)) lz4_decompress_split_kernel
     }
 }
 
-template <uint32_t NB>
-static hipError_t launch_nb(const DecompressArgs& a, hipStream_t s) {
+template <uint32_t NB, uint32_t G, uint32_t WB>
+static hipError_t launch_cfg(const DecompressArgs& a, hipStream_t s) {
     const uint32_t grid = (a.n + NB - 1u) / NB;
     const size_t lds = (size_t)NB * BLK_LDS;
-    auto kern = lz4_decompress_split_kernel<NB>;
+    auto kern = lz4_decompress_split_kernel<NB, G, WB>;
     if (lds > 65536u) {   // the attribute is per device: remember which devices have it (per instantiation)
         static unsigned long long have = 0ull;   // benign race: setting it twice is harmless
         int dev = 0;
@@ -312,7 +384,7 @@ static hipError_t launch_nb(const DecompressArgs& a, hipStream_t s) {
             have |= bit;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * (NB / 8u + 1u)), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * (NB * G / 64u + 1u)), lds, s, a);
     return hipGetLastError();
 }
 
@@ -324,12 +396,25 @@ hipError_t launch_decompress_split(const DecompressArgs& a, hipStream_t s, int b
     if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;   // dictionary / prefix: v1 kernel
     if (blocks_per_wg == 0) blocks_per_wg = a.n >= 64u * 256u ? 64 : (a.n >= 32u * 256u ? 32 : (a.n >= 16u * 256u ? 16 : 8));
     switch (blocks_per_wg) {
-        case 64: return v5::launch_nb<64>(a, s);
-        case 32: return v5::launch_nb<32>(a, s);
-        case 16: return v5::launch_nb<16>(a, s);
-        case 8: return v5::launch_nb<8>(a, s);
+        case 64: return v5::launch_cfg<64, 8, 4>(a, s);
+        case 32: return v5::launch_cfg<32, 8, 4>(a, s);
+        case 16: return v5::launch_cfg<16, 8, 4>(a, s);
+        case 8: return v5::launch_cfg<8, 8, 4>(a, s);
         default: return hipErrorInvalidValue;
     }
 }
 
 }  // namespace lz4flex_dev
+
+#ifdef LZ4FLEX_PROFILE_PHASES
+extern "C" int lz4flex_debug_phase_split(unsigned long long* vals, int reset) {
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(lz4flex_dev::g_split_prof), z, sizeof z);
+        return 0;
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(vals, HIP_SYMBOL(lz4flex_dev::g_split_prof), 128);
+    return 0;
+}
+#endif

@@ -37,8 +37,6 @@ typedef volatile uint32_t LZ4_LDS lds_vu32;
 typedef volatile u32x4 LZ4_LDS lds_vu128;
 typedef uint32_t LZ4_LDS lds_u32;
 
-constexpr uint32_t G = 8;             // copier lanes per block
-constexpr uint32_t PIECE = 4u * G;    // bytes per copy step
 constexpr uint32_t QD = 16;           // records per queue
 constexpr uint32_t OUT_H = 512;       // history kept in LDS after a write-back
 constexpr uint32_t OUT_SLACK = 32;
@@ -49,12 +47,15 @@ constexpr uint32_t TAIL_BUF = 80;     // + zero padding: a 24-byte window read a
 constexpr uint32_t Q_OFF = OUT_CAP;
 constexpr uint32_t CTL_OFF = Q_OFF + 16u * QD;   // head, tail
 constexpr uint32_t TAIL_OFF = CTL_OFF + 16u;
-constexpr uint32_t BLK_LDS = TAIL_OFF + TAIL_BUF;
-static_assert(BLK_LDS == 2432 && BLK_LDS % 16 == 0, "LDS per block");
+constexpr uint32_t SINK_OFF = TAIL_OFF + TAIL_BUF;   // 16 bytes nobody reads: target of the parser's record store when it has nothing to push
+constexpr uint32_t BLK_LDS = SINK_OFF + 16u;
+static_assert(BLK_LDS == 2448 && BLK_LDS % 16 == 0, "LDS per block");
 constexpr uint32_t PF_AHEAD = 512;    // compressed bytes kept warm ahead of the records being copied
 
-constexpr uint32_t F_FIN = 1u << 16;      // record: the block ends after these literals (or with an error)
-constexpr uint32_t F_CAREFUL = 1u << 17;  // record: literal source may end at the block's last byte (no wild reads)
+// record.w = offset | kind << 16; a non-zero kind takes the copier group out of its steady loop:
+constexpr uint32_t R_RARE = 2u;       // match whose offset is below the copier's bytes per lane (periodic copy)
+constexpr uint32_t R_CAREFUL = 3u;    // literals whose source may end at the block's last byte (no wild reads)
+constexpr uint32_t R_FINISH = 4u;     // same, and the block ends after them (or with an error)
 
 #ifdef LZ4FLEX_HOST_SIM
 static uint8_t g_pad[64] __attribute__((aligned(16)));
@@ -89,7 +90,8 @@ struct Parser {
     uint32_t A;              // gin - gal
     uint32_t ilen, cap;
     uint32_t ip, op;
-    uint32_t need_off, mlc_saved;
+    uint32_t tok_over;       // 0, or 0x100 | low nibble of the token whose literals were pushed separately: the next
+                             // step parses a synthetic token (no literals, that match nibble) at ip, the byte before the offset
     uint32_t done;
     int32_t status;
     uint64_t expected;
@@ -98,21 +100,45 @@ struct Parser {
     Queue q;
     // register window: stream bytes [base, base + 48) of the aligned space, N = the chunk at base + 48
     uint32_t base;
+    uint32_t rare_below;     // matches with a smaller offset are marked R_RARE (the copier moves this many bytes per lane)
+    uint32_t climit;         // start of the last chunk that lies entirely inside the block (loads are clamped to it)
     u32x4 C0, C1, C2, N;
 #ifdef LZ4FLEX_SPLIT_DEBUG
     uint32_t dbg_ip, dbg_w0, dbg_w1, dbg_kb;   // state at the first sequence that left the fast path
 #endif
+#ifdef LZ4FLEX_PROFILE_PHASES
+    uint32_t pr_steps, pr_noroom, pr_bubble, pr_slow, pr_pushed;
+#endif
 
     static LZ4_FN uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+    static LZ4_FN int32_t imin3(int32_t a, int32_t b, int32_t c) { const int32_t m = a < b ? a : b; return m < c ? m : c; }
     static LZ4_FN uint32_t sel4(uint32_t m0, uint32_t m1, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3) {
         return bfi(m1, bfi(m0, a3, a2), bfi(m0, a1, a0));
     }
-    LZ4_FN const uint8_t* chunk_addr(uint32_t c) const {
-        // a chunk is fetched only if it lies entirely inside the block (the tail copy serves the rest)
-        return (c + 16u <= ilen + A) ? gal + c : g_pad;
+    // Window geometry for a block at `g` of `n` bytes: chunks are fetched only if they lie entirely inside the block (a
+    // clamped load returns the last such chunk; by then the lane reads the LDS tail copy instead); a block without
+    // any full chunk points the window at g_pad.
+    LZ4_FN void init_window(const uint8_t* g, uint32_t n) {
+        gin = g;
+        ilen = n;
+        A = (uint32_t)(reinterpret_cast<uintptr_t>(g) & 3u);
+        const bool any = n + A >= 16u;
+        gal = any ? g - A : g_pad;
+        climit = any ? ((n + A) & ~15u) - 16u : 0u;
+        tstart = n > TAILB ? n - TAILB : 0u;
+        base = 0u;
     }
+    LZ4_FN const uint8_t* chunk_addr(uint32_t c) const { return gal + (c < climit ? c : climit); }
     LZ4_FN uint32_t rd8(uint32_t pos) const {   // pos < ilen
         return pos >= tstart ? (uint32_t)q.blk[TAIL_OFF + (pos - tstart)] : (uint32_t)gin[pos];
+    }
+    // branch-free push: the record goes to the queue slot or to the sink, the tail is rewritten either way
+    LZ4_FN void push_if(bool c, uint32_t lsrc, uint32_t ln, uint32_t ml, uint32_t off_flags) {
+        const u32x4 v = {lsrc, ln, ml, off_flags};
+        const uint32_t at = c ? Q_OFF + 16u * (qtail & (QD - 1u)) : SINK_OFF;
+        *reinterpret_cast<lds_vu128*>(q.blk + at) = v;
+        qtail += c ? 1u : 0u;
+        *reinterpret_cast<lds_vu32*>(q.blk + (c ? CTL_OFF + 4u : SINK_OFF)) = qtail;   // lanes without a block share block 0's area: they must not touch its tail
     }
     LZ4_FN void push(uint32_t lsrc, uint32_t ln, uint32_t ml, uint32_t off_flags) {
         q.put(qtail, lsrc, ln, ml, off_flags);
@@ -122,14 +148,14 @@ struct Parser {
     LZ4_FN void fail(int32_t code) {
         status = code;
         done = 1u;
-        push(0u, 0u, 0u, F_FIN);
+        push(0u, 0u, 0u, R_FINISH << 16);
     }
 
     // Exact handling of one sequence (or of the offset half when need_off is set), byte by byte, every check in the
     // reference's order (src/block/decompress.rs:244-444).  Needs three free queue slots.
     LZ4_COLD_FN void exact_step() {
         uint32_t mlc;
-        if (!need_off) {
+        if (tok_over == 0u) {
             const uint32_t tok = rd8(ip);
             ip += 1u;
             uint32_t lit = tok >> 4;
@@ -149,14 +175,15 @@ struct Parser {
             ip += lit;
             op += lit;
             if (ip >= ilen) {   // :366-368 the block's last sequence
-                push(lsrc, lit, 0u, F_FIN | F_CAREFUL);
+                push(lsrc, lit, 0u, R_FINISH << 16);
                 done = 1u;
                 return;
             }
-            if (lit != 0u) push(lsrc, lit, 0u, F_CAREFUL);
+            if (lit != 0u) push(lsrc, lit, 0u, R_CAREFUL << 16);
         } else {
-            mlc = mlc_saved;
-            need_off = 0u;
+            mlc = tok_over & 15u;
+            tok_over = 0u;
+            ip += 1u;   // ip was parked on the byte before the offset
         }
         if (ilen - ip < 2u) return fail(LZ4FLEX_DEV_E_EXPECTED_ANOTHER_BYTE);   // :373-375
         const uint32_t offset = rd8(ip) | (rd8(ip + 1u) << 8);
@@ -174,102 +201,110 @@ struct Parser {
         }
         if (offset > op) return fail(LZ4FLEX_DEV_E_OFFSET_OUT_OF_BOUNDS);       // :398-408, unsafe-flavour order
         if (ml > cap - op) { expected = (uint64_t)op + ml; return fail(LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL); }
-        push(ip, 0u, ml, offset);
+        push(ip, 0u, ml, offset | (offset < rare_below ? R_RARE << 16 : 0u));
         op += ml;
         if (ip >= ilen) return fail(LZ4FLEX_DEV_E_EXPECTED_ANOTHER_BYTE);       // :439-443
     }
 
+    // One step = window() ; [patch_tail() if any lane of the wave reads its tail copy] ; parse() ; [exact_step() for
+    // lanes whose sequence left the fast path].
+    uint32_t qhead_, k_, sh_, D0, D1, D2, D3, D4, D5;   // carried from window() to parse()
+    bool tailmode, slow;
+
     LZ4_FN void step() {
-        const uint32_t qhead = q.head();
+        window();
+        if (LZ4_ANY(tailmode)) patch_tail();
+        parse();
+        if (LZ4_ANY(slow)) {
+            if (slow) exact_step();
+        }
+    }
+    LZ4_FN void window() {
+        qhead_ = q.head();
         // ---- register window: take the chunk that was in flight, slide by at most one chunk, fetch the next one
         const uint32_t ipa = ip + A;
         uint32_t k = ipa - base;
+        const bool slide = k - 16u < 48u;        // 16 <= k < 64
         const bool rebase = k >= 64u;            // a long literal run was skipped: restart three chunks before the target
-        const bool slide = !rebase && k >= 16u;
         if (slide) { C0 = C1; C1 = C2; C2 = N; }
         base = rebase ? (ipa & ~15u) - 48u : (slide ? base + 16u : base);
         N = *reinterpret_cast<const u32x4*>(chunk_addr(base + 48u));
         k = ipa - base;
-        const bool tailmode = ip + 48u > ilen;
-        const bool have = k < 16u || tailmode;
+        k_ = k;
+        tailmode = ip + 48u > ilen;
         // ---- 24 bytes at ip: D0..D5 dwords -> W0..W4
         const uint32_t i = (k >> 2) & 3u;
-        // 4-way selects written as bit-field inserts on the two index bits (v_bfi_b32): three instructions per dword,
-        // no control flow (nested ?: chains on six values were lowered to exec-mask branches)
-        const uint32_t m0 = 0u - (i & 1u), m1 = 0u - (i >> 1);
-        uint32_t D0 = sel4(m0, m1, C0.x, C0.y, C0.z, C0.w);
-        uint32_t D1 = sel4(m0, m1, C0.y, C0.z, C0.w, C1.x);
-        uint32_t D2 = sel4(m0, m1, C0.z, C0.w, C1.x, C1.y);
-        uint32_t D3 = sel4(m0, m1, C0.w, C1.x, C1.y, C1.z);
-        uint32_t D4 = sel4(m0, m1, C1.x, C1.y, C1.z, C1.w);
-        uint32_t D5 = sel4(m0, m1, C1.y, C1.z, C1.w, C2.x);
-        uint32_t sh = k & 3u;
-        if (LZ4_ANY(tailmode)) {
-            const uint32_t rel = tailmode ? ip - tstart : 0u;
-            const lds_u32* tw = reinterpret_cast<const lds_u32*>(q.blk + TAIL_OFF + (rel & ~3u));
-            const uint32_t t0 = tw[0], t1 = tw[1], t2 = tw[2], t3 = tw[3], t4 = tw[4], t5 = tw[5];
-            D0 = tailmode ? t0 : D0; D1 = tailmode ? t1 : D1; D2 = tailmode ? t2 : D2;
-            D3 = tailmode ? t3 : D3; D4 = tailmode ? t4 : D4; D5 = tailmode ? t5 : D5;
-            sh = tailmode ? (rel & 3u) : sh;
-        }
+        const uint32_t m0 = 0u - (i & 1u), m1 = 0u - (i >> 1);   // 4-way selects on the two index bits, no control flow
+        D0 = sel4(m0, m1, C0.x, C0.y, C0.z, C0.w);
+        D1 = sel4(m0, m1, C0.y, C0.z, C0.w, C1.x);
+        D2 = sel4(m0, m1, C0.z, C0.w, C1.x, C1.y);
+        D3 = sel4(m0, m1, C0.w, C1.x, C1.y, C1.z);
+        D4 = sel4(m0, m1, C1.x, C1.y, C1.z, C1.w);
+        D5 = sel4(m0, m1, C1.y, C1.z, C1.w, C2.x);
+        sh_ = k & 3u;
+    }
+    // lanes within 48 bytes of their block's end take the 24-byte window from the LDS tail copy instead
+    LZ4_FN void patch_tail() {
+        const uint32_t rel = tailmode ? ip - tstart : 0u;
+        const lds_u32* tw = reinterpret_cast<const lds_u32*>(q.blk + TAIL_OFF + (rel & ~3u));
+        const uint32_t t0 = tw[0], t1 = tw[1], t2 = tw[2], t3 = tw[3], t4 = tw[4], t5 = tw[5];
+        D0 = tailmode ? t0 : D0; D1 = tailmode ? t1 : D1; D2 = tailmode ? t2 : D2;
+        D3 = tailmode ? t3 : D3; D4 = tailmode ? t4 : D4; D5 = tailmode ? t5 : D5;
+        sh_ = tailmode ? (rel & 3u) : sh_;
+    }
+    LZ4_FN void parse() {
+        const uint32_t qhead = qhead_, k = k_, sh = sh_;
         const uint32_t W0 = lz4_alignbyte(D1, D0, sh);
         const uint32_t W1 = lz4_alignbyte(D2, D1, sh);
         const uint32_t W2 = lz4_alignbyte(D3, D2, sh);
         const uint32_t W3 = lz4_alignbyte(D4, D3, sh);
         const uint32_t W4 = lz4_alignbyte(D5, D4, sh);
-        // ---- token fields (meaningful when !need)
-        const bool need = need_off != 0u;
-        const uint32_t lc = (W0 >> 4) & 15u;
-        const uint32_t mlc_t = W0 & 15u;
-        const uint32_t e1 = (W0 >> 8) & 0xFFu;
-        const bool lc15 = lc == 15u;
-        const uint32_t lit_t = lc15 ? 15u + e1 : lc;
-        const uint32_t hdr = lc15 ? 2u : 1u;
-        const bool rare_t = lc15 && e1 == 0xFFu;
-        const uint32_t lit_end = ip + hdr + lit_t;                 // blocks are far below 4 GiB - 272: no wrap
-        const bool lit_fits = lit_t <= cap - op;
-        const bool hdr_in = ilen - ip >= hdr;                      // ip < ilen always; the extension byte needs one more
-        const bool lit_in = hdr_in && lit_t <= ilen - ip - hdr;
-        // ---- offset / extension byte at window index pos_off (<= 17)
-        const uint32_t lit_s = need ? 0u : lit_t;
-        const uint32_t pos_off = need ? 0u : hdr + lit_t;
-        const uint32_t mlc = need ? mlc_saved : mlc_t;
-        const bool longlit = pos_off > 17u;
+        // ---- token (or the synthetic one left by a long literal run), literal length with at most one extension byte
+        const uint32_t tokb = tok_over != 0u ? tok_over : W0;
+        const uint32_t lc = (tokb >> 4) & 15u;
+        const uint32_t mlc = tokb & 15u;
+        const uint32_t lc15 = lc == 15u ? 1u : 0u;
+        const uint32_t lit = lc + (lc15 ? (W0 >> 8) & 0xFFu : 0u);       // 270 = the extension continues (exact path)
+        const uint32_t pos_off = 1u + lc15 + lit;                         // window index of the offset
+        // ---- offset and match-length extension at window index pos_off (used when pos_off <= 17)
         const uint32_t wi = pos_off >> 2;
-        const uint32_t lo = wi == 0u ? W0 : (wi == 1u ? W1 : (wi == 2u ? W2 : (wi == 3u ? W3 : W4)));
-        const uint32_t hi = wi == 0u ? W1 : (wi == 1u ? W2 : (wi == 2u ? W3 : (wi == 3u ? W4 : 0u)));
+        const uint32_t n0 = 0u - (wi & 1u), n1 = 0u - ((wi >> 1) & 1u), n2 = 0u - ((wi >> 2) & 1u);
+        const uint32_t lo = bfi(n2, W4, bfi(n1, bfi(n0, W3, W2), bfi(n0, W1, W0)));
+        const uint32_t hi = bfi(n2, 0u, bfi(n1, bfi(n0, W4, W3), bfi(n0, W2, W1)));
         const uint32_t t = lz4_alignbyte(hi, lo, pos_off & 3u);
         const uint32_t offset = t & 0xFFFFu;
-        const uint32_t e = (t >> 16) & 0xFFu;
-        const bool ext = mlc == 15u;
-        const uint32_t ml = 4u + mlc + (ext ? e : 0u);
-        const uint32_t seq_end = ip + pos_off + 2u + (ext ? 1u : 0u);
-        const uint32_t mstart = op + lit_s;
-        // ---- classify
-        const bool room = qtail - qhead <= QD - 3u;   // the exact path pushes up to three records
-        const bool active = done == 0u && have && room;
-        const bool tok_ok = need || (!rare_t && hdr_in);
-        const bool fin = active && !need && tok_ok && lit_in && lit_end == ilen && lit_fits;
-        const bool start_long = active && !need && tok_ok && longlit && lit_in && lit_end + 3u <= ilen && lit_fits;
-        const bool do_short = active && tok_ok && !longlit && !(ext && e == 0xFFu) && seq_end < ilen &&
-                              (need || lit_fits) && offset != 0u && offset <= mstart && ml <= cap - mstart;
-        const bool slow = active && !fin && !start_long && !do_short;
-        // ---- commit
-        if (fin | start_long | do_short) {
-            const uint32_t flags = fin ? (F_FIN | F_CAREFUL) : 0u;
-            push(ip + hdr, do_short ? lit_s : lit_t, do_short ? ml : 0u, (do_short ? offset : 0u) | flags);
-        }
-        ip = do_short ? seq_end : ((fin | start_long) ? lit_end : ip);
-        op = do_short ? mstart + ml : ((fin | start_long) ? op + lit_t : op);
-        need_off = do_short ? 0u : (start_long ? 1u : need_off);
-        mlc_saved = start_long ? mlc_t : mlc_saved;
-        done = fin ? 1u : done;
+        const uint32_t ee = mlc == 15u ? (t >> 16) & 0xFFu : 0u;          // 255 = the extension continues (exact path)
+        const uint32_t ml = 4u + mlc + ee;
+        const uint32_t lit_src = ip + 1u + lc15;
+        const uint32_t lit_end = lit_src + lit;
+        const uint32_t seq_end = lit_end + 2u + (mlc == 15u ? 1u : 0u);
+        const uint32_t mstart = op + lit;
+        // ---- classify.  Every condition is a signed slack (>= 0 holds), folded with min: sizes are below 2 GiB, larger
+        // values only send a sequence to the exact path.  decompress.rs:334-408 in one go for the plain sequence:
+        const int32_t common = imin3((int32_t)(0u - done), tailmode ? 0 : (int32_t)(15u - k),          // live, window holds ip
+                                     (int32_t)(QD - 3u - (qtail - qhead)));                              // queue has room
+        const int32_t short_s = imin3(imin3((int32_t)(ilen - 1u - seq_end),                              // a byte follows the sequence
+                                            (int32_t)(mstart - offset), (int32_t)(offset - 1u)),         // 1 <= offset <= output so far
+                                      imin3((int32_t)(cap - mstart - ml), (int32_t)(17u - pos_off),      // fits; offset inside the window
+                                            (int32_t)(254u - ee)), common);
+        // a literal run too long for the window: push it alone, parse the offset next time
+        const int32_t long_s = imin3(imin3((int32_t)(pos_off - 18u), (int32_t)(269u - lit), (int32_t)(ilen - 3u - lit_end)),
+                                     imin3((int32_t)(cap - mstart), (int32_t)(0u - tok_over), common), 0);
+        const bool is_short = short_s >= 0;
+        const bool is_long = long_s >= 0;
+        slow = common >= 0 && !is_short && !is_long;
+#ifdef LZ4FLEX_PROFILE_PHASES
+        pr_steps += done == 0u; pr_noroom += done == 0u && (int32_t)(QD - 3u - (qtail - qhead)) < 0;
+        pr_bubble += done == 0u && !tailmode && k >= 16u; pr_slow += slow; pr_pushed += (is_short | is_long);
+#endif
 #ifdef LZ4FLEX_SPLIT_DEBUG
         if (slow && dbg_ip == 0xFFFFFFFFu) { dbg_ip = ip; dbg_w0 = W0; dbg_w1 = W1; dbg_kb = (k << 24) | (base & 0xFFFFFFu); }
 #endif
-        if (LZ4_ANY(slow)) {
-            if (slow) exact_step();
-        }
+        // ---- commit
+        push_if(is_short | is_long, lit_src, lit, is_short ? ml : 0u, is_short ? (offset | (offset < rare_below ? R_RARE << 16 : 0u)) : 0u);
+        ip = is_short ? seq_end : (is_long ? lit_end - 1u : ip);
+        op = is_short ? mstart + ml : (is_long ? mstart : op);
+        tok_over = is_long ? (0x100u | mlc) : (is_short ? 0u : tok_over);
     }
 };
 

@@ -27,15 +27,11 @@ extern "C" int split_parser_sim(const uint8_t* in, uint32_t in_len, uint8_t* out
     p.q.blk = lds.data();
     p.q.set_head(0);
     p.q.set_tail(0);
-    p.gin = gin;
-    p.A = (uint32_t)((uintptr_t)gin & 3u);
-    p.gal = gin - p.A;
-    p.ilen = in_len;
+    p.init_window(gin, in_len);
+    p.rare_below = (misalign & 4u) ? 8u : 4u;
     p.cap = cap;
-    p.tstart = in_len > TAILB ? in_len - TAILB : 0u;
     for (uint32_t i = 0; i < TAIL_BUF; ++i) lds[TAIL_OFF + i] = (p.tstart + i < in_len) ? gin[p.tstart + i] : 0;
-    p.ip = 0; p.op = 0; p.need_off = 0; p.mlc_saved = 0; p.qtail = 0; p.status = 0; p.expected = 0; p.done = 0;
-    p.base = 0;
+    p.ip = 0; p.op = 0; p.tok_over = 0; p.qtail = 0; p.status = 0; p.expected = 0; p.done = 0;
     memcpy(&p.C0, p.chunk_addr(0), 16);
     memcpy(&p.C1, p.chunk_addr(16), 16);
     memcpy(&p.C2, p.chunk_addr(32), 16);
@@ -53,16 +49,17 @@ extern "C" int split_parser_sim(const uint8_t* in, uint32_t in_len, uint8_t* out
             const uint32_t lsrc = e.x, ln = e.y, ml = e.z, off = e.w & 0xFFFFu;
             if (ln) {
                 if ((uint64_t)lsrc + ln > in_len || (uint64_t)op + ln > cap) return -1000;   // protocol violation
-                if (!(e.w & F_CAREFUL) && (uint64_t)lsrc + ln + 3 > in_len) return -1001;   // wild reads must stay inside
+                if ((e.w >> 16) < R_CAREFUL && (uint64_t)lsrc + ln + 3 > in_len) return -1001;   // wild reads must stay inside
                 memcpy(out + op, gin + lsrc, ln);
                 op += ln;
             }
             if (ml) {
                 if (off == 0 || off > op || (uint64_t)op + ml > cap) return -1002;
+                if ((off < p.rare_below) != ((e.w >> 16) == R_RARE)) return -1006;   // periodic matches must be marked
                 for (uint32_t i = 0; i < ml; ++i) out[op + i] = out[op - off + i];
                 op += ml;
             }
-            if (e.w & F_FIN) finished = true;
+            if ((e.w >> 16) == R_FINISH) finished = true;
         }
         if (finished || p.done) {
             if (head == p.q.tail()) break;

@@ -32,14 +32,18 @@ def _gpu_decode(blk, data, cap, dict_data=None):
 
 
 # every decoder kernel behind lz4flex_decompress_batch: lanes > 0 = lz4_decompress.hip (variant 1) group widths,
-# -2 = LDS-staged generic loop, -30 / -31 = pipelined decoder with 8 lanes x 4 B / 4 lanes x 8 B per block
-DECODERS = [8, 16, 32, 64, -2, -30, -31]
+# -2 = LDS-staged generic loop, -30 / -31 = pipelined decoder with 8 lanes x 4 B / 4 lanes x 8 B per block,
+# -408 / -464 = parser / copier split decoder with 8 / 64 blocks per workgroup
+DECODERS = [8, 16, 32, 64, -2, -30, -31, -408, -464]
 
 
 def _select_decoder(lib, ctx, lanes):
     if lanes > 0:
         assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 1) == 0
         assert lib.lz4flex_set_tuning(ctx, b"decompress_lanes", lanes) == 0
+    elif lanes <= -400:
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 4) == 0
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_blocks_per_wg", -lanes - 400) == 0
     elif lanes <= -30:
         assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 3) == 0
         assert lib.lz4flex_set_tuning(ctx, b"decompress_geometry", -lanes - 30) == 0

@@ -80,7 +80,7 @@ def test_kats(sim):
 def test_fixtures_all_alignments(sim, stem):
     m = O.manifest()[stem]
     blk = O.golden_block(stem)
-    for mis in range(4):
+    for mis in range(8):   # bits 0-1: source misalignment; bit 2: the copier moves 8 bytes per lane (offsets < 8 are "rare")
         _same_as_oracle(sim, blk, m["plain_len"], mis)
     _same_as_oracle(sim, blk, m["plain_len"] + 1000)
     _same_as_oracle(sim, blk, m["plain_len"] - 1)
@@ -95,7 +95,7 @@ def test_roundtrip_corpus_and_entropies(sim):
         for comp in (O.compress(p), O.c_compress(p) if p else None):
             if comp is None:
                 continue
-            _same_as_oracle(sim, comp, len(p), len(p) % 4)
+            _same_as_oracle(sim, comp, len(p), len(p) % 8)
             if len(p):
                 _same_as_oracle(sim, comp, len(p) - 1)
 

@@ -209,6 +209,22 @@ def main():
                 if cnt[k]:
                     print("   %-28s cycles/visit %8.0f  visits/wave %8.1f  share %5.1f%%" %
                           (names[k], cyc[k] / cnt[k], cnt[k] / max(cnt[0] and (n * [8, 4][g] // 64), 1), 100.0 * cyc[k] / max(tot, 1)))
+        if a.phases and variant == 4:
+            v = (C.c_ulonglong * 16)()
+            dbg = lib.lz4flex_debug_phase_split
+            dbg.argtypes = [C.c_void_p, C.c_int]
+            dbg(None, 1)
+            decompress()
+            dbg(v, 0)
+            nwg = (n + g - 1) // g
+            ncw = nwg * (g // 8)
+            print("   parser: %.0f cycles/wave, %.0f wave-steps (%.0f cycles/step); per block: live steps %.0f, queue-full %.0f, "
+                  "window bubbles %.0f, exact path %.0f, records %.0f" %
+                  (v[0] / nwg, v[1] / nwg, v[0] / max(v[1], 1), v[2] / n, v[3] / n, v[4] / n, v[5] / n, v[6] / n))
+            print("   copier: %.0f cycles/wave, %.0f 4-step iterations (%.0f cycles/step), %.1f services/wave (%.0f cycles each, "
+                  "%.1f%% of the wave); per block: steps with a piece %.0f, idle on empty queue %.0f, blocked/done %.0f" %
+                  (v[8] / ncw, v[9] / ncw, v[8] / max(4 * v[9], 1), v[10] / ncw, v[14] / max(v[10], 1), 100.0 * v[14] / max(v[8], 1),
+                   v[11] / n, v[12] / n, v[13] / n))
         if not ok:
             bad = np.nonzero(status != 0)[0]
             print("   failing status blocks:", bad[:8], status[bad[:8]] if len(bad) else "", flush=True)
