@@ -115,3 +115,30 @@ def test_every_prefix_and_corruptions(sim):
     for junk in corpus.NO_PANIC_SIZE_PREPENDED + corpus.BUG_FUZZ:
         _same_as_oracle(sim, junk, 4096)
         _same_as_oracle(sim, junk[4:], 4096)
+
+
+def test_big_blocks_and_long_chains(sim):
+    """4 MiB blocks (config 4's block size), 255-chains of both kinds (the exact path), incompressible data (one literal run)"""
+    cases = [corpus.lcg_bytes(4 << 20, 21, 4, 50), bytes(1 << 20), corpus.lcg_bytes(1 << 20, 22, 256, 1),
+             b"ab" * 200000, corpus.lcg_bytes(300, 23, 256, 1) + bytes(70000) + corpus.lcg_bytes(70000, 24, 256, 1) + bytes(5000)]
+    for p in cases:
+        for comp in (O.compress(p), O.c_compress(p)):
+            _same_as_oracle(sim, comp, len(p), 1)
+            _same_as_oracle(sim, comp, len(p) + 17, 6)
+            _same_as_oracle(sim, comp, len(p) - 1, 3)
+            _same_as_oracle(sim, comp[:len(comp) - 1], len(p), 2)
+
+
+def test_seeded_mutations(sim):
+    """2 000 seeded multi-byte mutations of a real block: same error variant (or same bytes) as the oracle every time"""
+    blk = bytearray(O.golden_block("compression_34k"))
+    n = O.manifest()["compression_34k"]["plain_len"]
+    x = 0x9E3779B97F4A7C15
+    for it in range(2000):
+        bad = bytearray(blk)
+        for _ in range(1 + it % 3):
+            x = (x * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+            pos = (x >> 20) % len(bad)
+            bad[pos] = (x >> 50) & 0xFF
+        cut = len(bad) if it % 5 else (x >> 7) % len(bad)
+        _same_as_oracle(sim, bytes(bad[:cut]), n if it % 7 else n // 2, it % 8)
