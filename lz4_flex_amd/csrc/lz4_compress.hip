@@ -98,6 +98,18 @@ struct Grp {
         return (uint32_t)(__ballot(p) >> shift) & ((G == 32) ? 0xFFFFFFFFu : ((1u << G) - 1u));
     }
     __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t src) const { return __shfl(v, (int)(shift + src)); }
+    // bcast for a source lane that is the same in every lane of the group: the value of lane `src`, OR-reduced over the
+    // group with DPP (swap pairs, swap pair of pairs, mirror the half row[, mirror the row]) -- 4..5 VALU instructions
+    // on the sequence's dependency chain instead of a ds_bpermute round trip through the LDS crossbar (~130 cycles)
+    __device__ __forceinline__ uint32_t bcast_u(uint32_t v, uint32_t src) const {
+        if (G != 8 && G != 16) return bcast(v, src);
+        uint32_t x = g == src ? v : 0u;
+        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);   // row_half_mirror: lanes i <-> 7 - i of each 8
+        if (G == 16) x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true);   // row_mirror: i <-> 15 - i
+        return x;
+    }
 };
 
 // nearest EARLIER lane of the group with the same bucket: returns its distance (1..G-1) or 0
@@ -349,8 +361,8 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
             else x = cld64(in + (pn <= end_check ? pn : 0u));
             continue;
         }
-        uint32_t cur = grp.bcast(p, last);
-        uint32_t cnd = grp.bcast(cand, last);
+        uint32_t cur = grp.bcast_u(p, last);
+        uint32_t cnd = grp.bcast_u(cand, last);
         const uint32_t offset = cur - cnd;                                    // compress.rs:409
         PHASE_MARK(3)   // table stores + winner broadcast
         // ------------------------------------------------------------------ extension: ONE memory round trip for the
@@ -387,7 +399,7 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
             uint32_t part = grp.ballot(c != 8u);
             if (part != 0u) {
                 const uint32_t f = (uint32_t)__builtin_ctz(part);
-                dl = 8u * f + grp.bcast(c, f);
+                dl = 8u * f + grp.bcast_u(c, f);
             } else {
                 dl = 8u * G;
                 for (;;) {
@@ -406,7 +418,7 @@ __device__ __forceinline__ int32_t encode_block(const uint8_t* __restrict__ in, 
                     part = grp.ballot(c2 != 8u);
                     if (part == 0u) { dl += 8u * G; continue; }
                     const uint32_t f = (uint32_t)__builtin_ctz(part);
-                    dl += 8u * f + grp.bcast(c2, f);
+                    dl += 8u * f + grp.bcast_u(c2, f);
                     break;
                 }
             }
