@@ -159,8 +159,8 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
     }
     if (!strcmp(key, "ablate")) { c->ablate = value; return 0; }
     if (!strcmp(key, "decompress_blocks_per_wg")) {
-        if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return -LZ4FLEX_E_INVALID_ARG;
-        c->dec_blocks_per_wg = value;
+        if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64 && value != 64 + 256) return -LZ4FLEX_E_INVALID_ARG;
+        c->dec_blocks_per_wg = value;   // + 256: the small LDS layout (launch_decompress_split)
         return 0;
     }
     if (!strcmp(key, "decompress_variant")) {

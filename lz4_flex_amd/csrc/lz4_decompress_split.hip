@@ -20,8 +20,9 @@
 //     are needed, near matches are LDS -> LDS.  Steps without a load touch the compressed stream ahead of the
 //     parser (one 128-byte line per step), which keeps the parser's chunk loads out of HBM latency.
 //
-// LDS per block: 2 080 B output buffer + 16 x 16 B queue + 16 B head/tail + 80 B tail copy + 16 B sink = 2 448 B;
-// 64 blocks = 153 KiB of the CU's 160 KiB.
+// LDS per block (LayoutBig): 2 080 B output buffer + 16 x 16 B queue + 16 B head/tail + 80 B tail copy + 16 B sink =
+// 2 448 B; 64 blocks = 153 KiB of the CU's 160 KiB.  LayoutSmall (1 040 B buffer with 256 B of history, 8 records) is
+// 1 280 B: two 64-block workgroups per CU for batches that have more than 64 blocks per CU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -45,15 +46,16 @@ template <uint32_t WB> struct Word;
 template <> struct Word<4> { using type = uint32_t; };
 template <> struct Word<8> { using type = uint2; };
 
-// G lanes per block, WB bytes per lane and piece
-template <uint32_t G, uint32_t WB>
+// G lanes per block, WB bytes per lane and piece; L = the block's LDS layout
+template <class L, uint32_t G, uint32_t WB>
 struct Copier {
     static constexpr uint32_t PIECE = G * WB;
+    static constexpr uint32_t OUT_CAP = L::OUT_CAP, OUT_H = L::OUT_H, FLUSH_AT = L::FLUSH_AT, TAIL_OFF = L::TAIL_OFF;
     using word_t = typename Word<WB>::type;
     const uint8_t* gin;
     uint8_t* gout;
     lds_u8* lout;         // the block's LDS output buffer
-    Queue q;
+    QueueT<L> q;
     uint32_t g;
     uint32_t ilen;
     uint32_t op, L0, F;   // LDS output holds positions [L0, op); [0, F) is written back
@@ -283,7 +285,7 @@ struct Copier {
 // (half the copier wavefronts, each alone on its SIMD) 4.35 ms; two or four blocks per parser lane (independent
 // chains in one instruction stream) 2.94 / 14.4 ms: the compiler serialises them and the wider parser starves the
 // copiers that share its SIMD.  Only G = 8, WB = 4 is instantiated.
-template <uint32_t NB, uint32_t G, uint32_t WB>
+template <class L, uint32_t NB, uint32_t G, uint32_t WB>
 __global__ void __launch_bounds__(64 * (NB * G / 64 + 1)) lz4_decompress_split_kernel(DecompressArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
@@ -297,7 +299,8 @@ __global__ void __launch_bounds__(64 * (NB * G / 64 + 1)) lz4_decompress_split_k
         const uint32_t j = wave * (64u / G) + lane / G;
         const uint32_t b = first + j;
         const bool valid = b < a.n;
-        Copier<G, WB> c;
+        Copier<L, G, WB> c;
+        constexpr uint32_t BLK_LDS = L::BLK_LDS, TAIL_OFF = L::TAIL_OFF;
         c.g = lane % G;
         c.lout = lds + j * BLK_LDS;
         c.q.blk = c.lout;
@@ -313,7 +316,7 @@ __global__ void __launch_bounds__(64 * (NB * G / 64 + 1)) lz4_decompress_split_k
         c.gin_ld = c.ilen >= WB ? c.gin : g_pad;
         c.ilen_w = c.ilen >= WB ? c.ilen - WB : 0u;
         c.gout_ld = (valid && a.out_cap[b] >= WB) ? c.gout : g_pad;
-        c.blocked = Copier<G, WB>::K_NONE;
+        c.blocked = Copier<L, G, WB>::K_NONE;
         c.done = valid ? 0u : 1u;
         __syncthreads();
         c.run();
@@ -322,8 +325,8 @@ __global__ void __launch_bounds__(64 * (NB * G / 64 + 1)) lz4_decompress_split_k
         const uint32_t j = lane;
         const uint32_t b = first + j;
         const bool valid = j < NB && b < a.n;
-        Parser p;
-        p.q.blk = lds + (j < NB ? j : 0u) * BLK_LDS;
+        ParserT<L> p;
+        p.q.blk = lds + (j < NB ? j : 0u) * L::BLK_LDS;
         p.init_window(valid ? a.in_base + a.in_off[b] : g_pad, valid ? a.in_len[b] : 0u);
         p.rare_below = WB;
         p.cap = valid ? a.out_cap[b] : 0u;
@@ -368,11 +371,11 @@ __global__ void __launch_bounds__(64 * (NB * G / 64 + 1)) lz4_decompress_split_k
     }
 }
 
-template <uint32_t NB, uint32_t G, uint32_t WB>
+template <class L, uint32_t NB, uint32_t G, uint32_t WB>
 static hipError_t launch_cfg(const DecompressArgs& a, hipStream_t s) {
     const uint32_t grid = (a.n + NB - 1u) / NB;
-    const size_t lds = (size_t)NB * BLK_LDS;
-    auto kern = lz4_decompress_split_kernel<NB, G, WB>;
+    const size_t lds = (size_t)NB * L::BLK_LDS;
+    auto kern = lz4_decompress_split_kernel<L, NB, G, WB>;
     if (lds > 65536u) {   // the attribute is per device: remember which devices have it (per instantiation)
         static unsigned long long have = 0ull;   // benign race: setting it twice is harmless
         int dev = 0;
@@ -390,16 +393,21 @@ static hipError_t launch_cfg(const DecompressArgs& a, hipStream_t s) {
 
 }  // namespace v5
 
-// blocks_per_wg: 8, 16, 32 or 64; 0 = the largest that still gives every CU a workgroup
+// blocks_per_wg: 8, 16, 32 or 64 (0 = the largest that still gives every CU a workgroup); + 256: the small LDS layout
+// (1 280 B per block: two 64-block workgroups per CU).  Measured at 32 768 blocks: 4.28 ms against 4.56 ms for two
+// rounds of the big layout and 4.17 ms for the pipelined 4-lane geometry (which capi.cpp picks above 20 480 blocks);
+// at 16 384 blocks 2.74 ms against 2.39 ms (twice the write-backs, more far loads) -- kept as an option, never chosen.
 hipError_t launch_decompress_split(const DecompressArgs& a, hipStream_t s, int blocks_per_wg) {
     if (a.n == 0u) return hipSuccess;
     if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;   // dictionary / prefix: v1 kernel
-    if (blocks_per_wg == 0) blocks_per_wg = a.n >= 64u * 256u ? 64 : (a.n >= 32u * 256u ? 32 : (a.n >= 16u * 256u ? 16 : 8));
+    if (blocks_per_wg == 0)
+        blocks_per_wg = a.n >= 64u * 256u ? 64 : (a.n >= 32u * 256u ? 32 : (a.n >= 16u * 256u ? 16 : 8));
     switch (blocks_per_wg) {
-        case 64: return v5::launch_cfg<64, 8, 4>(a, s);
-        case 32: return v5::launch_cfg<32, 8, 4>(a, s);
-        case 16: return v5::launch_cfg<16, 8, 4>(a, s);
-        case 8: return v5::launch_cfg<8, 8, 4>(a, s);
+        case 64: return v5::launch_cfg<v5::LayoutBig, 64, 8, 4>(a, s);
+        case 32: return v5::launch_cfg<v5::LayoutBig, 32, 8, 4>(a, s);
+        case 16: return v5::launch_cfg<v5::LayoutBig, 16, 8, 4>(a, s);
+        case 8: return v5::launch_cfg<v5::LayoutBig, 8, 8, 4>(a, s);
+        case 64 + 256: return v5::launch_cfg<v5::LayoutSmall, 64, 8, 4>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -37,19 +37,31 @@ typedef volatile uint32_t LZ4_LDS lds_vu32;
 typedef volatile u32x4 LZ4_LDS lds_vu128;
 typedef uint32_t LZ4_LDS lds_u32;
 
-constexpr uint32_t QD = 16;           // records per queue
-constexpr uint32_t OUT_H = 512;       // history kept in LDS after a write-back
 constexpr uint32_t OUT_SLACK = 32;
-constexpr uint32_t OUT_CAP = 2080;
-constexpr uint32_t FLUSH_AT = 760;
 constexpr uint32_t TAILB = 48;        // bytes of the block's end staged in LDS
 constexpr uint32_t TAIL_BUF = 80;     // + zero padding: a 24-byte window read at any tail position stays inside
-constexpr uint32_t Q_OFF = OUT_CAP;
-constexpr uint32_t CTL_OFF = Q_OFF + 16u * QD;   // head, tail
-constexpr uint32_t TAIL_OFF = CTL_OFF + 16u;
-constexpr uint32_t SINK_OFF = TAIL_OFF + TAIL_BUF;   // 16 bytes nobody reads: target of the parser's record store when it has nothing to push
-constexpr uint32_t BLK_LDS = SINK_OFF + 16u;
-static_assert(BLK_LDS == 2448 && BLK_LDS % 16 == 0, "LDS per block");
+// LDS layout of one block: output buffer | record queue | head, tail | tail copy | sink
+template <uint32_t OUT_CAP_, uint32_t OUT_H_, uint32_t QD_>
+struct Layout {
+    static constexpr uint32_t QD = QD_;             // records per queue (power of two)
+    static constexpr uint32_t OUT_H = OUT_H_;       // history kept in LDS after a write-back
+    static constexpr uint32_t OUT_CAP = OUT_CAP_;
+    static constexpr uint32_t FLUSH_AT = (OUT_CAP - OUT_SLACK - OUT_H) / 2u - 8u;   // service: write back below this much space
+    static constexpr uint32_t Q_OFF = OUT_CAP;
+    static constexpr uint32_t CTL_OFF = Q_OFF + 16u * QD;   // head, tail
+    static constexpr uint32_t TAIL_OFF = CTL_OFF + 16u;
+    static constexpr uint32_t SINK_OFF = TAIL_OFF + TAIL_BUF;   // 16 bytes nobody reads: target of the parser's record store when it has nothing to push
+    static constexpr uint32_t BLK_LDS = SINK_OFF + 16u;
+    static_assert(BLK_LDS % 16 == 0 && OUT_H % 16 == 0 && (QD & (QD - 1u)) == 0 && QD >= 8, "layout");
+    static_assert(FLUSH_AT >= 4u * 32u + 64u + 64u, "a write-back must leave room for an iteration's pieces");
+};
+using LayoutBig = Layout<2080, 512, 16>;     // 2 448 B per block: 64 blocks = one workgroup per CU
+using LayoutSmall = Layout<1040, 256, 8>;    // 1 280 B per block: two 64-block workgroups per CU (an option; measured no faster, see launch_decompress_split)
+static_assert(LayoutBig::BLK_LDS == 2448 && LayoutBig::FLUSH_AT == 760 && LayoutSmall::BLK_LDS == 1280, "LDS per block");
+// the default layout's constants at namespace level (host simulation, tools)
+constexpr uint32_t QD = LayoutBig::QD, OUT_H = LayoutBig::OUT_H, OUT_CAP = LayoutBig::OUT_CAP, FLUSH_AT = LayoutBig::FLUSH_AT;
+constexpr uint32_t Q_OFF = LayoutBig::Q_OFF, CTL_OFF = LayoutBig::CTL_OFF, TAIL_OFF = LayoutBig::TAIL_OFF, SINK_OFF = LayoutBig::SINK_OFF;
+constexpr uint32_t BLK_LDS = LayoutBig::BLK_LDS;
 constexpr uint32_t PF_AHEAD = 512;    // compressed bytes kept warm ahead of the records being copied
 
 // record.w = offset | kind << 16; a non-zero kind takes the copier group out of its steady loop:
@@ -66,7 +78,9 @@ __device__ __attribute__((aligned(16))) uint8_t g_pad[64];
 LZ4_FN uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 LZ4_FN uint32_t ld32l(const lds_u8* p) { uint32_t v; __builtin_memcpy(&v, (const void*)p, 4); return v; }
 
-struct Queue {
+template <class L>
+struct QueueT {
+    static constexpr uint32_t QD = L::QD, Q_OFF = L::Q_OFF, CTL_OFF = L::CTL_OFF;
     lds_u8* blk;   // the block's LDS area
     LZ4_FN uint32_t head() const { return *reinterpret_cast<lds_vu32*>(blk + CTL_OFF); }
     LZ4_FN void set_head(uint32_t v) const { *reinterpret_cast<lds_vu32*>(blk + CTL_OFF) = v; }
@@ -84,7 +98,9 @@ struct Queue {
 // =====================================================================================================
 // PARSER: one lane = one block
 // =====================================================================================================
-struct Parser {
+template <class L>
+struct ParserT {
+    static constexpr uint32_t QD = L::QD, Q_OFF = L::Q_OFF, CTL_OFF = L::CTL_OFF, TAIL_OFF = L::TAIL_OFF, SINK_OFF = L::SINK_OFF;
     const uint8_t* gin;      // compressed block
     const uint8_t* gal;      // gin rounded down to 4 bytes: the register window lives in this "aligned space"
     uint32_t A;              // gin - gal
@@ -97,7 +113,7 @@ struct Parser {
     uint64_t expected;
     uint32_t qtail;
     uint32_t tstart;         // the LDS tail copy holds compressed positions [tstart, ilen)
-    Queue q;
+    QueueT<L> q;
     // register window: stream bytes [base, base + 48) of the aligned space, N = the chunk at base + 48
     uint32_t base;
     uint32_t rare_below;     // matches with a smaller offset are marked R_RARE (the copier moves this many bytes per lane)
@@ -307,6 +323,8 @@ struct Parser {
         tok_over = is_long ? (0x100u | mlc) : (is_short ? 0u : tok_over);
     }
 };
+using Queue = QueueT<LayoutBig>;
+using Parser = ParserT<LayoutBig>;
 
 }  // namespace v5
 }  // namespace lz4flex_dev

@@ -14,8 +14,10 @@ using namespace lz4flex_dev::v5;
 // returns the status code (0 ok); *out_len = bytes produced; detail[0..1] = expected, actual for OutputTooSmall.
 // pad_before: the block is copied to an address with this misalignment (exercises the aligned-space window);
 // every byte outside [0, in_len) of the private copy is poisoned and never legally read.
-extern "C" int split_parser_sim(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t cap, uint32_t* out_len,
-                                uint64_t* detail, uint32_t misalign, uint32_t* n_records, uint32_t* n_steps) {
+template <class L>
+static int sim_run(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t cap, uint32_t* out_len,
+                   uint64_t* detail, uint32_t misalign, uint32_t* n_records, uint32_t* n_steps) {
+    constexpr uint32_t BLK_LDS = L::BLK_LDS, TAIL_OFF = L::TAIL_OFF;
     std::vector<uint8_t> lds(BLK_LDS, 0);
     // private copy: [poison 64][block][poison 64]; the parser may read up to 3 bytes before an unaligned block
     std::vector<uint8_t> buf(64 + 4 + in_len + 64, 0xEE);
@@ -23,7 +25,7 @@ extern "C" int split_parser_sim(const uint8_t* in, uint32_t in_len, uint8_t* out
     gin += (4 - ((uintptr_t)gin & 3)) & 3;
     gin += misalign & 3;
     if (in_len) memcpy(gin, in, in_len);
-    Parser p;
+    ParserT<L> p;
     p.q.blk = lds.data();
     p.q.set_head(0);
     p.q.set_tail(0);
@@ -76,4 +78,11 @@ extern "C" int split_parser_sim(const uint8_t* in, uint32_t in_len, uint8_t* out
     if (n_records) *n_records = recs;
     if (n_steps) *n_steps = steps;
     return p.status;
+}
+
+// misalign: bits 0-1 source misalignment, bit 2 the copier moves 8 bytes per lane, bit 3 the small LDS layout (8-record queue)
+extern "C" int split_parser_sim(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t cap, uint32_t* out_len,
+                                uint64_t* detail, uint32_t misalign, uint32_t* n_records, uint32_t* n_steps) {
+    return (misalign & 8u) ? sim_run<LayoutSmall>(in, in_len, out, cap, out_len, detail, misalign, n_records, n_steps)
+                           : sim_run<LayoutBig>(in, in_len, out, cap, out_len, detail, misalign, n_records, n_steps);
 }

@@ -33,8 +33,8 @@ def _gpu_decode(blk, data, cap, dict_data=None):
 
 # every decoder kernel behind lz4flex_decompress_batch: lanes > 0 = lz4_decompress.hip (variant 1) group widths,
 # -2 = LDS-staged generic loop, -30 / -31 = pipelined decoder with 8 lanes x 4 B / 4 lanes x 8 B per block,
-# -408 / -464 = parser / copier split decoder with 8 / 64 blocks per workgroup
-DECODERS = [8, 16, 32, 64, -2, -30, -31, -408, -464]
+# -408 / -464 = parser / copier split decoder with 8 / 64 blocks per workgroup, -720 = 64 blocks and the small LDS layout
+DECODERS = [8, 16, 32, 64, -2, -30, -31, -408, -464, -720]
 
 
 def _select_decoder(lib, ctx, lanes):

@@ -80,7 +80,7 @@ def test_kats(sim):
 def test_fixtures_all_alignments(sim, stem):
     m = O.manifest()[stem]
     blk = O.golden_block(stem)
-    for mis in range(8):   # bits 0-1: source misalignment; bit 2: the copier moves 8 bytes per lane (offsets < 8 are "rare")
+    for mis in range(16):   # bits 0-1: source misalignment; bit 2: 8 bytes per copier lane (offsets < 8 are "rare"); bit 3: small LDS layout
         _same_as_oracle(sim, blk, m["plain_len"], mis)
     _same_as_oracle(sim, blk, m["plain_len"] + 1000)
     _same_as_oracle(sim, blk, m["plain_len"] - 1)
@@ -95,7 +95,7 @@ def test_roundtrip_corpus_and_entropies(sim):
         for comp in (O.compress(p), O.c_compress(p) if p else None):
             if comp is None:
                 continue
-            _same_as_oracle(sim, comp, len(p), len(p) % 8)
+            _same_as_oracle(sim, comp, len(p), len(p) % 16)
             if len(p):
                 _same_as_oracle(sim, comp, len(p) - 1)
 
@@ -124,7 +124,7 @@ def test_big_blocks_and_long_chains(sim):
     for p in cases:
         for comp in (O.compress(p), O.c_compress(p)):
             _same_as_oracle(sim, comp, len(p), 1)
-            _same_as_oracle(sim, comp, len(p) + 17, 6)
+            _same_as_oracle(sim, comp, len(p) + 17, 14)
             _same_as_oracle(sim, comp, len(p) - 1, 3)
             _same_as_oracle(sim, comp[:len(comp) - 1], len(p), 2)
 
@@ -141,4 +141,4 @@ def test_seeded_mutations(sim):
             pos = (x >> 20) % len(bad)
             bad[pos] = (x >> 50) & 0xFF
         cut = len(bad) if it % 5 else (x >> 7) % len(bad)
-        _same_as_oracle(sim, bytes(bad[:cut]), n if it % 7 else n // 2, it % 8)
+        _same_as_oracle(sim, bytes(bad[:cut]), n if it % 7 else n // 2, it % 16)
