@@ -353,7 +353,16 @@ __global__ void __launch_bounds__(64 * (NB * G / 64 + 1)) lz4_decompress_split_k
         if (lane == 0u) { SP_ADD(0, __builtin_readcyclecounter() - t_begin); SP_ADD(1, wsteps); }
         SP_ADD(2, p.pr_steps); SP_ADD(3, p.pr_noroom); SP_ADD(4, p.pr_bubble); SP_ADD(5, p.pr_slow); SP_ADD(6, p.pr_pushed);
 #else
-        while (!__all(p.done != 0u)) p.step();
+        // A lane only finishes (or fails) inside exact_step, so the hot loop below needs no "done" test and no slow-path
+        // code: it runs fast steps until some lane's sequence leaves the fast path.
+        while (!__all(p.done != 0u)) {
+            do {
+                p.window();
+                if (__any(p.tailmode)) p.patch_tail();
+                p.parse();
+            } while (!__any(p.slow));
+            if (p.slow) p.exact_step();
+        }
 #endif
         if (valid) {
             a.status[b] = p.status;
