@@ -22,7 +22,7 @@ for f in sorted(glob.glob(out+"/pmc_*/**/*counter_collection.csv", recursive=Tru
     for r in csv.DictReader(open(f)):
         k=r.get("Kernel_Name","")
         if "lz4" not in k and "CompareEq" not in k: continue
-        agg[k.split("(")[0][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[k.split("(lz4flex_dev::")[0][-80:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in agg.items():
     print("== kernel", k)
     for c,vals in sorted(v.items()):
