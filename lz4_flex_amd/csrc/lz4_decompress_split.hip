@@ -3,7 +3,7 @@
 // Same contract as lz4_decompress.hip (reference src/block/decompress.rs:201-449: result bytes, byte count,
 // error variant and OutputTooSmall{expected,actual}, unsafe-flavour check order), blocks without dictionary /
 // prefix.  What the pipelined decoder (lz4_decompress_lds.hip) spends its issue slots on is the token parse:
-// 8 lanes own a block and all 8 run the same ~150-instruction parse to produce ONE sequence.  Here the two
+// 8 lanes own a block and all 8 run the same parse (116 VALU + 75 SALU per step) to produce ONE sequence.  Here the two
 // halves of the reference loop run in different wavefronts of a workgroup:
 //
 //   * PARSER wavefront: ONE LANE PER BLOCK (up to 64 blocks).  A lane walks its block's token chain
@@ -17,12 +17,17 @@
 //   * COPIER wavefronts: G = 8 lanes per block as before.  A group pops records and executes them as 32-byte
 //     pieces on the LDS output buffer of lz4_decompress_lds.hip (512 B of history, 16 B/lane coalesced
 //     write-back): literal pieces and far match pieces are global loads issued three steps before their bytes
-//     are needed, near matches are LDS -> LDS.  Steps without a load touch the compressed stream ahead of the
-//     parser (one 128-byte line per step), which keeps the parser's chunk loads out of HBM latency.
+//     are needed, near matches are LDS -> LDS.  Once per 4-step iteration a group snapshots the queue's tail,
+//     publishes its head, checks the buffer space for four pieces and touches the next 128-byte line of the
+//     compressed stream ahead of the parser, which keeps the parser's chunk loads out of HBM latency.
+//
+// The parser is per-lane scalar code: lz4_split_parser.h also compiles for the host (tests/sim/), where it is checked
+// against the oracle.  Measurements, the instruction-issue model that bounds the kernel and the variants that were
+// tried and dropped: DESIGN.md section 5.1.1.
 //
 // LDS per block (LayoutBig): 2 080 B output buffer + 16 x 16 B queue + 16 B head/tail + 80 B tail copy + 16 B sink =
 // 2 448 B; 64 blocks = 153 KiB of the CU's 160 KiB.  LayoutSmall (1 040 B buffer with 256 B of history, 8 records) is
-// 1 280 B: two 64-block workgroups per CU for batches that have more than 64 blocks per CU.
+// 1 280 B: two 64-block workgroups per CU (an option that measured no faster, see launch_decompress_split).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
