@@ -318,9 +318,11 @@ struct ParserT {
 #endif
         // ---- commit
         push_if(is_short | is_long, lit_src, lit, is_short ? ml : 0u, is_short ? (offset | (offset < rare_below ? R_RARE << 16 : 0u)) : 0u);
-        ip = is_short ? seq_end : (is_long ? lit_end - 1u : ip);
-        op = is_short ? mstart + ml : (is_long ? mstart : op);
-        tok_over = is_long ? (0x100u | mlc) : (is_short ? 0u : tok_over);
+        // is_short and is_long exclude each other; one select per case (a nested ?: chain here became exec-mask branches)
+        uint32_t ip2 = is_short ? seq_end : ip, op2 = is_short ? mstart + ml : op, to2 = is_short ? 0u : tok_over;
+        ip = is_long ? lit_end - 1u : ip2;
+        op = is_long ? mstart : op2;
+        tok_over = is_long ? (0x100u | mlc) : to2;
     }
 };
 using Queue = QueueT<LayoutBig>;
