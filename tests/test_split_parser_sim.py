@@ -142,3 +142,24 @@ def test_seeded_mutations(sim):
             bad[pos] = (x >> 50) & 0xFF
         cut = len(bad) if it % 5 else (x >> 7) % len(bad)
         _same_as_oracle(sim, bytes(bad[:cut]), n if it % 7 else n // 2, it % 16)
+
+
+def test_hypothesis_random_inputs(sim):
+    """random byte strings (two entropy regimes) and random corruptions, decoded from both encoders' blocks"""
+    hyp = pytest.importorskip("hypothesis")
+    st = hyp.strategies
+
+    @hyp.settings(max_examples=150, deadline=None, database=None)
+    @hyp.given(st.binary(min_size=0, max_size=3000), st.integers(0, 15), st.integers(0, 2 ** 32 - 1))
+    def run(data, mis, seed):
+        low = bytes(b & 3 for b in data) * 3   # long matches, 255-chains, periodic offsets
+        for p in (data, low):
+            for comp in (O.compress(p), O.c_compress(p) if p else b"\x00"):
+                _same_as_oracle(sim, comp, len(p), mis)
+                if comp:
+                    bad = bytearray(comp)
+                    bad[seed % len(bad)] ^= 1 << (seed >> 8) % 8
+                    _same_as_oracle(sim, bytes(bad), len(p), mis)
+                    _same_as_oracle(sim, comp[:seed % (len(comp) + 1)], len(p) + (seed >> 12) % 5, mis)
+
+    run()
