@@ -70,6 +70,9 @@ int lz4flex_ctx_create(lz4flex_ctx **ctx, int device /* -1 = current */);
 void lz4flex_ctx_destroy(lz4flex_ctx *ctx);
 int lz4flex_device_count(void);
 const char *lz4flex_version(void);
+/* hash of the sources (csrc/ + include/ + compiler flags) this binary was built from; lz4_flex_amd/build.py
+ * recomputes it from the tree, so a stale library is detectable */
+const char *lz4flex_build_id(void);
 /* last HIP error string seen by this thread (diagnostics) */
 const char *lz4flex_last_error(void);
 

@@ -1,5 +1,11 @@
 """Build the in-tree HIP shared library (gfx950) with hipcc.  No JIT cache, no pip install:
-the .so lands next to this file so it travels with the repository snapshot."""
+the .so lands next to this file so it travels with the repository snapshot.
+
+Staleness is decided by CONTENT, not by a hand-kept dependency list: every file under csrc/ and include/ plus
+the compiler flags are hashed; the hash is stored next to the library (build/source_hash.txt) and compiled into
+it (`lz4flex_build_id()`), so a test can prove that the loaded binary was built from the sources in the tree."""
+import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -7,9 +13,37 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(HERE, "..", "include")
 LIB = os.path.join(HERE, "liblz4flex_amd.so")
-SOURCES = ["lz4_decompress.hip", "lz4_decompress_lds.hip", "lz4_decompress_split.hip", "lz4_compress.hip", "lz4_compress_lds.hip", "xxh32_kernel.hip", "capi.cpp", "frame.cpp"]
-DEPS = SOURCES + ["lz4_device.h", "xxh32.h", os.path.join("..", "..", "include", "lz4flex_amd.h")]
+BDIR = os.path.join(HERE, "build")
+STAMP = os.path.join(BDIR, "source_hash.txt")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    """every translation unit under csrc/ (kernels: *.hip, host: *.cpp)"""
+    return sorted(os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
+
+
+def dep_files():
+    """everything a translation unit can include: all of csrc/ and include/"""
+    out = []
+    for d in (CSRC, INCLUDE):
+        for p in sorted(glob.glob(os.path.join(d, "*"))):
+            if os.path.isfile(p) and p.rsplit(".", 1)[-1] in ("hip", "cpp", "h", "hpp", "inc"):
+                out.append(p)
+    return out
+
+
+def source_hash():
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    for p in dep_files():
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
 
 
 def _hipcc():
@@ -19,25 +53,28 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the HIP kernels are the product; there is no fallback build")
 
 
+def built_hash():
+    try:
+        with open(STAMP) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    return not os.path.exists(LIB) or built_hash() != source_hash()
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = _hipcc()
-    objs = []
-    bdir = os.path.join(HERE, "build")
-    os.makedirs(bdir, exist_ok=True)
-    procs = []
-    for src in SOURCES:
-        obj = os.path.join(bdir, src + ".o")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-               "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+    os.makedirs(BDIR, exist_ok=True)
+    sh = source_hash()
+    objs, procs = [], []
+    for src in sources():
+        obj = os.path.join(BDIR, src + ".o")
+        cmd = [hipcc] + FLAGS + ['-DLZ4FLEX_BUILD_ID="%s"' % sh, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -46,12 +83,16 @@ def build(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
+        if verbose and out.strip():
+            print(out.decode(errors="replace"), file=sys.stderr)
     tmp = LIB + ".tmp"
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))
     os.replace(tmp, LIB)
+    with open(STAMP, "w") as f:
+        f.write(sh + "\n")
     return LIB
 
 

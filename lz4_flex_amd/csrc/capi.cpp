@@ -105,7 +105,11 @@ __global__ void __launch_bounds__(256) lz4flex_pack_results_kernel(const uint8_t
 
 extern "C" {
 
-const char* lz4flex_version(void) { return "lz4flex-amd 0.1.0 (gfx950)"; }
+const char* lz4flex_version(void) { return "lz4flex-amd 0.2.0 (gfx950)"; }
+#ifndef LZ4FLEX_BUILD_ID
+#define LZ4FLEX_BUILD_ID "unstamped"
+#endif
+const char* lz4flex_build_id(void) { return LZ4FLEX_BUILD_ID; }
 const char* lz4flex_last_error(void) { return g_last_error.c_str(); }
 
 int lz4flex_device_count(void) {

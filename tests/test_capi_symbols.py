@@ -68,3 +68,24 @@ def test_host_logic_without_gpu(lib_path):
             block.compress(b"no gpu, no codec")
         with pytest.raises(block.DeviceError):
             block.decompress(bytes([0x10, 0x61]), 1)
+
+
+def test_stale_library_is_detected(lib_path):
+    """the build is keyed on a hash of EVERY file under csrc/ and include/ (round 1 shipped a library that
+    predated a header edit because a hand-kept dependency list missed it)"""
+    from lz4_flex_amd import _lib, build
+    assert not build.needs_build()
+    assert _lib.load().lz4flex_build_id().decode() == build.source_hash()
+    hdrs = [p for p in build.dep_files() if p.endswith(".h")]
+    assert len(hdrs) >= 3
+    for victim in hdrs:
+        with open(victim, "rb") as f:
+            orig = f.read()
+        try:
+            with open(victim, "ab") as f:
+                f.write(b"\n// touched by test_stale_library_is_detected\n")
+            assert build.needs_build(), victim
+        finally:
+            with open(victim, "wb") as f:
+                f.write(orig)
+    assert not build.needs_build()
