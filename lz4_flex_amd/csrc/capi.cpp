@@ -31,9 +31,8 @@ static int hip_fail(hipError_t e, const char* what) {
         if (_e != hipSuccess) return hip_fail(_e, #expr); \
     } while (0)
 
-// compress_variant -> launch_compress mode bits: 1 = encode_block + emitter wave (default), 3 = encode_block alone,
-// 5 = encode_block + prefetch-only wave, 6 = emitter wave + LDS input ring (experimental)
-static inline int comp_mode_bits(int v) { return (v == 1 ? 0x600 : (v == 5 ? 0x400 : (v == 6 ? 0x1000 : 0))); }
+// compress_variant -> launch_compress mode bits: 1 = encode_block + emitter wave (default), 3 = encode_block alone
+static inline int comp_mode_bits(int v) { return v == 1 ? 0x600 : 0; }
 
 struct lz4flex_ctx {
     int device = 0;
@@ -46,8 +45,10 @@ struct lz4flex_ctx {
     size_t pay_cap = 0;
     int dec_lanes = 16;           // lanes per block, decode
     int comp_lanes = 8;           // lanes per block, encode
-    int comp_variant = 1;         // 1 = group encoder + emitter wave (default), 3 = group encoder alone, 5 = group encoder + prefetch-only wave, 6 = emitter wave that also feeds an LDS input ring (slower), 2 = fully LDS-staged lz4_compress_lds.hip (<= 64 KiB, slower); all bit-exact
-    int ablate = 0;               // timing ablations (wrong output!), see lz4flex_set_tuning("ablate")
+    int comp_mode = 0;            // 0 = throughput ("wave") encoder, own parse (default); 1 = reference-exact encoder (lz4_flex's bytes)
+    int comp_variant = 1;         // reference-exact encoder: 1 = group encoder + emitter wave (default), 3 = group encoder alone
+    void* wave_ws = nullptr;      // wave encoder workspace: wave_wgs persistent workgroups
+    int wave_wgs = 0;
     int dec_blocks_per_wg = 0;    // split decoder: blocks per workgroup (8/16/32/64), 0 = by batch size
     int dec_geometry = -1;        // pipelined decoder geometry (lz4_decompress_lds.hip launch_decompress_pipe): -1 by batch size, 0 = 8 lanes x 4 B, 1 = 4 lanes x 8 B
     int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 2 = LDS-staged generic loop, 3 = LDS-staged pipelined (lz4_decompress_lds.hip), 4 = parser / copier split (lz4_decompress_split.hip)
@@ -60,8 +61,26 @@ static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressA
     // holds twice the blocks per CU: 32 768 blocks 4.19 ms against 4.60 ms)
     const int v = c->dec_variant != 0 ? c->dec_variant : (a.n > 20480u ? 3 : 4);
     if (v == 4) return launch_decompress_split(a, s, c->dec_blocks_per_wg);
-    if (v == 3) return launch_decompress_pipe(a, s, c->ablate, c->dec_geometry);
-    return launch_decompress_lds(a, s, c->ablate);
+    return launch_decompress_pipe(a, s, 0, c->dec_geometry);
+}
+
+// the encoders for independent blocks: throughput mode (own parse, any block length) or the reference-exact one
+static int launch_compress_any(lz4flex_ctx* c, const CompressArgs& a, bool big, hipStream_t s) {
+    hipError_t le;
+    if (c->comp_mode == 0) {
+        if (!c->wave_ws) {
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+            const int wgs = 2 * prop.multiProcessorCount;      // two 80 KiB workgroups per CU
+            HIP_TRY(hipMalloc(&c->wave_ws, compress_wave_workspace_bytes(wgs)));
+            c->wave_wgs = wgs;
+        }
+        le = launch_compress_wave(a, c->wave_ws, c->wave_wgs, s);
+    } else {
+        le = launch_compress(a, c->comp_lanes | (big ? 0x100 : 0) | comp_mode_bits(c->comp_variant), s);
+    }
+    if (le != hipSuccess) return hip_fail(le, "kernel launch");
+    return 0;
 }
 
 static int ensure_arena(lz4flex_ctx* c, size_t need) {
@@ -103,6 +122,8 @@ __global__ void __launch_bounds__(256) lz4flex_pack_results_kernel(const uint8_t
     for (uint32_t i = threadIdx.x; i < m; i += 256u) d[i] = s[i];
 }
 
+static int default_ctx(lz4flex_ctx** out);
+
 extern "C" {
 
 const char* lz4flex_version(void) { return "lz4flex-amd 0.2.0 (gfx950)"; }
@@ -132,8 +153,9 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
     lz4flex_ctx* c = new (std::nothrow) lz4flex_ctx();
     if (!c) return -LZ4FLEX_E_NOMEM;
     c->device = device;
-    if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v >= 1 && v <= 6 && v != 4) c->comp_variant = v; }
-    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v >= 0 && v <= 4) c->dec_variant = v; }
+    if (const char* e = getenv("LZ4FLEX_COMPRESS_MODE")) c->comp_mode = (!strcmp(e, "exact") || !strcmp(e, "1")) ? 1 : 0;
+    if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v == 1 || v == 3) c->comp_variant = v; }
+    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v == 0 || v == 1 || v == 3 || v == 4) c->dec_variant = v; }
     if (const char* e = getenv("LZ4FLEX_DECOMPRESS_GEOMETRY")) { const int v = atoi(e); if (v >= -1 && v <= 1) c->dec_geometry = v; }
     int prev = 0;
     (void)hipGetDevice(&prev);
@@ -148,6 +170,7 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
 void lz4flex_ctx_destroy(lz4flex_ctx* c) {
     if (!c) return;
     if (c->d_arena) (void)hipFree(c->d_arena);
+    if (c->wave_ws) (void)hipFree(c->wave_ws);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_pay) (void)hipHostFree(c->h_pay);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -155,20 +178,25 @@ void lz4flex_ctx_destroy(lz4flex_ctx* c) {
 }
 
 int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
-    if (!c || !key) return -LZ4FLEX_E_INVALID_ARG;
+    if (!key) return -LZ4FLEX_E_INVALID_ARG;
+    if (!c) { const int rc = default_ctx(&c); if (rc) return rc; }   // NULL: this thread's default context (the scalar calls)
     if (!strcmp(key, "decompress_lanes")) {
         if (value != 8 && value != 16 && value != 32 && value != 64) return -LZ4FLEX_E_INVALID_ARG;
         c->dec_lanes = value;
         return 0;
     }
-    if (!strcmp(key, "ablate")) { c->ablate = value; return 0; }
+    if (!strcmp(key, "compress_mode")) {
+        if (value != 0 && value != 1) return -LZ4FLEX_E_INVALID_ARG;
+        c->comp_mode = value;
+        return 0;
+    }
     if (!strcmp(key, "decompress_blocks_per_wg")) {
-        if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64 && value != 64 + 256) return -LZ4FLEX_E_INVALID_ARG;
-        c->dec_blocks_per_wg = value;   // + 256: the small LDS layout (launch_decompress_split)
+        if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return -LZ4FLEX_E_INVALID_ARG;
+        c->dec_blocks_per_wg = value;
         return 0;
     }
     if (!strcmp(key, "decompress_variant")) {
-        if (value < 0 || value > 4) return -LZ4FLEX_E_INVALID_ARG;
+        if (value != 0 && value != 1 && value != 3 && value != 4) return -LZ4FLEX_E_INVALID_ARG;
         c->dec_variant = value;
         return 0;
     }
@@ -178,7 +206,7 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "compress_variant")) {
-        if (value < 1 || value > 6 || value == 4) return -LZ4FLEX_E_INVALID_ARG;
+        if (value != 1 && value != 3) return -LZ4FLEX_E_INVALID_ARG;
         c->comp_variant = value;
         return 0;
     }
@@ -298,7 +326,8 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
         a.out_len = (uint32_t*)(dd + at_out_len); a.status = (int32_t*)(dd + at_status); a.n = n;
         bool big = false;
         for (uint32_t i = 0; i < n; i++) big |= in_len[i] > 65536u;
-        le = (c->comp_variant == 2 && !big) ? launch_compress_lds(a, s) : launch_compress(a, c->comp_lanes | (big ? 0x100 : 0) | comp_mode_bits(c->comp_variant), s);
+        if ((rc = launch_compress_any(c, a, big, s))) return rc;
+        le = hipSuccess;
     } else {
         DecompressArgs a{};
         a.in_base = d + a_in; a.in_off = (const uint64_t*)(dd + at_in_off); a.in_len = (const uint32_t*)(dd + at_in_len);
@@ -379,7 +408,9 @@ static int run_device_batch(lz4flex_ctx* c, bool compress, const void* in_base, 
         a.in_base = (const uint8_t*)in_base; a.in_off = in_off; a.in_len = in_len; a.flags = flags;
         a.out_base = (uint8_t*)out_base; a.out_off = out_off; a.out_cap = out_cap; a.out_len = out_len;
         a.status = status; a.n = n;
-        le = (c->comp_variant == 2 && !big_hint) ? launch_compress_lds(a, s) : launch_compress(a, c->comp_lanes | (big_hint ? 0x100 : 0) | comp_mode_bits(c->comp_variant), s);
+        const int rc = launch_compress_any(c, a, big_hint != 0, s);
+        if (rc) return rc;
+        le = hipSuccess;
     } else {
         DecompressArgs a{};
         a.in_base = (const uint8_t*)in_base; a.in_off = in_off; a.in_len = in_len;
@@ -396,7 +427,6 @@ static int run_device_batch(lz4flex_ctx* c, bool compress, const void* in_base, 
 }
 
 static thread_local lz4flex_ctx* g_default_ctx = nullptr;
-struct DefaultCtxReaper { ~DefaultCtxReaper() { /* device teardown order at exit is not ours to fix: leak */ } };
 static int default_ctx(lz4flex_ctx** out) {
     if (!g_default_ctx) {
         int rc = lz4flex_ctx_create(&g_default_ctx, -1);

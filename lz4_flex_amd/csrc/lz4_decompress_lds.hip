@@ -553,34 +553,6 @@ __global__ void __launch_bounds__(64) lz4_decompress_pipe_kernel(DecompressArgs 
     }
 }
 
-template <bool ABLATE_FAR>
-__global__ void __launch_bounds__(64) lz4_decompress_lds_kernel(DecompressArgs a) {
-    using GEO = Geo8;
-    constexpr uint32_t G = GEO::G, GROUP_LDS = GEO::GROUP_LDS, IN_CAP = GEO::IN_CAP, IN_PAD = GEO::IN_PAD;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[(64 / G) * GROUP_LDS];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t b = blockIdx.x * (64u / G) + lane / G;
-    if (b >= a.n) return;
-    Dec<GEO, ABLATE_FAR> d;
-    d.g = lane % G;
-    d.gin = a.in_base + a.in_off[b];
-    d.gout = a.out_base + a.out_off[b];
-    d.lin = lds + (lane / G) * GROUP_LDS;
-    d.lout = d.lin + IN_CAP + IN_PAD;
-    d.ilen = a.in_len[b];
-    d.cap = a.out_cap[b];
-    uint64_t expected = 0u;
-    const int32_t st = d.run(&expected);
-    if (d.g == 0u) {
-        a.status[b] = st;
-        a.out_len[b] = st == 0 ? d.op : 0u;
-        if (a.detail) {
-            a.detail[2u * b] = st == LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL ? expected : 0u;
-            a.detail[2u * b + 1u] = st == LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL ? (uint64_t)d.cap : 0u;
-        }
-    }
-}
-
 }  // namespace v2
 
 template <class GEO, bool ABLATE_FAR>
@@ -593,25 +565,15 @@ static hipError_t launch_pipe_geo(const DecompressArgs& a, hipStream_t s) {
 
 // geometry: 0 = 8 lanes x 4 B per block (Geo8), 1 = 4 lanes x 8 B with 1 248 B of LDS per block (Geo4s),
 // -1 = by batch size: Geo4s once the batch is large enough to give it two wavefronts per SIMD
-hipError_t launch_decompress_pipe(const DecompressArgs& a, hipStream_t s, int ablate, int geometry) {
+hipError_t launch_decompress_pipe(const DecompressArgs& a, hipStream_t s, int /*unused*/, int geometry) {
     if (a.n == 0u) return hipSuccess;
     if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;
     if (geometry < 0) geometry = a.n > 20480u ? 1 : 0;
     switch (geometry) {
-        case 0: return (ablate & 1) ? launch_pipe_geo<v2::Geo8, true>(a, s) : launch_pipe_geo<v2::Geo8, false>(a, s);
+        case 0: return launch_pipe_geo<v2::Geo8, false>(a, s);
         case 1: return launch_pipe_geo<v2::Geo4s, false>(a, s);
         default: return hipErrorInvalidValue;
     }
-}
-
-hipError_t launch_decompress_lds(const DecompressArgs& a, hipStream_t s, int ablate) {
-    if (a.n == 0u) return hipSuccess;
-    if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;   // dictionary / prefix: v1 kernel
-    const uint32_t per_wg = 64u / v2::Geo8::G;
-    const uint32_t grid = (a.n + per_wg - 1u) / per_wg;
-    if (ablate & 1) hipLaunchKernelGGL(v2::lz4_decompress_lds_kernel<true>, dim3(grid), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(v2::lz4_decompress_lds_kernel<false>, dim3(grid), dim3(64), 0, s, a);
-    return hipGetLastError();
 }
 
 }  // namespace lz4flex_dev

@@ -421,7 +421,6 @@ hipError_t launch_decompress_split(const DecompressArgs& a, hipStream_t s, int b
         case 32: return v5::launch_cfg<v5::LayoutBig, 32, 8, 4>(a, s);
         case 16: return v5::launch_cfg<v5::LayoutBig, 16, 8, 4>(a, s);
         case 8: return v5::launch_cfg<v5::LayoutBig, 8, 8, 4>(a, s);
-        case 64 + 256: return v5::launch_cfg<v5::LayoutSmall, 64, 8, 4>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -44,11 +44,13 @@ struct CompressArgs {
 };
 
 hipError_t launch_decompress(const DecompressArgs& a, int lanes_per_block, hipStream_t s);
-hipError_t launch_decompress_lds(const DecompressArgs& a, hipStream_t s, int ablate = 0);   // LDS-staged variant, no dict/prefix
 hipError_t launch_decompress_pipe(const DecompressArgs& a, hipStream_t s, int ablate = 0, int geometry = -1);  // pipelined LDS variant
 hipError_t launch_decompress_split(const DecompressArgs& a, hipStream_t s, int blocks_per_wg = 0);   // parser / copier wavefronts, no dict/prefix
 hipError_t launch_compress(const CompressArgs& a, int variant, hipStream_t s);
-hipError_t launch_compress_lds(const CompressArgs& a, hipStream_t s);   // LDS-staged encoder, blocks <= 64 KiB
+// throughput ("wave") encoder, lz4_compress_wave.hip: persistent workgroups, `workspace` holds
+// compress_wave_workspace_bytes(n_workgroups) bytes (cand[] slots + segment bodies, L2 / Infinity Cache resident)
+size_t compress_wave_workspace_bytes(int n_workgroups);
+hipError_t launch_compress_wave(const CompressArgs& a, void* workspace, int n_workgroups, hipStream_t s);
 
 // chains of dependent blocks (dictionary / Linked frames); `blocks` is an array of the 40-byte ChainBlock
 // records laid out as {u64 in_off, u64 dict_off, u32 in_len, in_pos, dict_len, so, repos, flags}

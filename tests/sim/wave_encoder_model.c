@@ -1,0 +1,158 @@
+/*
+ * wave_encoder_model.c -- scalar C model of the throughput ("wave") LZ4 encoder of
+ * lz4_flex_amd/csrc/lz4_compress_wave.hip.  TEST INFRASTRUCTURE: the GPU tests compare the kernels'
+ * bytes with this model (same parse decisions, position by position) and tools/ use it to explore ratio.
+ * It is NOT a restatement of the reference encoder (that is oracle/lz4flex_block.c): the throughput mode
+ * produces a valid LZ4 block that lz4_flex decodes to the input (BASELINE.json north_star), with its own
+ * parse.  Block format rules it must respect: src/block/mod.rs:37-61 of the reference (MFLIMIT 12,
+ * LAST_LITERALS 5, MINMATCH 4), token / length encoding src/block/compress.rs:237-247,463-486.
+ *
+ * Algorithm (one 64 KiB window at a time; a block longer than 64 KiB is a sequence of windows):
+ *  index  : positions are visited in steps of 64; every position p <= n-12 looks its 4-byte hash up in a
+ *           4096-entry table of 16-bit positions (all lookups of a step before all inserts of the step,
+ *           highest position wins an insert conflict) and records d[p] = distance to that candidate.
+ *  match  : a position whose distance differs from its predecessor's is a "head": its true match length is
+ *           counted byte by byte (<= CAP, never across a segment end, never into the last 5 bytes).
+ *           Every position then takes the match, from any head at or before it in its segment, that
+ *           reaches furthest ("best end", a prefix maximum), unless it is already buried >= SKIPD bytes
+ *           deep in one.
+ *  select : greedy with one-step lazy evaluation (a position yields to its successor if that one reaches
+ *           further by more than a byte), left to right inside a segment.
+ *  emit   : segments are independent parses of [s0, s1) that may reference any earlier byte of the
+ *           window; the trailing literals of a segment are carried into the first sequence of the next.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define WAVE 64
+#define HBITS 12
+#define WINDOW 65536u
+
+typedef struct {
+    uint32_t seg;    /* segment bytes (a power of two >= 64, <= 65536) */
+    uint32_t cap;    /* longest match a head counts */
+    uint32_t skipd;  /* a position buried this deep in a running match is not evaluated */
+} lz4w_params;
+
+static inline uint32_t ld32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+
+/* index pass: d[p] for every p (0 = no candidate).  The table is cleared at every 64 KiB window start, so a
+ * candidate never lies before its position's window. */
+void lz4w_index(const uint8_t *in, uint32_t n, uint16_t *d) {
+    uint16_t *tab = (uint16_t *)calloc(1u << HBITS, 2);
+    for (uint32_t b = 0; b < n; b += WAVE) {
+        uint32_t idx[WAVE];
+        int act[WAVE];
+        if ((b & (WINDOW - 1)) == 0) memset(tab, 0, 2u << HBITS);
+        for (int i = 0; i < WAVE; i++) {
+            const uint32_t p = b + i;
+            act[i] = (n >= 12 && p <= n - 12);
+            if (p < n) d[p] = 0;
+            if (!act[i]) continue;
+            idx[i] = (ld32(in + p) * 2654435761u) >> (32 - HBITS);
+            d[p] = (uint16_t)((p & (WINDOW - 1)) - tab[idx[i]]);
+        }
+        for (int i = 0; i < WAVE; i++)
+            if (act[i]) tab[idx[i]] = (uint16_t)((b + i) & (WINDOW - 1));
+    }
+    free(tab);
+}
+
+static size_t put_len(uint8_t *out, size_t o, uint32_t r) {   /* compress.rs:237-247 write_integer */
+    while (r >= 255) { out[o++] = 255; r -= 255; }
+    out[o++] = (uint8_t)r;
+    return o;
+}
+
+typedef struct { uint32_t lit_start, lit_len, off, mlen; } lz4w_seq;
+
+/* parse of one block; returns the number of sequences (the last one has mlen == 0: final literals) */
+size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_params *P, lz4w_seq *seqs) {
+    size_t ns = 0;
+    uint32_t anchor = 0;
+    uint32_t *best = (uint32_t *)calloc(WAVE, 4);
+    for (uint32_t s0 = 0; s0 < n; s0 += P->seg) {
+        const uint32_t s1 = (n - s0 < P->seg) ? n : s0 + P->seg;
+        const uint32_t wbase = s0 & ~(WINDOW - 1);                 /* candidates must lie in the segment's 64 KiB window */
+        uint32_t mend = (n >= 5) ? ((s1 < n - 5) ? s1 : n - 5) : 0;         /* matches end here at the latest */
+        if (mend > wbase + 65535u) mend = wbase + 65535u;                    /* ends are 16-bit window-relative numbers */
+        uint32_t carry = 0;    /* best (end << 16 | distance) so far in this segment; end is window-relative + 1.. see pack */
+        uint32_t cursor = s0;
+        for (uint32_t b = s0; b < s1; b += WAVE) {
+            /* heads and their own ends */
+            uint32_t own[WAVE];
+            for (int i = 0; i < WAVE; i++) {
+                const uint32_t p = b + i;
+                own[i] = 0;
+                if (p >= s1 || n < 12 || p > n - 12) continue;
+                const uint32_t dp = d[p], dprev = (p > s0) ? d[p - 1] : 0;
+                if (dp == 0 || dp == dprev) continue;
+                if (p - wbase < dp) continue;                         /* candidate before the window */
+                const uint32_t cend = carry >> 16;                    /* end of the running best match, window-relative */
+                if (cend > (p - wbase) && cend - (p - wbase) >= P->skipd) continue;
+                uint32_t lim = (mend > p) ? mend - p : 0;
+                if (lim > P->cap) lim = P->cap;
+                uint32_t k = 0;
+                while (k < lim && in[p + k] == in[p - dp + k]) k++;
+                if (k >= 4) own[i] = ((p - wbase + k) << 16) | dp;
+            }
+            /* prefix maximum, carried across steps */
+            uint32_t run = carry;
+            for (int i = 0; i < WAVE; i++) { if (own[i] > run) run = own[i]; best[i] = run; }
+            carry = run;
+            /* eligibility (lazy: yield to the successor if it reaches further by more than a byte; lane 63 never yields) */
+            uint64_t elig = 0;
+            for (int i = 0; i < WAVE; i++) {
+                const uint32_t p = b + i;
+                if (p >= s1) break;
+                const uint32_t rel = p - wbase, e = best[i] >> 16;
+                if (e < rel + 4) continue;
+                if (n < 12 || p > n - 12) continue;
+                if (i < WAVE - 1 && p + 1 < s1 && (best[i + 1] >> 16) > e + 1) continue;
+                elig |= 1ull << i;
+            }
+            /* greedy walk */
+            while (cursor < b + WAVE && cursor < s1) {
+                const uint32_t c = (cursor > b) ? cursor - b : 0;
+                const uint64_t m = elig & (~0ull << c);
+                if (!m) break;
+                const int q = __builtin_ctzll(m);
+                const uint32_t p = b + q, e = best[q] >> 16, len = e - (p - wbase);
+                seqs[ns].lit_start = anchor; seqs[ns].lit_len = p - anchor; seqs[ns].off = best[q] & 0xFFFF; seqs[ns].mlen = len;
+                ns++;
+                cursor = anchor = p + len;
+            }
+        }
+    }
+    seqs[ns].lit_start = anchor; seqs[ns].lit_len = n - anchor; seqs[ns].off = 0; seqs[ns].mlen = 0;
+    ns++;
+    free(best);
+    return ns;
+}
+
+/* whole encoder: returns the compressed size (out must hold get_maximum_output_size(n)) */
+size_t lz4w_compress(const uint8_t *in, uint32_t n, uint8_t *out, const lz4w_params *P, uint32_t *n_seq) {
+    uint16_t *d = (uint16_t *)calloc((size_t)n + WAVE, 2);
+    lz4w_seq *seqs = (lz4w_seq *)malloc(sizeof(lz4w_seq) * ((size_t)n / 4 + 2));
+    if (n) lz4w_index(in, n, d);
+    const size_t ns = n ? lz4w_parse(in, n, d, P, seqs) : 0;
+    size_t o = 0;
+    if (n == 0) { out[o++] = 0; }
+    for (size_t i = 0; i < ns; i++) {
+        const lz4w_seq *s = &seqs[i];
+        uint8_t *tok = out + o++;
+        *tok = (uint8_t)((s->lit_len >= 15 ? 15 : s->lit_len) << 4);
+        if (s->lit_len >= 15) o = put_len(out, o, s->lit_len - 15);
+        memcpy(out + o, in + s->lit_start, s->lit_len);
+        o += s->lit_len;
+        if (s->mlen == 0) break;                      /* final literals: no offset (compress.rs handle_last_literals) */
+        out[o++] = (uint8_t)s->off; out[o++] = (uint8_t)(s->off >> 8);
+        const uint32_t ml = s->mlen - 4;
+        *tok |= (uint8_t)(ml >= 15 ? 15 : ml);
+        if (ml >= 15) o = put_len(out, o, ml - 15);
+    }
+    if (n_seq) *n_seq = (uint32_t)ns;
+    free(d); free(seqs);
+    return o;
+}

@@ -1,0 +1,132 @@
+"""GPU (-m gpu): the throughput ("wave") encoder, lz4_compress_wave.hip, through the C ABI.
+
+Parity bar for this mode (BASELINE.json north_star, compress side): a valid LZ4 block that the reference's decoder
+(oracle restatement) and C liblz4 decode to the identical input.  On top of that the kernel must reproduce its
+scalar model (tests/sim/wave_encoder_model.c) byte for byte: same candidates, same parse, same bytes."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+import corpus
+import oracle_api as O
+import wave_model as W
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def blk():
+    from lz4_flex_amd import _lib, block
+    lib = _lib.load()
+    assert lib.lz4flex_device_count() >= 1
+    assert lib.lz4flex_set_tuning(None, b"compress_mode", 0) == 0     # throughput mode on the default context
+    return block
+
+
+def cases():
+    rnd = random.Random(99)
+    out = [b"", b"a", b"abcd" * 3, bytes(11), bytes(12), bytes(13), bytes(64), bytes(65), bytes(4096), bytes(100000)]
+    out += list(corpus.ROUNDTRIP_STRINGS) + list(corpus.BUG_FUZZ)
+    for stem in ("compression_1k", "compression_34k", "compression_65k", "compression_66k_JSON"):
+        out.append(O.fixture_plain(stem))
+    j = O.fixture_plain("compression_66k_JSON")
+    for n in (63, 64, 127, 8191, 8192, 8193, 16384 + 5, 65535, 65536, 65537, 65536 + 11, 65536 + 12, 131072 + 77, 300000):
+        out.append((j * 6)[:n])
+    out.append(bytes(rnd.getrandbits(8) for _ in range(70000)))
+    out.append(bytes(rnd.choice(b"ab") for _ in range(30000)))
+    out.append(b"".join(bytes([rnd.getrandbits(8)]) * rnd.randint(1, 700) for _ in range(300)))
+    out.append((bytes(range(256)) * 300)[:70001])
+    out.append(bytes(rnd.getrandbits(8) for _ in range(20)) * 4000)       # period 20: every step full of same-bucket lanes
+    return out
+
+
+@pytest.mark.parametrize("i", range(len(cases())))
+def test_wave_encoder_scalar_call(blk, i):
+    data = cases()[i]
+    comp = blk.compress(data)                         # lz4flex_compress_into: one block through the persistent kernel
+    assert O.decompress(comp, len(data)) == ("ok", bytes(data)), "not a valid LZ4 block for lz4_flex's decoder"
+    if data:
+        assert O.c_decompress(comp, len(data)) == bytes(data), "C liblz4 rejects the block"
+    assert comp == W.compress(data), "kernel and scalar model disagree (len %d vs %d)" % (len(comp), len(W.compress(data)))
+
+
+def test_wave_encoder_device_batch_many_blocks(blk):
+    """more blocks than persistent workgroups, mixed lengths (multi-window blocks included), device-resident:
+    every block == model, decodes with the oracle; the GPU decoder round-trips the batch"""
+    import torch
+    from lz4_flex_amd import _lib as L
+    lib = L.load()
+    rnd = random.Random(5)
+    j = O.fixture_plain("compression_66k_JSON")
+    t = O.fixture_plain("compression_65k")
+    blocks = []
+    for k in range(1500):
+        src = j if k % 3 else t
+        n = rnd.choice([0, 1, 100, 5000, 65536, 65536, 65536, 40000, 70000, 140000]) if k % 7 else 65536
+        ph = rnd.randrange(len(src))
+        blocks.append((src * 4)[ph:ph + n])
+    in_len = np.array([len(b) for b in blocks], dtype=np.uint32)
+    in_off = np.zeros(len(blocks), dtype=np.uint64)
+    in_off[1:] = np.cumsum(in_len.astype(np.uint64) + 3)[:-1]          # unaligned block starts
+    buf = np.zeros(int(in_off[-1] + in_len[-1]) + 64, dtype=np.uint8)
+    for b, o in zip(blocks, in_off):
+        buf[int(o):int(o) + len(b)] = np.frombuffer(b, dtype=np.uint8)
+    cap = np.array([O.max_out(len(b)) for b in blocks], dtype=np.uint32)
+    out_off = np.zeros(len(blocks), dtype=np.uint64)
+    out_off[1:] = np.cumsum(cap.astype(np.uint64))[:-1]
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(buf).to(dev)
+    d_out = torch.zeros(int(out_off[-1] + cap[-1]), dtype=torch.uint8, device=dev)
+    tt = lambda a, dt: torch.from_numpy(a.view(dt)).to(dev)
+    d_in_off, d_in_len = tt(in_off, np.int64), tt(in_len, np.int32)
+    d_out_off, d_cap = tt(out_off, np.int64), tt(cap, np.int32)
+    d_len = torch.zeros(len(blocks), dtype=torch.int32, device=dev)
+    d_st = torch.full((len(blocks),), -1, dtype=torch.int32, device=dev)
+    ctx = C.c_void_p()
+    assert lib.lz4flex_ctx_create(C.byref(ctx), 0) == 0
+    assert lib.lz4flex_set_tuning(ctx, b"compress_mode", 0) == 0
+    p = lambda x: C.c_void_p(x.data_ptr())
+    for rep in range(2):                              # twice: the second launch reuses the workspace
+        rc = lib.lz4flex_compress_batch(ctx, p(d_in), p(d_in_off), p(d_in_len), None, len(blocks), p(d_out), p(d_out_off),
+                                        p(d_cap), p(d_len), p(d_st), L.MEM_DEVICE, None)
+        assert rc == 0, L.last_error()
+        torch.cuda.synchronize()
+        assert int((d_st != 0).sum().item()) == 0
+    h_out, h_len = d_out.cpu().numpy(), d_len.cpu().numpy()
+    for k in range(0, len(blocks), 1):
+        got = bytes(h_out[int(out_off[k]):int(out_off[k]) + int(h_len[k])])
+        if k % 10 == 0 or len(blocks[k]) > 65536:
+            assert got == W.compress(blocks[k]), (k, len(blocks[k]))
+        assert O.decompress(got, len(blocks[k])) == ("ok", blocks[k]), k
+    # GPU decoder on the GPU encoder's output
+    d_back = torch.zeros_like(d_in)
+    d_blen = torch.zeros(len(blocks), dtype=torch.int32, device=dev)
+    d_bst = torch.full((len(blocks),), -1, dtype=torch.int32, device=dev)
+    rc = lib.lz4flex_decompress_batch(ctx, p(d_out), p(d_out_off), p(d_len), len(blocks), p(d_back), p(d_in_off), p(d_in_len),
+                                      p(d_blen), p(d_bst), None, L.MEM_DEVICE, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert int((d_bst != 0).sum().item()) == 0 and torch.equal(d_blen, d_in_len)
+    hb = d_back.cpu().numpy()
+    for k in range(len(blocks)):
+        assert bytes(hb[int(in_off[k]):int(in_off[k]) + len(blocks[k])]) == blocks[k], k
+    lib.lz4flex_ctx_destroy(ctx)
+
+
+def test_wave_encoder_output_too_small(blk):
+    """compress.rs:338-340: OutputTooSmall is decided up front from get_maximum_output_size, nothing is written"""
+    from lz4_flex_amd import _lib as L
+    data = O.fixture_plain("compression_1k")
+    out = bytearray(b"\xEE" * (O.max_out(len(data)) - 1))
+    with pytest.raises(blk.CompressOutputTooSmall):
+        blk.compress_into(data, out)
+    assert bytes(out) == b"\xEE" * len(out)
+    # per-block status of a batch
+    lib = L.load()
+    src = np.frombuffer(data * 2, dtype=np.uint8).copy()
+    outb = np.full(4096, 0xEE, dtype=np.uint8)
+    ol, st = blk.compress_batch(src, [0, len(data)], [len(data), len(data)], outb, [0, 2048], [10, 2048])
+    assert st.tolist() == [L.E_OUTPUT_TOO_SMALL, 0] and bytes(outb[:10]) == b"\xEE" * 10
+    assert O.decompress(bytes(outb[2048:2048 + int(ol[1])]), len(data)) == ("ok", data)

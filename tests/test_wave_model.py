@@ -1,0 +1,80 @@
+"""CPU: the scalar model of the throughput encoder (tests/sim/wave_encoder_model.c) emits valid LZ4 blocks that
+the oracle's restatement of lz4_flex's decoder AND C liblz4 decode to the input, honours the end-of-block rules
+of src/block/mod.rs:37-61, and compresses the reference's fixtures about as well as the reference encoder."""
+import random
+
+import pytest
+
+import corpus
+import oracle_api as O
+import wave_model as W
+
+
+def inputs():
+    rnd = random.Random(1234)
+    out = [b"", b"a", b"abcd" * 3, bytes(13), bytes(12), bytes(11), bytes(64), bytes(65), bytes(4096), bytes(100000)]
+    out += list(corpus.ROUNDTRIP_STRINGS) + list(corpus.BUG_FUZZ)
+    for stem in ("compression_1k", "compression_34k", "compression_65k", "compression_66k_JSON"):
+        out.append(O.fixture_plain(stem))
+    j = O.fixture_plain("compression_66k_JSON")
+    for n in (8191, 8192, 8193, 16384 + 5, 65535, 65536, 65537, 131072 + 77, 200000):
+        out.append((j * 4)[:n])
+    out.append(bytes(rnd.getrandbits(8) for _ in range(70000)))                      # incompressible
+    out.append(bytes(rnd.choice(b"ab") for _ in range(30000)))                       # tiny alphabet: long overlapping matches
+    out.append(b"".join(bytes([rnd.getrandbits(8)]) * rnd.randint(1, 700) for _ in range(300)))   # runs
+    out.append((bytes(range(256)) * 300)[:70001])                                    # period 256
+    return out
+
+
+@pytest.mark.parametrize("i", range(len(inputs())))
+def test_model_round_trip(i):
+    data = inputs()[i]
+    comp = W.compress(data)
+    assert len(comp) <= O.max_out(len(data))
+    assert O.decompress(comp, len(data)) == ("ok", bytes(data))
+    if data:
+        assert O.c_decompress(comp, len(data)) == bytes(data)      # C liblz4 1.9.3 enforces the end-of-block rules too
+
+
+def test_model_end_of_block_rules():
+    """src/block/mod.rs:37-61: the last 5 bytes are literals, the last match starts >= 12 bytes before the end"""
+    for n in (13, 14, 20, 64, 100, 1000, 70000):
+        data = b"a" * n
+        comp = W.compress(data)
+        # walk the sequences
+        i, o, last_match_start = 0, 0, None
+        while True:
+            t = comp[i]; i += 1
+            lit = t >> 4
+            if lit == 15:
+                while True:
+                    b = comp[i]; i += 1; lit += b
+                    if b != 255:
+                        break
+            i += lit; o += lit
+            if i >= len(comp):
+                final_lit = lit
+                break
+            i += 2
+            ml = (t & 15) + 4
+            if (t & 15) == 15:
+                while True:
+                    b = comp[i]; i += 1; ml += b
+                    if b != 255:
+                        break
+            last_match_start = o
+            o += ml
+        assert o == n and final_lit >= 5
+        if last_match_start is not None:
+            assert last_match_start <= n - 12
+
+
+def test_model_ratio_close_to_reference_encoder():
+    """the throughput parse is not the reference's, but it must not give away compression: within 3 % of the oracle
+    (= lz4_flex's bytes) on every reference fixture, better on most"""
+    for stem in ("compression_34k", "compression_65k", "compression_66k_JSON"):
+        data = O.fixture_plain(stem)
+        assert len(W.compress(data)) <= 1.03 * len(O.compress(data)), stem
+    j = O.fixture_plain("compression_66k_JSON")
+    tiles = (j * 3)[1000:1000 + 65536]
+    assert len(W.compress(tiles)) <= len(O.compress(tiles))

@@ -1,0 +1,38 @@
+"""ctypes view of tests/sim/wave_encoder_model.c: the scalar model of the throughput ("wave") encoder
+(lz4_flex_amd/csrc/lz4_compress_wave.hip).  Test infrastructure."""
+import ctypes as C
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "sim", "wave_encoder_model.c")
+SO = os.path.join(ROOT, "tests", "sim", "libwave_encoder_model.so")
+SEG, CAP, SKIPD = 8192, 1024, 64    # the kernel's constants (lz4_compress_wave.hip)
+
+
+class Params(C.Structure):
+    _fields_ = [("seg", C.c_uint32), ("cap", C.c_uint32), ("skipd", C.c_uint32)]
+
+
+_m = None
+
+
+def lib():
+    global _m
+    if _m is None:
+        if not os.path.exists(SO) or os.path.getmtime(SRC) > os.path.getmtime(SO):
+            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-Wall", SRC, "-o", SO])
+        m = C.CDLL(SO)
+        m.lz4w_compress.restype = C.c_size_t
+        m.lz4w_compress.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.POINTER(Params), C.POINTER(C.c_uint32)]
+        _m = m
+    return _m
+
+
+def compress(data, seg=SEG, cap=CAP, skipd=SKIPD):
+    data = bytes(data)
+    out = C.create_string_buffer(20 + len(data) * 110 // 100 + 16)
+    p = Params(seg, cap, skipd)
+    ns = C.c_uint32(0)
+    n = lib().lz4w_compress(data, len(data), out, C.byref(p), C.byref(ns))
+    return out.raw[:n]
