@@ -48,6 +48,7 @@ struct lz4flex_ctx {
     int comp_mode = 0;            // 0 = throughput ("wave") encoder, own parse (default); 1 = reference-exact encoder (lz4_flex's bytes)
     int comp_variant = 1;         // reference-exact encoder: 1 = group encoder + emitter wave (default), 3 = group encoder alone
     void* wave_ws = nullptr;      // wave encoder workspace: wave_wgs persistent workgroups
+    unsigned long long* wave_prof = nullptr;   // tools: per-role cycle counters of the wave encoder (lz4flex_debug_wave_prof)
     int wave_wgs = 0;
     int dec_blocks_per_wg = 0;    // split decoder: blocks per workgroup (8/16/32/64), 0 = by batch size
     int dec_geometry = -1;        // pipelined decoder geometry (lz4_decompress_lds.hip launch_decompress_pipe): -1 by batch size, 0 = 8 lanes x 4 B, 1 = 4 lanes x 8 B
@@ -75,7 +76,7 @@ static int launch_compress_any(lz4flex_ctx* c, const CompressArgs& a, bool big, 
             HIP_TRY(hipMalloc(&c->wave_ws, compress_wave_workspace_bytes(wgs)));
             c->wave_wgs = wgs;
         }
-        le = launch_compress_wave(a, c->wave_ws, c->wave_wgs, s);
+        le = launch_compress_wave(a, c->wave_ws, c->wave_wgs, s, c->wave_prof);
     } else {
         le = launch_compress(a, c->comp_lanes | (big ? 0x100 : 0) | comp_mode_bits(c->comp_variant), s);
     }
@@ -171,10 +172,29 @@ void lz4flex_ctx_destroy(lz4flex_ctx* c) {
     if (!c) return;
     if (c->d_arena) (void)hipFree(c->d_arena);
     if (c->wave_ws) (void)hipFree(c->wave_ws);
+    if (c->wave_prof) (void)hipFree(c->wave_prof);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_pay) (void)hipHostFree(c->h_pay);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+// tools only (not in the public header): enable != 0 starts / resets the wave encoder's per-role cycle counters of
+// this context, vals (nullable) receives the 8 sums accumulated so far
+int lz4flex_debug_wave_prof(lz4flex_ctx* c, int enable, unsigned long long* vals) {
+    if (!c) return -LZ4FLEX_E_INVALID_ARG;
+    if (vals && c->wave_prof) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(vals, c->wave_prof, 64, hipMemcpyDeviceToHost));
+    }
+    if (enable) {
+        if (!c->wave_prof) HIP_TRY(hipMalloc((void**)&c->wave_prof, 64));
+        HIP_TRY(hipMemset(c->wave_prof, 0, 64));
+    } else if (c->wave_prof) {
+        (void)hipFree(c->wave_prof);
+        c->wave_prof = nullptr;
+    }
+    return 0;
 }
 
 int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {

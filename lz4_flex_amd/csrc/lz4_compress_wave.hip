@@ -38,6 +38,10 @@ typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) uint8_t g_u8;          // global memory, named: pointers that cross a call would be flat
+typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+typedef __attribute__((address_space(1))) uint32_t g_u32;
+typedef __attribute__((address_space(1))) int32_t g_i32;
 
 constexpr uint32_t WINDOW = 65536u;
 constexpr uint32_t SEG = 8192u;
@@ -46,16 +50,21 @@ constexpr uint32_t CAP = 1024u;           // longest match a head counts
 constexpr uint32_t SKIPD = 64u;           // a position buried this deep in a running match is not evaluated
 constexpr uint32_t HBITS = 12u;
 constexpr uint32_t THREADS = 64u * (WORKERS + 1u);
-constexpr uint32_t STG_BYTES = 768u;      // per worker: encoded sequences waiting for a 16 B-per-lane flush
-constexpr uint32_t FLUSH_AT = 384u;
-// LDS layout (80 192 B: two workgroups per CU)
+constexpr uint32_t STG_BYTES = 512u;      // per worker: encoded sequences waiting for a 16 B-per-lane flush
+constexpr uint32_t FLUSH_AT = 208u;       // a step adds at most 16 x 18 = 288 bytes on the lane-parallel path
+constexpr uint32_t CHUNK = 1024u;         // the indexer streams the next window in 1 KiB chunks (16 steps)
+constexpr uint32_t CHUNK_SLOT = CHUNK + 16u;
+constexpr uint32_t IDX_DEPTH = 4u;        // chunks in flight (registers) ahead of the one being indexed
+// LDS layout (81 200 B: two workgroups per CU)
 constexpr uint32_t L_WIN = 0u;                              // the window + 64 B of slack for the 16-byte compares
 constexpr uint32_t L_TAB = WINDOW + 64u;                    // the indexer's table, 4096 x u16
 constexpr uint32_t L_STG = L_TAB + (2u << HBITS);
-constexpr uint32_t L_META = L_STG + WORKERS * STG_BYTES;
+constexpr uint32_t L_RING = L_STG + WORKERS * STG_BYTES;    // two chunk slots of the indexer
+constexpr uint32_t L_META = L_RING + 2u * CHUNK_SLOT;
 constexpr uint32_t LDS_BYTES = L_META + 256u;
+static_assert(LDS_BYTES <= 81920u, "two workgroups per CU");
 // workspace per workgroup
-constexpr uint32_t SLOT_BYTES = 2u * WINDOW;                // cand[] of one window
+constexpr uint32_t SLOT_BYTES = 2u * WINDOW;                // cand[] of one window, transposed: see index_window
 constexpr uint32_t BODY_STRIDE = SEG + 256u;                // a segment's encoded bytes never exceed SEG + SEG/255 + 16
 constexpr uint32_t WS_BYTES = 2u * SLOT_BYTES + WORKERS * BODY_STRIDE;
 static_assert(WS_BYTES % 256u == 0u, "workspace slots stay 256 B aligned");
@@ -101,38 +110,93 @@ __device__ __forceinline__ uint64_t ld64l(const lds_u8* p) { uint64_t v; __built
 __device__ __forceinline__ uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
 __device__ __forceinline__ uint32_t len_ext_bytes(uint32_t v) { return v >= 15u ? (v - 15u) / 255u + 1u : 0u; }   // compress.rs:237-247
 
+__device__ __forceinline__ uint32_t ffbl(uint32_t x) { return (uint32_t)(__ffs((int)x) - 1); }   // v_ffbl_b32: 0xFFFFFFFF for 0
+// arguments of a non-inlined function arrive in VGPRs as flat pointers: make them scalar, global-address-space pointers
+template <typename G, typename T>
+__device__ __forceinline__ G* uni_gptr(T* p) {
+    const uint64_t v = (uint64_t)p;
+    return (G*)(((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v));
+}
+
 // ---- indexer --------------------------------------------------------------------------------------------------
-// cand[p] = distance from p to the most recent earlier position of the window with the same 4-byte hash (0: none).
+// d(p) = distance from p to the most recent earlier position of the window with the same 4-byte hash (0: none).
 // All 64 lookups of a step precede its 64 inserts (LDS operations of a wavefront execute in order); when lanes of a
-// step share a bucket the highest one stays (checked on the device by tests/test_gpu_wave_encoder.py).
-__device__ void index_window(const uint8_t* __restrict__ gwin, uint32_t wl, uint32_t act_n, uint16_t* __restrict__ slot,
-                             lds_u8* lds, uint32_t lane) {
+// step share a bucket the highest one stays (the GPU tests compare with the scalar model, which assumes it).
+// Memory: the window is streamed in 1 KiB chunks, 16 B per lane, IDX_DEPTH chunks in flight in registers (a single
+// wavefront has to cover the HBM latency by itself), each chunk passes through an LDS slot from which the steps read
+// their unaligned 4-byte values.  cand[] is stored transposed so that one 16-byte load gives a worker lane its
+// distances for 8 consecutive steps: group g = positions [512 g, 512 g + 512), lane i, step u -> u16 at
+// (64 g + i) * 16 + 2 u.
+struct ChunkRegs { u32x4 main; uint32_t extra; };
+
+__device__ __forceinline__ ChunkRegs chunk_issue(const g_u8* __restrict__ gwin, uint32_t c, uint32_t nfull, uint32_t lane) {
+    ChunkRegs r;
+    r.main = u32x4{0u, 0u, 0u, 0u};
+    r.extra = 0u;
+    if (c < nfull) {
+        __builtin_memcpy(&r.main, (const void*)(gwin + c * CHUNK + 16u * lane), 16);
+        if (lane == 0u) __builtin_memcpy(&r.extra, (const void*)(gwin + c * CHUNK + CHUNK), 4);
+    }
+    return r;
+}
+__device__ __forceinline__ void chunk_fill(lds_u8* slot, const ChunkRegs& r, const g_u8* __restrict__ gwin, uint32_t c,
+                                           uint32_t nfull, uint32_t rd_n, uint32_t lane) {
+    if (c < nfull) {
+        __builtin_memcpy((void*)(slot + 16u * lane), &r.main, 16);
+        if (lane == 0u) __builtin_memcpy((void*)(slot + CHUNK), &r.extra, 4);
+    } else {                                        // the block's tail (at most once per window): byte by byte, zero padded
+        for (uint32_t i = lane; i < CHUNK + 4u; i += 64u) {
+            const uint32_t o = c * CHUNK + i;
+            slot[i] = o < rd_n ? gwin[o] : (uint8_t)0;
+        }
+    }
+}
+
+__device__ __attribute__((noinline)) void index_window(const uint8_t* __restrict__ gwin_, uint32_t wl_, uint32_t act_n_, uint32_t rd_n_,
+                             uint8_t* __restrict__ slot_t_, lds_u8* lds, uint32_t lane) {
+    const g_u8* __restrict__ gwin = uni_gptr<const g_u8>(gwin_);
+    g_u8* __restrict__ slot_t = uni_gptr<g_u8>(slot_t_);
+    const uint32_t wl = uni(wl_), act_n = uni(act_n_), rd_n = uni(rd_n_);
     lds_u16* tab = (lds_u16*)(lds + L_TAB);
     {
         lds_u32* t4 = (lds_u32*)(lds + L_TAB);
         for (uint32_t i = lane; i < (2u << HBITS) / 4u; i += 64u) t4[i] = 0u;
     }
-    for (uint32_t b = 0; b < wl; b += 256u) {
-        uint32_t v[4];
+    const uint32_t nchunks = (wl + CHUNK - 1u) / CHUNK;
+    const uint32_t nfull = rd_n >= CHUNK + 4u ? (rd_n - 4u) / CHUNK : 0u;       // chunks whose 1028 bytes are all readable
+    ChunkRegs q[IDX_DEPTH];
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; ++u) {
-            const uint32_t p = b + 64u * u + lane;
-            uint32_t x = 0u;
-            if (p < act_n) __builtin_memcpy(&x, gwin + p, 4);
-            v[u] = x;
-        }
+    for (uint32_t j = 0; j < IDX_DEPTH; ++j) q[j] = chunk_issue(gwin, j, nfull, lane);
+    for (uint32_t c0 = 0; c0 < nchunks; c0 += IDX_DEPTH) {
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; ++u) {
-            const uint32_t p = b + 64u * u + lane;
-            const bool act = p < act_n;
-            const uint32_t h = (v[u] * 2654435761u) >> (32u - HBITS);
-            uint32_t d = 0u;
-            if (act) {
-                const uint32_t e = tab[h];
-                tab[h] = (uint16_t)p;
-                d = (p - e) & 0xFFFFu;
+        for (uint32_t j = 0; j < IDX_DEPTH; ++j) {
+            const uint32_t c = c0 + j;
+            if (c < nchunks) {
+                lds_u8* sl = lds + L_RING + (j & 1u) * CHUNK_SLOT;
+                chunk_fill(sl, q[j], gwin, c, nfull, rd_n, lane);
+                q[j] = chunk_issue(gwin, c + IDX_DEPTH, c + IDX_DEPTH < nchunks ? nfull : 0u, lane);
+#pragma unroll
+                for (uint32_t g2 = 0; g2 < 2u; ++g2) {
+                    uint32_t pk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (uint32_t u = 0; u < 8u; ++u) {
+                        const uint32_t o = (g2 * 8u + u) * 64u + lane;       // offset in the chunk
+                        const uint32_t p = c * CHUNK + o;
+                        uint32_t x;
+                        __builtin_memcpy(&x, (const void*)(sl + o), 4);
+                        const uint32_t h = (x * 2654435761u) >> (32u - HBITS);
+                        uint32_t d = 0u;
+                        if (p < act_n) {
+                            const uint32_t e = tab[h];
+                            tab[h] = (uint16_t)p;
+                            d = (p - e) & 0xFFFFu;
+                        }
+                        pk[u >> 1] |= d << (16u * (u & 1u));
+                    }
+                    const u32x4 v = {pk[0], pk[1], pk[2], pk[3]};
+                    *reinterpret_cast<g_u32x4*>(slot_t + ((size_t)(c * 2u + g2) * 64u + lane) * 16u) = v;
+                }
             }
-            if (p < wl) slot[p] = (uint16_t)d;
         }
     }
 }
@@ -141,7 +205,7 @@ __device__ void index_window(const uint8_t* __restrict__ gwin, uint32_t wl, uint
 struct Worker {
     lds_u8* win;
     lds_u8* stg;
-    uint8_t* body;
+    g_u8* body;
     uint32_t lane;
     uint32_t fill, body_len;
     uint32_t has, first_lit, first_ml;
@@ -150,7 +214,7 @@ struct Worker {
         const uint32_t n16 = fill & ~15u;
         for (uint32_t i = 16u * lane; i < n16; i += 1024u) {
             const u32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(stg + i);
-            *reinterpret_cast<u32x4*>(body + body_len + i) = v;
+            *reinterpret_cast<g_u32x4*>(body + body_len + i) = v;
         }
         const uint32_t rem = fill - n16;
         if (all) {
@@ -209,63 +273,104 @@ struct Worker {
     }
 };
 
-__device__ __forceinline__ void copy_lit_small(lds_u8* dst, const lds_u8* src, uint32_t n) {   // n < 16, exact
-    if (n & 8u) { uint64_t t; __builtin_memcpy(&t, (const void*)src, 8); __builtin_memcpy((void*)dst, &t, 8); src += 8; dst += 8; }
-    if (n & 4u) { uint32_t t; __builtin_memcpy(&t, (const void*)src, 4); __builtin_memcpy((void*)dst, &t, 4); src += 4; dst += 4; }
-    if (n & 2u) { uint16_t t; __builtin_memcpy(&t, (const void*)src, 2); __builtin_memcpy((void*)dst, &t, 2); src += 2; dst += 2; }
-    if (n & 1u) { *dst = *src; }
+// n < 16 literal bytes, exactly: ONE 16-byte read (over-reading source bytes is harmless), then 8/4/2/1-byte writes
+__device__ __forceinline__ void copy_lit_small(lds_u8* dst, const lds_u8* src, uint32_t n) {
+    u32x4 v;
+    __builtin_memcpy(&v, (const void*)src, 16);
+    const bool n8 = (n & 8u) != 0u, n4 = (n & 4u) != 0u, n2 = (n & 2u) != 0u;
+    const uint32_t w4 = n8 ? v.z : v.x;                               // the dword at byte offset (n & 8)
+    const uint32_t wq = n8 ? (n4 ? v.w : v.z) : (n4 ? v.y : v.x);     // the dword at byte offset (n & 12)
+    if (n8) { const uint64_t t = (uint64_t)v.x | ((uint64_t)v.y << 32); __builtin_memcpy((void*)dst, &t, 8); }
+    if (n4) __builtin_memcpy((void*)(dst + (n & 8u)), &w4, 4);
+    if (n2) { const uint16_t t = (uint16_t)wq; __builtin_memcpy((void*)(dst + (n & 12u)), &t, 2); }
+    if (n & 1u) dst[n & 14u] = (uint8_t)(wq >> (n2 ? 16 : 0));
 }
 
 // One segment [s0, s1) of the window in LDS.  mfl: positions p < mfl_end may start a match (p <= n - 12);
 // mend: matches end here at the latest (segment end, block end - 5, 65535).
-__device__ void match_segment(lds_u8* lds, const uint16_t* __restrict__ cand, uint8_t* body, uint32_t w, uint32_t lane,
-                              uint32_t s0, uint32_t s1, uint32_t mfl_end, uint32_t mend) {
+__device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8_t* __restrict__ cand_t_, uint8_t* body_, uint32_t w_, uint32_t lane,
+                              uint32_t s0_, uint32_t s1_, uint32_t mfl_end_, uint32_t mend_) {
+    const uint32_t w = uni(w_), s0 = uni(s0_), s1 = uni(s1_), mfl_end = uni(mfl_end_), mend = uni(mend_);
+    const g_u8* __restrict__ cand_t = uni_gptr<const g_u8>(cand_t_);
     Worker W;
     W.win = lds + L_WIN;
     W.stg = lds + L_STG + w * STG_BYTES;
-    W.body = body;
+    W.body = uni_gptr<g_u8>(body_);
     W.lane = lane;
     W.fill = 0u; W.body_len = 0u; W.has = 0u; W.first_lit = 0u; W.first_ml = 0u;
     uint32_t cursor = s0, anchor = s0, carry = 0u, dlast = 0u;
-    uint32_t d_next = 0u;
-    if (s0 + lane < s1) d_next = cand[s0 + lane];
+    // cand[]: 16 bytes per lane and group of 8 steps (see index_window), fetched one group ahead
+    u32x4 dn = {0u, 0u, 0u, 0u};
+    if (s0 < s1) dn = *reinterpret_cast<const g_u32x4*>(cand_t + ((size_t)(s0 >> 9) * 64u + lane) * 16u);
+    u32x4 dc = dn;
     for (uint32_t b = s0; b < s1; b += 64u) {
+        if ((b & 511u) == 0u) {
+            dc = dn;
+            if (b + 512u < s1) dn = *reinterpret_cast<const g_u32x4*>(cand_t + ((size_t)((b + 512u) >> 9) * 64u + lane) * 16u);
+        }
         const uint32_t p = b + lane;
-        const uint32_t d = d_next;
-        d_next = 0u;
-        if (p + 64u < s1) d_next = cand[p + 64u];
-        // heads
+        const bool inseg = p < s1;
+        const uint32_t d = inseg ? (dc.x & 0xFFFFu) : 0u;
+        dc.x = __builtin_amdgcn_alignbit(dc.y, dc.x, 16);       // the 128-bit group moves down by one u16 per step
+        dc.y = __builtin_amdgcn_alignbit(dc.z, dc.y, 16);
+        dc.z = __builtin_amdgcn_alignbit(dc.w, dc.z, 16);
+        dc.w = dc.w >> 16;
         const uint32_t dprev = dpp_wave_shr1(d, dlast);
         dlast = rdlane(d, 63u);
         const uint32_t cend = carry >> 16;
-        bool head = (p < s1) && (p < mfl_end) && d != 0u && d != dprev && d <= p;
-        head = head && !(cend > p && cend - p >= SKIPD);
+        // the whole step lies deep inside a match already taken: nothing to evaluate, nothing to select
+        if (cursor >= b + 64u && cend >= b + 63u + SKIPD) continue;
+        // heads
+        const bool canstart = inseg & (p < mfl_end);
+        bool head = canstart & (d != 0u) & (d != dprev) & (d <= p);
+        head = head & !((cend > p) & (cend - p >= SKIPD));
         uint32_t lim = mend > p ? mend - p : 0u;
         lim = lim < CAP ? lim : CAP;
         uint32_t k = 0u;
-        bool act = head && lim >= 4u;
-        while (__ballot(act) != 0ull) {
-            if (act) {
-                const lds_u8* a = W.win + p + k;
-                const lds_u8* c = a - d;
-                const uint64_t x0 = ld64l(a) ^ ld64l(c);
-                const uint64_t x1 = ld64l(a + 8) ^ ld64l(c + 8);
-                if (x0 != 0ull) { k += ctz64(x0) >> 3; act = false; }
-                else if (x1 != 0ull) { k += 8u + (ctz64(x1) >> 3); act = false; }
-                else { k += 16u; act = k < lim; }
+        bool act = head & (lim >= 4u);
+        auto first_diff = [](const u32x4& va, const u32x4& vc) -> uint32_t {   // index of the first differing bit, 128 if none
+            const uint32_t f0 = ffbl(va.x ^ vc.x), f1 = ffbl(va.y ^ vc.y), f2 = ffbl(va.z ^ vc.z), f3 = ffbl(va.w ^ vc.w);
+            uint32_t bits = f3 < 32u ? f3 : 32u;
+            bits += 32u; bits = f2 < bits ? f2 : bits;
+            bits += 32u; bits = f1 < bits ? f1 : bits;
+            bits += 32u; bits = f0 < bits ? f0 : bits;
+            return bits;
+        };
+        if (__ballot(act) != 0ull) {
+            if (act) {                                          // 16 bytes, branch-free: most candidates end here
+                const lds_u8* ap = W.win + p;
+                u32x4 va, vc;
+                __builtin_memcpy(&va, (const void*)ap, 16);
+                __builtin_memcpy(&vc, (const void*)(ap - d), 16);
+                const uint32_t bits = first_diff(va, vc);
+                k = bits >> 3;
+                act = (bits == 128u) & (k < lim);
+            }
+            while (__ballot(act) != 0ull) {
+                if (act) {                                      // 32 bytes per further round
+                    const lds_u8* ap = W.win + p + k;
+                    u32x4 va0, vc0, va1, vc1;
+                    __builtin_memcpy(&va0, (const void*)ap, 16);
+                    __builtin_memcpy(&vc0, (const void*)(ap - d), 16);
+                    __builtin_memcpy(&va1, (const void*)(ap + 16), 16);
+                    __builtin_memcpy(&vc1, (const void*)(ap - d + 16), 16);
+                    const uint32_t b0 = first_diff(va0, vc0), b1 = first_diff(va1, vc1);
+                    const uint32_t bits = b0 < 128u ? b0 : 128u + b1;
+                    k += bits >> 3;
+                    act = (bits == 256u) & (k < lim);
+                }
             }
         }
         k = k < lim ? k : lim;
-        const uint32_t own = (head && k >= 4u) ? (((p + k) << 16) | d) : 0u;
+        const uint32_t own = (head & (k >= 4u)) ? (((p + k) << 16) | d) : 0u;
         // the match that reaches furthest, from any head at or before this position
         uint32_t best = wave_incl_max(own);
         best = best > carry ? best : carry;
         carry = rdlane(best, 63u);
         const uint32_t e = best >> 16;
         const uint32_t e_next = dpp_wave_shl1(e, 0u);
-        bool elig = (p < s1) && (p < mfl_end) && (e >= p + 4u);
-        elig = elig && !(lane < 63u && p + 1u < s1 && e_next > e + 1u);
-        const uint64_t em = __ballot(elig);
+        const bool yield = (lane < 63u) & (p + 1u < s1) & (e_next > e + 1u);
+        const uint64_t em = __ballot(canstart & (e >= p + 4u) & !yield);
         // greedy walk (scalar)
         uint64_t sel = 0ull;
         const uint32_t anchor_in = anchor;
@@ -287,11 +392,12 @@ __device__ void match_segment(lds_u8* lds, const uint16_t* __restrict__ cand, ui
         pe = pe > anchor_in ? pe : anchor_in;             // end of the previous sequence
         const uint32_t lit = p - pe;
         const uint32_t mlc = len - 4u;
-        const bool simple = !issel || (lit < 15u && mlc < 270u);
-        if (__ballot(!simple) == 0ull) {
+        const bool hard = issel & ((lit >= 15u) | (mlc >= 270u));
+        if (__ballot(hard) == 0ull) {
             const uint32_t fl = ctz64(sel);
-            const bool first = !W.has && lane == fl;
-            const uint32_t size = issel ? ((first ? 2u : 3u + lit) + (mlc >= 15u ? 1u : 0u)) : 0u;
+            const bool first = (W.has == 0u) & (lane == fl);
+            const uint32_t ext = mlc >= 15u ? 1u : 0u;
+            const uint32_t size = issel ? ((first ? 2u : 3u + lit) + ext) : 0u;
             const uint32_t incl = wave_incl_add(size);
             const uint32_t total = rdlane(incl, 63u);
             if (issel) {
@@ -301,11 +407,11 @@ __device__ void match_segment(lds_u8* lds, const uint16_t* __restrict__ cand, ui
                     copy_lit_small(o + 1, W.win + pe, lit);
                     o += 1u + lit;
                 }
-                o[0] = (uint8_t)off;
-                o[1] = (uint8_t)(off >> 8);
-                if (mlc >= 15u) o[2] = (uint8_t)(mlc - 15u);
+                const uint16_t o16 = (uint16_t)off;
+                __builtin_memcpy((void*)o, &o16, 2);
+                if (ext) o[2] = (uint8_t)(mlc - 15u);
             }
-            if (!W.has) { W.has = 1u; W.first_lit = rdlane(lit, fl); W.first_ml = rdlane(len, fl); }
+            if (W.has == 0u) { W.has = 1u; W.first_lit = rdlane(lit, fl); W.first_ml = rdlane(len, fl); }
             W.fill += total;
         } else {
             uint64_t m = sel;
@@ -319,8 +425,6 @@ __device__ void match_segment(lds_u8* lds, const uint16_t* __restrict__ cand, ui
     }
     W.flush(true);
     if (lane == 0u) {
-        SegMeta* M = (SegMeta*)nullptr;
-        (void)M;
         lds_u32* mp = (lds_u32*)(lds + L_META) + 5u * w;
         mp[0] = W.has; mp[1] = W.first_lit; mp[2] = W.first_ml; mp[3] = s1 - anchor; mp[4] = W.body_len;
     }
@@ -328,10 +432,37 @@ __device__ void match_segment(lds_u8* lds, const uint16_t* __restrict__ cand, ui
 
 // bytes [0, n) with a per-byte generator; 64 lanes
 template <typename F>
-__device__ __forceinline__ void put_bytes(uint8_t* dst, uint32_t n, uint32_t lane, F f) {
+__device__ __forceinline__ void put_bytes(g_u8* dst, uint32_t n, uint32_t lane, F f) {
     for (uint32_t i = lane; i < n; i += 64u) dst[i] = (uint8_t)f(i);
 }
-__device__ __forceinline__ void put_len_header(uint8_t* dst, uint32_t lit, uint32_t ml_nibble, uint32_t lane) {
+// n bytes global -> global, any alignment on either side: 16 bytes per lane and access, four in flight
+__device__ __forceinline__ void copy_bytes(g_u8* dst, const g_u8* src, uint32_t n, uint32_t lane) {
+    uint32_t i = 0u;
+    for (; i + 4096u <= n; i += 4096u) {
+        u32x4 v[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) __builtin_memcpy(&v[j], (const void*)(src + i + 1024u * j + 16u * lane), 16);
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) __builtin_memcpy((void*)(dst + i + 1024u * j + 16u * lane), &v[j], 16);
+    }
+    {
+        u32x4 v[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t o = i + 1024u * j + 16u * lane;
+            v[j] = u32x4{0u, 0u, 0u, 0u};
+            if (o + 16u <= n) __builtin_memcpy(&v[j], (const void*)(src + o), 16);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t o = i + 1024u * j + 16u * lane;
+            if (o + 16u <= n) __builtin_memcpy((void*)(dst + o), &v[j], 16);
+        }
+    }
+    const uint32_t done = i + ((n - i) & ~15u);
+    if (done + lane < n) dst[done + lane] = src[done + lane];
+}
+__device__ __forceinline__ void put_len_header(g_u8* dst, uint32_t lit, uint32_t ml_nibble, uint32_t lane) {
     const uint32_t ne = len_ext_bytes(lit);
     put_bytes(dst, 1u + ne, lane, [&](uint32_t j) -> uint32_t {
         if (j == 0u) return ((lit < 15u ? lit : 15u) << 4) | ml_nibble;
@@ -340,9 +471,16 @@ __device__ __forceinline__ void put_len_header(uint8_t* dst, uint32_t lit, uint3
 }
 
 // Place segment w of the current window (after the barrier: every worker's SegMeta is final).
-__device__ void place_segment(lds_u8* lds, const uint8_t* __restrict__ gin, uint32_t blk_len, uint32_t win_idx, bool last_win,
-                              uint32_t wl, const uint8_t* body, uint8_t* gout, uint32_t carry_slot, uint32_t w, uint32_t lane,
-                              uint32_t* out_len, int32_t* status) {
+__device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8_t* __restrict__ gin_, uint32_t blk_len_, uint32_t win_idx_, bool last_win_,
+                              uint32_t wl_, const uint8_t* body_, uint8_t* gout_, uint32_t carry_slot_, uint32_t w_, uint32_t lane,
+                              uint32_t* out_len_, int32_t* status_) {
+    const g_u8* __restrict__ gin = uni_gptr<const g_u8>(gin_);
+    const g_u8* body = uni_gptr<const g_u8>(body_);
+    g_u8* gout = uni_gptr<g_u8>(gout_);
+    g_u32* out_len = uni_gptr<g_u32>(out_len_);
+    g_i32* status = uni_gptr<g_i32>(status_);
+    const uint32_t blk_len = uni(blk_len_), win_idx = uni(win_idx_), wl = uni(wl_), carry_slot = uni(carry_slot_), w = uni(w_);
+    const bool last_win = uni((uint32_t)last_win_) != 0u;
     const lds_u32* mp = (const lds_u32*)(lds + L_META);
     lds_u32* cp = (lds_u32*)(lds + L_META) + 5u * WORKERS;          // BlkCarry[2]
     uint32_t out_pos = 0u, pend = 0u;
@@ -363,10 +501,9 @@ __device__ void place_segment(lds_u8* lds, const uint8_t* __restrict__ gin, uint
         const uint32_t fl = mp[5u * w + 1u], L = pend + fl, ml = mp[5u * w + 2u] - 4u, bl = mp[5u * w + 4u];
         put_len_header(gout + out_pos, L, ml < 15u ? ml : 15u, lane);
         out_pos += 1u + len_ext_bytes(L);
-        const uint8_t* src = gin + (abs0 + fl - L);
-        for (uint32_t i = lane; i < L; i += 64u) gout[out_pos + i] = src[i];
+        copy_bytes(gout + out_pos, gin + (abs0 + fl - L), L, lane);
         out_pos += L;
-        for (uint32_t i = lane; i < bl; i += 64u) gout[out_pos + i] = body[i];
+        copy_bytes(gout + out_pos, body, bl, lane);
         out_pos += bl;
         pend = mp[5u * w + 3u];
     } else {
@@ -377,8 +514,7 @@ __device__ void place_segment(lds_u8* lds, const uint8_t* __restrict__ gin, uint
             // the block's last literals (compress.rs handle_last_literals): token, length bytes, bytes; no offset
             put_len_header(gout + out_pos, pend, 0u, lane);
             out_pos += 1u + len_ext_bytes(pend);
-            const uint8_t* src = gin + (blk_len - pend);
-            for (uint32_t i = lane; i < pend; i += 64u) gout[out_pos + i] = src[i];
+            copy_bytes(gout + out_pos, gin + (blk_len - pend), pend, lane);
             out_pos += pend;
             if (lane == 0u) { *out_len = out_pos; *status = 0; }
         } else if (lane == 0u) {
@@ -386,6 +522,35 @@ __device__ void place_segment(lds_u8* lds, const uint8_t* __restrict__ gin, uint
             cp[2u * carry_slot + 1u] = pend;
         }
     }
+}
+
+// the current window into LDS: 512 worker threads, 16 B per thread and load, four loads in flight per thread
+__device__ __attribute__((noinline)) void load_window(const uint8_t* __restrict__ g_, uint32_t wl_, lds_u8* lds, uint32_t tid) {
+    const g_u8* __restrict__ g = uni_gptr<const g_u8>(g_);
+    const uint32_t wl = uni(wl_);
+    const uint32_t mis = (uint32_t)((16u - ((uintptr_t)g & 15u)) & 15u);    // bytes up to the first 16 B boundary
+    const uint32_t head = mis < wl ? mis : wl;
+    if (tid < head) lds[L_WIN + tid] = g[tid];
+    const uint32_t nvec = (wl - head) / 16u;                                // <= 4096
+    const g_u8* gp = g + head + 16u * tid;
+    lds_u8* lp = lds + L_WIN + head + 16u * tid;
+#pragma unroll 1
+    for (uint32_t i0 = 0; i0 < nvec; i0 += 2048u) {
+        u32x4 v[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            v[j] = u32x4{0u, 0u, 0u, 0u};
+            if (i0 + tid + 512u * j < nvec) v[j] = *reinterpret_cast<const g_u32x4*>(gp + 8192u * j);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j)
+            if (i0 + tid + 512u * j < nvec) __builtin_memcpy((void*)(lp + 8192u * j), &v[j], 16);
+        gp += 32768u;
+        lp += 32768u;
+    }
+    const uint32_t done = head + 16u * nvec;
+    if (tid < wl - done) lds[L_WIN + done + tid] = g[done + tid];
+    if (tid < 64u) lds[L_WIN + wl + tid] = 0;                               // slack read by the 16-byte compares
 }
 
 struct Item {
@@ -411,13 +576,17 @@ __device__ __forceinline__ void item_next(const CompressArgs& a, Item& it) {
     item_load(a, it);
 }
 
-__global__ void __launch_bounds__(THREADS) lz4_compress_wave_kernel(const CompressArgs a, uint8_t* __restrict__ ws) {
+// prof (nullable, tools only): cycle sums per role, [0] indexer busy, [1] indexer at barriers, [2] workers matching,
+// [3] workers at the barrier behind matching, [4] placing, [5] loading the next window, [6] at the barrier behind loading,
+// [7] windows
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) lz4_compress_wave_kernel(const CompressArgs a, uint8_t* __restrict__ ws,
+                                                                    unsigned long long* __restrict__ prof) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = uni(threadIdx.x >> 6);
     uint8_t* my_ws = ws + (size_t)blockIdx.x * WS_BYTES;
-    uint16_t* slots = (uint16_t*)my_ws;                           // two cand[] slots
+    uint8_t* slots = my_ws;                                        // two cand[] slots
     uint8_t* bodies = my_ws + 2u * SLOT_BYTES;
 
     Item it;
@@ -436,30 +605,26 @@ __global__ void __launch_bounds__(THREADS) lz4_compress_wave_kernel(const Compre
         const uint32_t base = t.win * WINDOW, wl = win_len(t);
         const uint32_t act_abs = t.len >= 12u ? t.len - 11u : 0u;            // positions p < act_abs start 4 readable bytes and may match
         const uint32_t act_n = act_abs > base ? (act_abs - base < wl ? act_abs - base : wl) : 0u;
-        index_window(a.in_base + t.in_off + base, wl, act_n, slots + (size_t)slot * WINDOW, lds, lane);
+        index_window(a.in_base + t.in_off + base, wl, act_n, t.len - base, slots + (size_t)slot * SLOT_BYTES, lds, lane);
     };
     auto do_load = [&](const Item& t) {
         if (t.skip) return;
-        const uint32_t wl = win_len(t);
-        const uint8_t* g = a.in_base + t.in_off + (size_t)t.win * WINDOW;
-        const uint32_t tid = threadIdx.x;                                       // 512 worker threads
-        const uint32_t mis = (uint32_t)((16u - ((uintptr_t)g & 15u)) & 15u);    // bytes up to the first 16 B boundary
-        const uint32_t head = mis < wl ? mis : wl;
-        if (tid < head) lds[L_WIN + tid] = g[tid];
-        const uint32_t nvec = (wl - head) / 16u;
-        for (uint32_t i = tid; i < nvec; i += 512u) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(g + head + 16u * i);
-            __builtin_memcpy((void*)(lds + L_WIN + head + 16u * i), &v, 16);
-        }
-        const uint32_t done = head + 16u * nvec;
-        if (tid < wl - done) lds[L_WIN + done + tid] = g[done + tid];
-        if (tid < 64u) lds[L_WIN + wl + tid] = 0;                               // slack read by the 16-byte compares
+        load_window(a.in_base + t.in_off + (size_t)t.win * WINDOW, win_len(t), lds, threadIdx.x);
     };
 
+    uint64_t t_prev = prof ? __builtin_readcyclecounter() : 0ull;
+    auto tick = [&](uint32_t slot) {
+        if (prof) {
+            const uint64_t t = __builtin_readcyclecounter();
+            if (lane == 0u) atomicAdd(prof + slot, (unsigned long long)(t - t_prev));
+            t_prev = t;
+        }
+    };
     // prologue: cand[] of the first window, the first window into LDS
-    if (w == WORKERS) { do_index(ix, 0u); item_next(a, ix); }
-    else do_load(it);
+    if (w == WORKERS) { do_index(ix, 0u); item_next(a, ix); tick(0u); }
+    else { do_load(it); tick(5u); }
     __syncthreads();
+    tick(w == WORKERS ? 1u : 6u);
     for (;;) {
         const uint32_t wl = win_len(it);
         const bool last_win = it.win + 1u == it.nwin;
@@ -475,9 +640,11 @@ __global__ void __launch_bounds__(THREADS) lz4_compress_wave_kernel(const Compre
             mend = mend > base ? mend - base : 0u;
             mend = mend < s1 ? mend : s1;
             mend = mend < 65535u ? mend : 65535u;
-            match_segment(lds, slots + (size_t)(k & 1u) * WINDOW, bodies + (size_t)w * BODY_STRIDE, w, lane, s0, s1, mfl_end, mend);
+            match_segment(lds, slots + (size_t)(k & 1u) * SLOT_BYTES, bodies + (size_t)w * BODY_STRIDE, w, lane, s0, s1, mfl_end, mend);
         }
+        tick(w == WORKERS ? 0u : 2u);
         __syncthreads();
+        tick(w == WORKERS ? 1u : 3u);
         if (w != WORKERS) {
             if (it.skip) {
                 if (threadIdx.x == 0u) { a.out_len[it.blk] = 0u; a.status[it.blk] = LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL; }
@@ -486,11 +653,15 @@ __global__ void __launch_bounds__(THREADS) lz4_compress_wave_kernel(const Compre
                               a.out_base + a.out_off[it.blk], k & 1u, w, lane, a.out_len + it.blk, a.status + it.blk);
             }
         }
+        tick(w == WORKERS ? 1u : 4u);
+        if (prof && threadIdx.x == 0u) atomicAdd(prof + 7, 1ull);
         item_next(a, it);
         k += 1u;
         if (it.blk >= a.n) break;
         if (w != WORKERS) do_load(it);
+        tick(w == WORKERS ? 1u : 5u);
         __syncthreads();
+        tick(w == WORKERS ? 1u : 6u);
     }
 }
 
@@ -498,7 +669,7 @@ __global__ void __launch_bounds__(THREADS) lz4_compress_wave_kernel(const Compre
 
 size_t compress_wave_workspace_bytes(int n_workgroups) { return (size_t)n_workgroups * wave::WS_BYTES; }
 
-hipError_t launch_compress_wave(const CompressArgs& a, void* workspace, int n_workgroups, hipStream_t s) {
+hipError_t launch_compress_wave(const CompressArgs& a, void* workspace, int n_workgroups, hipStream_t s, unsigned long long* prof) {
     if (a.n == 0u) return hipSuccess;
     if (!workspace || n_workgroups <= 0) return hipErrorInvalidValue;
     static unsigned long long have = 0ull;
@@ -512,7 +683,7 @@ hipError_t launch_compress_wave(const CompressArgs& a, void* workspace, int n_wo
         have |= bit;
     }
     const uint32_t grid = a.n < (uint32_t)n_workgroups ? a.n : (uint32_t)n_workgroups;
-    hipLaunchKernelGGL(wave::lz4_compress_wave_kernel, dim3(grid), dim3(wave::THREADS), wave::LDS_BYTES, s, a, (uint8_t*)workspace);
+    hipLaunchKernelGGL(wave::lz4_compress_wave_kernel, dim3(grid), dim3(wave::THREADS), wave::LDS_BYTES, s, a, (uint8_t*)workspace, prof);
     return hipGetLastError();
 }
 

@@ -1,0 +1,59 @@
+// LDS access cost on gfx950: aligned vs byte-unaligned reads of 4/8/16 bytes per lane, random and consecutive
+// addresses (the access shapes of lz4_compress_wave.hip).  hipcc --offload-arch=gfx950 -O3 tools/ubench_lds.hip -o /tmp/ubench_lds
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int BYTES>
+__global__ void k(const uint32_t* addr, uint64_t* out, int iters, int waves) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    for (int i = threadIdx.x; i < 65536 / 4; i += blockDim.x) ((uint32_t*)lds)[i] = i * 2654435761u;
+    __syncthreads();
+    uint32_t a[8];
+    for (int j = 0; j < 8; j++) a[j] = addr[(j * 64 + (threadIdx.x & 63)) ];
+    uint32_t acc = 0;
+    __syncthreads();
+    uint64_t t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            a[j] = (a[j] + 4112u) & 0xFFFFu;             // same alignment class, new bank every time; defeats hoisting
+            asm volatile("" : "+v"(a[j]));
+            if (BYTES == 16) { u32x4 v; __builtin_memcpy(&v, lds + a[j], 16); acc += v.x ^ v.y ^ v.z ^ v.w; }
+            if (BYTES == 8) { u32x2 v; __builtin_memcpy(&v, lds + a[j], 8); acc += v.x ^ v.y; }
+            if (BYTES == 4) { uint32_t v; __builtin_memcpy(&v, lds + a[j], 4); acc += v; }
+            if (BYTES == 2) { uint16_t v; __builtin_memcpy(&v, lds + a[j], 2); acc += v; }
+        }
+    }
+    uint64_t t1 = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * waves + (threadIdx.x >> 6)] = t1 - t0;
+    if (acc == 0x12345678) out[0] = acc;
+}
+int main() {
+    uint32_t* d_addr; uint64_t* d_out; hipMalloc(&d_addr, 512 * 4); hipMalloc(&d_out, 8 * 64 * 8);
+    const int iters = 200;
+    struct { const char* name; int mode; } pats[] = {{"random aligned", 0}, {"random unaligned", 1}, {"consecutive bytes (lane i at +i)", 2}, {"consecutive aligned (lane i at +16i)", 3}, {"14 random heads, others same", 4}};
+    for (int waves : {1, 4, 8}) for (auto& p : pats) for (int bytes : {2, 4, 8, 16}) {
+        uint32_t h[512]; srand(7);
+        for (int j = 0; j < 512; j++) {
+            uint32_t r = rand() % 60000;
+            if (p.mode == 0) r &= ~(bytes - 1u);
+            if (p.mode == 1) r |= 1u;
+            if (p.mode == 2) r = 1000 * (j / 64) + (j % 64) + 1;
+            if (p.mode == 3) r = 2048 * (j / 64) + (j % 64) * 16;
+            if (p.mode == 4) r = ((j % 64) % 5 == 0) ? (r | 1u) : 4096u * (j / 64) + 3u;
+            h[j] = r;
+        }
+        hipMemcpy(d_addr, h, sizeof h, hipMemcpyHostToDevice);
+        void (*kern)(const uint32_t*, uint64_t*, int, int) = bytes == 16 ? k<16> : bytes == 8 ? k<8> : bytes == 4 ? k<4> : k<2>;
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 64);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(64 * waves), 65536 + 64, 0, d_addr, d_out, iters, waves);
+        hipDeviceSynchronize();
+        uint64_t o[8]; hipMemcpy(o, d_out, sizeof o, hipMemcpyDeviceToHost);
+        double mx = 0; for (int w = 0; w < waves; w++) mx = o[w] > mx ? o[w] : mx;
+        printf("waves/CU %d  %-40s %2d B/lane: %.1f cycles per wave-instruction (%.1f per CU)\n", waves, p.name, bytes, mx / (iters * 8.0), mx / (iters * 8.0) / waves);
+    }
+    return 0;
+}

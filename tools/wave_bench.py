@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Quick timing of the batched encoder / decoder on the configs[1] workload (not the reported bench: bench.py)."""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--blocks", type=int, default=16384)
+    ap.add_argument("--mode", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--data", default="json")
+    ap.add_argument("--prof", action="store_true")
+    args = ap.parse_args()
+    import torch
+    import oracle_api as O
+    from lz4_flex_amd import _lib as L, workloads
+    lib = L.load()
+    dev = torch.device("cuda", 0)
+    n, B = args.blocks, 65536
+    if args.data == "json":
+        src = workloads.json_tiles(O.fixture_plain("compression_66k_JSON"), n * B, device=dev)
+    elif args.data == "text":
+        src = workloads.json_tiles(O.fixture_plain("compression_65k"), n * B, device=dev)
+    elif args.data == "zeros":
+        src = torch.zeros(n * B, dtype=torch.uint8, device=dev)
+    else:
+        src = torch.randint(0, 256, (n * B,), dtype=torch.uint8, device=dev)
+    stride = 72128
+    comp = torch.empty(n * stride, dtype=torch.uint8, device=dev)
+    back = torch.empty(n * B, dtype=torch.uint8, device=dev)
+    ar = torch.arange(n, dtype=torch.int64, device=dev)
+    in_off, comp_off = ar * B, ar * stride
+    in_len = torch.full((n,), B, dtype=torch.int32, device=dev)
+    cap = torch.full((n,), stride, dtype=torch.int32, device=dev)
+    clen = torch.zeros(n, dtype=torch.int32, device=dev)
+    st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    blen = torch.zeros(n, dtype=torch.int32, device=dev)
+    bst = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    ctx = C.c_void_p()
+    assert lib.lz4flex_ctx_create(C.byref(ctx), 0) == 0
+    assert lib.lz4flex_set_tuning(ctx, b"compress_mode", args.mode) == 0
+    p = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def comp_once():
+        assert lib.lz4flex_compress_batch(ctx, p(src), p(in_off), p(in_len), None, n, p(comp), p(comp_off), p(cap), p(clen), p(st),
+                                          L.MEM_DEVICE, stream) == 0, L.last_error()
+
+    def dec_once():
+        assert lib.lz4flex_decompress_batch(ctx, p(comp), p(comp_off), p(clen), n, p(back), p(in_off), p(in_len), p(blen), p(bst),
+                                            None, L.MEM_DEVICE, stream) == 0, L.last_error()
+
+    comp_once(); dec_once(); torch.cuda.synchronize()
+    if args.prof:
+        lib.lz4flex_debug_wave_prof.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        vals = (C.c_ulonglong * 8)()
+        assert lib.lz4flex_debug_wave_prof(ctx, 1, None) == 0
+        comp_once(); torch.cuda.synchronize()
+        assert lib.lz4flex_debug_wave_prof(ctx, 0, vals) == 0
+        v = list(vals)
+        nw = max(v[7], 1)
+        names = ["idx_busy", "idx_barrier", "match(sum 8 waves)", "wait_after_match", "place", "load_window", "wait_after_load"]
+        print("per window cycles: " + ", ".join("%s=%.0f" % (nm, x / nw) for nm, x in zip(names, v)) + " windows=%d" % v[7], flush=True)
+    ok = int((st != 0).sum().item()) == 0 and int((bst != 0).sum().item()) == 0 and torch.equal(back, src)
+    tc, td = [], []
+    for _ in range(args.reps):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record(); comp_once(); e[1].record(); dec_once(); e[2].record()
+        torch.cuda.synchronize()
+        tc.append(e[0].elapsed_time(e[1])); td.append(e[1].elapsed_time(e[2]))
+    ratio = float(clen.to(torch.int64).sum().item()) / (n * B)
+    print("data=%s blocks=%d mode=%d round_trip_ok=%s ratio=%.4f compress_ms=%s decompress_ms=%s" %
+          (args.data, n, args.mode, ok, ratio, ["%.3f" % x for x in tc], ["%.3f" % x for x in td]), flush=True)
+
+
+if __name__ == "__main__":
+    main()
