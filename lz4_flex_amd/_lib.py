@@ -92,7 +92,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("LZ4FLEX_LIB") or LIB_PATH     # LZ4FLEX_LIB: tools only (kernel experiments, build.build_variant)
+    if not os.path.exists(path):
         raise ImportError(
             "lz4_flex_amd: %s is missing. Build it with `python -m lz4_flex_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
@@ -101,7 +102,7 @@ def load():
             import torch  # noqa: F401  (HIP runtime unification; plumbing only)
         except Exception:
             pass
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res

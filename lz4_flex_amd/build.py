@@ -96,5 +96,34 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, extra_flags):
+    """tools only: a second copy of the library compiled with extra -D flags (kernel experiments), next to the
+    objects in build/; selected by LZ4FLEX_LIB=<path> (see _lib.load)"""
+    hipcc = _hipcc()
+    vdir = os.path.join(BDIR, "variant_" + name)
+    os.makedirs(vdir, exist_ok=True)
+    objs, procs = [], []
+    for src in sources():
+        obj = os.path.join(vdir, src + ".o")
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ['-DLZ4FLEX_BUILD_ID="variant-%s"' % name, "-x", "hip", "-c",
+                                                     os.path.join(CSRC, src), "-o", obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
+    lib = os.path.join(vdir, "liblz4flex_amd.so")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:      # python -m lz4_flex_amd.build --variant w11 -DLZ4W_WORKERS=11
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -44,8 +44,14 @@ typedef __attribute__((address_space(1))) uint32_t g_u32;
 typedef __attribute__((address_space(1))) int32_t g_i32;
 
 constexpr uint32_t WINDOW = 65536u;
-constexpr uint32_t SEG = 8192u;
-constexpr uint32_t WORKERS = 8u;          // WINDOW / SEG
+#ifndef LZ4W_WORKERS
+#define LZ4W_WORKERS 8
+#endif
+constexpr uint32_t WORKERS = LZ4W_WORKERS;   // worker wavefronts = segments per window
+constexpr uint32_t GROUPS = WINDOW / 512u;   // segment boundaries are multiples of 512 (one cand[] group)
+// segment w of a full window = [seg_lo(w), seg_lo(w + 1)); a shorter window clips them
+__host__ __device__ constexpr uint32_t seg_lo(uint32_t w) { return 512u * ((GROUPS * w) / WORKERS); }
+constexpr uint32_t SEG = seg_lo(1u) > WINDOW / WORKERS ? seg_lo(1u) : 512u * ((GROUPS + WORKERS - 1u) / WORKERS);   // longest segment
 constexpr uint32_t CAP = 1024u;           // longest match a head counts
 constexpr uint32_t SKIPD = 64u;           // a position buried this deep in a running match is not evaluated
 constexpr uint32_t HBITS = 12u;
@@ -53,7 +59,7 @@ constexpr uint32_t THREADS = 64u * (WORKERS + 1u);
 constexpr uint32_t STG_BYTES = 512u;      // per worker: encoded sequences waiting for a 16 B-per-lane flush
 constexpr uint32_t FLUSH_AT = 208u;       // a step adds at most 16 x 18 = 288 bytes on the lane-parallel path
 constexpr uint32_t CHUNK = 1024u;         // the indexer streams the next window in 1 KiB chunks (16 steps)
-constexpr uint32_t CHUNK_SLOT = CHUNK + 16u;
+constexpr uint32_t CHUNK_SLOT = CHUNK + 16u;      // + the first bytes of the next chunk (positions 1021..1023 hash across the end)
 constexpr uint32_t IDX_DEPTH = 4u;        // chunks in flight (registers) ahead of the one being indexed
 // LDS layout (81 200 B: two workgroups per CU)
 constexpr uint32_t L_WIN = 0u;                              // the window + 64 B of slack for the 16-byte compares
@@ -63,9 +69,10 @@ constexpr uint32_t L_RING = L_STG + WORKERS * STG_BYTES;    // two chunk slots o
 constexpr uint32_t L_META = L_RING + 2u * CHUNK_SLOT;
 constexpr uint32_t LDS_BYTES = L_META + 256u;
 static_assert(LDS_BYTES <= 81920u, "two workgroups per CU");
+static_assert(WORKERS >= 1u && WORKERS <= 15u && seg_lo(WORKERS) == WINDOW, "segments tile the window");
 // workspace per workgroup
 constexpr uint32_t SLOT_BYTES = 2u * WINDOW;                // cand[] of one window, transposed: see index_window
-constexpr uint32_t BODY_STRIDE = SEG + 256u;                // a segment's encoded bytes never exceed SEG + SEG/255 + 16
+constexpr uint32_t BODY_STRIDE = (SEG + SEG / 128u + 255u) / 256u * 256u + 256u;   // a segment's encoded bytes never exceed SEG + SEG/255 + 16
 constexpr uint32_t WS_BYTES = 2u * SLOT_BYTES + WORKERS * BODY_STRIDE;
 static_assert(WS_BYTES % 256u == 0u, "workspace slots stay 256 B aligned");
 
@@ -129,26 +136,49 @@ __device__ __forceinline__ G* uni_gptr(T* p) {
 // (64 g + i) * 16 + 2 u.
 struct ChunkRegs { u32x4 main; uint32_t extra; };
 
-__device__ __forceinline__ ChunkRegs chunk_issue(const g_u8* __restrict__ gwin, uint32_t c, uint32_t nfull, uint32_t lane) {
-    ChunkRegs r;
-    r.main = u32x4{0u, 0u, 0u, 0u};
-    r.extra = 0u;
-    if (c < nfull) {
-        __builtin_memcpy(&r.main, (const void*)(gwin + c * CHUNK + 16u * lane), 16);
-        if (lane == 0u) __builtin_memcpy(&r.extra, (const void*)(gwin + c * CHUNK + CHUNK), 4);
-    }
-    return r;
+// The chunk loads are inline assembly with hand-counted waits.  Written as plain loads hipcc sank them to their use
+// (register pressure), volatile loads are each followed by s_waitcnt vmcnt(0): either way a single wavefront saw the
+// full HBM latency 64 times per window.  gfx950 retires vector memory operations in issue order on one vmcnt, so "at
+// most N younger operations outstanding" means the two loads of the chunk have landed.  Between chunk_issue and
+// chunk_wait the destination registers must not be read, copied or spilled: tests/test_isa_checks.py verifies that on
+// the generated ISA (the "; lz4w-wait" marker names the registers).
+__device__ __forceinline__ void chunk_issue(ChunkRegs& r, const g_u8* __restrict__ gwin, uint32_t c, uint32_t lane) {
+    const g_u8* pm = gwin + c * CHUNK + 16u * lane;
+    const g_u8* pe = gwin + c * CHUNK + CHUNK;                     // same address in every lane
+    asm volatile("global_load_dwordx4 %0, %1, off ; lz4w-load" : "=v"(r.main) : "v"(pm) : "memory");
+    asm volatile("global_load_dword %0, %1, off ; lz4w-load" : "=v"(r.extra) : "v"(pe) : "memory");
 }
-__device__ __forceinline__ void chunk_fill(lds_u8* slot, const ChunkRegs& r, const g_u8* __restrict__ gwin, uint32_t c,
-                                           uint32_t nfull, uint32_t rd_n, uint32_t lane) {
-    if (c < nfull) {
-        __builtin_memcpy((void*)(slot + 16u * lane), &r.main, 16);
-        if (lane == 0u) __builtin_memcpy((void*)(slot + CHUNK), &r.extra, 4);
-    } else {                                        // the block's tail (at most once per window): byte by byte, zero padded
-        for (uint32_t i = lane; i < CHUNK + 4u; i += 64u) {
-            const uint32_t o = c * CHUNK + i;
-            slot[i] = o < rd_n ? gwin[o] : (uint8_t)0;
+template <int N>
+__device__ __forceinline__ void chunk_wait(ChunkRegs& r) {
+    asm volatile("s_waitcnt vmcnt(%2) ; lz4w-wait %0 %1" : "+v"(r.main), "+v"(r.extra) : "n"(N) : "memory");
+}
+// 16 steps of one chunk that sits in the LDS slot.  lp = slot + (lane & ~3): every LDS address below is lp + constant.
+// FULL: every position is active (p < act_n), no predication.
+template <bool FULL>
+__device__ __forceinline__ void index_chunk(const lds_u8* lp, lds_u16* tab, g_u8* __restrict__ cand_lane, uint32_t c, uint32_t act_n,
+                                            uint32_t lane) {
+#pragma unroll
+    for (uint32_t g2 = 0; g2 < 2u; ++g2) {
+        uint32_t pk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) {
+            const uint32_t st = g2 * 8u + u;                    // step in the chunk: offsets 64 st + lane
+            const uint32_t p = c * CHUNK + st * 64u + lane;
+            // the 4 bytes at that offset from two ALIGNED dwords: a byte-unaligned LDS access is executed one lane per
+            // cycle (64 cycles per instruction; tools/ubench_lds.hip), an aligned one in 2-4
+            const lds_u32* ap = (const lds_u32*)(lp + st * 64u);
+            const uint32_t x = __builtin_amdgcn_alignbyte(ap[1], ap[0], lane & 3u);
+            const uint32_t h = (x * 2654435761u) >> (32u - HBITS);
+            uint32_t d = 0u;
+            if (FULL || p < act_n) {
+                const uint32_t e = tab[h];
+                tab[h] = (uint16_t)p;
+                d = (p - e) & 0xFFFFu;
+            }
+            pk[u >> 1] |= d << (16u * (u & 1u));
         }
+        const u32x4 v = {pk[0], pk[1], pk[2], pk[3]};
+        *reinterpret_cast<g_u32x4*>(cand_lane + (size_t)(c * 2u + g2) * 1024u) = v;     // group (2 c + g2), lane: (64 g + lane) * 16
     }
 }
 
@@ -163,41 +193,73 @@ __device__ __attribute__((noinline)) void index_window(const uint8_t* __restrict
         for (uint32_t i = lane; i < (2u << HBITS) / 4u; i += 64u) t4[i] = 0u;
     }
     const uint32_t nchunks = (wl + CHUNK - 1u) / CHUNK;
-    const uint32_t nfull = rd_n >= CHUNK + 4u ? (rd_n - 4u) / CHUNK : 0u;       // chunks whose 1028 bytes are all readable
-    ChunkRegs q[IDX_DEPTH];
+    // main part: chunks whose 1028 bytes are readable and whose 1024 positions are all active -- straight-line code, so
+    // that the compiler's s_waitcnt counts stay exact and IDX_DEPTH chunks really are in flight
+    uint32_t n_main = rd_n >= CHUNK + 4u ? (rd_n - 4u) / CHUNK : 0u;
+    n_main = n_main < act_n / CHUNK ? n_main : act_n / CHUNK;
+    n_main = n_main < nchunks ? n_main : nchunks;
+    g_u8* cand_lane = slot_t + 16u * lane;
+    const uint32_t lane4 = lane & ~3u;
+    if (n_main != 0u) {
+        const uint32_t last = n_main - 1u;
+        ChunkRegs q[IDX_DEPTH];
 #pragma unroll
-    for (uint32_t j = 0; j < IDX_DEPTH; ++j) q[j] = chunk_issue(gwin, j, nfull, lane);
-    for (uint32_t c0 = 0; c0 < nchunks; c0 += IDX_DEPTH) {
-#pragma unroll
-        for (uint32_t j = 0; j < IDX_DEPTH; ++j) {
-            const uint32_t c = c0 + j;
-            if (c < nchunks) {
-                lds_u8* sl = lds + L_RING + (j & 1u) * CHUNK_SLOT;
-                chunk_fill(sl, q[j], gwin, c, nfull, rd_n, lane);
-                q[j] = chunk_issue(gwin, c + IDX_DEPTH, c + IDX_DEPTH < nchunks ? nfull : 0u, lane);
-#pragma unroll
-                for (uint32_t g2 = 0; g2 < 2u; ++g2) {
-                    uint32_t pk[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                    for (uint32_t u = 0; u < 8u; ++u) {
-                        const uint32_t o = (g2 * 8u + u) * 64u + lane;       // offset in the chunk
-                        const uint32_t p = c * CHUNK + o;
-                        uint32_t x;
-                        __builtin_memcpy(&x, (const void*)(sl + o), 4);
-                        const uint32_t h = (x * 2654435761u) >> (32u - HBITS);
-                        uint32_t d = 0u;
-                        if (p < act_n) {
-                            const uint32_t e = tab[h];
-                            tab[h] = (uint16_t)p;
-                            d = (p - e) & 0xFFFFu;
-                        }
-                        pk[u >> 1] |= d << (16u * (u & 1u));
-                    }
-                    const u32x4 v = {pk[0], pk[1], pk[2], pk[3]};
-                    *reinterpret_cast<g_u32x4*>(slot_t + ((size_t)(c * 2u + g2) * 64u + lane) * 16u) = v;
-                }
-            }
+        for (uint32_t j = 0; j < IDX_DEPTH; ++j) chunk_issue(q[j], gwin, j < last ? j : last, lane);   // past the end: the last chunk again
+        // one chunk: wait for its two loads (N = vector memory operations issued after them), LDS slot, refill the
+        // registers, 16 steps.  Issue order per chunk: [wait], 2 loads, 2 cand[] stores.
+#define LZ4W_ONE_CHUNK(N, CC, J)                                                                    \
+        {                                                                                           \
+            lds_u8* sl = lds + L_RING + ((J) & 1u) * CHUNK_SLOT;                                    \
+            chunk_wait<N>(q[J]);                                                                    \
+            __builtin_memcpy((void*)(sl + 16u * lane), &q[J].main, 16);                             \
+            __builtin_memcpy((void*)(sl + CHUNK), &q[J].extra, 4);   /* every lane writes the same dword */ \
+            const uint32_t cn = (CC) + IDX_DEPTH;                                                   \
+            chunk_issue(q[J], gwin, cn < last ? cn : last, lane);                                   \
+            index_chunk<true>(sl + lane4, tab, cand_lane, (CC), act_n, lane);                       \
         }
+        static_assert(IDX_DEPTH == 4u, "the wait counts below are for four chunks in flight");
+        uint32_t c = 0u;
+        if (n_main >= IDX_DEPTH) {                       // first round: fewer stores are in flight yet
+            LZ4W_ONE_CHUNK(6, 0u, 0)
+            LZ4W_ONE_CHUNK(8, 1u, 1)
+            LZ4W_ONE_CHUNK(10, 2u, 2)
+            LZ4W_ONE_CHUNK(12, 3u, 3)
+            c = IDX_DEPTH;
+        }
+        for (; c + IDX_DEPTH <= n_main; c += IDX_DEPTH) {   // steady state: 3 x 2 loads + 4 x 2 stores are younger
+            LZ4W_ONE_CHUNK(14, c, 0)
+            LZ4W_ONE_CHUNK(14, c + 1u, 1)
+            LZ4W_ONE_CHUNK(14, c + 2u, 2)
+            LZ4W_ONE_CHUNK(14, c + 3u, 3)
+        }
+#undef LZ4W_ONE_CHUNK
+        // the <= 3 chunks left are already requested (q[0..2]): drain everything, then index them
+        chunk_wait<0>(q[0]); chunk_wait<0>(q[1]); chunk_wait<0>(q[2]); chunk_wait<0>(q[3]);
+        for (uint32_t j = 0; c < n_main; ++c, ++j) {
+            lds_u8* sl = lds + L_RING + (j & 1u) * CHUNK_SLOT;
+            const ChunkRegs r = j == 0u ? q[0] : (j == 1u ? q[1] : q[2]);
+            __builtin_memcpy((void*)(sl + 16u * lane), &r.main, 16);
+            __builtin_memcpy((void*)(sl + CHUNK), &r.extra, 4);
+            index_chunk<true>(sl + lane4, tab, cand_lane, c, act_n, lane);
+        }
+    }
+    // tail (the block's last chunk or two): readable bytes end inside the chunk and / or its last positions may not start a
+    // match; filled synchronously, zero padded
+    for (uint32_t c = n_main; c < nchunks; ++c) {
+        lds_u8* sl = lds + L_RING;
+        const uint32_t base = c * CHUNK;
+        for (uint32_t i = lane; i < (CHUNK + 16u) / 16u; i += 64u) {
+            const uint32_t o = base + 16u * i;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (o + 16u <= rd_n) __builtin_memcpy(&v, (const void*)(gwin + o), 16);
+            __builtin_memcpy((void*)(sl + 16u * i), &v, 16);
+        }
+        const uint32_t part = rd_n > base ? ((rd_n - base) & ~15u) : 0u;             // bytes of this chunk covered by 16-byte loads
+        if (part < CHUNK + 16u && lane < 16u) {
+            const uint32_t o = base + part + lane;
+            if (part + lane < CHUNK + 16u) sl[part + lane] = o < rd_n ? gwin[o] : (uint8_t)0;
+        }
+        index_chunk<false>(sl + lane4, tab, cand_lane, c, act_n, lane);
     }
 }
 
@@ -299,15 +361,15 @@ __device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8
     W.lane = lane;
     W.fill = 0u; W.body_len = 0u; W.has = 0u; W.first_lit = 0u; W.first_ml = 0u;
     uint32_t cursor = s0, anchor = s0, carry = 0u, dlast = 0u;
-    // cand[]: 16 bytes per lane and group of 8 steps (see index_window), fetched one group ahead
-    u32x4 dn = {0u, 0u, 0u, 0u};
-    if (s0 < s1) dn = *reinterpret_cast<const g_u32x4*>(cand_t + ((size_t)(s0 >> 9) * 64u + lane) * 16u);
+    // cand[]: 16 bytes per lane and group of 8 steps (see index_window), fetched one group ahead.  The load is
+    // unconditional (the group behind the last one is still inside the workspace): a conditional load made hipcc wait
+    // for the data right where it was requested.
+    u32x4 dn = *reinterpret_cast<const g_u32x4*>(cand_t + ((size_t)(s0 >> 9) * 64u + lane) * 16u);
+    for (uint32_t gb = s0; gb < s1; gb += 512u) {
     u32x4 dc = dn;
-    for (uint32_t b = s0; b < s1; b += 64u) {
-        if ((b & 511u) == 0u) {
-            dc = dn;
-            if (b + 512u < s1) dn = *reinterpret_cast<const g_u32x4*>(cand_t + ((size_t)((b + 512u) >> 9) * 64u + lane) * 16u);
-        }
+    dn = *reinterpret_cast<const g_u32x4*>(cand_t + ((size_t)((gb + 512u) >> 9) * 64u + lane) * 16u);
+    const uint32_t ge = gb + 512u < s1 ? gb + 512u : s1;
+    for (uint32_t b = gb; b < ge; b += 64u) {
         const uint32_t p = b + lane;
         const bool inseg = p < s1;
         const uint32_t d = inseg ? (dc.x & 0xFFFFu) : 0u;
@@ -423,6 +485,7 @@ __device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8
         }
         if (W.fill >= FLUSH_AT) W.flush(false);
     }
+    }
     W.flush(true);
     if (lane == 0u) {
         lds_u32* mp = (lds_u32*)(lds + L_META) + 5u * w;
@@ -485,8 +548,12 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
     lds_u32* cp = (lds_u32*)(lds + L_META) + 5u * WORKERS;          // BlkCarry[2]
     uint32_t out_pos = 0u, pend = 0u;
     if (win_idx != 0u) { out_pos = cp[2u * (carry_slot ^ 1u)]; pend = cp[2u * (carry_slot ^ 1u) + 1u]; }
+    auto seg_len = [&](uint32_t j) -> uint32_t {
+        const uint32_t lo = seg_lo(j) < wl ? seg_lo(j) : wl, hi = seg_lo(j + 1u) < wl ? seg_lo(j + 1u) : wl;
+        return hi - lo;
+    };
     for (uint32_t j = 0; j < w; ++j) {
-        const uint32_t sl = wl > j * SEG ? (wl - j * SEG < SEG ? wl - j * SEG : SEG) : 0u;
+        const uint32_t sl = seg_len(j);
         if (mp[5u * j] != 0u) {
             const uint32_t L = pend + mp[5u * j + 1u];
             out_pos += 1u + len_ext_bytes(L) + L + mp[5u * j + 4u];
@@ -495,8 +562,8 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
             pend += sl;
         }
     }
-    const uint32_t sl = wl > w * SEG ? (wl - w * SEG < SEG ? wl - w * SEG : SEG) : 0u;
-    const uint32_t abs0 = win_idx * WINDOW + w * SEG;              // block-relative start of this segment
+    const uint32_t sl = seg_len(w);
+    const uint32_t abs0 = win_idx * WINDOW + seg_lo(w);            // block-relative start of this segment
     if (mp[5u * w] != 0u) {
         const uint32_t fl = mp[5u * w + 1u], L = pend + fl, ml = mp[5u * w + 2u] - 4u, bl = mp[5u * w + 4u];
         put_len_header(gout + out_pos, L, ml < 15u ? ml : 15u, lane);
@@ -524,8 +591,9 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
     }
 }
 
-// the current window into LDS: 512 worker threads, 16 B per thread and load, four loads in flight per thread
+// the current window into LDS: the worker threads, 16 B per thread and load, four loads in flight per thread
 __device__ __attribute__((noinline)) void load_window(const uint8_t* __restrict__ g_, uint32_t wl_, lds_u8* lds, uint32_t tid) {
+    constexpr uint32_t NT = 64u * WORKERS;
     const g_u8* __restrict__ g = uni_gptr<const g_u8>(g_);
     const uint32_t wl = uni(wl_);
     const uint32_t mis = (uint32_t)((16u - ((uintptr_t)g & 15u)) & 15u);    // bytes up to the first 16 B boundary
@@ -535,18 +603,18 @@ __device__ __attribute__((noinline)) void load_window(const uint8_t* __restrict_
     const g_u8* gp = g + head + 16u * tid;
     lds_u8* lp = lds + L_WIN + head + 16u * tid;
 #pragma unroll 1
-    for (uint32_t i0 = 0; i0 < nvec; i0 += 2048u) {
+    for (uint32_t i0 = 0; i0 < nvec; i0 += 4u * NT) {
         u32x4 v[4];
 #pragma unroll
         for (uint32_t j = 0; j < 4u; ++j) {
             v[j] = u32x4{0u, 0u, 0u, 0u};
-            if (i0 + tid + 512u * j < nvec) v[j] = *reinterpret_cast<const g_u32x4*>(gp + 8192u * j);
+            if (i0 + tid + NT * j < nvec) v[j] = *reinterpret_cast<const g_u32x4*>(gp + 16u * NT * j);
         }
 #pragma unroll
         for (uint32_t j = 0; j < 4u; ++j)
-            if (i0 + tid + 512u * j < nvec) __builtin_memcpy((void*)(lp + 8192u * j), &v[j], 16);
-        gp += 32768u;
-        lp += 32768u;
+            if (i0 + tid + NT * j < nvec) __builtin_memcpy((void*)(lp + 16u * NT * j), &v[j], 16);
+        gp += 64u * NT;
+        lp += 64u * NT;
     }
     const uint32_t done = head + 16u * nvec;
     if (tid < wl - done) lds[L_WIN + done + tid] = g[done + tid];
@@ -632,8 +700,8 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
             if (ix.blk < a.n) { do_index(ix, (k + 1u) & 1u); item_next(a, ix); }
         } else if (!it.skip) {
             const uint32_t base = it.win * WINDOW;
-            const uint32_t s0 = w * SEG < wl ? w * SEG : wl;
-            const uint32_t s1 = (w + 1u) * SEG < wl ? (w + 1u) * SEG : wl;
+            const uint32_t s0 = seg_lo(w) < wl ? seg_lo(w) : wl;
+            const uint32_t s1 = seg_lo(w + 1u) < wl ? seg_lo(w + 1u) : wl;
             const uint32_t act_abs = it.len >= 12u ? it.len - 11u : 0u;
             const uint32_t mfl_end = act_abs > base ? act_abs - base : 0u;      // window-relative, may exceed wl
             uint32_t mend = it.len >= 5u ? it.len - 5u : 0u;                    // block-relative

@@ -30,7 +30,7 @@
 #define WINDOW 65536u
 
 typedef struct {
-    uint32_t seg;    /* segment bytes (a power of two >= 64, <= 65536) */
+    uint32_t nseg;   /* segments per 64 KiB window (the kernel's worker wavefronts); boundaries are multiples of 512 */
     uint32_t cap;    /* longest match a head counts */
     uint32_t skipd;  /* a position buried this deep in a running match is not evaluated */
 } lz4w_params;
@@ -72,9 +72,14 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
     size_t ns = 0;
     uint32_t anchor = 0;
     uint32_t *best = (uint32_t *)calloc(WAVE, 4);
-    for (uint32_t s0 = 0; s0 < n; s0 += P->seg) {
-        const uint32_t s1 = (n - s0 < P->seg) ? n : s0 + P->seg;
-        const uint32_t wbase = s0 & ~(WINDOW - 1);                 /* candidates must lie in the segment's 64 KiB window */
+    const uint32_t nwin = (n + WINDOW - 1) / WINDOW;
+    for (uint32_t sj = 0; sj < nwin * P->nseg; sj++) {
+        const uint32_t wbase = (sj / P->nseg) * WINDOW;            /* candidates must lie in the segment's 64 KiB window */
+        const uint32_t wj = sj % P->nseg;
+        uint32_t s0 = wbase + 512u * ((128u * wj) / P->nseg), s1 = wbase + 512u * ((128u * (wj + 1)) / P->nseg);
+        if (s0 > n) s0 = n;
+        if (s1 > n) s1 = n;
+        if (s0 == s1) continue;
         uint32_t mend = (n >= 5) ? ((s1 < n - 5) ? s1 : n - 5) : 0;         /* matches end here at the latest */
         if (mend > wbase + 65535u) mend = wbase + 65535u;                    /* ends are 16-bit window-relative numbers */
         uint32_t carry = 0;    /* best (end << 16 | distance) so far in this segment; end is window-relative + 1.. see pack */

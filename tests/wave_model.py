@@ -7,11 +7,11 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "sim", "wave_encoder_model.c")
 SO = os.path.join(ROOT, "tests", "sim", "libwave_encoder_model.so")
-SEG, CAP, SKIPD = 8192, 1024, 64    # the kernel's constants (lz4_compress_wave.hip)
+NSEG, CAP, SKIPD = 8, 1024, 64    # the kernel's constants (lz4_compress_wave.hip: WORKERS, CAP, SKIPD)
 
 
 class Params(C.Structure):
-    _fields_ = [("seg", C.c_uint32), ("cap", C.c_uint32), ("skipd", C.c_uint32)]
+    _fields_ = [("nseg", C.c_uint32), ("cap", C.c_uint32), ("skipd", C.c_uint32)]
 
 
 _m = None
@@ -29,10 +29,10 @@ def lib():
     return _m
 
 
-def compress(data, seg=SEG, cap=CAP, skipd=SKIPD):
+def compress(data, nseg=NSEG, cap=CAP, skipd=SKIPD):
     data = bytes(data)
     out = C.create_string_buffer(20 + len(data) * 110 // 100 + 16)
-    p = Params(seg, cap, skipd)
+    p = Params(nseg, cap, skipd)
     ns = C.c_uint32(0)
     n = lib().lz4w_compress(data, len(data), out, C.byref(p), C.byref(ns))
     return out.raw[:n]

@@ -7,7 +7,7 @@
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 template <int BYTES>
-__global__ void k(const uint32_t* addr, uint64_t* out, int iters, int waves) {
+__global__ void k(const uint32_t* addr, uint64_t* out, int iters, int waves, int nact) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     for (int i = threadIdx.x; i < 65536 / 4; i += blockDim.x) ((uint32_t*)lds)[i] = i * 2654435761u;
     __syncthreads();
@@ -16,6 +16,7 @@ __global__ void k(const uint32_t* addr, uint64_t* out, int iters, int waves) {
     uint32_t acc = 0;
     __syncthreads();
     uint64_t t0 = __builtin_readcyclecounter();
+    if ((int)(threadIdx.x & 63) < nact)
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -25,6 +26,7 @@ __global__ void k(const uint32_t* addr, uint64_t* out, int iters, int waves) {
             if (BYTES == 8) { u32x2 v; __builtin_memcpy(&v, lds + a[j], 8); acc += v.x ^ v.y; }
             if (BYTES == 4) { uint32_t v; __builtin_memcpy(&v, lds + a[j], 4); acc += v; }
             if (BYTES == 2) { uint16_t v; __builtin_memcpy(&v, lds + a[j], 2); acc += v; }
+            if (BYTES == 1) { acc += lds[a[j]]; }
         }
     }
     uint64_t t1 = __builtin_readcyclecounter();
@@ -34,8 +36,8 @@ __global__ void k(const uint32_t* addr, uint64_t* out, int iters, int waves) {
 int main() {
     uint32_t* d_addr; uint64_t* d_out; hipMalloc(&d_addr, 512 * 4); hipMalloc(&d_out, 8 * 64 * 8);
     const int iters = 200;
-    struct { const char* name; int mode; } pats[] = {{"random aligned", 0}, {"random unaligned", 1}, {"consecutive bytes (lane i at +i)", 2}, {"consecutive aligned (lane i at +16i)", 3}, {"14 random heads, others same", 4}};
-    for (int waves : {1, 4, 8}) for (auto& p : pats) for (int bytes : {2, 4, 8, 16}) {
+    struct { const char* name; int mode; } pats[] = {{"random aligned", 0}, {"random unaligned", 1}};
+    for (int waves : {8}) for (int nact : {64, 32, 16, 8, 4, 1}) for (auto& p : pats) for (int bytes : {1, 2, 4, 16}) {
         uint32_t h[512]; srand(7);
         for (int j = 0; j < 512; j++) {
             uint32_t r = rand() % 60000;
@@ -47,13 +49,13 @@ int main() {
             h[j] = r;
         }
         hipMemcpy(d_addr, h, sizeof h, hipMemcpyHostToDevice);
-        void (*kern)(const uint32_t*, uint64_t*, int, int) = bytes == 16 ? k<16> : bytes == 8 ? k<8> : bytes == 4 ? k<4> : k<2>;
+        void (*kern)(const uint32_t*, uint64_t*, int, int, int) = bytes == 16 ? k<16> : bytes == 1 ? k<1> : bytes == 4 ? k<4> : k<2>;
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 64);
-        hipLaunchKernelGGL(kern, dim3(1), dim3(64 * waves), 65536 + 64, 0, d_addr, d_out, iters, waves);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(64 * waves), 65536 + 64, 0, d_addr, d_out, iters, waves, nact);
         hipDeviceSynchronize();
         uint64_t o[8]; hipMemcpy(o, d_out, sizeof o, hipMemcpyDeviceToHost);
         double mx = 0; for (int w = 0; w < waves; w++) mx = o[w] > mx ? o[w] : mx;
-        printf("waves/CU %d  %-40s %2d B/lane: %.1f cycles per wave-instruction (%.1f per CU)\n", waves, p.name, bytes, mx / (iters * 8.0), mx / (iters * 8.0) / waves);
+        printf("waves/CU %d active lanes %2d  %-40s %2d B/lane: %.1f cycles per wave-instruction (%.1f per CU)\n", waves, nact, p.name, bytes, mx / (iters * 8.0), mx / (iters * 8.0) / waves);
     }
     return 0;
 }
