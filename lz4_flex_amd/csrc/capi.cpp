@@ -180,16 +180,16 @@ void lz4flex_ctx_destroy(lz4flex_ctx* c) {
 }
 
 // tools only (not in the public header): enable != 0 starts / resets the wave encoder's per-role cycle counters of
-// this context, vals (nullable) receives the 8 sums accumulated so far
+// this context, vals (nullable) receives the 16 sums accumulated so far
 int lz4flex_debug_wave_prof(lz4flex_ctx* c, int enable, unsigned long long* vals) {
     if (!c) return -LZ4FLEX_E_INVALID_ARG;
     if (vals && c->wave_prof) {
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(vals, c->wave_prof, 64, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(vals, c->wave_prof, 128, hipMemcpyDeviceToHost));
     }
     if (enable) {
-        if (!c->wave_prof) HIP_TRY(hipMalloc((void**)&c->wave_prof, 64));
-        HIP_TRY(hipMemset(c->wave_prof, 0, 64));
+        if (!c->wave_prof) HIP_TRY(hipMalloc((void**)&c->wave_prof, 128));
+        HIP_TRY(hipMemset(c->wave_prof, 0, 128));
     } else if (c->wave_prof) {
         (void)hipFree(c->wave_prof);
         c->wave_prof = nullptr;

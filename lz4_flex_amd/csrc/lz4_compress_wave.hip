@@ -56,8 +56,9 @@ constexpr uint32_t CAP = 1024u;           // longest match a head counts
 constexpr uint32_t SKIPD = 64u;           // a position buried this deep in a running match is not evaluated
 constexpr uint32_t HBITS = 12u;
 constexpr uint32_t THREADS = 64u * (WORKERS + 1u);
-constexpr uint32_t STG_BYTES = 512u;      // per worker: encoded sequences waiting for a 16 B-per-lane flush
-constexpr uint32_t FLUSH_AT = 208u;       // a step adds at most 16 x 18 = 288 bytes on the lane-parallel path
+constexpr uint32_t STG_BYTES = 448u;      // per worker: encoded sequences waiting for a 16 B-per-lane flush
+constexpr uint32_t FLUSH_AT = 160u;       // a staging round adds at most 16 x 18 = 288 bytes on the lane-parallel path
+constexpr uint32_t WORKER_LDS = STG_BYTES + 256u;   // + the compaction buffer of a superstep: 64 heads x 4 B
 constexpr uint32_t CHUNK = 1024u;         // the indexer streams the next window in 1 KiB chunks (16 steps)
 constexpr uint32_t CHUNK_SLOT = CHUNK + 16u;      // + the first bytes of the next chunk (positions 1021..1023 hash across the end)
 constexpr uint32_t IDX_DEPTH = 4u;        // chunks in flight (registers) ahead of the one being indexed
@@ -65,7 +66,7 @@ constexpr uint32_t IDX_DEPTH = 4u;        // chunks in flight (registers) ahead 
 constexpr uint32_t L_WIN = 0u;                              // the window + 64 B of slack for the 16-byte compares
 constexpr uint32_t L_TAB = WINDOW + 64u;                    // the indexer's table, 4096 x u16
 constexpr uint32_t L_STG = L_TAB + (2u << HBITS);
-constexpr uint32_t L_RING = L_STG + WORKERS * STG_BYTES;    // two chunk slots of the indexer
+constexpr uint32_t L_RING = L_STG + WORKERS * WORKER_LDS;   // two chunk slots of the indexer
 constexpr uint32_t L_META = L_RING + 2u * CHUNK_SLOT;
 constexpr uint32_t LDS_BYTES = L_META + 256u;
 static_assert(LDS_BYTES <= 81920u, "two workgroups per CU");
@@ -276,7 +277,11 @@ struct Worker {
         const uint32_t n16 = fill & ~15u;
         for (uint32_t i = 16u * lane; i < n16; i += 1024u) {
             const u32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(stg + i);
+#ifndef LZ4W_EXP_NOSTORE     // timing experiment only (tools): how much do the flush stores cost the cand[] wait?
             *reinterpret_cast<g_u32x4*>(body + body_len + i) = v;
+#else
+            asm volatile("" :: "v"(v));
+#endif
         }
         const uint32_t rem = fill - n16;
         if (all) {
@@ -348,19 +353,35 @@ __device__ __forceinline__ void copy_lit_small(lds_u8* dst, const lds_u8* src, u
     if (n & 1u) dst[n & 14u] = (uint8_t)(wq >> (n2 ? 16 : 0));
 }
 
-// One segment [s0, s1) of the window in LDS.  mfl: positions p < mfl_end may start a match (p <= n - 12);
+// One segment [s0, s1) of the window in LDS.  mfl_end: positions p < mfl_end may start a match (p <= n - 12);
 // mend: matches end here at the latest (segment end, block end - 5, 65535).
+//
+// The segment is walked in SUPERSTEPS of up to 256 positions (4 steps of 64: lane i looks at positions b + 64 u + i).
+// Only ~1 position in 5 is a head, and everything expensive happens per head, so the heads of a superstep are
+// compacted into the 64 lanes (rank = popcount of the head ballots below the lane, a 256-byte LDS buffer), counted,
+// prefix-maximised and handed to a scalar greedy walk that sees the superstep through the four head ballots:
+//   rank(p) = number of heads at or before p (s_bcnt1 on the ballots), best(p) = v_readlane(bestv, rank(p) - 1).
+// A superstep holds at most 64 heads by construction: 256 positions if that many fit, else 128, else 64 (the scalar
+// model walks the same supersteps).  The selected sequences (at most 64: a match is >= 4 long) are placed in lanes
+// (lane k = sequence k) and encoded lane-parallel, 16 sequences per staging round.
 __device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8_t* __restrict__ cand_t_, uint8_t* body_, uint32_t w_, uint32_t lane,
-                              uint32_t s0_, uint32_t s1_, uint32_t mfl_end_, uint32_t mend_) {
+                              uint32_t s0_, uint32_t s1_, uint32_t mfl_end_, uint32_t mend_, unsigned long long* prof_) {
     const uint32_t w = uni(w_), s0 = uni(s0_), s1 = uni(s1_), mfl_end = uni(mfl_end_), mend = uni(mend_);
     const g_u8* __restrict__ cand_t = uni_gptr<const g_u8>(cand_t_);
     Worker W;
     W.win = lds + L_WIN;
-    W.stg = lds + L_STG + w * STG_BYTES;
+    W.stg = lds + L_STG + w * WORKER_LDS;
+    lds_u32* cmp = (lds_u32*)(lds + L_STG + w * WORKER_LDS + STG_BYTES);
     W.body = uni_gptr<g_u8>(body_);
     W.lane = lane;
     W.fill = 0u; W.body_len = 0u; W.has = 0u; W.first_lit = 0u; W.first_ml = 0u;
     uint32_t cursor = s0, anchor = s0, carry = 0u, dlast = 0u;
+#ifdef LZ4W_PROF_STEPS      // tools: cycles per part of a superstep -> prof[8..13] (heads, compaction + lengths, scan, walk, encode, supersteps)
+    uint64_t pt[5] = {0, 0, 0, 0, 0}, pn = 0, pt0 = __builtin_readcyclecounter();
+#define LZ4W_TICK(i) { const uint64_t t_ = __builtin_readcyclecounter(); pt[i] += t_ - pt0; pt0 = t_; }
+#else
+#define LZ4W_TICK(i)
+#endif
     // cand[]: 16 bytes per lane and group of 8 steps (see index_window), fetched one group ahead.  The load is
     // unconditional (the group behind the last one is still inside the workspace): a conditional load made hipcc wait
     // for the data right where it was requested.
@@ -368,125 +389,223 @@ __device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8
     for (uint32_t gb = s0; gb < s1; gb += 512u) {
     u32x4 dc = dn;
     dn = *reinterpret_cast<const g_u32x4*>(cand_t + ((size_t)((gb + 512u) >> 9) * 64u + lane) * 16u);
-    const uint32_t ge = gb + 512u < s1 ? gb + 512u : s1;
-    for (uint32_t b = gb; b < ge; b += 64u) {
-        const uint32_t p = b + lane;
-        const bool inseg = p < s1;
-        const uint32_t d = inseg ? (dc.x & 0xFFFFu) : 0u;
-        dc.x = __builtin_amdgcn_alignbit(dc.y, dc.x, 16);       // the 128-bit group moves down by one u16 per step
-        dc.y = __builtin_amdgcn_alignbit(dc.z, dc.y, 16);
-        dc.z = __builtin_amdgcn_alignbit(dc.w, dc.z, 16);
-        dc.w = dc.w >> 16;
-        const uint32_t dprev = dpp_wave_shr1(d, dlast);
-        dlast = rdlane(d, 63u);
-        const uint32_t cend = carry >> 16;
-        // the whole step lies deep inside a match already taken: nothing to evaluate, nothing to select
-        if (cursor >= b + 64u && cend >= b + 63u + SKIPD) continue;
-        // heads
-        const bool canstart = inseg & (p < mfl_end);
-        bool head = canstart & (d != 0u) & (d != dprev) & (d <= p);
-        head = head & !((cend > p) & (cend - p >= SKIPD));
-        uint32_t lim = mend > p ? mend - p : 0u;
-        lim = lim < CAP ? lim : CAP;
-        uint32_t k = 0u;
-        bool act = head & (lim >= 4u);
-        auto first_diff = [](const u32x4& va, const u32x4& vc) -> uint32_t {   // index of the first differing bit, 128 if none
-            const uint32_t f0 = ffbl(va.x ^ vc.x), f1 = ffbl(va.y ^ vc.y), f2 = ffbl(va.z ^ vc.z), f3 = ffbl(va.w ^ vc.w);
-            uint32_t bits = f3 < 32u ? f3 : 32u;
-            bits += 32u; bits = f2 < bits ? f2 : bits;
-            bits += 32u; bits = f1 < bits ? f1 : bits;
-            bits += 32u; bits = f0 < bits ? f0 : bits;
-            return bits;
-        };
-        if (__ballot(act) != 0ull) {
-            if (act) {                                          // 16 bytes, branch-free: most candidates end here
-                const lds_u8* ap = W.win + p;
-                u32x4 va, vc;
-                __builtin_memcpy(&va, (const void*)ap, 16);
-                __builtin_memcpy(&vc, (const void*)(ap - d), 16);
-                const uint32_t bits = first_diff(va, vc);
-                k = bits >> 3;
-                act = (bits == 128u) & (k < lim);
-            }
-            while (__ballot(act) != 0ull) {
-                if (act) {                                      // 32 bytes per further round
-                    const lds_u8* ap = W.win + p + k;
-                    u32x4 va0, vc0, va1, vc1;
-                    __builtin_memcpy(&va0, (const void*)ap, 16);
-                    __builtin_memcpy(&vc0, (const void*)(ap - d), 16);
-                    __builtin_memcpy(&va1, (const void*)(ap + 16), 16);
-                    __builtin_memcpy(&vc1, (const void*)(ap - d + 16), 16);
-                    const uint32_t b0 = first_diff(va0, vc0), b1 = first_diff(va1, vc1);
-                    const uint32_t bits = b0 < 128u ? b0 : 128u + b1;
-                    k += bits >> 3;
-                    act = (bits == 256u) & (k < lim);
+    for (uint32_t B0 = gb; B0 < gb + 512u && B0 < s1; B0 += 256u) {
+        // the four steps of this 256-block
+        uint32_t dq0 = dc.x & 0xFFFFu, dq1 = dc.x >> 16, dq2 = dc.y & 0xFFFFu, dq3 = dc.y >> 16;
+        dc.x = dc.z; dc.y = dc.w;
+        dq0 = (B0 + lane < s1) ? dq0 : 0u;
+        dq1 = (B0 + 64u + lane < s1) ? dq1 : 0u;
+        dq2 = (B0 + 128u + lane < s1) ? dq2 : 0u;
+        dq3 = (B0 + 192u + lane < s1) ? dq3 : 0u;
+        for (uint32_t j0 = 0u; j0 < 4u && B0 + 64u * j0 < s1;) {
+            const uint32_t b = B0 + 64u * j0;
+            const uint32_t maxs = j0 == 0u ? 4u : (j0 == 2u ? 2u : 1u);       // steps an aligned superstep may span from here
+            // t_u = distances of step u of this superstep
+            const uint32_t t0 = j0 == 0u ? dq0 : (j0 == 1u ? dq1 : (j0 == 2u ? dq2 : dq3));
+            const uint32_t t1 = j0 == 0u ? dq1 : dq3;
+            const uint32_t t2 = dq2, t3 = dq3;
+            LZ4W_TICK(4)
+            const uint32_t cend = carry >> 16;
+            {
+                const uint32_t e1m = b + 64u * maxs < s1 ? b + 64u * maxs : s1;
+                if (cursor >= e1m && cend >= e1m - 1u + SKIPD) {      // everything here lies deep inside a match already taken
+                    const uint32_t tl = maxs == 4u ? t3 : (maxs == 2u ? t1 : t0);
+                    dlast = rdlane(tl, 63u);
+                    j0 += maxs;
+                    continue;
                 }
             }
-        }
-        k = k < lim ? k : lim;
-        const uint32_t own = (head & (k >= 4u)) ? (((p + k) << 16) | d) : 0u;
-        // the match that reaches furthest, from any head at or before this position
-        uint32_t best = wave_incl_max(own);
-        best = best > carry ? best : carry;
-        carry = rdlane(best, 63u);
-        const uint32_t e = best >> 16;
-        const uint32_t e_next = dpp_wave_shl1(e, 0u);
-        const bool yield = (lane < 63u) & (p + 1u < s1) & (e_next > e + 1u);
-        const uint64_t em = __ballot(canstart & (e >= p + 4u) & !yield);
-        // greedy walk (scalar)
-        uint64_t sel = 0ull;
-        const uint32_t anchor_in = anchor;
-        while (cursor < b + 64u) {
-            const uint32_t c = cursor > b ? cursor - b : 0u;
-            const uint64_t m = em & (~0ull << c);
-            if (m == 0ull) break;
-            const uint32_t q = ctz64(m);
-            sel |= 1ull << q;
-            cursor = anchor = rdlane(e, q);
-        }
-        if (sel == 0ull) continue;
-        // encode the selected sequences
-        const bool issel = (sel >> lane) & 1ull;
-        const uint32_t len = e - p;
-        const uint32_t off = best & 0xFFFFu;
-        uint32_t pe = wave_incl_max(issel ? e : 0u);
-        pe = dpp_wave_shr1(pe, 0u);
-        pe = pe > anchor_in ? pe : anchor_in;             // end of the previous sequence
-        const uint32_t lit = p - pe;
-        const uint32_t mlc = len - 4u;
-        const bool hard = issel & ((lit >= 15u) | (mlc >= 270u));
-        if (__ballot(hard) == 0ull) {
-            const uint32_t fl = ctz64(sel);
-            const bool first = (W.has == 0u) & (lane == fl);
-            const uint32_t ext = mlc >= 15u ? 1u : 0u;
-            const uint32_t size = issel ? ((first ? 2u : 3u + lit) + ext) : 0u;
-            const uint32_t incl = wave_incl_add(size);
-            const uint32_t total = rdlane(incl, 63u);
-            if (issel) {
-                lds_u8* o = W.stg + W.fill + incl - size;
-                if (!first) {
-                    o[0] = (uint8_t)((lit << 4) | (mlc < 15u ? mlc : 15u));
-                    copy_lit_small(o + 1, W.win + pe, lit);
-                    o += 1u + lit;
+            // heads of the (up to) four steps: the distance changes, and the candidate's first 4 bytes equal the position's
+            // (both read as aligned dword pairs: an unaligned LDS access costs a cycle per active lane)
+            const uint32_t p0 = b + lane, p1 = p0 + 64u, p2 = p0 + 128u, p3 = p0 + 192u;
+            const uint32_t pv0 = dpp_wave_shr1(t0, dlast);
+            const uint32_t pv1 = dpp_wave_shr1(t1, rdlane(t0, 63u));
+            const uint32_t pv2 = dpp_wave_shr1(t2, rdlane(t1, 63u));
+            const uint32_t pv3 = dpp_wave_shr1(t3, rdlane(t2, 63u));
+            auto cand_ok = [&](uint32_t pp, uint32_t d, uint32_t dprev) -> bool {
+                const bool buried = (cend > pp) & (cend - pp >= SKIPD);
+                return (pp < s1) & (pp < mfl_end) & (d != 0u) & (d != dprev) & (d <= pp) & !buried;
+            };
+            const bool k0 = cand_ok(p0, t0, pv0);
+            const bool k1 = (maxs > 1u) & cand_ok(p1, t1, pv1);
+            const bool k2 = (maxs > 2u) & cand_ok(p2, t2, pv2);
+            const bool k3 = (maxs > 2u) & cand_ok(p3, t3, pv3);
+            // all eight 4-byte reads are issued before the first compare (one LDS round trip, not four): lanes without a
+            // candidate read their own position twice
+            auto ld4 = [&](uint32_t pos) -> uint32_t {
+                const lds_u32* ap = (const lds_u32*)(W.win + (pos & ~3u));
+                return __builtin_amdgcn_alignbyte(ap[1], ap[0], pos & 3u);
+            };
+            const uint32_t a0 = ld4(p0), a1 = ld4(p1 < WINDOW ? p1 : p0), a2 = ld4(p2 < WINDOW ? p2 : p0), a3 = ld4(p3 < WINDOW ? p3 : p0);
+            const uint32_t g0 = ld4(k0 ? p0 - t0 : p0), g1 = ld4(k1 ? p1 - t1 : p0), g2 = ld4(k2 ? p2 - t2 : p0), g3 = ld4(k3 ? p3 - t3 : p0);
+            const bool h0 = k0 & (a0 == g0), h1 = k1 & (a1 == g1), h2 = k2 & (a2 == g2), h3 = k3 & (a3 == g3);
+            const uint64_t m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+            const uint32_t c0 = (uint32_t)__builtin_popcountll(m0), c1 = (uint32_t)__builtin_popcountll(m1),
+                           c2 = (uint32_t)__builtin_popcountll(m2), c3 = (uint32_t)__builtin_popcountll(m3);
+            // the largest superstep that holds at most 64 heads
+            uint32_t ns = maxs, H = c0 + c1 + c2 + c3;
+            if (H > 64u && ns == 4u) { ns = 2u; H = c0 + c1; }
+            if (H > 64u && ns == 2u) { ns = 1u; H = c0; }
+            const uint32_t e1 = b + 64u * ns < s1 ? b + 64u * ns : s1;
+            const uint64_t M0 = m0, M1 = ns > 1u ? m1 : 0ull, M2 = ns > 2u ? m2 : 0ull, M3 = ns > 2u ? m3 : 0ull;
+            const uint32_t b1 = c0, b2 = c0 + c1, b3 = c0 + c1 + c2;             // heads before step u
+            {
+                const uint32_t tl = ns == 4u ? t3 : (ns == 2u ? t1 : t0);
+                dlast = rdlane(tl, 63u);
+            }
+            j0 += ns;
+            LZ4W_TICK(0)
+            if (H == 0u && cursor >= e1) continue;               // no head, nothing to select: the running best is unchanged
+            // compaction: head of rank r -> lane r, as (position << 16 | distance)
+            auto mbcnt = [&](uint64_t m) -> uint32_t {
+                return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            };
+            const uint32_t r0 = mbcnt(M0), r1 = b1 + mbcnt(M1), r2 = b2 + mbcnt(M2), r3 = b3 + mbcnt(M3);   // heads before this position
+            if (h0) cmp[r0] = (p0 << 16) | t0;
+            if (h1 & (ns > 1u)) cmp[r1] = (p1 << 16) | t1;
+            if (h2 & (ns > 2u)) cmp[r2] = (p2 << 16) | t2;
+            if (h3 & (ns > 2u)) cmp[r3] = (p3 << 16) | t3;
+            const bool isH = lane < H;
+            uint32_t hv = 0u;
+            if (isH) hv = cmp[lane];
+            const uint32_t p = hv >> 16, d = hv & 0xFFFFu;
+            // true match lengths of the heads (their first 4 bytes are known to match)
+            uint32_t lim = mend > p ? mend - p : 0u;
+            lim = lim < CAP ? lim : CAP;
+            uint32_t k = 4u;
+            bool act = isH & (lim > 4u);
+            auto first_diff = [](const u32x4& va, const u32x4& vc) -> uint32_t {   // index of the first differing bit, 128 if none
+                const uint32_t f0 = ffbl(va.x ^ vc.x), f1 = ffbl(va.y ^ vc.y), f2 = ffbl(va.z ^ vc.z), f3 = ffbl(va.w ^ vc.w);
+                uint32_t bits = f3 < 32u ? f3 : 32u;
+                bits += 32u; bits = f2 < bits ? f2 : bits;
+                bits += 32u; bits = f1 < bits ? f1 : bits;
+                bits += 32u; bits = f0 < bits ? f0 : bits;
+                return bits;
+            };
+            if (__ballot(act) != 0ull) {
+                if (act) {                                          // 16 bytes, branch-free: most candidates end here
+                    const lds_u8* ap = W.win + p + 4u;
+                    u32x4 va, vc;
+                    __builtin_memcpy(&va, (const void*)ap, 16);
+                    __builtin_memcpy(&vc, (const void*)(ap - d), 16);
+                    const uint32_t bits = first_diff(va, vc);
+                    k = 4u + (bits >> 3);
+                    act = (bits == 128u) & (k < lim);
                 }
-                const uint16_t o16 = (uint16_t)off;
-                __builtin_memcpy((void*)o, &o16, 2);
-                if (ext) o[2] = (uint8_t)(mlc - 15u);
+                while (__ballot(act) != 0ull) {
+                    if (act) {                                      // 32 bytes per further round
+                        const lds_u8* ap = W.win + p + k;
+                        u32x4 va0, vc0, va1, vc1;
+                        __builtin_memcpy(&va0, (const void*)ap, 16);
+                        __builtin_memcpy(&vc0, (const void*)(ap - d), 16);
+                        __builtin_memcpy(&va1, (const void*)(ap + 16), 16);
+                        __builtin_memcpy(&vc1, (const void*)(ap - d + 16), 16);
+                        const uint32_t d0 = first_diff(va0, vc0), d1 = first_diff(va1, vc1);
+                        const uint32_t bits = d0 < 128u ? d0 : 128u + d1;
+                        k += bits >> 3;
+                        act = (bits == 256u) & (k < lim);
+                    }
+                }
             }
-            if (W.has == 0u) { W.has = 1u; W.first_lit = rdlane(lit, fl); W.first_ml = rdlane(len, fl); }
-            W.fill += total;
-        } else {
-            uint64_t m = sel;
-            while (m != 0ull) {
-                const uint32_t q = ctz64(m);
-                m &= m - 1ull;
-                W.emit_generic(rdlane(pe, q), rdlane(lit, q), rdlane(off, q), rdlane(len, q));
+            k = k < lim ? k : lim;
+            LZ4W_TICK(1)
+            const uint32_t own = (isH & (k >= 4u)) ? (((p + k) << 16) | d) : 0u;
+            // bestv[r]: the match that reaches furthest among heads 0..r and everything before the superstep;
+            // bestsh[r]: the same before head r, i.e. with r heads passed
+            uint32_t bestv = wave_incl_max(own);
+            bestv = bestv > carry ? bestv : carry;
+            const uint32_t bestsh = dpp_wave_shr1(bestv, carry);
+            carry = rdlane(bestv, 63u);
+            // back to positions: every position takes the best of the heads at or before it (a gather by rank), then the
+            // eligibility mask of each step: a match of >= 4 that does not yield to the next position (one-step lazy
+            // evaluation: the successor reaches further by more than a byte; the last position of a superstep has none)
+            const uint32_t e1c = e1 < mfl_end ? e1 : mfl_end;
+            auto best_at = [&](uint32_t rbefore, bool hd) -> uint32_t {
+                const uint32_t ri = rbefore + (hd ? 1u : 0u);
+                const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((ri < 63u ? ri : 63u) << 2), (int)bestsh);
+                return ri >= 64u ? carry : g;
+            };
+            const uint32_t q0 = best_at(r0, h0);
+            const uint32_t q1 = best_at(r1, h1 & (ns > 1u));
+            const uint32_t q2 = best_at(r2, h2 & (ns > 2u));
+            const uint32_t q3 = best_at(r3, h3 & (ns > 2u));
+            const uint32_t e0 = q0 >> 16, ee1 = q1 >> 16, ee2 = q2 >> 16, ee3 = q3 >> 16;
+            auto elig = [&](uint32_t pp, uint32_t e, uint32_t enext) -> uint64_t {
+                return __ballot((pp < e1c) & (e >= pp + 4u) & !(enext > e + 1u));
+            };
+            const uint64_t em0 = elig(p0, e0, dpp_wave_shl1(e0, ns > 1u ? rdlane(ee1, 0u) : 0u));
+            const uint64_t em1 = ns > 1u ? elig(p1, ee1, dpp_wave_shl1(ee1, ns > 2u ? rdlane(ee2, 0u) : 0u)) : 0ull;
+            const uint64_t em2 = ns > 2u ? elig(p2, ee2, dpp_wave_shl1(ee2, rdlane(ee3, 0u))) : 0ull;
+            const uint64_t em3 = ns > 2u ? elig(p3, ee3, dpp_wave_shl1(ee3, 0u)) : 0ull;
+            LZ4W_TICK(2)
+            // ---- greedy walk (scalar): the first eligible position at or behind the cursor, step by step ----
+            uint32_t sqa = 0u, sqb = 0u, nsel = 0u;                  // sequence k: lane k of sqa = p | e << 16, sqb = prev end | distance << 16
+            auto walk = [&](uint64_t em, uint32_t qv, uint32_t base) {
+                while (cursor < base + 64u) {
+                    const uint32_t c = cursor > base ? cursor - base : 0u;
+                    const uint64_t m = em & (~0ull << c);
+                    if (m == 0ull) break;
+                    const uint32_t q = ctz64(m);
+                    const uint32_t bv = rdlane(qv, q);
+                    const bool mine = lane == nsel;
+                    sqa = mine ? ((base + q) | (bv & 0xFFFF0000u)) : sqa;
+                    sqb = mine ? (anchor | (bv << 16)) : sqb;
+                    nsel += 1u;
+                    cursor = anchor = bv >> 16;
+                }
+            };
+            walk(em0, q0, b);
+            if (ns > 1u) walk(em1, q1, b + 64u);
+            if (ns > 2u) { walk(em2, q2, b + 128u); walk(em3, q3, b + 192u); }
+            cursor = cursor > e1 ? cursor : e1;
+            LZ4W_TICK(3)
+#ifdef LZ4W_PROF_STEPS
+            pn += 1;
+#endif
+            if (nsel == 0u) continue;
+            // ---- encode the selected sequences: lane k = sequence k ----
+            const bool issel = lane < nsel;
+            const uint32_t sp = sqa & 0xFFFFu, se = sqa >> 16, pe = sqb & 0xFFFFu, off = sqb >> 16;
+            const uint32_t lit = sp - pe, len = se - sp, mlc = len - 4u;
+            const bool hard = issel & ((lit >= 15u) | (mlc >= 270u));
+            if (__ballot(hard) == 0ull) {
+                const bool first = (W.has == 0u) & (lane == 0u);
+                const uint32_t ext = mlc >= 15u ? 1u : 0u;
+                const uint32_t size = issel ? ((first ? 2u : 3u + lit) + ext) : 0u;
+                const uint32_t incl = wave_incl_add(size);
+                if (W.has == 0u) { W.has = 1u; W.first_lit = rdlane(lit, 0u); W.first_ml = rdlane(len, 0u); }
+                for (uint32_t c0q = 0u; c0q < nsel; c0q += 16u) {   // 16 sequences (<= 288 bytes) per staging round
+                    const uint32_t basec = c0q != 0u ? rdlane(incl, c0q - 1u) : 0u;
+                    const uint32_t endc = rdlane(incl, c0q + 15u);
+                    if (issel & (lane >= c0q) & (lane < c0q + 16u)) {
+                        lds_u8* o = W.stg + W.fill + (incl - size - basec);
+                        if (!first) {
+                            o[0] = (uint8_t)((lit << 4) | (mlc < 15u ? mlc : 15u));
+                            copy_lit_small(o + 1, W.win + pe, lit);
+                            o += 1u + lit;
+                        }
+                        const uint16_t o16 = (uint16_t)off;
+                        __builtin_memcpy((void*)o, &o16, 2);
+                        if (ext) o[2] = (uint8_t)(mlc - 15u);
+                    }
+                    W.fill += endc - basec;
+                    if (W.fill >= FLUSH_AT) W.flush(false);
+                }
+            } else {
+                for (uint32_t q = 0u; q < nsel; ++q)
+                    W.emit_generic(rdlane(pe, q), rdlane(lit, q), rdlane(off, q), rdlane(len, q));
+                if (W.fill >= FLUSH_AT) W.flush(false);
             }
         }
-        if (W.fill >= FLUSH_AT) W.flush(false);
     }
     }
     W.flush(true);
+#ifdef LZ4W_PROF_STEPS
+    if (prof_ && lane == 0u) {
+        for (int i = 0; i < 5; ++i) atomicAdd(prof_ + 8 + i, (unsigned long long)pt[i]);
+        atomicAdd(prof_ + 13, (unsigned long long)pn);
+    }
+#endif
     if (lane == 0u) {
         lds_u32* mp = (lds_u32*)(lds + L_META) + 5u * w;
         mp[0] = W.has; mp[1] = W.first_lit; mp[2] = W.first_ml; mp[3] = s1 - anchor; mp[4] = W.body_len;
@@ -708,7 +827,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
             mend = mend > base ? mend - base : 0u;
             mend = mend < s1 ? mend : s1;
             mend = mend < 65535u ? mend : 65535u;
-            match_segment(lds, slots + (size_t)(k & 1u) * SLOT_BYTES, bodies + (size_t)w * BODY_STRIDE, w, lane, s0, s1, mfl_end, mend);
+            match_segment(lds, slots + (size_t)(k & 1u) * SLOT_BYTES, bodies + (size_t)w * BODY_STRIDE, w, lane, s0, s1, mfl_end, mend, prof);
         }
         tick(w == WORKERS ? 0u : 2u);
         __syncthreads();

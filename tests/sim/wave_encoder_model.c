@@ -11,11 +11,12 @@
  *  index  : positions are visited in steps of 64; every position p <= n-12 looks its 4-byte hash up in a
  *           4096-entry table of 16-bit positions (all lookups of a step before all inserts of the step,
  *           highest position wins an insert conflict) and records d[p] = distance to that candidate.
- *  match  : a position whose distance differs from its predecessor's is a "head": its true match length is
- *           counted byte by byte (<= CAP, never across a segment end, never into the last 5 bytes).
+ *  match  : a position whose distance differs from its predecessor's and whose candidate starts with the same 4
+ *           bytes is a "head": its true match length is
+ *           counted byte by byte (<= CAP, never across a segment end, never into the last 5 bytes), unless
+ *           the position is already buried >= SKIPD bytes deep in a match found in an earlier superstep.
  *           Every position then takes the match, from any head at or before it in its segment, that
- *           reaches furthest ("best end", a prefix maximum), unless it is already buried >= SKIPD bytes
- *           deep in one.
+ *           reaches furthest ("best end", a prefix maximum).
  *  select : greedy with one-step lazy evaluation (a position yields to its successor if that one reaches
  *           further by more than a byte), left to right inside a segment.
  *  emit   : segments are independent parses of [s0, s1) that may reference any earlier byte of the
@@ -67,11 +68,25 @@ static size_t put_len(uint8_t *out, size_t o, uint32_t r) {   /* compress.rs:237
 
 typedef struct { uint32_t lit_start, lit_len, off, mlen; } lz4w_seq;
 
-/* parse of one block; returns the number of sequences (the last one has mlen == 0: final literals) */
+/* is p a head of segment [s0, s1) given the running best match `carry` (window-relative end << 16 | distance)? */
+static int is_head(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_params *P, uint32_t wbase, uint32_t s0, uint32_t s1,
+                   uint32_t carry, uint32_t p) {
+    if (p >= s1 || n < 12 || p > n - 12) return 0;
+    const uint32_t dp = d[p], dprev = (p > s0) ? d[p - 1] : 0;
+    if (dp == 0 || dp == dprev) return 0;
+    if (p - wbase < dp) return 0;                                 /* candidate before the window */
+    const uint32_t cend = carry >> 16;                            /* end of the running best match, window-relative */
+    if (cend > (p - wbase) && cend - (p - wbase) >= P->skipd) return 0;   /* buried deep in a match already found */
+    return ld32(in + p) == ld32(in + p - dp);                     /* the candidate's first 4 bytes match (p <= n - 12: readable) */
+}
+
+/* parse of one block; returns the number of sequences (the last one has mlen == 0: final literals).
+ * A segment is walked in "supersteps": 256 positions at a time when they hold at most 64 heads (the kernel
+ * compacts the heads of a superstep into the 64 lanes of its wavefront), else 128, else 64. */
 size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_params *P, lz4w_seq *seqs) {
     size_t ns = 0;
     uint32_t anchor = 0;
-    uint32_t *best = (uint32_t *)calloc(WAVE, 4);
+    uint32_t best[256], own[256];
     const uint32_t nwin = (n + WINDOW - 1) / WINDOW;
     for (uint32_t sj = 0; sj < nwin * P->nseg; sj++) {
         const uint32_t wbase = (sj / P->nseg) * WINDOW;            /* candidates must lie in the segment's 64 KiB window */
@@ -82,57 +97,56 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
         if (s0 == s1) continue;
         uint32_t mend = (n >= 5) ? ((s1 < n - 5) ? s1 : n - 5) : 0;         /* matches end here at the latest */
         if (mend > wbase + 65535u) mend = wbase + 65535u;                    /* ends are 16-bit window-relative numbers */
-        uint32_t carry = 0;    /* best (end << 16 | distance) so far in this segment; end is window-relative + 1.. see pack */
+        uint32_t carry = 0;    /* the match that reaches furthest so far in this segment: window-relative end << 16 | distance */
         uint32_t cursor = s0;
-        for (uint32_t b = s0; b < s1; b += WAVE) {
+        uint32_t b = s0;
+        while (b < s1) {
+            /* superstep size: the largest aligned power of two <= 256 whose positions hold <= 64 heads (64: always) */
+            uint32_t size = 256, e1 = 0;
+            for (;; size >>= 1) {
+                if ((b & (size - 1)) == 0) {
+                    e1 = (b + size < s1) ? b + size : s1;
+                    uint32_t h = 0;
+                    for (uint32_t p = b; p < e1; p++) h += (uint32_t)is_head(in, n, d, P, wbase, s0, s1, carry, p);
+                    if (h <= 64 || size == 64) break;
+                }
+            }
+            const uint32_t cnt = e1 - b;
             /* heads and their own ends */
-            uint32_t own[WAVE];
-            for (int i = 0; i < WAVE; i++) {
+            for (uint32_t i = 0; i < cnt; i++) {
                 const uint32_t p = b + i;
                 own[i] = 0;
-                if (p >= s1 || n < 12 || p > n - 12) continue;
-                const uint32_t dp = d[p], dprev = (p > s0) ? d[p - 1] : 0;
-                if (dp == 0 || dp == dprev) continue;
-                if (p - wbase < dp) continue;                         /* candidate before the window */
-                const uint32_t cend = carry >> 16;                    /* end of the running best match, window-relative */
-                if (cend > (p - wbase) && cend - (p - wbase) >= P->skipd) continue;
+                if (!is_head(in, n, d, P, wbase, s0, s1, carry, p)) continue;
+                const uint32_t dp = d[p];
                 uint32_t lim = (mend > p) ? mend - p : 0;
                 if (lim > P->cap) lim = P->cap;
                 uint32_t k = 0;
                 while (k < lim && in[p + k] == in[p - dp + k]) k++;
                 if (k >= 4) own[i] = ((p - wbase + k) << 16) | dp;
             }
-            /* prefix maximum, carried across steps */
+            /* prefix maximum, carried across supersteps */
             uint32_t run = carry;
-            for (int i = 0; i < WAVE; i++) { if (own[i] > run) run = own[i]; best[i] = run; }
+            for (uint32_t i = 0; i < cnt; i++) { if (own[i] > run) run = own[i]; best[i] = run; }
             carry = run;
-            /* eligibility (lazy: yield to the successor if it reaches further by more than a byte; lane 63 never yields) */
-            uint64_t elig = 0;
-            for (int i = 0; i < WAVE; i++) {
-                const uint32_t p = b + i;
-                if (p >= s1) break;
-                const uint32_t rel = p - wbase, e = best[i] >> 16;
-                if (e < rel + 4) continue;
-                if (n < 12 || p > n - 12) continue;
-                if (i < WAVE - 1 && p + 1 < s1 && (best[i + 1] >> 16) > e + 1) continue;
-                elig |= 1ull << i;
-            }
-            /* greedy walk */
-            while (cursor < b + WAVE && cursor < s1) {
-                const uint32_t c = (cursor > b) ? cursor - b : 0;
-                const uint64_t m = elig & (~0ull << c);
-                if (!m) break;
-                const int q = __builtin_ctzll(m);
-                const uint32_t p = b + q, e = best[q] >> 16, len = e - (p - wbase);
-                seqs[ns].lit_start = anchor; seqs[ns].lit_len = p - anchor; seqs[ns].off = best[q] & 0xFFFF; seqs[ns].mlen = len;
+            /* greedy walk with one-step lazy evaluation: a position yields to its successor if that one reaches further
+             * by more than a byte (the last position of a superstep never yields: its successor is not known yet) */
+            while (cursor < e1) {
+                const uint32_t i = cursor - b;           /* cursor >= b: a match never ends before the superstep it was taken in... */
+                const uint32_t p = cursor, rel = p - wbase, e = best[i] >> 16;
+                const int can = (e >= rel + 4) && !(n < 12 || p > n - 12);
+                if (!can) { cursor++; continue; }
+                if (i + 1 < cnt && (best[i + 1] >> 16) > e + 1) { cursor++; continue; }
+                const uint32_t len = e - rel;
+                seqs[ns].lit_start = anchor; seqs[ns].lit_len = p - anchor; seqs[ns].off = best[i] & 0xFFFF; seqs[ns].mlen = len;
                 ns++;
                 cursor = anchor = p + len;
             }
+            if (cursor < e1) cursor = e1;                /* (not reached: the loop runs until cursor >= e1) */
+            b = e1;
         }
     }
     seqs[ns].lit_start = anchor; seqs[ns].lit_len = n - anchor; seqs[ns].off = 0; seqs[ns].mlen = 0;
     ns++;
-    free(best);
     return ns;
 }
 

@@ -61,7 +61,7 @@ def main():
     comp_once(); dec_once(); torch.cuda.synchronize()
     if args.prof:
         lib.lz4flex_debug_wave_prof.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-        vals = (C.c_ulonglong * 8)()
+        vals = (C.c_ulonglong * 16)()
         assert lib.lz4flex_debug_wave_prof(ctx, 1, None) == 0
         comp_once(); torch.cuda.synchronize()
         assert lib.lz4flex_debug_wave_prof(ctx, 0, vals) == 0
@@ -69,6 +69,10 @@ def main():
         nw = max(v[7], 1)
         names = ["idx_busy", "idx_barrier", "match(sum 8 waves)", "wait_after_match", "place", "load_window", "wait_after_load"]
         print("per window cycles: " + ", ".join("%s=%.0f" % (nm, x / nw) for nm, x in zip(names, v)) + " windows=%d" % v[7], flush=True)
+        if v[13]:
+            sn = ["heads", "compact+lengths", "scan", "walk", "encode+rest"]
+            print("per superstep cycles (LZ4W_PROF_STEPS build): " + ", ".join("%s=%.0f" % (nm, x / v[13]) for nm, x in zip(sn, v[8:13])) +
+                  " supersteps/window=%.1f" % (v[13] / nw), flush=True)
     ok = int((st != 0).sum().item()) == 0 and int((bst != 0).sum().item()) == 0 and torch.equal(back, src)
     tc, td = [], []
     for _ in range(args.reps):
