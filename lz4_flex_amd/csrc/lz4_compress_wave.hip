@@ -554,10 +554,16 @@ __device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8
                     cursor = anchor = bv >> 16;
                 }
             };
+#ifdef LZ4W_EXP_PRIO
+            __builtin_amdgcn_s_setprio(3);
+#endif
             walk(em0, q0, b);
             if (ns > 1u) walk(em1, q1, b + 64u);
             if (ns > 2u) { walk(em2, q2, b + 128u); walk(em3, q3, b + 192u); }
             cursor = cursor > e1 ? cursor : e1;
+#ifdef LZ4W_EXP_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             LZ4W_TICK(3)
 #ifdef LZ4W_PROF_STEPS
             pn += 1;
@@ -567,17 +573,23 @@ __device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8
             const bool issel = lane < nsel;
             const uint32_t sp = sqa & 0xFFFFu, se = sqa >> 16, pe = sqb & 0xFFFFu, off = sqb >> 16;
             const uint32_t lit = sp - pe, len = se - sp, mlc = len - 4u;
-            const bool hard = issel & ((lit >= 15u) | (mlc >= 270u));
-            if (__ballot(hard) == 0ull) {
-                const bool first = (W.has == 0u) & (lane == 0u);
-                const uint32_t ext = mlc >= 15u ? 1u : 0u;
-                const uint32_t size = issel ? ((first ? 2u : 3u + lit) + ext) : 0u;
-                const uint32_t incl = wave_incl_add(size);
-                if (W.has == 0u) { W.has = 1u; W.first_lit = rdlane(lit, 0u); W.first_ml = rdlane(len, 0u); }
-                for (uint32_t c0q = 0u; c0q < nsel; c0q += 16u) {   // 16 sequences (<= 288 bytes) per staging round
-                    const uint32_t basec = c0q != 0u ? rdlane(incl, c0q - 1u) : 0u;
-                    const uint32_t endc = rdlane(incl, c0q + 15u);
-                    if (issel & (lane >= c0q) & (lane < c0q + 16u)) {
+            // A sequence with >= 15 literals or a match of >= 274 bytes needs length bytes beyond the lane-parallel path: such
+            // "hard" sequences are written one at a time, the runs of ordinary ones between them 16 at a time.
+            const uint64_t hardm = __ballot(issel & ((lit >= 15u) | (mlc >= 270u)));
+            const bool hardl = (hardm >> lane) & 1ull;
+            const bool first = (W.has == 0u) & (lane == 0u) & !hardl;       // the segment's first sequence: its token comes later
+            const uint32_t ext = mlc >= 15u ? 1u : 0u;
+            const uint32_t size = (issel & !hardl) ? ((first ? 2u : 3u + lit) + ext) : 0u;
+            const uint32_t incl = wave_incl_add(size);
+            if (W.has == 0u && (hardm & 1ull) == 0ull) { W.has = 1u; W.first_lit = rdlane(lit, 0u); W.first_ml = rdlane(len, 0u); }
+            for (uint32_t cur = 0u; cur < nsel;) {
+                const uint64_t hm = hardm & (~0ull << cur);
+                const uint32_t hq = hm != 0ull ? ctz64(hm) : nsel;         // the next hard sequence
+                while (cur < hq) {                                          // <= 16 ordinary sequences (<= 288 bytes) per staging round
+                    const uint32_t end = cur + 16u < hq ? cur + 16u : hq;
+                    const uint32_t basec = cur != 0u ? rdlane(incl, cur - 1u) : 0u;
+                    const uint32_t endc = rdlane(incl, end - 1u);
+                    if ((lane >= cur) & (lane < end)) {
                         lds_u8* o = W.stg + W.fill + (incl - size - basec);
                         if (!first) {
                             o[0] = (uint8_t)((lit << 4) | (mlc < 15u ? mlc : 15u));
@@ -590,11 +602,13 @@ __device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8
                     }
                     W.fill += endc - basec;
                     if (W.fill >= FLUSH_AT) W.flush(false);
+                    cur = end;
                 }
-            } else {
-                for (uint32_t q = 0u; q < nsel; ++q)
-                    W.emit_generic(rdlane(pe, q), rdlane(lit, q), rdlane(off, q), rdlane(len, q));
-                if (W.fill >= FLUSH_AT) W.flush(false);
+                if (hq < nsel) {
+                    W.emit_generic(rdlane(pe, hq), rdlane(lit, hq), rdlane(off, hq), rdlane(len, hq));
+                    if (W.fill >= FLUSH_AT) W.flush(false);
+                    cur = hq + 1u;
+                }
             }
         }
     }
