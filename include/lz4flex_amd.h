@@ -241,6 +241,22 @@ uint32_t lz4flex_xxh32(const uint8_t *data, size_t len, uint32_t seed);
 int lz4flex_xxh32_batch_device(const void *base, const uint64_t *off, const uint32_t *len, uint32_t n, uint32_t seed,
                                uint32_t *out, void *hip_stream);
 
+/* ---- frame segments on the device (multi-GPU frame path: every rank assembles the segment of its block range) ---------
+ * What FrameEncoder::write_block does around the codec call for each block (src/frame/compress.rs:282-316): the 4-byte
+ * BlockInfo (frame/header.rs:108-124), the store-raw rule (compress.rs:301-306: a block that did not shrink is stored
+ * uncompressed, high bit set), the payload and the optional XXH32 of the payload -- for n blocks already compressed by
+ * lz4flex_compress_batch (MEM_DEVICE), back to back into `seg`.  Every pointer is device memory, the work is enqueued
+ * on hip_stream.  seg_off: n + 1 u64, filled with each block's offset in seg and, last, the bytes written (read it
+ * back to size the exchange).  seg must hold sum(in_len) + 8 n bytes.  scratch: 16 n bytes, needed with
+ * block_checksums only. */
+int lz4flex_frame_assemble_device(const void *src_base, const uint64_t *src_off, const uint32_t *in_len,
+                                  const void *comp_base, const uint64_t *comp_off, const uint32_t *comp_len, uint32_t n,
+                                  int block_checksums, void *seg, uint64_t *seg_off, void *scratch, void *hip_stream);
+/* n independent byte ranges src_base[src_off[i] .. +len[i]) -> dst_base[dst_off[i] ..) in one launch (decode side: blocks
+ * stored raw go straight to their place in the output, src/frame/decompress.rs:262-271) */
+int lz4flex_copy_batch_device(const void *src_base, const uint64_t *src_off, const uint32_t *len, void *dst_base,
+                              const uint64_t *dst_off, uint32_t n, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

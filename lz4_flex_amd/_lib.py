@@ -81,6 +81,8 @@ SIGNATURES = {
     "lz4flex_frame_info_read": (_I64, [_VP, _SZ, C.POINTER(FrameInfoC), C.POINTER(ErrDetail)]),
     "lz4flex_xxh32": (_U32, [_VP, _SZ, _U32]),
     "lz4flex_xxh32_batch_device": (_I32, [_VP, _VP, _VP, _U32, _U32, _VP, _VP]),
+    "lz4flex_frame_assemble_device": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _U32, _I32, _VP, _VP, _VP, _VP]),
+    "lz4flex_copy_batch_device": (_I32, [_VP, _VP, _VP, _VP, _VP, _U32, _VP]),
 }
 
 _lib = None

@@ -70,6 +70,15 @@ def _buf(b):
     return C.c_void_p(a.ctypes.data if a.size else 0), int(a.size), a
 
 
+def set_compress_mode(mode, ctx=None):
+    """Encoder of this thread's default context (or of `ctx`): "fast" = throughput encoder (own parse: a valid LZ4 block
+    that lz4_flex decodes to the input; default), "exact" = lz4_flex's own bytes (src/block/compress.rs:318-489)."""
+    v = {"fast": 0, "exact": 1}[mode]
+    rc = L.load().lz4flex_set_tuning(ctx, b"compress_mode", v)
+    if rc:
+        raise DeviceError("lz4flex_set_tuning(compress_mode) failed (%d): %s" % (rc, L.last_error()))
+
+
 def get_maximum_output_size(input_len):
     """block::get_maximum_output_size (compress.rs:588-590)"""
     return int(L.load().lz4flex_get_maximum_output_size(int(input_len)))

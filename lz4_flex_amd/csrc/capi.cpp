@@ -679,6 +679,25 @@ int lz4flex_xxh32_batch_device(const void* base, const uint64_t* off, const uint
     return le == hipSuccess ? 0 : hip_fail(le, "xxh32 kernel launch");
 }
 
+int lz4flex_frame_assemble_device(const void* src_base, const uint64_t* src_off, const uint32_t* in_len, const void* comp_base,
+                                  const uint64_t* comp_off, const uint32_t* comp_len, uint32_t n, int block_checksums, void* seg,
+                                  uint64_t* seg_off, void* scratch, void* hip_stream) {
+    if (!seg_off || (n && (!src_base || !src_off || !in_len || !comp_base || !comp_off || !comp_len || !seg))) return -LZ4FLEX_E_INVALID_ARG;
+    if (block_checksums && n && !scratch) return -LZ4FLEX_E_INVALID_ARG;
+    uint8_t* sc = (uint8_t*)scratch;                                     // 16 bytes per block: u64 payload offset, u32 length, u32 XXH32
+    hipError_t le = launch_frame_assemble((const uint8_t*)src_base, src_off, in_len, (const uint8_t*)comp_base, comp_off, comp_len, n,
+                                          block_checksums, (uint8_t*)seg, seg_off, (uint64_t*)sc, (uint32_t*)(sc + 8ull * n),
+                                          (uint32_t*)(sc + 12ull * n), (hipStream_t)hip_stream);
+    return le == hipSuccess ? 0 : hip_fail(le, "frame assemble launch");
+}
+
+int lz4flex_copy_batch_device(const void* src_base, const uint64_t* src_off, const uint32_t* len, void* dst_base, const uint64_t* dst_off,
+                              uint32_t n, void* hip_stream) {
+    if (n && (!src_base || !src_off || !len || !dst_base || !dst_off)) return -LZ4FLEX_E_INVALID_ARG;
+    hipError_t le = launch_copy_batch((const uint8_t*)src_base, src_off, len, (uint8_t*)dst_base, dst_off, n, (hipStream_t)hip_stream);
+    return le == hipSuccess ? 0 : hip_fail(le, "copy batch launch");
+}
+
 int64_t lz4flex_uncompressed_size(const uint8_t* in, size_t in_len) {
     if (in_len < 4) return -LZ4FLEX_E_EXPECTED_ANOTHER_BYTE;   // mod.rs:152
     return (int64_t)((uint32_t)in[0] | ((uint32_t)in[1] << 8) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 24));

@@ -1,0 +1,138 @@
+// frame_kernels.hip -- device-side assembly of LZ4 frame segments for the sharded (multi-GPU) frame path.
+//
+// What it replaces: the per-block bookkeeping of FrameEncoder::write_block (src/frame/compress.rs:261-371) for a rank's
+// contiguous block range whose blocks were compressed by the batched block encoder: the 4-byte block header (length,
+// high bit = stored raw), the store-raw rule (:301-306: a block that did not shrink is stored uncompressed), the payload
+// and the optional block checksum (:313-316), laid out back to back.  Round 1 did this in a Python loop with three tiny
+// tensor copies per block; here it is three launches for any number of blocks:
+//   1. sizes + exclusive prefix sum (one workgroup),
+//   2. header + payload copy, one workgroup per block, 16 B per lane where source and destination allow it,
+//   3. (block checksums) XXH32 of every payload (xxh32_kernel.hip), then 4 bytes per block.
+// lz4flex_copy_batch_device is the decode-side companion: n independent byte ranges copied in one launch (blocks stored
+// raw go straight to their place in the output; compressed ones are decoded there by the batched decoder).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lz4_device.h"
+
+namespace lz4flex_dev {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// one workgroup of 1024 threads: per[i] = 4 + min(comp_len, in_len stored raw) (+ 4), seg_off = exclusive sum, seg_off[n] = total
+__global__ void __launch_bounds__(1024) frame_sizes_scan_kernel(const uint32_t* __restrict__ in_len, const uint32_t* __restrict__ comp_len,
+                                                                uint32_t n, uint32_t tail, uint64_t* __restrict__ seg_off) {
+    __shared__ uint64_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per_thread = (n + 1023u) / 1024u;
+    const uint32_t lo = t * per_thread, hi = lo + per_thread < n ? lo + per_thread : n;
+    uint64_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t c = comp_len[i], u = in_len[i];
+        s += 4ull + (c >= u ? u : c) + tail;
+    }
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {          // Hillis-Steele inclusive scan of the 1024 partial sums
+        const uint64_t v = t >= d ? part[t - d] : 0ull;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint64_t o = t == 0u ? 0ull : part[t - 1u];
+    for (uint32_t i = lo; i < hi; ++i) {
+        seg_off[i] = o;
+        const uint32_t c = comp_len[i], u = in_len[i];
+        o += 4ull + (c >= u ? u : c) + tail;
+    }
+    if (t == 1023u) seg_off[n] = part[1023];
+}
+
+__device__ __forceinline__ void copy_range(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint64_t n, uint32_t t, uint32_t nt) {
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15u) == 0u) {
+        const uint64_t nv = n / 16u;
+        for (uint64_t i = t; i < nv; i += nt) reinterpret_cast<u32x4*>(dst)[i] = reinterpret_cast<const u32x4*>(src)[i];
+        for (uint64_t i = nv * 16u + t; i < n; i += nt) dst[i] = src[i];
+    } else if (((uintptr_t)dst & 15u) == ((uintptr_t)src & 15u)) {
+        const uint64_t head = (16u - ((uintptr_t)dst & 15u)) & 15u;
+        const uint64_t h = head < n ? head : n;
+        for (uint64_t i = t; i < h; i += nt) dst[i] = src[i];
+        const uint64_t nv = (n - h) / 16u;
+        for (uint64_t i = t; i < nv; i += nt) reinterpret_cast<u32x4*>(dst + h)[i] = reinterpret_cast<const u32x4*>(src + h)[i];
+        for (uint64_t i = h + nv * 16u + t; i < n; i += nt) dst[i] = src[i];
+    } else {
+        // different phase: aligned 16-byte stores, unaligned loads (global memory takes any alignment)
+        const uint64_t head = (16u - ((uintptr_t)dst & 15u)) & 15u;
+        const uint64_t h = head < n ? head : n;
+        for (uint64_t i = t; i < h; i += nt) dst[i] = src[i];
+        const uint64_t nv = (n - h) / 16u;
+        for (uint64_t i = t; i < nv; i += nt) {
+            u32x4 v;
+            __builtin_memcpy(&v, src + h + 16u * i, 16);
+            reinterpret_cast<u32x4*>(dst + h)[i] = v;
+        }
+        for (uint64_t i = h + nv * 16u + t; i < n; i += nt) dst[i] = src[i];
+    }
+}
+
+// block b: [u32 header][payload]; the checksum slot behind it is filled by frame_checksum_kernel
+__global__ void __launch_bounds__(256) frame_assemble_kernel(const uint8_t* __restrict__ src_base, const uint64_t* __restrict__ src_off,
+                                                             const uint32_t* __restrict__ in_len, const uint8_t* __restrict__ comp_base,
+                                                             const uint64_t* __restrict__ comp_off, const uint32_t* __restrict__ comp_len,
+                                                             uint32_t n, const uint64_t* __restrict__ seg_off, uint8_t* __restrict__ seg,
+                                                             uint64_t* __restrict__ pay_off, uint32_t* __restrict__ pay_len) {
+    const uint32_t b = blockIdx.x;
+    if (b >= n) return;
+    const uint32_t c = comp_len[b], u = in_len[b];
+    const bool raw = c >= u;                                         // frame/compress.rs:301-306
+    const uint32_t size = raw ? u : c;
+    uint8_t* d = seg + seg_off[b];
+    if (threadIdx.x == 0u) {
+        const uint32_t w = raw ? (u | 0x80000000u) : c;              // BlockInfo::write, frame/header.rs:108-124
+        d[0] = (uint8_t)w; d[1] = (uint8_t)(w >> 8); d[2] = (uint8_t)(w >> 16); d[3] = (uint8_t)(w >> 24);
+        if (pay_off) { pay_off[b] = seg_off[b] + 4ull; pay_len[b] = size; }
+    }
+    copy_range(d + 4, raw ? src_base + src_off[b] : comp_base + comp_off[b], size, threadIdx.x, 256u);
+}
+
+__global__ void frame_checksum_kernel(const uint64_t* __restrict__ pay_off, const uint32_t* __restrict__ pay_len, const uint32_t* __restrict__ sums,
+                                      uint32_t n, uint8_t* __restrict__ seg) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    uint8_t* d = seg + pay_off[b] + pay_len[b];
+    const uint32_t w = sums[b];
+    d[0] = (uint8_t)w; d[1] = (uint8_t)(w >> 8); d[2] = (uint8_t)(w >> 16); d[3] = (uint8_t)(w >> 24);
+}
+
+__global__ void __launch_bounds__(256) copy_batch_kernel(const uint8_t* __restrict__ src_base, const uint64_t* __restrict__ src_off,
+                                                         const uint32_t* __restrict__ len, uint8_t* __restrict__ dst_base,
+                                                         const uint64_t* __restrict__ dst_off, uint32_t n) {
+    const uint32_t b = blockIdx.x;
+    if (b >= n) return;
+    copy_range(dst_base + dst_off[b], src_base + src_off[b], len[b], threadIdx.x, 256u);
+}
+
+hipError_t launch_frame_assemble(const uint8_t* src_base, const uint64_t* src_off, const uint32_t* in_len, const uint8_t* comp_base,
+                                 const uint64_t* comp_off, const uint32_t* comp_len, uint32_t n, int block_checksums, uint8_t* seg,
+                                 uint64_t* seg_off, uint64_t* pay_off, uint32_t* pay_len, uint32_t* sums, hipStream_t s) {
+    if (n == 0u) return hipMemsetAsync(seg_off, 0, 8, s);
+    hipLaunchKernelGGL(frame_sizes_scan_kernel, dim3(1), dim3(1024), 0, s, in_len, comp_len, n, block_checksums ? 4u : 0u, seg_off);
+    hipLaunchKernelGGL(frame_assemble_kernel, dim3(n), dim3(256), 0, s, src_base, src_off, in_len, comp_base, comp_off, comp_len, n,
+                       (const uint64_t*)seg_off, seg, block_checksums ? pay_off : nullptr, pay_len);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !block_checksums) return e;
+    e = launch_xxh32_batch(seg, pay_off, pay_len, n, 0u, sums, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(frame_checksum_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, (const uint64_t*)pay_off, (const uint32_t*)pay_len,
+                       (const uint32_t*)sums, n, seg);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_batch(const uint8_t* src_base, const uint64_t* src_off, const uint32_t* len, uint8_t* dst_base, const uint64_t* dst_off,
+                             uint32_t n, hipStream_t s) {
+    if (n == 0u) return hipSuccess;
+    hipLaunchKernelGGL(copy_batch_kernel, dim3(n), dim3(256), 0, s, src_base, src_off, len, dst_base, dst_off, n);
+    return hipGetLastError();
+}
+
+}  // namespace lz4flex_dev

@@ -63,4 +63,12 @@ hipError_t launch_compress_chain(const uint8_t* in_base, const void* blocks, con
 hipError_t launch_xxh32_batch(const uint8_t* base, const uint64_t* off, const uint32_t* len, uint32_t n, uint32_t seed,
                               uint32_t* out, hipStream_t s);
 
+// frame_kernels.hip: a rank's block range -> [header | payload | (checksum)]* on the device; seg_off holds n + 1 offsets
+// (the last one = bytes written); pay_off / pay_len / sums are n-element scratch arrays, needed with block_checksums only
+hipError_t launch_frame_assemble(const uint8_t* src_base, const uint64_t* src_off, const uint32_t* in_len, const uint8_t* comp_base,
+                                 const uint64_t* comp_off, const uint32_t* comp_len, uint32_t n, int block_checksums, uint8_t* seg,
+                                 uint64_t* seg_off, uint64_t* pay_off, uint32_t* pay_len, uint32_t* sums, hipStream_t s);
+hipError_t launch_copy_batch(const uint8_t* src_base, const uint64_t* src_off, const uint32_t* len, uint8_t* dst_base, const uint64_t* dst_off,
+                             uint32_t n, hipStream_t s);
+
 }  // namespace lz4flex_dev

@@ -127,9 +127,27 @@ def _le32(word):
 # ---- segment assembly ------------------------------------------------------------------------------------
 def build_segment(src, comp, comp_off, comp_len, in_len, block_size, block_checksums=False, xxh32_blocks=None):
     """[4-byte block header | payload | (XXH32 of the payload)]* for this rank's blocks; store-raw rule of
-    frame/compress.rs:301-306, block checksum :313-316"""
+    frame/compress.rs:301-306, block checksum :313-316.  CUDA tensors: three kernel launches for any number of blocks
+    (lz4flex_frame_assemble_device, csrc/frame_kernels.hip); CPU tensors (the gloo tests, whose codec is the oracle):
+    the same layout built with tensor slices."""
     dev = src.device
     n = comp_len.numel()
+    if dev.type == "cuda" and xxh32_blocks is None:
+        lib = L.load()
+        src_off = torch.arange(n, dtype=torch.int64, device=dev) * block_size
+        seg = torch.empty(int(src.numel()) + 8 * n + 16, dtype=torch.uint8, device=dev)
+        seg_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        scratch = torch.empty(16 * max(n, 1), dtype=torch.uint8, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        il = in_len.to(torch.int32).contiguous()
+        cl = comp_len.to(torch.int32).contiguous()
+        co = comp_off.to(torch.int64).contiguous()
+        with torch.cuda.device(dev):
+            rc = lib.lz4flex_frame_assemble_device(_p(src), _p(src_off), _p(il), _p(comp), _p(co), _p(cl), n, int(bool(block_checksums)),
+                                                   _p(seg), _p(seg_off), _p(scratch), stream)
+        if rc:
+            raise RuntimeError("lz4flex_frame_assemble_device: %d %s" % (rc, L.last_error()))
+        return seg[:int(seg_off[n].item())]                       # one scalar read-back sizes the exchange
     clen = comp_len.to(torch.int64)
     ilen = in_len.to(torch.int64)
     raw = clen >= ilen
@@ -217,8 +235,10 @@ def compress_frame_sharded(local, first_block, frame_info, group=None, root=0, c
     return None
 
 
-def walk_blocks(frame_host, header_len, block_checksums=False):
-    """host-side block-header walk (frame/decompress.rs:231-241): returns [(payload_off, len, raw)], end offset"""
+def walk_blocks(frame_host, header_len, block_checksums=False, block_size=None):
+    """host-side block-header walk (frame/decompress.rs:231-241): returns [(payload_off, len, raw)], end offset.
+    A block longer than the frame's block size is BlockTooBig (:242-247), as in the reference."""
+    from .frame import BlockTooBig
     out, p = [], header_len
     n = len(frame_host)
     while True:
@@ -230,6 +250,10 @@ def walk_blocks(frame_host, header_len, block_checksums=False):
             return out, p
         raw = bool(w & UNCOMPRESSED_BIT)
         ln = w & ~UNCOMPRESSED_BIT
+        if block_size is not None and ln > block_size:
+            raise BlockTooBig()
+        if p + ln + (4 if block_checksums else 0) > n:
+            raise ValueError("truncated frame")
         out.append((p, ln, raw))
         p += ln + (4 if block_checksums else 0)
 
@@ -243,11 +267,11 @@ def decompress_frame_sharded(frame, group=None, root=0, decompress_blocks=decomp
     meta = [None]
     if rank == root:
         host = frame.cpu().numpy()
-        hdr_len = 7 + (8 if host[4] & 0x08 else 0)
-        fi = FrameInfo.read(bytes(host[:hdr_len]))
-        if fi.block_mode != BlockMode.Independent or fi.content_checksum:
+        fi = FrameInfo.read(bytes(host[:19]))                      # validates magic, version, flags, header checksum (header.rs:277-373)
+        hdr_len = len(fi.write())
+        if fi.legacy_frame or fi.block_mode != BlockMode.Independent or fi.content_checksum:
             raise ValueError("only Independent frames without a content checksum shard")
-        blocks, _end = walk_blocks(host, hdr_len, fi.block_checksums)
+        blocks, _end = walk_blocks(host, hdr_len, fi.block_checksums, fi.block_size.get_size())
         meta = [(blocks, int(fi.block_size), bool(fi.block_checksums))]
     if world > 1:
         dist.broadcast_object_list(meta, src=root, group=group)
@@ -289,18 +313,51 @@ def decompress_frame_sharded(frame, group=None, root=0, decompress_blocks=decomp
     out = torch.empty(n * bs, dtype=torch.uint8, device=dev)
     produced = [0] * n
     comp_idx = [i for i, m in enumerate(mine) if not m[2]]
-    if comp_idx:
-        coff = torch.tensor([mine[i][0] - a for i in comp_idx], dtype=torch.int64, device=dev)
-        clen = torch.tensor([mine[i][1] for i in comp_idx], dtype=torch.int32, device=dev)
-        dec, dlen, st = decompress_blocks(local, coff, clen, None, bs)
-        if int((st != 0).sum().item()):
-            raise RuntimeError("DecompressionError in a sharded block")
-        dl = dlen.tolist()
-        for k, i in enumerate(comp_idx):
-            out[i * bs:i * bs + dl[k]] = dec[k * bs:k * bs + dl[k]]
-            produced[i] = dl[k]
-    for i, m in enumerate(mine):
-        if m[2]:
+    raw_idx = [i for i, m in enumerate(mine) if m[2]]
+    if dev.type == "cuda" and decompress_blocks is decompress_blocks_device:
+        # every block goes straight to its place: compressed ones through the batched decoder (out_off = i * bs), stored ones
+        # through one batched copy (csrc/frame_kernels.hip); no per-block Python work on the data path
+        lib = L.load()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if comp_idx:
+            coff = torch.tensor([mine[i][0] - a for i in comp_idx], dtype=torch.int64, device=dev)
+            clen = torch.tensor([mine[i][1] for i in comp_idx], dtype=torch.int32, device=dev)
+            ooff = torch.tensor(comp_idx, dtype=torch.int64, device=dev) * bs
+            ocap = torch.full((len(comp_idx),), bs, dtype=torch.int32, device=dev)
+            dlen = torch.zeros(len(comp_idx), dtype=torch.int32, device=dev)
+            st = torch.zeros(len(comp_idx), dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.lz4flex_decompress_batch(None, _p(local), _p(coff), _p(clen), len(comp_idx), _p(out), _p(ooff), _p(ocap),
+                                                  _p(dlen), _p(st), None, L.MEM_DEVICE, stream)
+            if rc:
+                raise RuntimeError("lz4flex_decompress_batch: %d %s" % (rc, L.last_error()))
+            if int((st != 0).sum().item()):
+                raise RuntimeError("DecompressionError in a sharded block")
+            for k, i in zip(dlen.tolist(), comp_idx):
+                produced[i] = k
+        if raw_idx:
+            roff = torch.tensor([mine[i][0] - a for i in raw_idx], dtype=torch.int64, device=dev)
+            rlen = torch.tensor([mine[i][1] for i in raw_idx], dtype=torch.int32, device=dev)
+            doff = torch.tensor(raw_idx, dtype=torch.int64, device=dev) * bs
+            with torch.cuda.device(dev):
+                rc = lib.lz4flex_copy_batch_device(_p(local), _p(roff), _p(rlen), _p(out), _p(doff), len(raw_idx), stream)
+            if rc:
+                raise RuntimeError("lz4flex_copy_batch_device: %d %s" % (rc, L.last_error()))
+            for i in raw_idx:
+                produced[i] = mine[i][1]
+    else:
+        if comp_idx:
+            coff = torch.tensor([mine[i][0] - a for i in comp_idx], dtype=torch.int64, device=dev)
+            clen = torch.tensor([mine[i][1] for i in comp_idx], dtype=torch.int32, device=dev)
+            dec, dlen, st = decompress_blocks(local, coff, clen, None, bs)
+            if int((st != 0).sum().item()):
+                raise RuntimeError("DecompressionError in a sharded block")
+            dl = dlen.tolist()
+            for k, i in enumerate(comp_idx):
+                out[i * bs:i * bs + dl[k]] = dec[k * bs:k * bs + dl[k]]
+                produced[i] = dl[k]
+        for i in raw_idx:
+            m = mine[i]
             out[i * bs:i * bs + m[1]] = local[m[0] - a:m[0] - a + m[1]]
             produced[i] = m[1]
     # blocks are full except possibly the frame's last one: compact view

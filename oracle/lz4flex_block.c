@@ -327,11 +327,18 @@ int64_t lz4o__decompress_internal(const uint8_t *in, size_t in_len, uint8_t *out
             }
             match_length -= dict_match_length;
         }
-        /* :431-437 duplicate(): byte-serial forward copy semantics (:57-82) */
+        /* :431-437 duplicate(): byte-serial forward copy semantics (:57-82).  Like the reference's hot loop
+         * (:259-328, 16-byte wild copies when nothing can run out of bounds) the common case copies 8 bytes at a
+         * time: legal when source and destination chunks cannot overlap (offset >= 8) and the up to 7 bytes
+         * written behind the match stay inside the sink; every other case keeps the checked byte loop. */
         {
             const uint8_t *src = out + op - offset;
             uint8_t *dst = out + op;
-            for (size_t i = 0; i < match_length; i++) dst[i] = src[i];
+            if (offset >= 8 && match_length + 8 <= out_cap - op) {
+                for (size_t i = 0; i < match_length; i += 8) memcpy(dst + i, src + i, 8);
+            } else {
+                for (size_t i = 0; i < match_length; i++) dst[i] = src[i];
+            }
             op += match_length;
         }
         if (ip >= in_len) return -LZ4O_E_EXPECTED_ANOTHER_BYTE;            /* :439-443 */

@@ -136,6 +136,12 @@ double lz4o_bench_batch(int dir, const uint8_t *in_base, const uint64_t *in_off,
                         uint8_t *out_base, const uint64_t *out_off, const uint32_t *out_cap,
                         uint32_t *out_len, uint32_t n_blocks, int threads, int reps);
 
+/* the same batch loop around a foreign codec with liblz4's signature int f(const char*, char*, int, int)
+ * (LZ4_compress_default / LZ4_decompress_safe of the system liblz4 1.9.3, loaded by the caller) */
+double lz4o_bench_batch_fn(int dir, void *fn, const uint8_t *in_base, const uint64_t *in_off, const uint32_t *in_len,
+                           uint8_t *out_base, const uint64_t *out_off, const uint32_t *out_cap,
+                           uint32_t *out_len, uint32_t n_blocks, int threads, int reps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,3 +23,13 @@ def _build_oracle():
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     yield
+
+
+@pytest.fixture
+def exact_encoder():
+    """GPU tests that compare encoder bytes with the oracle (= lz4_flex's bytes) run the reference-exact encoder; the
+    default is the throughput encoder, whose contract is a valid block (tests/test_gpu_wave_encoder.py)."""
+    from lz4_flex_amd import block
+    block.set_compress_mode("exact")
+    yield
+    block.set_compress_mode("fast")

@@ -60,6 +60,9 @@ def lib():
         o.lz4o_bench_batch.restype = C.c_double
         o.lz4o_bench_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_uint32, C.c_int, C.c_int]
+        o.lz4o_bench_batch_fn.restype = C.c_double
+        o.lz4o_bench_batch_fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_uint32, C.c_int, C.c_int]
         _o = o
     return _o
 

@@ -10,7 +10,7 @@ import pytest
 import corpus
 import oracle_api as O
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("exact_encoder")]   # encoder bytes are compared with lz4_flex's: reference-exact mode
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -25,7 +25,7 @@ def test_cli_roundtrip(mods, tmp_path):
     data = O.fixture_plain("compression_66k_JSON") * 3
     src = tmp_path / "data.json"
     src.write_bytes(data)
-    env = dict(os.environ, PYTHONPATH=ROOT)
+    env = dict(os.environ, PYTHONPATH=ROOT, LZ4FLEX_COMPRESS_MODE="exact")   # compared with the oracle's frame bytes
     r = subprocess.run([sys.executable, "-m", "lz4_flex_amd.cli", str(src)], capture_output=True, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr
     lz = tmp_path / "data.json.lz4"

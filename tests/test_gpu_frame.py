@@ -7,7 +7,7 @@ import pytest
 import corpus
 import oracle_api as O
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("exact_encoder")]   # encoder bytes are compared with lz4_flex's: reference-exact mode
 
 
 @pytest.fixture(scope="module")
