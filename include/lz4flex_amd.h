@@ -87,6 +87,20 @@ int64_t lz4flex_compress_into_with_dict(const uint8_t *in, size_t in_len, uint8_
                                         const uint8_t *dict, size_t dict_len);
 /* block::compress_prepend_size, src/block/compress.rs:673-675 (LE u32 length prefix) */
 int64_t lz4flex_compress_prepend_size(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap);
+/* block::compress_prepend_size_with_dict, src/block/compress.rs:692-694 (dictionaries of <= 3 bytes are ignored, :626-628) */
+int64_t lz4flex_compress_prepend_size_with_dict(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                                                const uint8_t *dict, size_t dict_len);
+/* block::CompressTable + compress_into_with_table, src/block/compress.rs:710-766.  The reference clears the table on every
+ * call; the handle avoids re-allocating it and carries its variant: Small (u16 entries, 4-byte hash: what compress_into
+ * uses below 65 535 bytes) or Large (u32 entries, 5-byte hash).  An input of >= 65 535 bytes upgrades a Small table to
+ * Large for good (:752-754), which changes the bytes later small inputs compress to -- reproduced here.  The handle owns
+ * the device workspace reused across calls. */
+typedef struct lz4flex_compress_table lz4flex_compress_table;
+lz4flex_compress_table *lz4flex_compress_table_new(int large /* 0 = CompressTable::small() / default, 1 = large() */);
+void lz4flex_compress_table_free(lz4flex_compress_table *t);
+int lz4flex_compress_table_is_large(const lz4flex_compress_table *t);
+int64_t lz4flex_compress_into_with_table(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                                         lz4flex_compress_table *table);
 /* block::decompress_into, src/block/decompress.rs:454-456 */
 int64_t lz4flex_decompress_into(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
                                 lz4flex_err_detail *detail /* nullable */);
@@ -98,6 +112,10 @@ int64_t lz4flex_uncompressed_size(const uint8_t *in, size_t in_len);
 /* block::decompress_size_prepended, src/block/decompress.rs:493-496; out_cap must be >= the prefix */
 int64_t lz4flex_decompress_size_prepended(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
                                           lz4flex_err_detail *detail);
+
+/* block::decompress_size_prepended_with_dict, src/block/decompress.rs:521-527 */
+int64_t lz4flex_decompress_size_prepended_with_dict(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                                                    const uint8_t *dict, size_t dict_len, lz4flex_err_detail *detail);
 
 /* ---- block: batched (the hot entry; the frame layer's per-block calls
  *      src/frame/compress.rs:282-298 and src/frame/decompress.rs:288-305, batched) ------------ */
@@ -219,6 +237,11 @@ typedef struct lz4flex_frame_decoder lz4flex_frame_decoder;
 lz4flex_frame_decoder *lz4flex_frame_decoder_new(lz4flex_read_fn r, void *user);
 /* io::Read::read, :353-367: bytes read, 0 at end of frame / EOF, < 0 = -code */
 int64_t lz4flex_frame_decoder_read(lz4flex_frame_decoder *d, uint8_t *buf, size_t len, lz4flex_err_detail *detail);
+/* io::BufRead::fill_buf, :410-416: *buf = the decoded bytes not consumed yet (valid until the next call on this decoder),
+ * return value = their count; decodes the next batch of blocks when there are none; 0 at end of frame / EOF, < 0 = -code */
+int64_t lz4flex_frame_decoder_fill_buf(lz4flex_frame_decoder *d, const uint8_t **buf, lz4flex_err_detail *detail);
+/* io::BufRead::consume, :418-421; amt must not exceed what the last fill_buf returned (the reference asserts) */
+int lz4flex_frame_decoder_consume(lz4flex_frame_decoder *d, size_t amt);
 int lz4flex_frame_decoder_set_batch_bytes(lz4flex_frame_decoder *d, size_t bytes);
 void lz4flex_frame_decoder_free(lz4flex_frame_decoder *d);
 

@@ -52,6 +52,12 @@ SIGNATURES = {
     "lz4flex_compress_into": (_I64, [_VP, _SZ, _VP, _SZ]),
     "lz4flex_compress_into_with_dict": (_I64, [_VP, _SZ, _VP, _SZ, _VP, _SZ]),
     "lz4flex_compress_prepend_size": (_I64, [_VP, _SZ, _VP, _SZ]),
+    "lz4flex_compress_prepend_size_with_dict": (_I64, [_VP, _SZ, _VP, _SZ, _VP, _SZ]),
+    "lz4flex_compress_table_new": (_VP, [_I32]),
+    "lz4flex_compress_table_free": (None, [_VP]),
+    "lz4flex_compress_table_is_large": (_I32, [_VP]),
+    "lz4flex_compress_into_with_table": (_I64, [_VP, _SZ, _VP, _SZ, _VP]),
+    "lz4flex_decompress_size_prepended_with_dict": (_I64, [_VP, _SZ, _VP, _SZ, _VP, _SZ, C.POINTER(ErrDetail)]),
     "lz4flex_decompress_into": (_I64, [_VP, _SZ, _VP, _SZ, C.POINTER(ErrDetail)]),
     "lz4flex_decompress_into_with_dict": (_I64, [_VP, _SZ, _VP, _SZ, _VP, _SZ, C.POINTER(ErrDetail)]),
     "lz4flex_uncompressed_size": (_I64, [_VP, _SZ]),
@@ -72,6 +78,8 @@ SIGNATURES = {
     "lz4flex_frame_encoder_free": (None, [_VP]),
     "lz4flex_frame_decoder_new": (_VP, [READ_FN, _VP]),
     "lz4flex_frame_decoder_read": (_I64, [_VP, _VP, _SZ, C.POINTER(ErrDetail)]),
+    "lz4flex_frame_decoder_fill_buf": (_I64, [_VP, C.POINTER(_VP), C.POINTER(ErrDetail)]),
+    "lz4flex_frame_decoder_consume": (_I32, [_VP, _SZ]),
     "lz4flex_frame_decoder_set_batch_bytes": (_I32, [_VP, _SZ]),
     "lz4flex_frame_decoder_free": (None, [_VP]),
     "lz4flex_frame_compress": (_I64, [_VP, _SZ, C.POINTER(FrameInfoC), _VP, _SZ, C.POINTER(ErrDetail)]),

@@ -110,6 +110,62 @@ def compress_prepend_size(input):
     return len(input).to_bytes(4, "little") + compress(input)
 
 
+class CompressTable:
+    """block::CompressTable (compress.rs:710-740): small() / large() / default; reused across compress_into_with_table calls"""
+
+    def __init__(self, large=False):
+        self._h = L.load().lz4flex_compress_table_new(1 if large else 0)
+        if not self._h:
+            raise DeviceError("lz4flex_compress_table_new failed: " + L.last_error())
+
+    @classmethod
+    def small(cls):
+        return cls(False)
+
+    @classmethod
+    def large(cls):
+        return cls(True)
+
+    @property
+    def is_large(self):
+        return bool(L.load().lz4flex_compress_table_is_large(self._h))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                L.load().lz4flex_compress_table_free(h)
+            except Exception:
+                pass
+
+
+def compress_into_with_table(input, output, table):
+    """block::compress_into_with_table (compress.rs:742-766)"""
+    lib = L.load()
+    ip, n, _k = _buf(input)
+    out = (C.c_uint8 * max(len(output), 1)).from_buffer(output) if len(output) else (C.c_uint8 * 1)()
+    r = lib.lz4flex_compress_into_with_table(ip, n, C.cast(out, C.c_void_p), len(output), table._h)
+    if r == -L.E_OUTPUT_TOO_SMALL:
+        raise CompressOutputTooSmall()
+    if r < 0:
+        raise DeviceError("lz4flex error %d: %s" % (-r, L.last_error()))
+    return int(r)
+
+
+def compress_prepend_size_with_dict(input, ext_dict):
+    """block::compress_prepend_size_with_dict (compress.rs:692-694), through the C entry point"""
+    lib = L.load()
+    ip, n, _k = _buf(input)
+    dp, dn, _k2 = _buf(ext_dict)
+    out = bytearray(4 + get_maximum_output_size(n))
+    o = (C.c_uint8 * len(out)).from_buffer(out)
+    r = lib.lz4flex_compress_prepend_size_with_dict(ip, n, C.cast(o, C.c_void_p), len(out), dp, dn)
+    if r < 0:
+        raise DeviceError("lz4flex error %d: %s" % (-r, L.last_error()))
+    del o
+    return bytes(out[:r])
+
+
 def compress_into_with_dict(input, output, dict_data):
     """block::compress_into_with_dict (compress.rs:610-616)"""
     lib = L.load()
@@ -186,9 +242,19 @@ def decompress_size_prepended(input):
 
 
 def decompress_size_prepended_with_dict(input, ext_dict):
-    """block::decompress_size_prepended_with_dict (decompress.rs:521-527)"""
-    size, rest = uncompressed_size(input)
-    return decompress_with_dict(rest, size, ext_dict)
+    """block::decompress_size_prepended_with_dict (decompress.rs:521-527), through the C entry point"""
+    lib = L.load()
+    size, _rest = uncompressed_size(input)
+    ip, n, _k = _buf(input)
+    dp, dn, _k2 = _buf(ext_dict)
+    out = bytearray(max(size, 1))
+    o = (C.c_uint8 * len(out)).from_buffer(out)
+    d = L.ErrDetail()
+    r = lib.lz4flex_decompress_size_prepended_with_dict(ip, n, C.cast(o, C.c_void_p), size, dp, dn, C.byref(d))
+    del o
+    if r < 0:
+        _raise_decode(int(-r), d)
+    return bytes(out[:r])
 
 
 # ---- batched entry points (host numpy arrays) -----------------------------------------------------

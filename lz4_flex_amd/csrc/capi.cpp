@@ -376,8 +376,12 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
     // copy results back: dense outputs in one transfer, sparse ones block by block
     if (out_bytes && produced * 2 >= out_bytes && !has_pos) {
         // every successful block owns [out_off, out_off+len); failed blocks must leave the caller's bytes alone
+        // ... and the one-shot copy covers the whole span, so the blocks must TILE it: with gaps between the callers' slots (a
+        // padded stride) it would overwrite host bytes that belong to nobody with whatever the device arena holds
         bool all_ok = true;
-        for (uint32_t i = 0; i < n; i++) all_ok &= (r_st[i] == 0 && r_len[i] == out_cap[i]);
+        uint64_t cap_sum = 0;
+        for (uint32_t i = 0; i < n; i++) { all_ok &= (r_st[i] == 0 && r_len[i] == out_cap[i]); cap_sum += out_cap[i]; }
+        all_ok &= cap_sum == (uint64_t)out_bytes;
         if (all_ok) {
             HIP_TRY(hipMemcpyAsync(out_base + hb.out_span.lo, d + a_out, out_bytes, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
@@ -698,6 +702,64 @@ int lz4flex_copy_batch_device(const void* src_base, const uint64_t* src_off, con
     return le == hipSuccess ? 0 : hip_fail(le, "copy batch launch");
 }
 
+// ---- CompressTable / compress_into_with_table, src/block/compress.rs:710-766 --------------------------------------
+// The reference clears the table on every call: the handle only avoids re-allocating it and remembers its variant
+// (Small = u16 entries + 4-byte hash, Large = u32 entries + 5-byte hash; upgraded, never downgraded).  Here the handle
+// owns a context, i.e. the device workspace that is reused from call to call.
+struct lz4flex_compress_table {
+    lz4flex_ctx* ctx = nullptr;
+    int large = 0;
+};
+
+lz4flex_compress_table* lz4flex_compress_table_new(int large) {
+    lz4flex_compress_table* t = new (std::nothrow) lz4flex_compress_table();
+    if (!t) return nullptr;
+    t->large = large ? 1 : 0;
+    if (lz4flex_ctx_create(&t->ctx, -1) != 0) { delete t; return nullptr; }
+    return t;
+}
+void lz4flex_compress_table_free(lz4flex_compress_table* t) {
+    if (!t) return;
+    lz4flex_ctx_destroy(t->ctx);
+    delete t;
+}
+int lz4flex_compress_table_is_large(const lz4flex_compress_table* t) { return t ? t->large : -LZ4FLEX_E_INVALID_ARG; }
+
+int64_t lz4flex_compress_into_with_table(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, lz4flex_compress_table* t) {
+    if (!t || in_len > 0xFFFFFFFFull) return -LZ4FLEX_E_INVALID_ARG;
+    if (out_cap < lz4flex_get_maximum_output_size(in_len)) return -LZ4FLEX_E_OUTPUT_TOO_SMALL;   // compress.rs:338-340
+    if (in_len >= 65535u) t->large = 1;                        // compress.rs:752-754: transparently upgraded, never downgraded
+    lz4flex_ctx* dc = nullptr;
+    int rc = default_ctx(&dc);
+    if (rc) return rc;
+    t->ctx->comp_mode = dc->comp_mode;                         // the thread's encoder choice (throughput / reference-exact)
+    t->ctx->comp_variant = dc->comp_variant;
+    const uint64_t off0 = 0;
+    const uint32_t len = (uint32_t)in_len, cap = (uint32_t)std::min<size_t>(out_cap, 0xFFFFFFFFull);
+    // Large: HashTable4K, cleared, stream offset 0 == the frame encoder's first block (LZ4FLEX_BLOCK_FRAME_FIRST);
+    // Small: what compress_into picks for inputs below 65 535 bytes
+    const uint32_t flags = t->large ? LZ4FLEX_BLOCK_FRAME_FIRST : LZ4FLEX_BLOCK_DEFAULT;
+    uint32_t olen = 0;
+    int32_t st = 0;
+    static const uint8_t empty = 0;
+    rc = run_host_batch(t->ctx, true, in ? in : &empty, &off0, &len, &flags, 1, out, &off0, &cap, &olen, &st, nullptr, nullptr);
+    if (rc) return rc;
+    if (st) return -(int64_t)st;
+    return (int64_t)olen;
+}
+
+// compress_prepend_size_with_dict, src/block/compress.rs:692-694: LE u32 length, then compress_into_with_dict's block
+int64_t lz4flex_compress_prepend_size_with_dict(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, const uint8_t* dict,
+                                                size_t dict_len) {
+    if (out_cap < 4 || out_cap - 4 < lz4flex_get_maximum_output_size(in_len)) return -LZ4FLEX_E_OUTPUT_TOO_SMALL;
+    const uint32_t n = (uint32_t)in_len;
+    out[0] = (uint8_t)n; out[1] = (uint8_t)(n >> 8); out[2] = (uint8_t)(n >> 16); out[3] = (uint8_t)(n >> 24);
+    // compress_into_vec_with_dict: dictionaries of <= 3 bytes are ignored (compress.rs:626-628)
+    const int64_t r = dict_len <= 3 ? lz4flex_compress_into(in, in_len, out + 4, out_cap - 4)
+                                    : lz4flex_compress_into_with_dict(in, in_len, out + 4, out_cap - 4, dict, dict_len);
+    return r < 0 ? r : r + 4;
+}
+
 int64_t lz4flex_uncompressed_size(const uint8_t* in, size_t in_len) {
     if (in_len < 4) return -LZ4FLEX_E_EXPECTED_ANOTHER_BYTE;   // mod.rs:152
     return (int64_t)((uint32_t)in[0] | ((uint32_t)in[1] << 8) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 24));
@@ -710,6 +772,15 @@ int64_t lz4flex_decompress_size_prepended(const uint8_t* in, size_t in_len, uint
     if ((uint64_t)sz > out_cap) return -LZ4FLEX_E_INVALID_ARG;   // the Vec variant allocates `sz`; here the caller must
     // decompress.rs:493-496 -> decompress(input, uncompressed_size): capacity is exactly the prefix
     return decompress_common(in + 4, in_len - 4, out, (size_t)sz, nullptr, 0, false, detail);
+}
+
+// decompress_size_prepended_with_dict, src/block/decompress.rs:521-527
+int64_t lz4flex_decompress_size_prepended_with_dict(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, const uint8_t* dict,
+                                                    size_t dict_len, lz4flex_err_detail* detail) {
+    const int64_t sz = lz4flex_uncompressed_size(in, in_len);
+    if (sz < 0) return sz;
+    if ((uint64_t)sz > out_cap) return -LZ4FLEX_E_INVALID_ARG;   // the Vec variant allocates `sz`; here the caller must
+    return decompress_common(in + 4, in_len - 4, out, (size_t)sz, dict, dict_len, true, detail);
 }
 
 }  // extern "C"

@@ -481,7 +481,8 @@ struct lz4flex_frame_decoder {
         std::vector<Slot> slots;
         size_t out_need = 0;
         bool saw_end = false;
-        while (slots.size() < max_blocks) {
+        const size_t out_budget = std::max<size_t>(batch_bytes, mbs) * (batch_auto ? 4u : 1u);   // bytes of output reserved per launch
+        while (slots.size() < max_blocks && (slots.empty() || out_need + mbs <= out_budget)) {
             uint8_t bi[4];
             const int rc = read_exact(bi, 4);
             if (rc != 0) {
@@ -503,7 +504,11 @@ struct lz4flex_frame_decoder {
                 if (XxHash32::oneshot(0, comp.data() + at, len) != rd32(c)) { comp.resize(at); fail(-LZ4FLEX_FE_BLOCK_CHECKSUM); break; }
             }
             Slot s{raw, out_need, in_off.size(), len};
-            if (!raw) { in_off.push_back(at); in_len.push_back((uint32_t)len); out_off.push_back(out_need); out_cap.push_back((uint32_t)mbs); out_need += mbs; }
+            // An LZ4 block expands by less than 255x (one length byte adds at most 255 output bytes), so min(block size,
+            // 255 len + 64) is as good a sink as the reference's block-size buffer and a frame of tiny blocks cannot make the
+            // read-ahead reserve (and the device arena mirror) gigabytes.
+            const size_t cap_i = std::min<size_t>(mbs, 255u * len + 64u);
+            if (!raw) { in_off.push_back(at); in_len.push_back((uint32_t)len); out_off.push_back(out_need); out_cap.push_back((uint32_t)cap_i); out_need += cap_i; }
             else { s.idx = at; out_need += len; }
             slots.push_back(s);
         }
@@ -597,6 +602,42 @@ struct lz4flex_frame_decoder {
     }
 
     // io::Read::read, frame/decompress.rs:353-367
+    // io::BufRead::fill_buf, frame/decompress.rs:410-416: the decoded bytes not consumed yet (decodes more when there are
+    // none); *p stays valid until the next call on this decoder.  0 = end of frame / EOF, < 0 = -code.
+    int64_t fill_buf(const uint8_t** p, lz4flex_err_detail* d) {
+        for (;;) {
+            while (ready_idx < ready.size()) {
+                const Item& it = ready[ready_idx];
+                if (it.len == 0 || ready_pos == it.len) {
+                    const bool empty_block = it.len == 0;
+                    ready_idx++; ready_pos = 0;
+                    if (empty_block) { *p = out.data(); return 0; }      // read_more() == 0: an empty slice
+                    continue;
+                }
+                *p = out.data() + it.off + ready_pos;
+                return (int64_t)(it.len - ready_pos);
+            }
+            if (pending_err) { if (d) *d = pending_detail; return pending_err; }
+            if (pending_zero) { pending_zero = false; *p = out.data(); return 0; }
+            if (!have_frame) {
+                lz4flex_err_detail hd{};
+                const int rc = read_frame_info(&hd);
+                if (rc == 1) { *p = out.data(); return 0; }
+                if (rc < 0) { if (d) *d = hd; return rc; }
+            }
+            if (fi.block_mode == 1) read_block_linked(); else read_blocks_independent();
+        }
+    }
+    // io::BufRead::consume, :418-421 (the reference asserts amt <= available)
+    int consume(size_t amt) {
+        if (amt == 0) return 0;
+        if (ready_idx >= ready.size()) return -LZ4FLEX_E_INVALID_ARG;
+        const Item& it = ready[ready_idx];
+        if (amt > it.len - ready_pos) return -LZ4FLEX_E_INVALID_ARG;
+        ready_pos += amt;
+        if (ready_pos == it.len) { ready_idx++; ready_pos = 0; }
+        return 0;
+    }
     int64_t read(uint8_t* buf, size_t len, lz4flex_err_detail* d) {
         for (;;) {
             while (ready_idx < ready.size()) {
@@ -661,6 +702,15 @@ int64_t lz4flex_frame_decoder_read(lz4flex_frame_decoder* dcd, uint8_t* buf, siz
     if (!dcd || (!buf && len)) return -LZ4FLEX_E_INVALID_ARG;
     if (d) memset(d, 0, sizeof *d);
     return dcd->read(buf, len, d);
+}
+int64_t lz4flex_frame_decoder_fill_buf(lz4flex_frame_decoder* dcd, const uint8_t** buf, lz4flex_err_detail* d) {
+    if (!dcd || !buf) return -LZ4FLEX_E_INVALID_ARG;
+    if (d) memset(d, 0, sizeof *d);
+    return dcd->fill_buf(buf, d);
+}
+int lz4flex_frame_decoder_consume(lz4flex_frame_decoder* dcd, size_t amt) {
+    if (!dcd) return -LZ4FLEX_E_INVALID_ARG;
+    return dcd->consume(amt);
 }
 int lz4flex_frame_decoder_set_batch_bytes(lz4flex_frame_decoder* d, size_t bytes) {
     if (!d || bytes == 0) return -LZ4FLEX_E_INVALID_ARG;

@@ -297,6 +297,20 @@ class FrameDecoder:
             raise _frame_error(int(-r), d)
         return bytes(buf[:r])
 
+    def fill_buf(self):
+        """io::BufRead::fill_buf (frame/decompress.rs:410-416): the decoded bytes not consumed yet (b"" at the end)"""
+        p = C.c_void_p()
+        d = L.ErrDetail()
+        r = L.load().lz4flex_frame_decoder_fill_buf(self._h, C.byref(p), C.byref(d))
+        if r < 0:
+            raise _frame_error(int(-r), d)
+        return C.string_at(p, r) if r else b""
+
+    def consume(self, amt):
+        """io::BufRead::consume (:418-421)"""
+        if L.load().lz4flex_frame_decoder_consume(self._h, int(amt)) != 0:
+            raise ValueError("consume(%d): more than fill_buf returned" % amt)
+
     def read_to_end(self):
         """io::Read::read_to_end (decompress.rs:385-399): until a read returns 0 (one frame)."""
         out = []

@@ -334,3 +334,37 @@ def test_decompress_batch_bit_exact_vs_oracle(blk, lanes):
         assert bytes(out[:-1]) == b"".join(plains)
     finally:
         lib.lz4flex_ctx_destroy(ctx)
+
+
+def test_compress_into_with_table_variants(blk):
+    """compress.rs:742-766: Small == compress_into below 65 535 bytes; an input >= 65 535 upgrades the table to Large for
+    good, after which small inputs compress with the u32 table + 5-byte hash (== the frame encoder's first block)"""
+    small = O.fixture_plain("compression_34k")
+    big = (O.fixture_plain("compression_66k_JSON") * 2)[:100000]
+    t = blk.CompressTable.small()
+    out = bytearray(O.max_out(len(big)))
+    for _ in range(2):                                       # reused across calls
+        n = blk.compress_into_with_table(small, out, t)
+        assert bytes(out[:n]) == O.compress(small) and not t.is_large
+    n = blk.compress_into_with_table(big, out, t)
+    assert bytes(out[:n]) == O.compress(big) and t.is_large
+    n = blk.compress_into_with_table(small, out, t)
+    assert bytes(out[:n]) == O.compress_frame_block(small, first_block=True)     # Large table, never downgraded
+    assert O.decompress(bytes(out[:n]), len(small)) == ("ok", small)
+    t2 = blk.CompressTable.large()
+    n = blk.compress_into_with_table(small, out, t2)
+    assert bytes(out[:n]) == O.compress_frame_block(small, first_block=True)
+    with pytest.raises(blk.CompressOutputTooSmall):
+        blk.compress_into_with_table(small, bytearray(10), t2)
+
+
+def test_size_prepended_with_dict_entry_points(blk):
+    """compress.rs:692-694, decompress.rs:521-527 through their own C entry points"""
+    d = O.fixture_plain("compression_1k")
+    data = (d * 3)[100:1500]
+    c = blk.compress_prepend_size_with_dict(data, d)
+    assert c[:4] == len(data).to_bytes(4, "little") and c[4:] == O.compress_with_dict(data, d)
+    assert blk.decompress_size_prepended_with_dict(c, d) == data
+    assert blk.compress_prepend_size_with_dict(data, b"ab") == len(data).to_bytes(4, "little") + O.compress(data)   # dict <= 3 bytes ignored
+    with pytest.raises(blk.ExpectedAnotherByte):
+        blk.decompress_size_prepended_with_dict(b"\x01\x00", d)

@@ -206,3 +206,23 @@ def test_one_shot_helpers(fr):
     assert f == O.frame_compress(data)[1]
     out, used = fr.decompress_frame(f, len(data))
     assert out == data and used == len(f)
+
+
+def test_frame_decoder_bufread(fr):
+    """io::BufRead for FrameDecoder (frame/decompress.rs:410-422): fill_buf / consume walk the same bytes read() returns"""
+    data = (O.fixture_plain("compression_66k_JSON") * 5)[:300000]
+    for mode in (0, 1):
+        rc, f = O.frame_compress(data, block_mode=mode, block_size=4)
+        assert rc == 0
+        dec = fr.FrameDecoder.new(io.BytesIO(f))
+        got = bytearray()
+        while True:
+            b = dec.fill_buf()
+            if not b:
+                break
+            k = max(1, len(b) // 3)                          # consume less than offered: the rest is offered again
+            got += b[:k]
+            dec.consume(k)
+        assert bytes(got) == data
+        with pytest.raises(ValueError):
+            dec.consume(1)
