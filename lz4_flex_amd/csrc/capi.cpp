@@ -65,6 +65,14 @@ static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressA
     return launch_decompress_pipe(a, s, 0, c->dec_geometry);
 }
 
+// Reference-exact encoder, MEM_DEVICE batches without LZ4FLEX_MEM_BIG_BLOCKS: the u16-table kernel is only right for blocks
+// of <= 64 KiB and the host cannot see the device-resident lengths, so a block that breaks the promise is flagged on the
+// device (its bytes would be a valid block, but not lz4_flex's) instead of passing silently.
+__global__ void lz4flex_flag_long_blocks_kernel(const uint32_t* in_len, uint32_t n, uint32_t* out_len, int32_t* status) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n && in_len[b] > 65536u) { status[b] = LZ4FLEX_E_INVALID_ARG; out_len[b] = 0u; }
+}
+
 // the encoders for independent blocks: throughput mode (own parse, any block length) or the reference-exact one
 static int launch_compress_any(lz4flex_ctx* c, const CompressArgs& a, bool big, hipStream_t s) {
     hipError_t le;
@@ -79,6 +87,10 @@ static int launch_compress_any(lz4flex_ctx* c, const CompressArgs& a, bool big, 
         le = launch_compress_wave(a, c->wave_ws, c->wave_wgs, s, c->wave_prof);
     } else {
         le = launch_compress(a, c->comp_lanes | (big ? 0x100 : 0) | comp_mode_bits(c->comp_variant), s);
+        if (le == hipSuccess && !big && a.n) {
+            hipLaunchKernelGGL(lz4flex_flag_long_blocks_kernel, dim3((a.n + 255u) / 256u), dim3(256), 0, s, a.in_len, a.n, a.out_len, a.status);
+            le = hipGetLastError();
+        }
     }
     if (le != hipSuccess) return hip_fail(le, "kernel launch");
     return 0;
