@@ -61,6 +61,15 @@ static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressA
     // 16 384 blocks against 2.39 / 2.55 / 2.93 ms pipelined; above one split round per CU the 4-lane pipelined geometry
     // holds twice the blocks per CU: 32 768 blocks 4.19 ms against 4.60 ms)
     const int v = c->dec_variant != 0 ? c->dec_variant : (a.n > 20480u ? 3 : 4);
+    if (v == 5) {
+        // one block per wavefront; blocks it marks (errors, sinks too small) are decoded again in the reference's order
+        constexpr int32_t REDO = 0x7F000001;
+        hipError_t e = launch_decompress_wave(a, REDO, s);
+        if (e != hipSuccess) return e;
+        DecompressArgs r = a;
+        r.only_status = REDO;
+        return launch_decompress(r, c->dec_lanes, s);
+    }
     if (v == 4) return launch_decompress_split(a, s, c->dec_blocks_per_wg);
     return launch_decompress_pipe(a, s, 0, c->dec_geometry);
 }
@@ -168,7 +177,7 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
     c->device = device;
     if (const char* e = getenv("LZ4FLEX_COMPRESS_MODE")) c->comp_mode = (!strcmp(e, "exact") || !strcmp(e, "1")) ? 1 : 0;
     if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v == 1 || v == 3) c->comp_variant = v; }
-    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v == 0 || v == 1 || v == 3 || v == 4) c->dec_variant = v; }
+    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v == 0 || v == 1 || v == 3 || v == 4 || v == 5) c->dec_variant = v; }
     if (const char* e = getenv("LZ4FLEX_DECOMPRESS_GEOMETRY")) { const int v = atoi(e); if (v >= -1 && v <= 1) c->dec_geometry = v; }
     int prev = 0;
     (void)hipGetDevice(&prev);
@@ -228,7 +237,7 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "decompress_variant")) {
-        if (value != 0 && value != 1 && value != 3 && value != 4) return -LZ4FLEX_E_INVALID_ARG;
+        if (value != 0 && value != 1 && value != 3 && value != 4 && value != 5) return -LZ4FLEX_E_INVALID_ARG;
         c->dec_variant = value;
         return 0;
     }

@@ -195,6 +195,7 @@ __global__ void __launch_bounds__(256) lz4_decompress_blocks_kernel(DecompressAr
     const uint32_t b = tid / G;
     const uint32_t g = tid % G;
     if (b >= a.n) return;
+    if (a.only_status != 0 && a.status[b] != a.only_status) return;   // second pass behind the wave decoder: marked blocks only
     const uint8_t* in = a.in_base + a.in_off[b];
     uint8_t* out = a.out_base + a.out_off[b];
     const uint32_t ilen = a.in_len[b];

@@ -1,0 +1,331 @@
+// lz4_decompress_wave.hip -- batched LZ4 block decoder, one block per wavefront ("wave decoder"), gfx950.
+//
+// What it replaces: lz4_flex::block::decompress_into / decompress_internal (src/block/decompress.rs:201-449) for many
+// independent blocks.  Output bytes are the reference's; every irregular block (any error of src/block/mod.rs:82-98, a
+// sink too small, an offset behind the output) is NOT diagnosed here: the block is marked and the reference-order
+// decoder of lz4_decompress.hip decodes it again and reports the exact error variant and detail.
+//
+// Round 1 ran the reference's token loop as one serial chain per block (a lane per block parsing, eight lanes copying):
+// 64 chains per CU, ~1 350 cycles per sequence, and a 4 MiB block took as long as 64 small ones.  Here a block is
+// decoded by a whole wavefront and the 64 lanes are the parallelism INSIDE the block:
+//   * parse: a window of 64 compressed bytes at a time, lane i assuming a token at byte i (two small loads: token +
+//     first length byte, then the offset / match-length byte behind its literals); the real token chain through the
+//     window is a scalar hop over v_readlane (~14 sequences per window, ~5 instructions each);
+//   * a DPP prefix sum of literal + match lengths places every sequence of the window in the output at once;
+//   * copies: the window's literals (<= 16 bytes each) and every match whose source lies before the window's own
+//     output are written lane-parallel (lane = sequence: 16-byte unaligned LDS reads, exact-length writes), matches
+//     whose source is older than the LDS ring come from the already written output (requested before the other copies,
+//     consumed after them); only matches that read bytes produced inside the window, ring wrap-arounds and long runs go
+//     through a serial loop in which the whole wavefront copies one sequence, 64 bytes per step;
+//   * the output lives in an 8 KiB LDS ring per wavefront (20 wavefronts per CU), written back 16 bytes per lane.
+// Anything the speculative parse cannot express (length bytes beyond one, runs longer than 2 KiB) is decoded by
+// exact_token(): the same work done by the wavefront for ONE sequence of any length.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lz4_device.h"
+
+namespace lz4flex_dev {
+namespace wdec {
+
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(1))) uint8_t g_u8;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+
+constexpr uint32_t RB = 8192u, RM = RB - 1u;      // LDS ring bytes per wavefront
+constexpr uint32_t WPB = 4u;                      // wavefronts (= blocks) per workgroup
+constexpr uint32_t TMAX = 2048u;                  // output bytes of one window
+constexpr uint32_t FLUSH_AT = 512u;               // write back when this much is pending
+
+#define LZ4D_DPP(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xf, false))
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
+    v += LZ4D_DPP(v, 0x111, 0xf);
+    v += LZ4D_DPP(v, 0x112, 0xf);
+    v += LZ4D_DPP(v, 0x114, 0xf);
+    v += LZ4D_DPP(v, 0x118, 0xf);
+    v += LZ4D_DPP(v, 0x142, 0xa);
+    v += LZ4D_DPP(v, 0x143, 0xc);
+    return v;
+}
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
+
+// n (1..16) bytes of v to LDS, exactly
+__device__ __forceinline__ void write_exact16(lds_u8* dst, const u32x4& v, uint32_t n) {
+    if (n >= 16u) { __builtin_memcpy((void*)dst, &v, 16); return; }
+    const bool n8 = (n & 8u) != 0u, n4 = (n & 4u) != 0u, n2 = (n & 2u) != 0u;
+    const uint32_t w4 = n8 ? v.z : v.x;                               // the dword at byte offset (n & 8)
+    const uint32_t wq = n8 ? (n4 ? v.w : v.z) : (n4 ? v.y : v.x);     // the dword at byte offset (n & 12)
+    if (n8) { const uint64_t t = (uint64_t)v.x | ((uint64_t)v.y << 32); __builtin_memcpy((void*)dst, &t, 8); }
+    if (n4) __builtin_memcpy((void*)(dst + (n & 8u)), &w4, 4);
+    if (n2) { const uint16_t t = (uint16_t)wq; __builtin_memcpy((void*)(dst + (n & 12u)), &t, 2); }
+    if (n & 1u) dst[n & 14u] = (uint8_t)(wq >> (n2 ? 16 : 0));
+}
+
+struct Dec {
+    const g_u8* in;
+    g_u8* out;
+    lds_u8* ring;
+    uint32_t ilen, cap, lane;
+    uint32_t op, F;          // bytes produced; bytes written back (a multiple of 16)
+
+    __device__ __forceinline__ void flush() {            // ring -> output, whole 16-byte units
+        const uint32_t lim = op & ~15u;
+        for (uint32_t pos = F + 16u * lane; pos < lim; pos += 1024u) {
+            u32x4 v;
+            __builtin_memcpy(&v, (const void*)(ring + (pos & RM)), 16);
+            __builtin_memcpy((void*)(out + pos), &v, 16);
+        }
+        F = lim;
+    }
+    __device__ __forceinline__ void finish() {
+        flush();
+        if (F + lane < op) out[F + lane] = ring[(F + lane) & RM];
+        F = op;
+    }
+    // literals of any length from the compressed stream, whole wavefront; the caller bounds n so that the ring keeps
+    // everything not written back yet
+    __device__ __forceinline__ void coop_literals(uint32_t src, uint32_t dst, uint32_t n) {
+        for (uint32_t c = 0; c < n; c += 64u) {
+            const uint32_t i = c + lane;
+            if (i < n) ring[(dst + i) & RM] = in[src + i];
+        }
+    }
+    // a match of any offset / length, whole wavefront, 64 bytes per step.  Source bytes come from the ring when it still
+    // holds them (position >= near_lo), else from the output written back earlier.  offset < 64: the periodic form
+    // out[d + i] = out[d - offset + i mod offset], which only reads bytes that precede the match.
+    __device__ __forceinline__ void coop_match(uint32_t dst, uint32_t offset, uint32_t n, uint32_t near_lo) {
+        const uint32_t src = dst - offset;
+        const float rcp = offset < 64u ? 1.0f / (float)offset : 0.0f;
+        for (uint32_t c = 0; c < n; c += 64u) {
+            const uint32_t i = c + lane;
+            if (i < n) {
+                uint32_t si = i;
+                if (offset < 64u) {
+                    uint32_t q = (uint32_t)((float)i * rcp);
+                    uint32_t r = i - q * offset;                  // q is off by at most one either way
+                    r = (int32_t)r < 0 ? r + offset : r;
+                    r = r >= offset ? r - offset : r;
+                    si = r;
+                }
+                const uint32_t pos = src + si;
+                uint8_t byte;
+                if (pos >= near_lo) byte = ring[pos & RM];
+                else byte = out[pos];
+                ring[(dst + i) & RM] = byte;
+            }
+        }
+    }
+};
+
+// One sequence of any shape at `ip`, decoded by the whole wavefront with the reference's checks (any violation -> false:
+// the block is decoded again by the reference-order kernel, which reports the error).  *done: the block ended here.
+__device__ bool exact_token(Dec& D, uint32_t& ip, bool& done) {
+    const g_u8* in = D.in;
+    const uint32_t ilen = D.ilen;
+    uint32_t t = in[ip];
+    ip += 1u;
+    uint32_t lit = t >> 4;
+    if (lit == 15u) {
+        for (;;) {
+            if (ip >= ilen) return false;
+            const uint32_t b = in[ip];
+            ip += 1u;
+            lit += b;
+            if (b != 255u) break;
+        }
+    }
+    if (lit > ilen - ip || lit > D.cap - D.op) return false;
+    for (uint32_t c = 0; c < lit; c += 1024u) {
+        const uint32_t n = lit - c < 1024u ? lit - c : 1024u;
+        D.coop_literals(ip + c, D.op, n);
+        D.op += n;
+        if (D.op - D.F >= FLUSH_AT) D.flush();
+    }
+    ip += lit;
+    if (ip >= ilen) { done = true; return true; }
+    if (ilen - ip < 2u) return false;
+    const uint32_t offset = (uint32_t)in[ip] | ((uint32_t)in[ip + 1u] << 8);
+    ip += 2u;
+    if (offset == 0u) return false;
+    uint32_t ml = 4u + (t & 15u);
+    if (ml == 19u) {
+        for (;;) {
+            if (ip >= ilen) return false;
+            const uint32_t b = in[ip];
+            ip += 1u;
+            ml += b;
+            if (b != 255u) break;
+        }
+    }
+    if (offset > D.op || ml > D.cap - D.op) return false;
+    for (uint32_t c = 0; c < ml; c += 1024u) {
+        const uint32_t n = ml - c < 1024u ? ml - c : 1024u;
+        const uint32_t wend = D.op + n;
+        D.coop_match(D.op, offset, n, wend > RB ? wend - RB : 0u);
+        D.op += n;
+        if (D.op - D.F >= FLUSH_AT) D.flush();
+    }
+    if (ip >= ilen) return false;              // a match is always followed by another token (decompress.rs:439-443)
+    return true;
+}
+
+__global__ void __launch_bounds__(64 * WPB) lz4_decompress_wave_kernel(DecompressArgs a, int32_t redo_code) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds_raw[WPB * RB];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = uni(threadIdx.x >> 6);
+    const uint32_t b = blockIdx.x * WPB + wv;
+    if (b >= a.n) return;
+    Dec D;
+    D.in = (const g_u8*)(a.in_base + a.in_off[b]);
+    D.out = (g_u8*)(a.out_base + a.out_off[b]);
+    D.ring = (lds_u8*)lds_raw + wv * RB;
+    D.ilen = a.in_len[b];
+    D.cap = a.out_cap[b];
+    D.lane = lane;
+    D.op = 0u; D.F = 0u;
+    const g_u8* in = D.in;
+    const uint32_t ilen = D.ilen;
+    bool ok = ilen != 0u, done = false;
+    uint32_t ip = 0u;
+    while (ok && !done) {
+        // ---- speculative parse: lane i takes byte ip + i for a token -------------------------------------------------
+        const uint32_t p = ip + lane;
+        uint32_t t2 = 0u;
+        if (p + 1u < ilen) { uint16_t h; __builtin_memcpy(&h, (const void*)(in + p), 2); t2 = h; }
+        else if (p < ilen) t2 = in[p];
+        const uint32_t tok = t2 & 0xFFu, e1 = t2 >> 8;
+        uint32_t lit = tok >> 4;
+        const uint32_t mlc = tok & 15u;
+        uint32_t lhdr = 1u;
+        bool cx = p >= ilen;                        // cx: not expressible here (or simply wrong): exact_token decides
+        if (lit == 15u) { lhdr = 2u; cx |= (p + 1u >= ilen) | (e1 == 255u); lit = 15u + e1; }
+        const uint32_t ls = p + lhdr, le = ls + lit;
+        cx |= le > ilen;
+        const bool fin = !cx & (le == ilen);        // the block's last sequence: literals only
+        const bool seq = !cx & !fin;
+        cx |= seq & (le + 2u > ilen);
+        uint32_t w4 = 0u;
+        if (seq & !cx) {
+            if (le + 4u <= ilen) __builtin_memcpy(&w4, (const void*)(in + le), 4);
+            else { w4 = (uint32_t)in[le] | ((uint32_t)in[le + 1u] << 8); if (le + 2u < ilen) w4 |= (uint32_t)in[le + 2u] << 16; }
+        }
+        const uint32_t offs = w4 & 0xFFFFu, m1 = (w4 >> 16) & 0xFFu;
+        uint32_t mlen = 4u + mlc, nx = le + 2u;
+        if (mlc == 15u) { cx |= seq & ((le + 3u > ilen) | (m1 == 255u)); mlen += m1; nx += 1u; }
+        cx |= seq & (nx >= ilen);                   // a match must be followed by another token: leave it to exact_token
+        if (fin) { mlen = 0u; nx = ilen; }
+        // ---- the real token chain through the window (scalar hop) ---------------------------------------------------
+        const uint64_t cxm = __ballot(cx), finm = __ballot(fin);
+        uint64_t tokm = 0ull;
+        uint32_t cur = 0u;
+        bool stop_cx = false;
+        while (cur < 64u) {
+            if ((cxm >> cur) & 1ull) { stop_cx = true; break; }
+            tokm |= 1ull << cur;
+            if ((finm >> cur) & 1ull) { done = true; break; }
+            cur = rdlane(nx, cur) - ip;
+        }
+        // ---- place the window's sequences ---------------------------------------------------------------------------
+        bool tk = (tokm >> lane) & 1ull;
+        uint32_t tl = tk ? lit + mlen : 0u;
+        uint32_t incl = wave_incl_add(tl);
+        {
+            const uint64_t big = __ballot(tk & (incl > TMAX));     // keep a window's output small: cut behind the last fitting sequence
+            if (big != 0ull) {
+                const uint32_t cut = ctz64(big);
+                tokm &= (1ull << cut) - 1ull;
+                done = false;
+                cur = cut;                                          // the sequence at `cut` starts the next window ...
+                stop_cx = tokm == 0ull;                             // ... or is a long run by itself: exact_token
+                tk = (tokm >> lane) & 1ull;
+                tl = tk ? tl : 0u;
+                incl = wave_incl_add(tl);
+            }
+        }
+        const uint32_t T = rdlane(incl, 63u);
+        const uint32_t o = D.op + incl - tl;
+        const bool mt = tk & !fin;                                  // has a match
+        const uint32_t dm = o + lit;                                // match destination
+        if (T > D.cap - D.op || __ballot(mt & ((offs == 0u) | (offs > dm))) != 0ull) { ok = false; break; }
+        const uint32_t sm = dm - offs;
+        const uint32_t wend = D.op + T;
+        const uint32_t near_lo = wend > RB ? wend - RB : 0u;        // positions from here on are in the ring after this window
+        auto crosses = [](uint32_t pos, uint32_t n) -> bool { return (pos & RM) + n > RB; };
+        // ---- phase A: lane = sequence -------------------------------------------------------------------------------
+        const bool lpl = tk & (lit != 0u) & (lit <= 16u) & !crosses(o, 16u) & (ls + 16u <= ilen);          // literals, 16-byte read
+        const bool far = mt & (sm + mlen <= near_lo);                                                        // source older than the ring
+        const bool lpf = far & (mlen <= 32u) & !crosses(dm, 32u);
+        const bool lpn = mt & !far & (sm >= near_lo) & (sm + mlen <= D.op) & (mlen <= 64u) & !crosses(sm, mlen + 15u) & !crosses(dm, mlen + 15u);
+        u32x4 f0 = {0u, 0u, 0u, 0u}, f1 = {0u, 0u, 0u, 0u};
+        if (lpf) {                                                   // requested first, written last in phase A
+            __builtin_memcpy(&f0, (const void*)(D.out + sm), 16);
+            __builtin_memcpy(&f1, (const void*)(D.out + sm + 16u), 16);
+        }
+        if (lpl) {
+            u32x4 v;
+            __builtin_memcpy(&v, (const void*)(in + ls), 16);
+            write_exact16(D.ring + (o & RM), v, lit);
+        }
+        if (__ballot(lpn) != 0ull) {
+#pragma unroll 1
+            for (uint32_t k = 0u; k < 64u; k += 16u) {
+                const bool act = lpn & (k < mlen);
+                if (__ballot(act) == 0ull) break;
+                if (act) {
+                    u32x4 v;
+                    __builtin_memcpy(&v, (const void*)(D.ring + ((sm + k) & RM)), 16);
+                    write_exact16(D.ring + ((dm + k) & RM), v, mlen - k);
+                }
+            }
+        }
+        if (lpf) {
+            write_exact16(D.ring + (dm & RM), f0, mlen);
+            if (mlen > 16u) write_exact16(D.ring + ((dm + 16u) & RM), f1, mlen - 16u);
+        }
+        // ---- phase B: what is left, one sequence at a time, in order -------------------------------------------------
+        const bool litB = tk & (lit != 0u) & !lpl;
+        const bool matB = mt & !lpf & !lpn;
+        uint64_t rest = __ballot(litB | matB);
+        const uint64_t litBm = __ballot(litB), matBm = __ballot(matB);
+        while (rest != 0ull) {
+            const uint32_t q = ctz64(rest);
+            rest &= rest - 1ull;
+            const uint32_t oq = rdlane(o, q), lq = rdlane(lit, q);
+            if ((litBm >> q) & 1ull) D.coop_literals(rdlane(ls, q), oq, lq);
+            if ((matBm >> q) & 1ull) D.coop_match(oq + lq, rdlane(offs, q), rdlane(mlen, q), near_lo);
+        }
+        D.op = wend;
+        if (D.op - D.F >= FLUSH_AT) D.flush();
+        ip += cur;
+        if (done) break;
+        if (stop_cx) ok = exact_token(D, ip, done);
+    }
+    if (ok) {
+        D.finish();
+        if (lane == 0u) {
+            a.status[b] = 0;
+            a.out_len[b] = D.op;
+            if (a.detail) { a.detail[2u * b] = 0u; a.detail[2u * b + 1u] = 0u; }
+        }
+    } else if (lane == 0u) {
+        a.status[b] = redo_code;          // decoded again, with the reference's check order, by lz4_decompress_blocks_kernel
+        a.out_len[b] = 0u;
+    }
+}
+
+}  // namespace wdec
+
+// Blocks without dictionary / prefix.  Irregular blocks get status `redo_code`; the caller runs launch_decompress with
+// only_status = redo_code behind this launch.
+hipError_t launch_decompress_wave(const DecompressArgs& a, int32_t redo_code, hipStream_t s) {
+    if (a.n == 0u) return hipSuccess;
+    if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;
+    const uint32_t grid = (a.n + wdec::WPB - 1u) / wdec::WPB;
+    hipLaunchKernelGGL(wdec::lz4_decompress_wave_kernel, dim3(grid), dim3(64u * wdec::WPB), 0, s, a, redo_code);
+    return hipGetLastError();
+}
+
+}  // namespace lz4flex_dev

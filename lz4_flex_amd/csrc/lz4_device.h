@@ -28,6 +28,7 @@ struct DecompressArgs {
     int32_t* status;
     uint64_t* detail;          // nullable: 2 per block (expected, actual)
     uint32_t n;
+    int32_t only_status;       // lz4_decompress_blocks_kernel: 0 = every block, else only blocks whose status equals it (second pass)
 };
 
 struct CompressArgs {
@@ -45,6 +46,9 @@ struct CompressArgs {
 
 hipError_t launch_decompress(const DecompressArgs& a, int lanes_per_block, hipStream_t s);
 hipError_t launch_decompress_pipe(const DecompressArgs& a, hipStream_t s, int ablate = 0, int geometry = -1);  // pipelined LDS variant
+// one block per wavefront (lz4_decompress_wave.hip); irregular blocks are left with status redo_code for a second pass of
+// launch_decompress (only_status = redo_code), which decodes them in the reference's check order
+hipError_t launch_decompress_wave(const DecompressArgs& a, int32_t redo_code, hipStream_t s);
 hipError_t launch_decompress_split(const DecompressArgs& a, hipStream_t s, int blocks_per_wg = 0);   // parser / copier wavefronts, no dict/prefix
 hipError_t launch_compress(const CompressArgs& a, int variant, hipStream_t s);
 // throughput ("wave") encoder, lz4_compress_wave.hip: persistent workgroups, `workspace` holds

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--data", default="json")
     ap.add_argument("--prof", action="store_true")
+    ap.add_argument("--dec", type=int, default=0, help="decompress_variant")
     args = ap.parse_args()
     import torch
     import oracle_api as O
@@ -47,6 +48,8 @@ def main():
     ctx = C.c_void_p()
     assert lib.lz4flex_ctx_create(C.byref(ctx), 0) == 0
     assert lib.lz4flex_set_tuning(ctx, b"compress_mode", args.mode) == 0
+    if args.dec:
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", args.dec) == 0
     p = lambda t: C.c_void_p(t.data_ptr())
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
