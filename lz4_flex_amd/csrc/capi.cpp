@@ -60,7 +60,10 @@ static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressA
     // 0: by batch size (tools/dec_geometry.py on the configs[1] workload: split 1.69 / 1.80 / 2.36 ms for 1 024 / 8 192 /
     // 16 384 blocks against 2.39 / 2.55 / 2.93 ms pipelined; above one split round per CU the 4-lane pipelined geometry
     // holds twice the blocks per CU: 32 768 blocks 4.19 ms against 4.60 ms)
-    const int v = c->dec_variant != 0 ? c->dec_variant : (a.n > 20480u ? 3 : 4);
+    // by batch shape: up to ~6 000 blocks the wave decoder (a wavefront per block: a block is done in a third of the time the
+    // split decoder's serial chain needs, and blocks larger than 64 KiB stay tolerable); larger batches have enough blocks
+    // to fill the chip with one chain per lane, which costs half the instructions per byte
+    const int v = c->dec_variant != 0 ? c->dec_variant : (a.n <= 6144u ? 5 : (a.n > 20480u ? 3 : 4));
     if (v == 5) {
         // one block per wavefront; blocks it marks (errors, sinks too small) are decoded again in the reference's order
         constexpr int32_t REDO = 0x7F000001;

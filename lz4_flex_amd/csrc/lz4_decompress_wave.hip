@@ -34,6 +34,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) u32x4 g_u32x4;
 
 constexpr uint32_t RB = 8192u, RM = RB - 1u;      // LDS ring bytes per wavefront
+constexpr uint32_t IB = 1024u;                    // LDS copy of the compressed stream around the parse position (a window reads < 352 bytes ahead)
+constexpr uint32_t IB_PAD = 32u;                  // bytes readable behind it (16-byte literal reads)
+constexpr uint32_t WAVE_LDS = RB + IB + IB_PAD;
 constexpr uint32_t WPB = 4u;                      // wavefronts (= blocks) per workgroup
 constexpr uint32_t TMAX = 2048u;                  // output bytes of one window
 constexpr uint32_t FLUSH_AT = 512u;               // write back when this much is pending
@@ -68,8 +71,29 @@ struct Dec {
     const g_u8* in;
     g_u8* out;
     lds_u8* ring;
+    lds_u8* ibuf;            // compressed bytes [ib0, ib0 + IB) (zero beyond the block)
     uint32_t ilen, cap, lane;
     uint32_t op, F;          // bytes produced; bytes written back (a multiple of 16)
+    uint32_t ib0;            // a multiple of 16
+
+    // make [pos, pos + IB / 2) readable from ibuf: one coalesced reload of the whole buffer when pos has moved past its
+    // first half (the compressed stream is read about twice from L2, never byte-wise from the parse chain)
+    __device__ __forceinline__ void input_at(uint32_t pos) {
+        if (pos - ib0 < IB / 2u) return;
+        ib0 = pos & ~15u;
+        for (uint32_t i = 16u * lane; i < IB + IB_PAD; i += 1024u) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            const uint32_t g = ib0 + i;
+            if (g + 16u <= ilen) __builtin_memcpy(&v, (const void*)(in + g), 16);
+            else if (g < ilen) {
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+                for (uint32_t k = 0; k < 16u; ++k) if (g + k < ilen) w[k >> 2] |= (uint32_t)in[g + k] << (8u * (k & 3u));
+                v = u32x4{w[0], w[1], w[2], w[3]};
+            }
+            __builtin_memcpy((void*)(ibuf + i), &v, 16);
+        }
+    }
+    __device__ __forceinline__ bool in_ibuf(uint32_t pos, uint32_t n) const { return pos >= ib0 && pos + n <= ib0 + IB + IB_PAD; }
 
     __device__ __forceinline__ void flush() {            // ring -> output, whole 16-byte units
         const uint32_t lim = op & ~15u;
@@ -172,8 +196,135 @@ __device__ bool exact_token(Dec& D, uint32_t& ip, bool& done) {
     return true;
 }
 
+// A parsed window: what its (up to 21) sequences are and where they go.  Everything that needs memory outside LDS -- the
+// literal bytes, the sources of matches older than the ring -- is requested while the window is parsed, i.e. one window
+// before it is executed.
+struct Win {
+    uint32_t lit, ls, mlen, offs, o;      // per lane (= per byte of the window; meaningful on token lanes)
+    u32x4 lv, f0, f1;                     // the 16 literal bytes; 32 source bytes of a far match
+    bool tk, mt, lpl, lpf, lpn;           // token lane; has a match; literals / far match / near match written lane-parallel
+    uint32_t op0, T, near_lo, adv;        // uniform: output position before / bytes produced / ring horizon / input bytes consumed
+    bool ok, done, stop_cx;               // uniform: regular so far; the block's last sequence is inside; exact_token comes next
+};
+
+__device__ __forceinline__ Win parse_window(Dec& D, uint32_t ip, uint32_t op0) {
+    Win W;
+    const uint32_t lane = D.lane, ilen = D.ilen;
+    D.input_at(ip);
+    const lds_u8* ib = D.ibuf - D.ib0;                // ib + position
+    // ---- speculative parse: lane i takes byte ip + i for a token (bytes behind the block read as 0) ---------------------
+    const uint32_t p = ip + lane;
+    uint16_t h;
+    __builtin_memcpy(&h, (const void*)(ib + p), 2);
+    const uint32_t tok = h & 0xFFu, e1 = h >> 8;
+    uint32_t lit = tok >> 4;
+    const uint32_t mlc = tok & 15u;
+    uint32_t lhdr = 1u;
+    bool cx = p >= ilen;                               // cx: not expressible here (or simply wrong): exact_token decides
+    if (lit == 15u) { lhdr = 2u; cx |= (p + 1u >= ilen) | (e1 == 255u); lit = 15u + e1; }
+    const uint32_t ls = p + lhdr, le = ls + lit;
+    cx |= le > ilen;
+    const bool fin = !cx & (le == ilen);               // the block's last sequence: literals only
+    const bool seq = !cx & !fin;
+    cx |= seq & (le + 2u > ilen);
+    uint32_t w4;
+    __builtin_memcpy(&w4, (const void*)(ib + le), 4);
+    __builtin_memcpy(&W.lv, (const void*)(ib + ls), 16);
+    const uint32_t offs = w4 & 0xFFFFu, m1 = (w4 >> 16) & 0xFFu;
+    uint32_t mlen = 4u + mlc, nx = le + 2u;
+    if (mlc == 15u) { cx |= seq & ((le + 3u > ilen) | (m1 == 255u)); mlen += m1; nx += 1u; }
+    cx |= seq & (nx >= ilen);                          // a match must be followed by another token: leave it to exact_token
+    if (fin) { mlen = 0u; nx = ilen; }
+    // ---- the real token chain through the window (scalar hop) ----------------------------------------------------------
+    const uint64_t cxm = __ballot(cx), finm = __ballot(fin);
+    uint64_t tokm = 0ull;
+    uint32_t cur = 0u;
+    W.done = false; W.stop_cx = false;
+    while (cur < 64u) {
+        if ((cxm >> cur) & 1ull) { W.stop_cx = true; break; }
+        tokm |= 1ull << cur;
+        if ((finm >> cur) & 1ull) { W.done = true; break; }
+        cur = rdlane(nx, cur) - ip;
+    }
+    // ---- place the window's sequences ----------------------------------------------------------------------------------
+    bool tk = (tokm >> lane) & 1ull;
+    uint32_t tl = tk ? lit + mlen : 0u;
+    uint32_t incl = wave_incl_add(tl);
+    {
+        const uint64_t big = __ballot(tk & (incl > TMAX));     // keep a window's output small: cut behind the last fitting sequence
+        if (big != 0ull) {
+            const uint32_t cut = ctz64(big);
+            tokm &= (1ull << cut) - 1ull;
+            W.done = false;
+            cur = cut;                                          // the sequence at `cut` starts the next window ...
+            W.stop_cx = tokm == 0ull;                           // ... or is a long run by itself: exact_token
+            tk = (tokm >> lane) & 1ull;
+            tl = tk ? tl : 0u;
+            incl = wave_incl_add(tl);
+        }
+    }
+    W.adv = cur;
+    W.T = rdlane(incl, 63u);
+    W.op0 = op0;
+    const uint32_t o = op0 + incl - tl;
+    const bool mt = tk & !fin;
+    const uint32_t dm = o + lit;
+    W.ok = !(W.T > D.cap - op0 || __ballot(mt & ((offs == 0u) | (offs > dm))) != 0ull);
+    const uint32_t sm = dm - offs;
+    const uint32_t wend = op0 + W.T;
+    W.near_lo = wend > RB ? wend - RB : 0u;                    // positions from here on are in the ring once this window is done
+    auto crosses = [](uint32_t pos, uint32_t n) -> bool { return (pos & RM) + n > RB; };
+    W.lpl = tk & (lit != 0u) & (lit <= 16u) & !crosses(o, 16u);
+    const bool far = mt & (sm + mlen <= W.near_lo);            // source older than the ring: read it from the output
+    W.lpf = W.ok & far & (mlen <= 32u) & !crosses(dm, 32u);
+    W.lpn = mt & !far & (sm >= W.near_lo) & (sm + mlen <= op0) & (mlen <= 64u) & !crosses(sm, mlen + 15u) & !crosses(dm, mlen + 15u);
+    W.f0 = u32x4{0u, 0u, 0u, 0u}; W.f1 = W.f0;
+    if (W.lpf) {                                               // requested now, written when the window is executed
+        __builtin_memcpy(&W.f0, (const void*)(D.out + sm), 16);
+        __builtin_memcpy(&W.f1, (const void*)(D.out + sm + 16u), 16);
+    }
+    W.lit = lit; W.ls = ls; W.mlen = mlen; W.offs = offs; W.o = o; W.tk = tk; W.mt = mt;
+    return W;
+}
+
+__device__ __forceinline__ void exec_window(Dec& D, const Win& W) {
+    const uint32_t dm = W.o + W.lit, sm = dm - W.offs;
+    // ---- phase A: lane = sequence --------------------------------------------------------------------------------------
+    if (W.lpl) write_exact16(D.ring + (W.o & RM), W.lv, W.lit);
+    if (__ballot(W.lpn) != 0ull) {
+#pragma unroll 1
+        for (uint32_t k = 0u; k < 64u; k += 16u) {
+            const bool act = W.lpn & (k < W.mlen);
+            if (__ballot(act) == 0ull) break;
+            if (act) {
+                u32x4 v;
+                __builtin_memcpy(&v, (const void*)(D.ring + ((sm + k) & RM)), 16);
+                write_exact16(D.ring + ((dm + k) & RM), v, W.mlen - k);
+            }
+        }
+    }
+    if (W.lpf) {
+        write_exact16(D.ring + (dm & RM), W.f0, W.mlen);
+        if (W.mlen > 16u) write_exact16(D.ring + ((dm + 16u) & RM), W.f1, W.mlen - 16u);
+    }
+    // ---- phase B: what is left, one sequence at a time, in order -------------------------------------------------------
+    const bool litB = W.tk & (W.lit != 0u) & !W.lpl;
+    const bool matB = W.mt & !W.lpf & !W.lpn;
+    uint64_t rest = __ballot(litB | matB);
+    const uint64_t litBm = __ballot(litB), matBm = __ballot(matB);
+    while (rest != 0ull) {
+        const uint32_t q = ctz64(rest);
+        rest &= rest - 1ull;
+        const uint32_t oq = rdlane(W.o, q), lq = rdlane(W.lit, q);
+        if ((litBm >> q) & 1ull) D.coop_literals(rdlane(W.ls, q), oq, lq);
+        if ((matBm >> q) & 1ull) D.coop_match(oq + lq, rdlane(W.offs, q), rdlane(W.mlen, q), W.near_lo);
+    }
+    D.op = W.op0 + W.T;
+    if (D.op - D.F >= FLUSH_AT) D.flush();
+}
+
 __global__ void __launch_bounds__(64 * WPB) lz4_decompress_wave_kernel(DecompressArgs a, int32_t redo_code) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_raw[WPB * RB];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_raw[WPB * WAVE_LDS];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = uni(threadIdx.x >> 6);
     const uint32_t b = blockIdx.x * WPB + wv;
@@ -181,129 +332,36 @@ __global__ void __launch_bounds__(64 * WPB) lz4_decompress_wave_kernel(Decompres
     Dec D;
     D.in = (const g_u8*)(a.in_base + a.in_off[b]);
     D.out = (g_u8*)(a.out_base + a.out_off[b]);
-    D.ring = (lds_u8*)lds_raw + wv * RB;
+    D.ring = (lds_u8*)lds_raw + wv * WAVE_LDS;
+    D.ibuf = D.ring + RB;
     D.ilen = a.in_len[b];
     D.cap = a.out_cap[b];
     D.lane = lane;
     D.op = 0u; D.F = 0u;
-    const g_u8* in = D.in;
-    const uint32_t ilen = D.ilen;
-    bool ok = ilen != 0u, done = false;
+    D.ib0 = 0xFFFF0000u;                              // nothing buffered yet
+    bool ok = D.ilen != 0u, done = false;
     uint32_t ip = 0u;
-    while (ok && !done) {
-        // ---- speculative parse: lane i takes byte ip + i for a token -------------------------------------------------
-        const uint32_t p = ip + lane;
-        uint32_t t2 = 0u;
-        if (p + 1u < ilen) { uint16_t h; __builtin_memcpy(&h, (const void*)(in + p), 2); t2 = h; }
-        else if (p < ilen) t2 = in[p];
-        const uint32_t tok = t2 & 0xFFu, e1 = t2 >> 8;
-        uint32_t lit = tok >> 4;
-        const uint32_t mlc = tok & 15u;
-        uint32_t lhdr = 1u;
-        bool cx = p >= ilen;                        // cx: not expressible here (or simply wrong): exact_token decides
-        if (lit == 15u) { lhdr = 2u; cx |= (p + 1u >= ilen) | (e1 == 255u); lit = 15u + e1; }
-        const uint32_t ls = p + lhdr, le = ls + lit;
-        cx |= le > ilen;
-        const bool fin = !cx & (le == ilen);        // the block's last sequence: literals only
-        const bool seq = !cx & !fin;
-        cx |= seq & (le + 2u > ilen);
-        uint32_t w4 = 0u;
-        if (seq & !cx) {
-            if (le + 4u <= ilen) __builtin_memcpy(&w4, (const void*)(in + le), 4);
-            else { w4 = (uint32_t)in[le] | ((uint32_t)in[le + 1u] << 8); if (le + 2u < ilen) w4 |= (uint32_t)in[le + 2u] << 16; }
-        }
-        const uint32_t offs = w4 & 0xFFFFu, m1 = (w4 >> 16) & 0xFFu;
-        uint32_t mlen = 4u + mlc, nx = le + 2u;
-        if (mlc == 15u) { cx |= seq & ((le + 3u > ilen) | (m1 == 255u)); mlen += m1; nx += 1u; }
-        cx |= seq & (nx >= ilen);                   // a match must be followed by another token: leave it to exact_token
-        if (fin) { mlen = 0u; nx = ilen; }
-        // ---- the real token chain through the window (scalar hop) ---------------------------------------------------
-        const uint64_t cxm = __ballot(cx), finm = __ballot(fin);
-        uint64_t tokm = 0ull;
-        uint32_t cur = 0u;
-        bool stop_cx = false;
-        while (cur < 64u) {
-            if ((cxm >> cur) & 1ull) { stop_cx = true; break; }
-            tokm |= 1ull << cur;
-            if ((finm >> cur) & 1ull) { done = true; break; }
-            cur = rdlane(nx, cur) - ip;
-        }
-        // ---- place the window's sequences ---------------------------------------------------------------------------
-        bool tk = (tokm >> lane) & 1ull;
-        uint32_t tl = tk ? lit + mlen : 0u;
-        uint32_t incl = wave_incl_add(tl);
-        {
-            const uint64_t big = __ballot(tk & (incl > TMAX));     // keep a window's output small: cut behind the last fitting sequence
-            if (big != 0ull) {
-                const uint32_t cut = ctz64(big);
-                tokm &= (1ull << cut) - 1ull;
-                done = false;
-                cur = cut;                                          // the sequence at `cut` starts the next window ...
-                stop_cx = tokm == 0ull;                             // ... or is a long run by itself: exact_token
-                tk = (tokm >> lane) & 1ull;
-                tl = tk ? tl : 0u;
-                incl = wave_incl_add(tl);
-            }
-        }
-        const uint32_t T = rdlane(incl, 63u);
-        const uint32_t o = D.op + incl - tl;
-        const bool mt = tk & !fin;                                  // has a match
-        const uint32_t dm = o + lit;                                // match destination
-        if (T > D.cap - D.op || __ballot(mt & ((offs == 0u) | (offs > dm))) != 0ull) { ok = false; break; }
-        const uint32_t sm = dm - offs;
-        const uint32_t wend = D.op + T;
-        const uint32_t near_lo = wend > RB ? wend - RB : 0u;        // positions from here on are in the ring after this window
-        auto crosses = [](uint32_t pos, uint32_t n) -> bool { return (pos & RM) + n > RB; };
-        // ---- phase A: lane = sequence -------------------------------------------------------------------------------
-        const bool lpl = tk & (lit != 0u) & (lit <= 16u) & !crosses(o, 16u) & (ls + 16u <= ilen);          // literals, 16-byte read
-        const bool far = mt & (sm + mlen <= near_lo);                                                        // source older than the ring
-        const bool lpf = far & (mlen <= 32u) & !crosses(dm, 32u);
-        const bool lpn = mt & !far & (sm >= near_lo) & (sm + mlen <= D.op) & (mlen <= 64u) & !crosses(sm, mlen + 15u) & !crosses(dm, mlen + 15u);
-        u32x4 f0 = {0u, 0u, 0u, 0u}, f1 = {0u, 0u, 0u, 0u};
-        if (lpf) {                                                   // requested first, written last in phase A
-            __builtin_memcpy(&f0, (const void*)(D.out + sm), 16);
-            __builtin_memcpy(&f1, (const void*)(D.out + sm + 16u), 16);
-        }
-        if (lpl) {
-            u32x4 v;
-            __builtin_memcpy(&v, (const void*)(in + ls), 16);
-            write_exact16(D.ring + (o & RM), v, lit);
-        }
-        if (__ballot(lpn) != 0ull) {
-#pragma unroll 1
-            for (uint32_t k = 0u; k < 64u; k += 16u) {
-                const bool act = lpn & (k < mlen);
-                if (__ballot(act) == 0ull) break;
-                if (act) {
-                    u32x4 v;
-                    __builtin_memcpy(&v, (const void*)(D.ring + ((sm + k) & RM)), 16);
-                    write_exact16(D.ring + ((dm + k) & RM), v, mlen - k);
-                }
-            }
-        }
-        if (lpf) {
-            write_exact16(D.ring + (dm & RM), f0, mlen);
-            if (mlen > 16u) write_exact16(D.ring + ((dm + 16u) & RM), f1, mlen - 16u);
-        }
-        // ---- phase B: what is left, one sequence at a time, in order -------------------------------------------------
-        const bool litB = tk & (lit != 0u) & !lpl;
-        const bool matB = mt & !lpf & !lpn;
-        uint64_t rest = __ballot(litB | matB);
-        const uint64_t litBm = __ballot(litB), matBm = __ballot(matB);
-        while (rest != 0ull) {
-            const uint32_t q = ctz64(rest);
-            rest &= rest - 1ull;
-            const uint32_t oq = rdlane(o, q), lq = rdlane(lit, q);
-            if ((litBm >> q) & 1ull) D.coop_literals(rdlane(ls, q), oq, lq);
-            if ((matBm >> q) & 1ull) D.coop_match(oq + lq, rdlane(offs, q), rdlane(mlen, q), near_lo);
-        }
-        D.op = wend;
-        if (D.op - D.F >= FLUSH_AT) D.flush();
-        ip += cur;
-        if (done) break;
-        if (stop_cx) ok = exact_token(D, ip, done);
-    }
     if (ok) {
+        Win A = parse_window(D, 0u, 0u);
+        for (;;) {
+            if (!A.ok) { ok = false; break; }
+            const uint32_t ip_next = ip + A.adv;
+            const bool pipe = !A.done && !A.stop_cx;
+            Win B = A;
+            if (pipe) B = parse_window(D, ip_next, A.op0 + A.T);   // the next window's loads are in flight while this one is executed
+            exec_window(D, A);
+            ip = ip_next;
+            if (A.done) { done = true; break; }
+            if (A.stop_cx) {
+                ok = exact_token(D, ip, done);
+                if (!ok || done) break;
+                A = parse_window(D, ip, D.op);
+                continue;
+            }
+            A = B;
+        }
+    }
+    if (ok && done) {
         D.finish();
         if (lane == 0u) {
             a.status[b] = 0;
