@@ -932,9 +932,9 @@ static hipError_t launch_c(const CompressArgs& a, hipStream_t s) {
 
 template <int G, typename TblT, int BPW>
 static hipError_t launch_m(const CompressArgs& a, int mode, hipStream_t s) {
-    if (mode == 2) return launch_c<G, TblT, 2, BPW>(a, s);
+    // MODE 2 (prefetch-only second wavefront) and MODE 4 (LDS input ring) were round-1 experiments that measured slower than
+    // MODE 3; they are no longer instantiated
     if (mode == 3) return launch_c<G, TblT, 3, BPW>(a, s);
-    if (mode == 4) return launch_c<G, TblT, 4, BPW>(a, s);
     return launch_c<G, TblT, 0, BPW>(a, s);
 }
 

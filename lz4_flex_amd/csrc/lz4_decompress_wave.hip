@@ -41,6 +41,15 @@ constexpr uint32_t WPB = 4u;                      // wavefronts (= blocks) per w
 constexpr uint32_t TMAX = 2048u;                  // output bytes of one window
 constexpr uint32_t FLUSH_AT = 512u;               // write back when this much is pending
 
+#ifdef LZ4D_PROF      // tools: cycles of wavefront 0 of every workgroup per part of a window -> g_wdec_prof[0..7], windows in [8]
+__device__ unsigned long long g_wdec_prof[16];
+#define LZ4D_T0 uint64_t pt_ = __builtin_readcyclecounter();
+#define LZ4D_TICK(i) { const uint64_t t_ = __builtin_readcyclecounter(); if (D.lane == 0u) atomicAdd(&g_wdec_prof[i], (unsigned long long)(t_ - pt_)); pt_ = __builtin_readcyclecounter(); }
+#else
+#define LZ4D_T0
+#define LZ4D_TICK(i)
+#endif
+
 #define LZ4D_DPP(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xf, false))
 __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
     v += LZ4D_DPP(v, 0x111, 0xf);
@@ -209,8 +218,10 @@ struct Win {
 
 __device__ __forceinline__ Win parse_window(Dec& D, uint32_t ip, uint32_t op0) {
     Win W;
+    LZ4D_T0
     const uint32_t lane = D.lane, ilen = D.ilen;
     D.input_at(ip);
+    LZ4D_TICK(0)
     const lds_u8* ib = D.ibuf - D.ib0;                // ib + position
     // ---- speculative parse: lane i takes byte ip + i for a token (bytes behind the block read as 0) ---------------------
     const uint32_t p = ip + lane;
@@ -235,17 +246,22 @@ __device__ __forceinline__ Win parse_window(Dec& D, uint32_t ip, uint32_t op0) {
     if (mlc == 15u) { cx |= seq & ((le + 3u > ilen) | (m1 == 255u)); mlen += m1; nx += 1u; }
     cx |= seq & (nx >= ilen);                          // a match must be followed by another token: leave it to exact_token
     if (fin) { mlen = 0u; nx = ilen; }
+    LZ4D_TICK(1)
     // ---- the real token chain through the window (scalar hop) ----------------------------------------------------------
-    const uint64_t cxm = __ballot(cx), finm = __ballot(fin);
+    const uint64_t cxm = __ballot(cx), finm = __ballot(fin), stopm = cxm | finm;
+    const uint32_t nrel = nx - ip;                     // >= 3: the window always advances
     uint64_t tokm = 0ull;
     uint32_t cur = 0u;
     W.done = false; W.stop_cx = false;
-    while (cur < 64u) {
-        if ((cxm >> cur) & 1ull) { W.stop_cx = true; break; }
+    while (cur < 64u && ((stopm >> cur) & 1ull) == 0ull) {       // four scalar instructions and a v_readlane per sequence
         tokm |= 1ull << cur;
-        if ((finm >> cur) & 1ull) { W.done = true; break; }
-        cur = rdlane(nx, cur) - ip;
+        cur = rdlane(nrel, cur);
     }
+    if (cur < 64u) {
+        if ((cxm >> cur) & 1ull) W.stop_cx = true;
+        else { W.done = true; tokm |= 1ull << cur; }
+    }
+    LZ4D_TICK(2)
     // ---- place the window's sequences ----------------------------------------------------------------------------------
     bool tk = (tokm >> lane) & 1ull;
     uint32_t tl = tk ? lit + mlen : 0u;
@@ -284,10 +300,12 @@ __device__ __forceinline__ Win parse_window(Dec& D, uint32_t ip, uint32_t op0) {
         __builtin_memcpy(&W.f1, (const void*)(D.out + sm + 16u), 16);
     }
     W.lit = lit; W.ls = ls; W.mlen = mlen; W.offs = offs; W.o = o; W.tk = tk; W.mt = mt;
+    LZ4D_TICK(3)
     return W;
 }
 
 __device__ __forceinline__ void exec_window(Dec& D, const Win& W) {
+    LZ4D_T0
     const uint32_t dm = W.o + W.lit, sm = dm - W.offs;
     // ---- phase A: lane = sequence --------------------------------------------------------------------------------------
     if (W.lpl) write_exact16(D.ring + (W.o & RM), W.lv, W.lit);
@@ -307,20 +325,35 @@ __device__ __forceinline__ void exec_window(Dec& D, const Win& W) {
         write_exact16(D.ring + (dm & RM), W.f0, W.mlen);
         if (W.mlen > 16u) write_exact16(D.ring + ((dm + 16u) & RM), W.f1, W.mlen - 16u);
     }
+    LZ4D_TICK(4)
     // ---- phase B: what is left, one sequence at a time, in order -------------------------------------------------------
     const bool litB = W.tk & (W.lit != 0u) & !W.lpl;
     const bool matB = W.mt & !W.lpf & !W.lpn;
+    // the usual member of this loop: a match that reads bytes written earlier in this window -- up to 64 bytes, source in
+    // the ring, not overlapping itself: one LDS read and one write by the wavefront
+    const bool easy = matB & !litB & (W.mlen <= 64u) & (sm >= W.near_lo) & (W.offs >= W.mlen);
+    const uint32_t pk = W.offs | (W.mlen << 16);
     uint64_t rest = __ballot(litB | matB);
-    const uint64_t litBm = __ballot(litB), matBm = __ballot(matB);
+    const uint64_t litBm = __ballot(litB), matBm = __ballot(matB), easym = __ballot(easy);
     while (rest != 0ull) {
         const uint32_t q = ctz64(rest);
         rest &= rest - 1ull;
+        if ((easym >> q) & 1ull) {
+            const uint32_t dq = rdlane(dm, q), pq = rdlane(pk, q);
+            if (D.lane < (pq >> 16)) D.ring[(dq + D.lane) & RM] = D.ring[(dq - (pq & 0xFFFFu) + D.lane) & RM];
+            continue;
+        }
         const uint32_t oq = rdlane(W.o, q), lq = rdlane(W.lit, q);
         if ((litBm >> q) & 1ull) D.coop_literals(rdlane(W.ls, q), oq, lq);
         if ((matBm >> q) & 1ull) D.coop_match(oq + lq, rdlane(W.offs, q), rdlane(W.mlen, q), W.near_lo);
     }
+    LZ4D_TICK(5)
     D.op = W.op0 + W.T;
     if (D.op - D.F >= FLUSH_AT) D.flush();
+    LZ4D_TICK(6)
+#ifdef LZ4D_PROF
+    if (D.lane == 0u) { atomicAdd(&g_wdec_prof[8], 1ull); atomicAdd(&g_wdec_prof[9], (unsigned long long)__builtin_popcountll(__ballot(W.tk))); atomicAdd(&g_wdec_prof[10], (unsigned long long)__builtin_popcountll(__ballot(matB))); atomicAdd(&g_wdec_prof[11], (unsigned long long)__builtin_popcountll(easym)); atomicAdd(&g_wdec_prof[12], (unsigned long long)__builtin_popcountll(__ballot(W.lpf))); atomicAdd(&g_wdec_prof[13], (unsigned long long)__builtin_popcountll(__ballot(W.lpn))); }
+#endif
 }
 
 __global__ void __launch_bounds__(64 * WPB) lz4_decompress_wave_kernel(DecompressArgs a, int32_t redo_code) {
@@ -387,3 +420,17 @@ hipError_t launch_decompress_wave(const DecompressArgs& a, int32_t redo_code, hi
 }
 
 }  // namespace lz4flex_dev
+
+#ifdef LZ4D_PROF
+extern "C" int lz4flex_debug_wdec_prof(unsigned long long* vals, int reset) {
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(lz4flex_dev::wdec::g_wdec_prof), z, sizeof z);
+        return 0;
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(vals, HIP_SYMBOL(lz4flex_dev::wdec::g_wdec_prof), 128);
+    return 0;
+}
+#endif
+

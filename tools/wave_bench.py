@@ -77,6 +77,17 @@ def main():
             print("per superstep cycles (LZ4W_PROF_STEPS build): " + ", ".join("%s=%.0f" % (nm, x / v[13]) for nm, x in zip(sn, v[8:13])) +
                   " supersteps/window=%.1f" % (v[13] / nw), flush=True)
     ok = int((st != 0).sum().item()) == 0 and int((bst != 0).sum().item()) == 0 and torch.equal(back, src)
+    if hasattr(lib, "lz4flex_debug_wdec_prof"):          # -DLZ4D_PROF variant build
+        lib.lz4flex_debug_wdec_prof.argtypes = [C.c_void_p, C.c_int]
+        v = (C.c_ulonglong * 16)()
+        lib.lz4flex_debug_wdec_prof(None, 1)
+        dec_once(); torch.cuda.synchronize()
+        lib.lz4flex_debug_wdec_prof(v, 0)
+        v = list(v); nw = max(v[8], 1)
+        names = ["input", "spec-parse", "hop", "place+classify", "phaseA", "phaseB", "flush"]
+        print("wave decoder, cycles per window: " + ", ".join("%s=%.0f" % (a_, x / nw) for a_, x in zip(names, v)) +
+              "; per window: sequences %.1f, phase-B matches %.1f (easy %.1f), far-LP %.1f, near-LP %.1f; windows %d" %
+              (v[9] / nw, v[10] / nw, v[11] / nw, v[12] / nw, v[13] / nw, v[8]), flush=True)
     tc, td = [], []
     for _ in range(args.reps):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
