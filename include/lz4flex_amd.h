@@ -190,16 +190,18 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
                                 uint32_t *out_len, int32_t *status, uint64_t *detail,
                                 const lz4flex_decompress_ext *ext, int mem_kind, void *hip_stream);
 
-/* Tuning knobs for measurements: "decompress_variant" (0 = default: by batch size; 4 = parser / copier split decoder;
- * 3 = pipelined LDS-staged decoder, with "decompress_geometry" -1 / 0 / 1 = by batch size / 8 lanes x 4 B / 4 lanes
- * x 8 B per block; 2 = LDS-staged decoder with the generic loop; 1 = decoder whose window lives in HBM/L2, always
- * used for dictionary/prefix blocks), "decompress_blocks_per_wg" (variant 4: 0 = by batch size, 8/16/32/64),
- * "decompress_lanes" (8/16/32/64, variant 1),
- * "compress_lanes" (8/16) = lanes of a wavefront cooperating on one block, "compress_variant" (1 = default:
- * the group encoder pushes sequences to a second wavefront that writes the output; 3 = the group encoder alone;
- * 5 = group encoder + a wavefront that only prefetches the input; 6 = variant 1 with the current-side bytes read
- * from an LDS ring fed by the second wavefront; 2 = fully LDS-staged encoder.  2 and 6 are experiments that
- * measured slower; every variant produces the reference's bytes). */
+/* Settings (ctx NULL = the default context the scalar / frame entry points use):
+ * "compress_mode": 0 = throughput encoder (default; lz4_compress_wave.hip: a valid LZ4 block with this library's own
+ *   parse -- any LZ4 decoder returns the input; ratio within a percent of the reference's, usually better), 1 = the
+ *   reference's exact bytes (src/block/compress.rs:318-489 restated; about 3x slower).  Blocks with a dictionary / prefix
+ *   and Linked frames always use the exact encoder.  Environment: LZ4FLEX_COMPRESS_MODE=exact|fast.
+ * Kernel selection, for measurements only (every choice produces the same bytes / lengths / error variants):
+ * "decompress_variant": 0 = by batch size (default), 5 = one block per wavefront (lz4_decompress_wave.hip), 4 = parser /
+ *   copier split decoder, 3 = pipelined LDS-staged decoder (with "decompress_geometry" -1 / 0 / 1 = by batch size /
+ *   8 lanes x 4 B / 4 lanes x 8 B per block), 1 = decoder whose window lives in HBM/L2 (always used for dictionary /
+ *   prefix blocks); "decompress_blocks_per_wg" (variant 4: 0 = by batch size, 8/16/32/64); "decompress_lanes"
+ *   (8/16/32/64, variant 1); exact encoder: "compress_lanes" (8/16 lanes of a wavefront per block), "compress_variant"
+ *   (1 = group encoder + emitter wavefront, 3 = group encoder alone). */
 int lz4flex_set_tuning(lz4flex_ctx *ctx, const char *key, int value);
 
 /* ---- frame (src/frame/) ------------------------------------------------------------------ */
