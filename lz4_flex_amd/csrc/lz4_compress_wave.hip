@@ -379,6 +379,8 @@ __device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8
 #ifdef LZ4W_PROF_STEPS      // tools: cycles per part of a superstep -> prof[8..13] (heads, compaction + lengths, scan, walk, encode, supersteps)
     uint64_t pt[5] = {0, 0, 0, 0, 0}, pn = 0, pt0 = __builtin_readcyclecounter();
 #define LZ4W_TICK(i) { const uint64_t t_ = __builtin_readcyclecounter(); pt[i] += t_ - pt0; pt0 = t_; }
+#elif defined(LZ4W_MARK)   // tools: phase boundaries visible in a -S listing
+#define LZ4W_TICK(i) asm volatile("; LZ4W_PHASE_END " #i);
 #else
 #define LZ4W_TICK(i)
 #endif
@@ -482,6 +484,9 @@ __device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8
                 bits += 32u; bits = f0 < bits ? f0 : bits;
                 return bits;
             };
+#ifdef LZ4W_EXP_NOLEN
+            act = false;
+#endif
             if (__ballot(act) != 0ull) {
                 if (act) {                                          // 16 bytes, branch-free: most candidates end here
                     const lds_u8* ap = W.win + p + 4u;
@@ -538,40 +543,57 @@ __device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8
             const uint64_t em2 = ns > 2u ? elig(p2, ee2, dpp_wave_shl1(ee2, rdlane(ee3, 0u))) : 0ull;
             const uint64_t em3 = ns > 2u ? elig(p3, ee3, dpp_wave_shl1(ee3, 0u)) : 0ull;
             LZ4W_TICK(2)
-            // ---- greedy walk (scalar): the first eligible position at or behind the cursor, step by step ----
-            uint32_t sqa = 0u, sqb = 0u, nsel = 0u;                  // sequence k: lane k of sqa = p | e << 16, sqb = prev end | distance << 16
-            auto walk = [&](uint64_t em, uint32_t qv, uint32_t base) {
-                while (cursor < base + 64u) {
-                    const uint32_t c = cursor > base ? cursor - base : 0u;
-                    const uint64_t m = em & (~0ull << c);
+            // ---- greedy walk (scalar): the first eligible position at or behind the cursor, step by step.  The loop only
+            // marks the chosen positions (one bit each) and hops to the end of the chosen match: a handful of scalar
+            // instructions per sequence; everything else about a sequence is known to its position's lane already ----
+            uint64_t S0 = 0ull, S1 = 0ull, S2 = 0ull, S3 = 0ull;
+            const uint32_t anchor0 = anchor;
+            auto walk = [&](uint64_t em, uint32_t ev, uint32_t base, uint64_t& S) {
+                if (cursor >= base + 64u) return;
+                uint32_t c = (cursor > base ? cursor : base) - base;
+                for (;;) {
+                    const uint64_t m = em >> c;
                     if (m == 0ull) break;
-                    const uint32_t q = ctz64(m);
-                    const uint32_t bv = rdlane(qv, q);
-                    const bool mine = lane == nsel;
-                    sqa = mine ? ((base + q) | (bv & 0xFFFF0000u)) : sqa;
-                    sqb = mine ? (anchor | (bv << 16)) : sqb;
-                    nsel += 1u;
-                    cursor = anchor = bv >> 16;
+                    const uint32_t q = c + ctz64(m);
+                    S |= 1ull << q;
+                    cursor = anchor = rdlane(ev, q);                // the end of the chosen match
+                    c = cursor - base;
+                    if (c >= 64u) break;
                 }
             };
-#ifdef LZ4W_EXP_PRIO
-            __builtin_amdgcn_s_setprio(3);
+#ifndef LZ4W_EXP_NOWALK
+            walk(em0, e0, b, S0);
+            if (ns > 1u) walk(em1, ee1, b + 64u, S1);
+            if (ns > 2u) { walk(em2, ee2, b + 128u, S2); walk(em3, ee3, b + 192u, S3); }
+#else
+            asm volatile("" :: "s"(em0), "s"(em1), "s"(em2), "s"(em3), "v"(q0), "v"(q1), "v"(q2), "v"(q3));
 #endif
-            walk(em0, q0, b);
-            if (ns > 1u) walk(em1, q1, b + 64u);
-            if (ns > 2u) { walk(em2, q2, b + 128u); walk(em3, q3, b + 192u); }
             cursor = cursor > e1 ? cursor : e1;
-#ifdef LZ4W_EXP_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
             LZ4W_TICK(3)
 #ifdef LZ4W_PROF_STEPS
             pn += 1;
 #endif
+            const uint32_t n0 = (uint32_t)__builtin_popcountll(S0), n1 = (uint32_t)__builtin_popcountll(S1),
+                           n2 = (uint32_t)__builtin_popcountll(S2), n3 = (uint32_t)__builtin_popcountll(S3);
+            const uint32_t nsel = n0 + n1 + n2 + n3;
             if (nsel == 0u) continue;
-            // ---- encode the selected sequences: lane k = sequence k ----
+#ifdef LZ4W_EXP_NOENC
+            asm volatile("" :: "s"(S0), "s"(S1), "s"(S2), "s"(S3));
+            continue;
+#endif
+            // ---- the chosen sequences, compacted: lane k = sequence k (through LDS: best | position of the chosen
+            // positions by rank; the staging buffer holds < FLUSH_AT bytes here, its upper part is free) ----
+            lds_u32* tmp = (lds_u32*)(W.stg + 192u);
+            static_assert(FLUSH_AT <= 192u && 192u + 256u <= STG_BYTES, "scratch inside the staging buffer");
+            if ((S0 >> lane) & 1ull) { const uint32_t r = mbcnt(S0); cmp[r] = q0; tmp[r] = p0; }
+            if ((S1 >> lane) & 1ull) { const uint32_t r = n0 + mbcnt(S1); cmp[r] = q1; tmp[r] = p1; }
+            if ((S2 >> lane) & 1ull) { const uint32_t r = n0 + n1 + mbcnt(S2); cmp[r] = q2; tmp[r] = p2; }
+            if ((S3 >> lane) & 1ull) { const uint32_t r = n0 + n1 + n2 + mbcnt(S3); cmp[r] = q3; tmp[r] = p3; }
             const bool issel = lane < nsel;
-            const uint32_t sp = sqa & 0xFFFFu, se = sqa >> 16, pe = sqb & 0xFFFFu, off = sqb >> 16;
+            uint32_t sq = 0u, sp = 0u;
+            if (issel) { sq = cmp[lane]; sp = tmp[lane]; }
+            const uint32_t se = sq >> 16, off = sq & 0xFFFFu;
+            const uint32_t pe = dpp_wave_shr1(se, anchor0);
             const uint32_t lit = sp - pe, len = se - sp, mlc = len - 4u;
             // A sequence with >= 15 literals or a match of >= 274 bytes needs length bytes beyond the lane-parallel path: such
             // "hard" sequences are written one at a time, the runs of ordinary ones between them 16 at a time.
