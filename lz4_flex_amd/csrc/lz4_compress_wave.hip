@@ -115,6 +115,7 @@ __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t ld64l(const lds_u8* p) { uint64_t v; __builtin_memcpy(&v, (const void*)p, 8); return v; }
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t t = a < b ? a : b; return t < c ? t : c; }
 __device__ __forceinline__ uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
 __device__ __forceinline__ uint32_t len_ext_bytes(uint32_t v) { return v >= 15u ? (v - 15u) / 255u + 1u : 0u; }   // compress.rs:237-247
 
@@ -364,18 +365,25 @@ __device__ __forceinline__ void copy_lit_small(lds_u8* dst, const lds_u8* src, u
 // A superstep holds at most 64 heads by construction: 256 positions if that many fit, else 128, else 64 (the scalar
 // model walks the same supersteps).  The selected sequences (at most 64: a match is >= 4 long) are placed in lanes
 // (lane k = sequence k) and encoded lane-parallel, 16 sequences per staging round.
-__device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8_t* __restrict__ cand_t_, uint8_t* body_, uint32_t w_, uint32_t lane,
+__device__ __attribute__((noinline)) void match_segment(const uint8_t* __restrict__ cand_t_, uint8_t* body_, uint32_t w_, uint32_t lane,
                               uint32_t s0_, uint32_t s1_, uint32_t mfl_end_, uint32_t mend_, unsigned long long* prof_) {
     const uint32_t w = uni(w_), s0 = uni(s0_), s1 = uni(s1_), mfl_end = uni(mfl_end_), mend = uni(mend_);
     const g_u8* __restrict__ cand_t = uni_gptr<const g_u8>(cand_t_);
+    // The kernel's LDS starts at address 0 (it has no static LDS; the kernel checks): with the base a compile-time constant
+    // every LDS address below is a VGPR offset plus an immediate, not a 64-lane add per access.  The loop is bound by the
+    // number of vector instructions issued (a wavefront instruction occupies its SIMD for 4 cycles whatever the number of
+    // active lanes), so instructions, not latencies, are what is counted here.
+    lds_u8* const lds = reinterpret_cast<lds_u8*>((uintptr_t)0);
     Worker W;
     W.win = lds + L_WIN;
     W.stg = lds + L_STG + w * WORKER_LDS;
     lds_u32* cmp = (lds_u32*)(lds + L_STG + w * WORKER_LDS + STG_BYTES);
+    const lds_u32* cmp_lane = cmp + lane;
     W.body = uni_gptr<g_u8>(body_);
     W.lane = lane;
     W.fill = 0u; W.body_len = 0u; W.has = 0u; W.first_lit = 0u; W.first_ml = 0u;
     uint32_t cursor = s0, anchor = s0, carry = 0u, dlast = 0u;
+    const uint32_t lane4 = lane & ~3u, lane3 = lane & 3u;
 #ifdef LZ4W_PROF_STEPS      // tools: cycles per part of a superstep -> prof[8..13] (heads, compaction + lengths, scan, walk, encode, supersteps)
     uint64_t pt[5] = {0, 0, 0, 0, 0}, pn = 0, pt0 = __builtin_readcyclecounter();
 #define LZ4W_TICK(i) { const uint64_t t_ = __builtin_readcyclecounter(); pt[i] += t_ - pt0; pt0 = t_; }
@@ -386,19 +394,16 @@ __device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8
 #endif
     // cand[]: 16 bytes per lane and group of 8 steps (see index_window), fetched one group ahead.  The load is
     // unconditional (the group behind the last one is still inside the workspace): a conditional load made hipcc wait
-    // for the data right where it was requested.
+    // for the data right where it was requested.  Positions at or behind the window's last match start (and with them
+    // everything behind a clipped segment end) carry distance 0 already: the indexer writes it.
     u32x4 dn = *reinterpret_cast<const g_u32x4*>(cand_t + ((size_t)(s0 >> 9) * 64u + lane) * 16u);
     for (uint32_t gb = s0; gb < s1; gb += 512u) {
     u32x4 dc = dn;
     dn = *reinterpret_cast<const g_u32x4*>(cand_t + ((size_t)((gb + 512u) >> 9) * 64u + lane) * 16u);
     for (uint32_t B0 = gb; B0 < gb + 512u && B0 < s1; B0 += 256u) {
         // the four steps of this 256-block
-        uint32_t dq0 = dc.x & 0xFFFFu, dq1 = dc.x >> 16, dq2 = dc.y & 0xFFFFu, dq3 = dc.y >> 16;
+        const uint32_t dq0 = dc.x & 0xFFFFu, dq1 = dc.x >> 16, dq2 = dc.y & 0xFFFFu, dq3 = dc.y >> 16;
         dc.x = dc.z; dc.y = dc.w;
-        dq0 = (B0 + lane < s1) ? dq0 : 0u;
-        dq1 = (B0 + 64u + lane < s1) ? dq1 : 0u;
-        dq2 = (B0 + 128u + lane < s1) ? dq2 : 0u;
-        dq3 = (B0 + 192u + lane < s1) ? dq3 : 0u;
         for (uint32_t j0 = 0u; j0 < 4u && B0 + 64u * j0 < s1;) {
             const uint32_t b = B0 + 64u * j0;
             const uint32_t maxs = j0 == 0u ? 4u : (j0 == 2u ? 2u : 1u);       // steps an aligned superstep may span from here
@@ -424,24 +429,27 @@ __device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8
             const uint32_t pv1 = dpp_wave_shr1(t1, rdlane(t0, 63u));
             const uint32_t pv2 = dpp_wave_shr1(t2, rdlane(t1, 63u));
             const uint32_t pv3 = dpp_wave_shr1(t3, rdlane(t2, 63u));
-            auto cand_ok = [&](uint32_t pp, uint32_t d, uint32_t dprev) -> bool {
-                const bool buried = (cend > pp) & (cend - pp >= SKIPD);
-                return (pp < s1) & (pp < mfl_end) & (d != 0u) & (d != dprev) & (d <= pp) & !buried;
-            };
-            const bool k0 = cand_ok(p0, t0, pv0);
-            const bool k1 = (maxs > 1u) & cand_ok(p1, t1, pv1);
-            const bool k2 = (maxs > 2u) & cand_ok(p2, t2, pv2);
-            const bool k3 = (maxs > 2u) & cand_ok(p3, t3, pv3);
-            // all eight 4-byte reads are issued before the first compare (one LDS round trip, not four): lanes without a
-            // candidate read their own position twice
+            bool k0 = (t0 != 0u) & (t0 != pv0);
+            bool k1 = (maxs > 1u) & (t1 != 0u) & (t1 != pv1);
+            bool k2 = (maxs > 2u) & (t2 != 0u) & (t2 != pv2);
+            bool k3 = (maxs > 2u) & (t3 != 0u) & (t3 != pv3);
+            if (cend >= b + SKIPD) {                                 // positions buried >= SKIPD deep in the running best match
+                const uint32_t T = cend - SKIPD;                      // p <= T: buried
+                k0 &= p0 > T; k1 &= p1 > T; k2 &= p2 > T; k3 &= p3 > T;
+            }
+            // all eight 4-byte reads are issued before the first compare (one LDS round trip, not four); lanes without a
+            // candidate read something harmless.  Own side: dwords at b + 64 u + (lane & ~3), one address for all four steps.
+            const lds_u32* own = (const lds_u32*)(W.win + (b + lane4));
+            const uint32_t a0 = __builtin_amdgcn_alignbyte(own[1], own[0], lane3), a1 = __builtin_amdgcn_alignbyte(own[17], own[16], lane3),
+                           a2 = __builtin_amdgcn_alignbyte(own[33], own[32], lane3), a3 = __builtin_amdgcn_alignbyte(own[49], own[48], lane3);
             auto ld4 = [&](uint32_t pos) -> uint32_t {
                 const lds_u32* ap = (const lds_u32*)(W.win + (pos & ~3u));
                 return __builtin_amdgcn_alignbyte(ap[1], ap[0], pos & 3u);
             };
-            const uint32_t a0 = ld4(p0), a1 = ld4(p1 < WINDOW ? p1 : p0), a2 = ld4(p2 < WINDOW ? p2 : p0), a3 = ld4(p3 < WINDOW ? p3 : p0);
-            const uint32_t g0 = ld4(k0 ? p0 - t0 : p0), g1 = ld4(k1 ? p1 - t1 : p0), g2 = ld4(k2 ? p2 - t2 : p0), g3 = ld4(k3 ? p3 - t3 : p0);
+            const uint32_t g0 = ld4(p0 - t0), g1 = ld4(p1 - t1), g2 = ld4(p2 - t2), g3 = ld4(p3 - t3);
             const bool h0 = k0 & (a0 == g0), h1 = k1 & (a1 == g1), h2 = k2 & (a2 == g2), h3 = k3 & (a3 == g3);
-            const uint64_t m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+            const uint64_t m0 = __builtin_amdgcn_ballot_w64(h0), m1 = __builtin_amdgcn_ballot_w64(h1),
+                           m2 = __builtin_amdgcn_ballot_w64(h2), m3 = __builtin_amdgcn_ballot_w64(h3);
             const uint32_t c0 = (uint32_t)__builtin_popcountll(m0), c1 = (uint32_t)__builtin_popcountll(m1),
                            c2 = (uint32_t)__builtin_popcountll(m2), c3 = (uint32_t)__builtin_popcountll(m3);
             // the largest superstep that holds at most 64 heads
@@ -458,36 +466,35 @@ __device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8
             j0 += ns;
             LZ4W_TICK(0)
             if (H == 0u && cursor >= e1) continue;               // no head, nothing to select: the running best is unchanged
-            // compaction: head of rank r -> lane r, as (position << 16 | distance)
-            auto mbcnt = [&](uint64_t m) -> uint32_t {
-                return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            // compaction: head of rank r -> lane r, as (position << 16 | distance).  v_mbcnt adds the heads of the earlier
+            // steps for free (its accumulator operand).
+            auto mbcnt = [&](uint64_t m, uint32_t base) -> uint32_t {
+                return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
             };
-            const uint32_t r0 = mbcnt(M0), r1 = b1 + mbcnt(M1), r2 = b2 + mbcnt(M2), r3 = b3 + mbcnt(M3);   // heads before this position
-            if (h0) cmp[r0] = (p0 << 16) | t0;
-            if (h1 & (ns > 1u)) cmp[r1] = (p1 << 16) | t1;
-            if (h2 & (ns > 2u)) cmp[r2] = (p2 << 16) | t2;
-            if (h3 & (ns > 2u)) cmp[r3] = (p3 << 16) | t3;
+            const uint32_t r0 = mbcnt(M0, 0u), r1 = mbcnt(M1, b1), r2 = mbcnt(M2, b2), r3 = mbcnt(M3, b3);   // heads before this position
+            const bool hh0 = __builtin_amdgcn_inverse_ballot_w64(M0), hh1 = __builtin_amdgcn_inverse_ballot_w64(M1),
+                       hh2 = __builtin_amdgcn_inverse_ballot_w64(M2), hh3 = __builtin_amdgcn_inverse_ballot_w64(M3);
+            if (hh0) cmp[r0] = (p0 << 16) | t0;
+            if (hh1) cmp[r1] = (p1 << 16) | t1;
+            if (hh2) cmp[r2] = (p2 << 16) | t2;
+            if (hh3) cmp[r3] = (p3 << 16) | t3;
             const bool isH = lane < H;
             uint32_t hv = 0u;
-            if (isH) hv = cmp[lane];
+            if (isH) hv = *cmp_lane;
             const uint32_t p = hv >> 16, d = hv & 0xFFFFu;
             // true match lengths of the heads (their first 4 bytes are known to match)
-            uint32_t lim = mend > p ? mend - p : 0u;
+            uint32_t lim = __builtin_elementwise_sub_sat(mend, p);
             lim = lim < CAP ? lim : CAP;
             uint32_t k = 4u;
             bool act = isH & (lim > 4u);
-            auto first_diff = [](const u32x4& va, const u32x4& vc) -> uint32_t {   // index of the first differing bit, 128 if none
-                const uint32_t f0 = ffbl(va.x ^ vc.x), f1 = ffbl(va.y ^ vc.y), f2 = ffbl(va.z ^ vc.z), f3 = ffbl(va.w ^ vc.w);
-                uint32_t bits = f3 < 32u ? f3 : 32u;
-                bits += 32u; bits = f2 < bits ? f2 : bits;
-                bits += 32u; bits = f1 < bits ? f1 : bits;
-                bits += 32u; bits = f0 < bits ? f0 : bits;
-                return bits;
+            auto first_diff = [](const u32x4& va, const u32x4& vc) -> uint32_t {   // index of the first differing bit, >= 128 if none
+                const uint32_t f0 = ffbl(va.x ^ vc.x), f1 = ffbl(va.y ^ vc.y), f2 = ffbl(va.z ^ vc.z), f3 = ffbl(va.w ^ vc.w);   // 0xFFFFFFFF: equal
+                return umin3(umin3(f0, f1 | 32u, f2 | 64u), f3 | 96u, 128u);        // f < 32 or all ones: "or" is "add" or keeps "none"
             };
 #ifdef LZ4W_EXP_NOLEN
             act = false;
 #endif
-            if (__ballot(act) != 0ull) {
+            if (__builtin_amdgcn_ballot_w64(act) != 0ull) {
                 if (act) {                                          // 16 bytes, branch-free: most candidates end here
                     const lds_u8* ap = W.win + p + 4u;
                     u32x4 va, vc;
@@ -497,7 +504,7 @@ __device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8
                     k = 4u + (bits >> 3);
                     act = (bits == 128u) & (k < lim);
                 }
-                while (__ballot(act) != 0ull) {
+                while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
                     if (act) {                                      // 32 bytes per further round
                         const lds_u8* ap = W.win + p + k;
                         u32x4 va0, vc0, va1, vc1;
@@ -514,34 +521,43 @@ __device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8
             }
             k = k < lim ? k : lim;
             LZ4W_TICK(1)
-            const uint32_t own = (isH & (k >= 4u)) ? (((p + k) << 16) | d) : 0u;
+            const uint32_t own_e = (isH & (k >= 4u)) ? hv + (k << 16) : 0u;      // (p + k) << 16 | d
             // bestv[r]: the match that reaches furthest among heads 0..r and everything before the superstep;
             // bestsh[r]: the same before head r, i.e. with r heads passed
-            uint32_t bestv = wave_incl_max(own);
+            uint32_t bestv = wave_incl_max(own_e);
             bestv = bestv > carry ? bestv : carry;
             const uint32_t bestsh = dpp_wave_shr1(bestv, carry);
             carry = rdlane(bestv, 63u);
             // back to positions: every position takes the best of the heads at or before it (a gather by rank), then the
             // eligibility mask of each step: a match of >= 4 that does not yield to the next position (one-step lazy
             // evaluation: the successor reaches further by more than a byte; the last position of a superstep has none)
-            const uint32_t e1c = e1 < mfl_end ? e1 : mfl_end;
             auto best_at = [&](uint32_t rbefore, bool hd) -> uint32_t {
-                const uint32_t ri = rbefore + (hd ? 1u : 0u);
-                const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((ri < 63u ? ri : 63u) << 2), (int)bestsh);
-                return ri >= 64u ? carry : g;
+                const uint32_t ri = rbefore + (hd ? 1u : 0u);          // <= 64; 64 (only with 64 heads) is patched below
+                return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ri << 2), (int)bestsh);
             };
-            const uint32_t q0 = best_at(r0, h0);
-            const uint32_t q1 = best_at(r1, h1 & (ns > 1u));
-            const uint32_t q2 = best_at(r2, h2 & (ns > 2u));
-            const uint32_t q3 = best_at(r3, h3 & (ns > 2u));
+            uint32_t q0 = best_at(r0, hh0), q1 = best_at(r1, hh1), q2 = best_at(r2, hh2), q3 = best_at(r3, hh3);
+            if (H == 64u) {                                          // rank 64 = all heads passed: the new running best
+                q0 = r0 + (hh0 ? 1u : 0u) >= 64u ? carry : q0;
+                q1 = r1 + (hh1 ? 1u : 0u) >= 64u ? carry : q1;
+                q2 = r2 + (hh2 ? 1u : 0u) >= 64u ? carry : q2;
+                q3 = r3 + (hh3 ? 1u : 0u) >= 64u ? carry : q3;
+            }
             const uint32_t e0 = q0 >> 16, ee1 = q1 >> 16, ee2 = q2 >> 16, ee3 = q3 >> 16;
-            auto elig = [&](uint32_t pp, uint32_t e, uint32_t enext) -> uint64_t {
-                return __ballot((pp < e1c) & (e >= pp + 4u) & !(enext > e + 1u));
+            auto elig = [&](uint32_t pp, uint32_t e, uint32_t enext) -> bool {
+                return (e >= pp + 4u) & !(enext > e + 1u);
             };
-            const uint64_t em0 = elig(p0, e0, dpp_wave_shl1(e0, ns > 1u ? rdlane(ee1, 0u) : 0u));
-            const uint64_t em1 = ns > 1u ? elig(p1, ee1, dpp_wave_shl1(ee1, ns > 2u ? rdlane(ee2, 0u) : 0u)) : 0ull;
-            const uint64_t em2 = ns > 2u ? elig(p2, ee2, dpp_wave_shl1(ee2, rdlane(ee3, 0u))) : 0ull;
-            const uint64_t em3 = ns > 2u ? elig(p3, ee3, dpp_wave_shl1(ee3, 0u)) : 0ull;
+            bool g0e = elig(p0, e0, dpp_wave_shl1(e0, ns > 1u ? rdlane(ee1, 0u) : 0u));
+            bool g1e = elig(p1, ee1, dpp_wave_shl1(ee1, ns > 2u ? rdlane(ee2, 0u) : 0u));
+            bool g2e = elig(p2, ee2, dpp_wave_shl1(ee2, rdlane(ee3, 0u)));
+            bool g3e = elig(p3, ee3, dpp_wave_shl1(ee3, 0u));
+            const uint32_t e1c = e1 < mfl_end ? e1 : mfl_end;
+            if (e1c < b + 64u * ns) {                                // the segment's or the block's last positions
+                g0e &= p0 < e1c; g1e &= p1 < e1c; g2e &= p2 < e1c; g3e &= p3 < e1c;
+            }
+            const uint64_t em0 = __builtin_amdgcn_ballot_w64(g0e);
+            const uint64_t em1 = ns > 1u ? __builtin_amdgcn_ballot_w64(g1e) : 0ull;
+            const uint64_t em2 = ns > 2u ? __builtin_amdgcn_ballot_w64(g2e) : 0ull;
+            const uint64_t em3 = ns > 2u ? __builtin_amdgcn_ballot_w64(g3e) : 0ull;
             LZ4W_TICK(2)
             // ---- greedy walk (scalar): the first eligible position at or behind the cursor, step by step.  The loop only
             // marks the chosen positions (one bit each) and hops to the end of the chosen match: a handful of scalar
@@ -585,20 +601,20 @@ __device__ __attribute__((noinline)) void match_segment(lds_u8* lds, const uint8
             // positions by rank; the staging buffer holds < FLUSH_AT bytes here, its upper part is free) ----
             lds_u32* tmp = (lds_u32*)(W.stg + 192u);
             static_assert(FLUSH_AT <= 192u && 192u + 256u <= STG_BYTES, "scratch inside the staging buffer");
-            if ((S0 >> lane) & 1ull) { const uint32_t r = mbcnt(S0); cmp[r] = q0; tmp[r] = p0; }
-            if ((S1 >> lane) & 1ull) { const uint32_t r = n0 + mbcnt(S1); cmp[r] = q1; tmp[r] = p1; }
-            if ((S2 >> lane) & 1ull) { const uint32_t r = n0 + n1 + mbcnt(S2); cmp[r] = q2; tmp[r] = p2; }
-            if ((S3 >> lane) & 1ull) { const uint32_t r = n0 + n1 + n2 + mbcnt(S3); cmp[r] = q3; tmp[r] = p3; }
+            if (__builtin_amdgcn_inverse_ballot_w64(S0)) { const uint32_t r = mbcnt(S0, 0u); cmp[r] = q0; tmp[r] = p0; }
+            if (__builtin_amdgcn_inverse_ballot_w64(S1)) { const uint32_t r = mbcnt(S1, n0); cmp[r] = q1; tmp[r] = p1; }
+            if (__builtin_amdgcn_inverse_ballot_w64(S2)) { const uint32_t r = mbcnt(S2, n0 + n1); cmp[r] = q2; tmp[r] = p2; }
+            if (__builtin_amdgcn_inverse_ballot_w64(S3)) { const uint32_t r = mbcnt(S3, n0 + n1 + n2); cmp[r] = q3; tmp[r] = p3; }
             const bool issel = lane < nsel;
             uint32_t sq = 0u, sp = 0u;
-            if (issel) { sq = cmp[lane]; sp = tmp[lane]; }
+            if (issel) { sq = cmp_lane[0]; sp = cmp_lane[(int)(192u - STG_BYTES) / 4]; }      // tmp[lane]: tmp = stg + 192, cmp = stg + STG_BYTES
             const uint32_t se = sq >> 16, off = sq & 0xFFFFu;
             const uint32_t pe = dpp_wave_shr1(se, anchor0);
             const uint32_t lit = sp - pe, len = se - sp, mlc = len - 4u;
             // A sequence with >= 15 literals or a match of >= 274 bytes needs length bytes beyond the lane-parallel path: such
             // "hard" sequences are written one at a time, the runs of ordinary ones between them 16 at a time.
-            const uint64_t hardm = __ballot(issel & ((lit >= 15u) | (mlc >= 270u)));
-            const bool hardl = (hardm >> lane) & 1ull;
+            const uint64_t hardm = __builtin_amdgcn_ballot_w64(issel & ((lit >= 15u) | (mlc >= 270u)));
+            const bool hardl = __builtin_amdgcn_inverse_ballot_w64(hardm);
             const bool first = (W.has == 0u) & (lane == 0u) & !hardl;       // the segment's first sequence: its token comes later
             const uint32_t ext = mlc >= 15u ? 1u : 0u;
             const uint32_t size = (issel & !hardl) ? ((first ? 2u : 3u + lit) + ext) : 0u;
@@ -806,6 +822,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
                                                                     unsigned long long* __restrict__ prof) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
+    if ((uint32_t)(uintptr_t)lds != 0u) __builtin_trap();        // match_segment addresses LDS from 0 (no static LDS in this kernel)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = uni(threadIdx.x >> 6);
     uint8_t* my_ws = ws + (size_t)blockIdx.x * WS_BYTES;
@@ -863,7 +880,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
             mend = mend > base ? mend - base : 0u;
             mend = mend < s1 ? mend : s1;
             mend = mend < 65535u ? mend : 65535u;
-            match_segment(lds, slots + (size_t)(k & 1u) * SLOT_BYTES, bodies + (size_t)w * BODY_STRIDE, w, lane, s0, s1, mfl_end, mend, prof);
+            match_segment(slots + (size_t)(k & 1u) * SLOT_BYTES, bodies + (size_t)w * BODY_STRIDE, w, lane, s0, s1, mfl_end, mend, prof);
         }
         tick(w == WORKERS ? 0u : 2u);
         __syncthreads();
