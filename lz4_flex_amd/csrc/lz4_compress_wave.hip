@@ -392,6 +392,57 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
 #else
 #define LZ4W_TICK(i)
 #endif
+    // Sequences chosen but not encoded yet: lane k < npend holds the k-th (psq = end << 16 | distance, psp = start); the
+    // literals of the first one start at panchor.
+    uint32_t psq = 0u, psp = 0u, npend = 0u, panchor = s0;
+    // Lane-parallel encoding of the pending sequences into the staging buffer.  A sequence with >= 15 literals or a match of
+    // >= 274 bytes needs length bytes beyond the lane-parallel path: such "hard" sequences are written one at a time, the
+    // runs of ordinary ones between them as many at a time as the staging buffer takes (STG_BYTES - FLUSH_AT bytes).
+    auto encode_pending = [&]() {
+        const bool issel = lane < npend;
+        const uint32_t se = psq >> 16, off = psq & 0xFFFFu, sp = psp;
+        const uint32_t pe = dpp_wave_shr1(se, panchor);
+        const uint32_t lit = sp - pe, len = se - sp, mlc = len - 4u;
+        const uint64_t hardm = __builtin_amdgcn_ballot_w64(issel & ((lit >= 15u) | (mlc >= 270u)));
+        const bool hardl = __builtin_amdgcn_inverse_ballot_w64(hardm);
+        const bool first = (W.has == 0u) & (lane == 0u) & !hardl;       // the segment's first sequence: its token comes later
+        const uint32_t ext = mlc >= 15u ? 1u : 0u;
+        const uint32_t size = (issel & !hardl) ? ((first ? 2u : 3u + lit) + ext) : 0u;
+        const uint32_t incl = wave_incl_add(size);
+        if (W.has == 0u && (hardm & 1ull) == 0ull) { W.has = 1u; W.first_lit = rdlane(lit, 0u); W.first_ml = rdlane(len, 0u); }
+        for (uint32_t cur = 0u; cur < npend;) {
+            const uint64_t hm = hardm & (~0ull << cur);
+            const uint32_t hq = hm != 0ull ? ctz64(hm) : npend;         // the next hard sequence
+            while (cur < hq) {
+                const uint32_t basec = cur != 0u ? rdlane(incl, cur - 1u) : 0u;
+                const uint32_t rel = incl - basec;                       // bytes of sequences cur .. lane
+                // the sequences of this round: cur <= lane < hq and everything up to the lane fits (rel is monotonous)
+                const uint64_t fits = __builtin_amdgcn_ballot_w64((lane >= cur) & (lane < hq) & (rel <= STG_BYTES - FLUSH_AT));
+                const uint32_t end = cur + (uint32_t)__builtin_popcountll(fits);   // > cur: one ordinary sequence is <= 18 bytes
+                const uint32_t endc = rdlane(incl, end - 1u);
+                if (__builtin_amdgcn_inverse_ballot_w64(fits)) {
+                    lds_u8* o = W.stg + W.fill + (rel - size);
+                    if (!first) {
+                        o[0] = (uint8_t)((lit << 4) | (mlc < 15u ? mlc : 15u));
+                        copy_lit_small(o + 1, W.win + pe, lit);
+                        o += 1u + lit;
+                    }
+                    const uint16_t o16 = (uint16_t)off;
+                    __builtin_memcpy((void*)o, &o16, 2);
+                    if (ext) o[2] = (uint8_t)(mlc - 15u);
+                }
+                W.fill += endc - basec;
+                if (W.fill >= FLUSH_AT) W.flush(false);
+                cur = end;
+            }
+            if (hq < npend) {
+                W.emit_generic(rdlane(pe, hq), rdlane(lit, hq), rdlane(off, hq), rdlane(len, hq));
+                if (W.fill >= FLUSH_AT) W.flush(false);
+                cur = hq + 1u;
+            }
+        }
+        npend = 0u;
+    };
     // cand[]: 16 bytes per lane and group of 8 steps (see index_window), fetched one group ahead.  The load is
     // unconditional (the group behind the last one is still inside the workspace): a conditional load made hipcc wait
     // for the data right where it was requested.  Positions at or behind the window's last match start (and with them
@@ -597,60 +648,23 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
             asm volatile("" :: "s"(S0), "s"(S1), "s"(S2), "s"(S3));
             continue;
 #endif
-            // ---- the chosen sequences, compacted: lane k = sequence k (through LDS: best | position of the chosen
-            // positions by rank; the staging buffer holds < FLUSH_AT bytes here, its upper part is free) ----
+            // ---- the chosen sequences join the pending ones: lane k = k-th sequence not encoded yet (through LDS: best |
+            // position of the chosen positions by rank; the staging buffer holds < FLUSH_AT bytes here, its upper part is
+            // free).  Encoding costs the same instructions for 5 sequences as for 60, so it waits for a full wavefront. ----
+            if (npend + nsel > 64u) encode_pending();
+            if (npend == 0u) panchor = anchor0;
             lds_u32* tmp = (lds_u32*)(W.stg + 192u);
             static_assert(FLUSH_AT <= 192u && 192u + 256u <= STG_BYTES, "scratch inside the staging buffer");
-            if (__builtin_amdgcn_inverse_ballot_w64(S0)) { const uint32_t r = mbcnt(S0, 0u); cmp[r] = q0; tmp[r] = p0; }
-            if (__builtin_amdgcn_inverse_ballot_w64(S1)) { const uint32_t r = mbcnt(S1, n0); cmp[r] = q1; tmp[r] = p1; }
-            if (__builtin_amdgcn_inverse_ballot_w64(S2)) { const uint32_t r = mbcnt(S2, n0 + n1); cmp[r] = q2; tmp[r] = p2; }
-            if (__builtin_amdgcn_inverse_ballot_w64(S3)) { const uint32_t r = mbcnt(S3, n0 + n1 + n2); cmp[r] = q3; tmp[r] = p3; }
-            const bool issel = lane < nsel;
-            uint32_t sq = 0u, sp = 0u;
-            if (issel) { sq = cmp_lane[0]; sp = cmp_lane[(int)(192u - STG_BYTES) / 4]; }      // tmp[lane]: tmp = stg + 192, cmp = stg + STG_BYTES
-            const uint32_t se = sq >> 16, off = sq & 0xFFFFu;
-            const uint32_t pe = dpp_wave_shr1(se, anchor0);
-            const uint32_t lit = sp - pe, len = se - sp, mlc = len - 4u;
-            // A sequence with >= 15 literals or a match of >= 274 bytes needs length bytes beyond the lane-parallel path: such
-            // "hard" sequences are written one at a time, the runs of ordinary ones between them 16 at a time.
-            const uint64_t hardm = __builtin_amdgcn_ballot_w64(issel & ((lit >= 15u) | (mlc >= 270u)));
-            const bool hardl = __builtin_amdgcn_inverse_ballot_w64(hardm);
-            const bool first = (W.has == 0u) & (lane == 0u) & !hardl;       // the segment's first sequence: its token comes later
-            const uint32_t ext = mlc >= 15u ? 1u : 0u;
-            const uint32_t size = (issel & !hardl) ? ((first ? 2u : 3u + lit) + ext) : 0u;
-            const uint32_t incl = wave_incl_add(size);
-            if (W.has == 0u && (hardm & 1ull) == 0ull) { W.has = 1u; W.first_lit = rdlane(lit, 0u); W.first_ml = rdlane(len, 0u); }
-            for (uint32_t cur = 0u; cur < nsel;) {
-                const uint64_t hm = hardm & (~0ull << cur);
-                const uint32_t hq = hm != 0ull ? ctz64(hm) : nsel;         // the next hard sequence
-                while (cur < hq) {                                          // <= 16 ordinary sequences (<= 288 bytes) per staging round
-                    const uint32_t end = cur + 16u < hq ? cur + 16u : hq;
-                    const uint32_t basec = cur != 0u ? rdlane(incl, cur - 1u) : 0u;
-                    const uint32_t endc = rdlane(incl, end - 1u);
-                    if ((lane >= cur) & (lane < end)) {
-                        lds_u8* o = W.stg + W.fill + (incl - size - basec);
-                        if (!first) {
-                            o[0] = (uint8_t)((lit << 4) | (mlc < 15u ? mlc : 15u));
-                            copy_lit_small(o + 1, W.win + pe, lit);
-                            o += 1u + lit;
-                        }
-                        const uint16_t o16 = (uint16_t)off;
-                        __builtin_memcpy((void*)o, &o16, 2);
-                        if (ext) o[2] = (uint8_t)(mlc - 15u);
-                    }
-                    W.fill += endc - basec;
-                    if (W.fill >= FLUSH_AT) W.flush(false);
-                    cur = end;
-                }
-                if (hq < nsel) {
-                    W.emit_generic(rdlane(pe, hq), rdlane(lit, hq), rdlane(off, hq), rdlane(len, hq));
-                    if (W.fill >= FLUSH_AT) W.flush(false);
-                    cur = hq + 1u;
-                }
-            }
+            if (__builtin_amdgcn_inverse_ballot_w64(S0)) { const uint32_t r = mbcnt(S0, npend); cmp[r] = q0; tmp[r] = p0; }
+            if (__builtin_amdgcn_inverse_ballot_w64(S1)) { const uint32_t r = mbcnt(S1, npend + n0); cmp[r] = q1; tmp[r] = p1; }
+            if (__builtin_amdgcn_inverse_ballot_w64(S2)) { const uint32_t r = mbcnt(S2, npend + n0 + n1); cmp[r] = q2; tmp[r] = p2; }
+            if (__builtin_amdgcn_inverse_ballot_w64(S3)) { const uint32_t r = mbcnt(S3, npend + n0 + n1 + n2); cmp[r] = q3; tmp[r] = p3; }
+            if ((lane >= npend) & (lane < npend + nsel)) { psq = cmp_lane[0]; psp = cmp_lane[(int)(192u - STG_BYTES) / 4]; }   // tmp[lane]: tmp = stg + 192, cmp = stg + STG_BYTES
+            npend += nsel;
         }
     }
     }
+    if (npend != 0u) encode_pending();
     W.flush(true);
 #ifdef LZ4W_PROF_STEPS
     if (prof_ && lane == 0u) {
