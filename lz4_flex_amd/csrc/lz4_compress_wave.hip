@@ -463,6 +463,12 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
             const uint32_t t1 = j0 == 0u ? dq1 : dq3;
             const uint32_t t2 = dq2, t3 = dq3;
             LZ4W_TICK(4)
+#ifdef LZ4W_EXP_PAD_VALU     // tools: what does one more vector / scalar / LDS instruction per superstep cost?
+            { uint32_t pad_ = lane; _Pragma("unroll") for (int i_ = 0; i_ < LZ4W_EXP_PAD_VALU; ++i_) asm volatile("v_add_u32 %0, 1, %0" : "+v"(pad_)); asm volatile("" :: "v"(pad_)); }
+#endif
+#ifdef LZ4W_EXP_PAD_SALU
+            { uint32_t pad_ = s0; _Pragma("unroll") for (int i_ = 0; i_ < LZ4W_EXP_PAD_SALU; ++i_) asm volatile("s_add_u32 %0, %0, 1" : "+s"(pad_) :: "scc"); asm volatile("" :: "s"(pad_)); }
+#endif
             const uint32_t cend = carry >> 16;
             {
                 const uint32_t e1m = b + 64u * maxs < s1 ? b + 64u * maxs : s1;
@@ -615,23 +621,38 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
             // instructions per sequence; everything else about a sequence is known to its position's lane already ----
             uint64_t S0 = 0ull, S1 = 0ull, S2 = 0ull, S3 = 0ull;
             const uint32_t anchor0 = anchor;
-            auto walk = [&](uint64_t em, uint32_t ev, uint32_t base, uint64_t& S) {
+            // Scalar instructions are the scarcest resource of this kernel (one scalar unit serves all the wavefronts of the
+            // CU), so the loop is written out: 5 scalar instructions, 2 branches and a v_readlane per sequence.
+            // er = end of the position's best match relative to the step's base (>= 64: the next sequence starts behind this step).
+            auto walk = [&](uint64_t em, uint32_t er, uint32_t base, uint64_t& S) {
                 if (cursor >= base + 64u) return;
-                uint32_t c = (cursor > base ? cursor : base) - base;
-                for (;;) {
-                    const uint64_t m = em >> c;
-                    if (m == 0ull) break;
-                    const uint32_t q = c + ctz64(m);
-                    S |= 1ull << q;
-                    cursor = anchor = rdlane(ev, q);                // the end of the chosen match
-                    c = cursor - base;
-                    if (c >= 64u) break;
-                }
+                uint32_t c;                                          // (written as max - base hipcc forms a saturating subtraction, a vector instruction)
+                asm("s_max_u32 %0, %1, %2" : "=s"(c) : "s"(cursor), "s"(base) : "scc");
+                c -= base;
+                uint64_t m; uint32_t t;
+                asm volatile(
+                    "s_lshr_b64 %[m], %[em], %[c]\n\t"
+                    "s_cbranch_scc0 1f\n"
+                    "0:\n\t"
+                    "s_ff1_i32_b64 %[t], %[m]\n\t"
+                    "s_add_u32 %[t], %[t], %[c]\n\t"
+                    "s_bitset1_b64 %[S], %[t]\n\t"
+                    "v_readlane_b32 %[c], %[er], %[t]\n\t"
+                    "s_cmp_lt_u32 %[c], 64\n\t"
+                    "s_cbranch_scc0 1f\n\t"
+                    "s_lshr_b64 %[m], %[em], %[c]\n\t"
+                    "s_cbranch_scc1 0b\n"
+                    "1:"
+                    : [m] "=&s"(m), [t] "=&s"(t), [c] "+s"(c), [S] "+s"(S)
+                    : [em] "s"(em), [er] "v"(er)
+                    : "scc");
+                if (S != 0ull) cursor = anchor = base + c;          // c = the last chosen match's end when anything was chosen
             };
+            const uint32_t er0 = e0 - b, er1 = ee1 - (b + 64u), er2 = ee2 - (b + 128u), er3 = ee3 - (b + 192u);
 #ifndef LZ4W_EXP_NOWALK
-            walk(em0, e0, b, S0);
-            if (ns > 1u) walk(em1, ee1, b + 64u, S1);
-            if (ns > 2u) { walk(em2, ee2, b + 128u, S2); walk(em3, ee3, b + 192u, S3); }
+            walk(em0, er0, b, S0);
+            if (ns > 1u) walk(em1, er1, b + 64u, S1);
+            if (ns > 2u) { walk(em2, er2, b + 128u, S2); walk(em3, er3, b + 192u, S3); }
 #else
             asm volatile("" :: "s"(em0), "s"(em1), "s"(em2), "s"(em3), "v"(q0), "v"(q1), "v"(q2), "v"(q3));
 #endif
@@ -866,11 +887,15 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
         load_window(a.in_base + t.in_off + (size_t)t.win * WINDOW, win_len(t), lds, threadIdx.x);
     };
 
+    // (sums are kept in registers and added to prof[] once, when the workgroup is done: an atomic per tick made the
+    // waits look twice as long as they are)
     uint64_t t_prev = prof ? __builtin_readcyclecounter() : 0ull;
+    uint64_t t_acc[7] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     auto tick = [&](uint32_t slot) {
         if (prof) {
             const uint64_t t = __builtin_readcyclecounter();
-            if (lane == 0u) atomicAdd(prof + slot, (unsigned long long)(t - t_prev));
+#pragma unroll
+            for (uint32_t i = 0; i < 7u; ++i) t_acc[i] += i == slot ? t - t_prev : 0ull;
             t_prev = t;
         }
     };
@@ -911,7 +936,12 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
         if (prof && threadIdx.x == 0u) atomicAdd(prof + 7, 1ull);
         item_next(a, it);
         k += 1u;
-        if (it.blk >= a.n) break;
+        if (it.blk >= a.n) {
+            if (prof && lane == 0u)
+                for (uint32_t i = 0; i < 7u; ++i)
+                    if (t_acc[i] != 0ull) atomicAdd(prof + i, (unsigned long long)t_acc[i]);
+            break;
+        }
         if (w != WORKERS) do_load(it);
         tick(w == WORKERS ? 1u : 5u);
         __syncthreads();
