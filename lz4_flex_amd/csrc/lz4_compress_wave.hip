@@ -40,6 +40,8 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) uint8_t g_u8;          // global memory, named: pointers that cross a call would be flat
 typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) u32x2 g_u32x2;
 typedef __attribute__((address_space(1))) uint32_t g_u32;
 typedef __attribute__((address_space(1))) int32_t g_i32;
 
@@ -133,9 +135,9 @@ __device__ __forceinline__ G* uni_gptr(T* p) {
 // step share a bucket the highest one stays (the GPU tests compare with the scalar model, which assumes it).
 // Memory: the window is streamed in 1 KiB chunks, 16 B per lane, IDX_DEPTH chunks in flight in registers (a single
 // wavefront has to cover the HBM latency by itself), each chunk passes through an LDS slot from which the steps read
-// their unaligned 4-byte values.  cand[] is stored transposed so that one 16-byte load gives a worker lane its
-// distances for 8 consecutive steps: group g = positions [512 g, 512 g + 512), lane i, step u -> u16 at
-// (64 g + i) * 16 + 2 u.
+// their unaligned 4-byte values.  cand[] is stored transposed so that one 8-byte load gives a worker lane its
+// distances for the 4 steps of a 256-block: block g = positions [256 g, 256 g + 256), lane i, step u -> u16 at
+// (64 g + i) * 8 + 2 u.
 struct ChunkRegs { u32x4 main; uint32_t extra; };
 
 // The chunk loads are inline assembly with hand-counted waits.  Written as plain loads hipcc sank them to their use
@@ -160,11 +162,11 @@ template <bool FULL>
 __device__ __forceinline__ void index_chunk(const lds_u8* lp, lds_u16* tab, g_u8* __restrict__ cand_lane, uint32_t c, uint32_t act_n,
                                             uint32_t lane) {
 #pragma unroll
-    for (uint32_t g2 = 0; g2 < 2u; ++g2) {
-        uint32_t pk[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t g4 = 0; g4 < 4u; ++g4) {
+        uint32_t pk[2] = {0u, 0u};
 #pragma unroll
-        for (uint32_t u = 0; u < 8u; ++u) {
-            const uint32_t st = g2 * 8u + u;                    // step in the chunk: offsets 64 st + lane
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t st = g4 * 4u + u;                    // step in the chunk: offsets 64 st + lane
             const uint32_t p = c * CHUNK + st * 64u + lane;
             // the 4 bytes at that offset from two ALIGNED dwords: a byte-unaligned LDS access is executed one lane per
             // cycle (64 cycles per instruction; tools/ubench_lds.hip), an aligned one in 2-4
@@ -179,8 +181,8 @@ __device__ __forceinline__ void index_chunk(const lds_u8* lp, lds_u16* tab, g_u8
             }
             pk[u >> 1] |= d << (16u * (u & 1u));
         }
-        const u32x4 v = {pk[0], pk[1], pk[2], pk[3]};
-        *reinterpret_cast<g_u32x4*>(cand_lane + (size_t)(c * 2u + g2) * 1024u) = v;     // group (2 c + g2), lane: (64 g + lane) * 16
+        const u32x2 v = {pk[0], pk[1]};
+        *reinterpret_cast<g_u32x2*>(cand_lane + (size_t)(c * 4u + g4) * 512u) = v;      // group (4 c + g4), lane: (64 g + lane) * 8
     }
 }
 
@@ -200,7 +202,7 @@ __device__ __attribute__((noinline)) void index_window(const uint8_t* __restrict
     uint32_t n_main = rd_n >= CHUNK + 4u ? (rd_n - 4u) / CHUNK : 0u;
     n_main = n_main < act_n / CHUNK ? n_main : act_n / CHUNK;
     n_main = n_main < nchunks ? n_main : nchunks;
-    g_u8* cand_lane = slot_t + 16u * lane;
+    g_u8* cand_lane = slot_t + 8u * lane;
     const uint32_t lane4 = lane & ~3u;
     if (n_main != 0u) {
         const uint32_t last = n_main - 1u;
@@ -208,7 +210,7 @@ __device__ __attribute__((noinline)) void index_window(const uint8_t* __restrict
 #pragma unroll
         for (uint32_t j = 0; j < IDX_DEPTH; ++j) chunk_issue(q[j], gwin, j < last ? j : last, lane);   // past the end: the last chunk again
         // one chunk: wait for its two loads (N = vector memory operations issued after them), LDS slot, refill the
-        // registers, 16 steps.  Issue order per chunk: [wait], 2 loads, 2 cand[] stores.
+        // registers, 16 steps.  Issue order per chunk: [wait], 2 loads, 4 cand[] stores.
 #define LZ4W_ONE_CHUNK(N, CC, J)                                                                    \
         {                                                                                           \
             lds_u8* sl = lds + L_RING + ((J) & 1u) * CHUNK_SLOT;                                    \
@@ -223,16 +225,16 @@ __device__ __attribute__((noinline)) void index_window(const uint8_t* __restrict
         uint32_t c = 0u;
         if (n_main >= IDX_DEPTH) {                       // first round: fewer stores are in flight yet
             LZ4W_ONE_CHUNK(6, 0u, 0)
-            LZ4W_ONE_CHUNK(8, 1u, 1)
-            LZ4W_ONE_CHUNK(10, 2u, 2)
-            LZ4W_ONE_CHUNK(12, 3u, 3)
+            LZ4W_ONE_CHUNK(10, 1u, 1)
+            LZ4W_ONE_CHUNK(14, 2u, 2)
+            LZ4W_ONE_CHUNK(18, 3u, 3)
             c = IDX_DEPTH;
         }
-        for (; c + IDX_DEPTH <= n_main; c += IDX_DEPTH) {   // steady state: 3 x 2 loads + 4 x 2 stores are younger
-            LZ4W_ONE_CHUNK(14, c, 0)
-            LZ4W_ONE_CHUNK(14, c + 1u, 1)
-            LZ4W_ONE_CHUNK(14, c + 2u, 2)
-            LZ4W_ONE_CHUNK(14, c + 3u, 3)
+        for (; c + IDX_DEPTH <= n_main; c += IDX_DEPTH) {   // steady state: 3 x 2 loads + 4 x 4 stores are younger
+            LZ4W_ONE_CHUNK(22, c, 0)
+            LZ4W_ONE_CHUNK(22, c + 1u, 1)
+            LZ4W_ONE_CHUNK(22, c + 2u, 2)
+            LZ4W_ONE_CHUNK(22, c + 3u, 3)
         }
 #undef LZ4W_ONE_CHUNK
         // the <= 3 chunks left are already requested (q[0..2]): drain everything, then index them
@@ -354,54 +356,33 @@ __device__ __forceinline__ void copy_lit_small(lds_u8* dst, const lds_u8* src, u
     if (n & 1u) dst[n & 14u] = (uint8_t)(wq >> (n2 ? 16 : 0));
 }
 
-// One segment [s0, s1) of the window in LDS.  mfl_end: positions p < mfl_end may start a match (p <= n - 12);
-// mend: matches end here at the latest (segment end, block end - 5, 65535).
-//
-// The segment is walked in SUPERSTEPS of up to 256 positions (4 steps of 64: lane i looks at positions b + 64 u + i).
-// Only ~1 position in 5 is a head, and everything expensive happens per head, so the heads of a superstep are
-// compacted into the 64 lanes (rank = popcount of the head ballots below the lane, a 256-byte LDS buffer), counted,
-// prefix-maximised and handed to a scalar greedy walk that sees the superstep through the four head ballots:
-//   rank(p) = number of heads at or before p (s_bcnt1 on the ballots), best(p) = v_readlane(bestv, rank(p) - 1).
-// A superstep holds at most 64 heads by construction: 256 positions if that many fit, else 128, else 64 (the scalar
-// model walks the same supersteps).  The selected sequences (at most 64: a match is >= 4 long) are placed in lanes
-// (lane k = sequence k) and encoded lane-parallel, 16 sequences per staging round.
-__device__ __attribute__((noinline)) void match_segment(const uint8_t* __restrict__ cand_t_, uint8_t* body_, uint32_t w_, uint32_t lane,
-                              uint32_t s0_, uint32_t s1_, uint32_t mfl_end_, uint32_t mend_, unsigned long long* prof_) {
-    const uint32_t w = uni(w_), s0 = uni(s0_), s1 = uni(s1_), mfl_end = uni(mfl_end_), mend = uni(mend_);
-    const g_u8* __restrict__ cand_t = uni_gptr<const g_u8>(cand_t_);
-    // The kernel's LDS starts at address 0 (it has no static LDS; the kernel checks): with the base a compile-time constant
-    // every LDS address below is a VGPR offset plus an immediate, not a 64-lane add per access.  The loop is bound by the
-    // number of vector instructions issued (a wavefront instruction occupies its SIMD for 4 cycles whatever the number of
-    // active lanes), so instructions, not latencies, are what is counted here.
+// What a segment's encoder carries from one call to the next (all uniform).
+struct EncState {
+    uint32_t fill, body_len;          // bytes in the staging buffer / already flushed to the body
+    uint32_t has, first_lit, first_ml;   // the segment's first sequence (its token is written when the segments are placed)
+    uint32_t last_end;                // end of the last encoded match: the next sequence's literals start here
+};
+
+// Lane-parallel encoding of the chosen sequences (lane k < npend: psq = match end << 16 | distance, psp = match start; the
+// literals of sequence 0 start at st.last_end) into the staging buffer.  A sequence with >= 15 literals or a match of
+// >= 274 bytes needs length bytes beyond the lane-parallel path: such "hard" sequences are written one at a time, the runs of
+// ordinary ones between them as many at a time as the staging buffer takes (STG_BYTES - FLUSH_AT bytes).  Not inlined: it
+// runs once per ~4 supersteps and has four call sites.
+__device__ __attribute__((noinline)) EncState encode_seqs(uint32_t psq, uint32_t psp, uint32_t npend_, uint32_t w_, uint8_t* body_, uint32_t lane,
+                                                          uint32_t final_, EncState st_) {
+    const uint32_t npend = uni(npend_), w = uni(w_), final = uni(final_);
     lds_u8* const lds = reinterpret_cast<lds_u8*>((uintptr_t)0);
     Worker W;
     W.win = lds + L_WIN;
     W.stg = lds + L_STG + w * WORKER_LDS;
-    lds_u32* cmp = (lds_u32*)(lds + L_STG + w * WORKER_LDS + STG_BYTES);
-    const lds_u32* cmp_lane = cmp + lane;
     W.body = uni_gptr<g_u8>(body_);
     W.lane = lane;
-    W.fill = 0u; W.body_len = 0u; W.has = 0u; W.first_lit = 0u; W.first_ml = 0u;
-    uint32_t cursor = s0, anchor = s0, carry = 0u, dlast = 0u;
-    const uint32_t lane4 = lane & ~3u, lane3 = lane & 3u;
-#ifdef LZ4W_PROF_STEPS      // tools: cycles per part of a superstep -> prof[8..13] (heads, compaction + lengths, scan, walk, encode, supersteps)
-    uint64_t pt[5] = {0, 0, 0, 0, 0}, pn = 0, pt0 = __builtin_readcyclecounter();
-#define LZ4W_TICK(i) { const uint64_t t_ = __builtin_readcyclecounter(); pt[i] += t_ - pt0; pt0 = t_; }
-#elif defined(LZ4W_MARK)   // tools: phase boundaries visible in a -S listing
-#define LZ4W_TICK(i) asm volatile("; LZ4W_PHASE_END " #i);
-#else
-#define LZ4W_TICK(i)
-#endif
-    // Sequences chosen but not encoded yet: lane k < npend holds the k-th (psq = end << 16 | distance, psp = start); the
-    // literals of the first one start at panchor.
-    uint32_t psq = 0u, psp = 0u, npend = 0u, panchor = s0;
-    // Lane-parallel encoding of the pending sequences into the staging buffer.  A sequence with >= 15 literals or a match of
-    // >= 274 bytes needs length bytes beyond the lane-parallel path: such "hard" sequences are written one at a time, the
-    // runs of ordinary ones between them as many at a time as the staging buffer takes (STG_BYTES - FLUSH_AT bytes).
-    auto encode_pending = [&]() {
+    W.fill = uni(st_.fill); W.body_len = uni(st_.body_len); W.has = uni(st_.has); W.first_lit = uni(st_.first_lit); W.first_ml = uni(st_.first_ml);
+    uint32_t last_end = uni(st_.last_end);
+    if (npend != 0u) {
         const bool issel = lane < npend;
         const uint32_t se = psq >> 16, off = psq & 0xFFFFu, sp = psp;
-        const uint32_t pe = dpp_wave_shr1(se, panchor);
+        const uint32_t pe = dpp_wave_shr1(se, last_end);
         const uint32_t lit = sp - pe, len = se - sp, mlc = len - 4u;
         const uint64_t hardm = __builtin_amdgcn_ballot_w64(issel & ((lit >= 15u) | (mlc >= 270u)));
         const bool hardl = __builtin_amdgcn_inverse_ballot_w64(hardm);
@@ -441,252 +422,306 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
                 cur = hq + 1u;
             }
         }
-        npend = 0u;
+        last_end = rdlane(se, npend - 1u);
+    }
+    if (final) W.flush(true);
+    EncState r;
+    r.fill = W.fill; r.body_len = W.body_len; r.has = W.has; r.first_lit = W.first_lit; r.first_ml = W.first_ml; r.last_end = last_end;
+    return r;
+}
+
+template <uint32_t V> struct UConst { static constexpr uint32_t value = V; };
+
+// One segment [s0, s1) of the window in LDS.  mfl_end: positions p < mfl_end may start a match (p <= n - 12);
+// mend: matches end here at the latest (segment end, block end - 5, 65535).
+//
+// The segment is walked in SUPERSTEPS of up to 256 positions (4 steps of 64: lane i looks at positions b + 64 u + i).
+// Only ~1 position in 5 is a head, and everything expensive happens per head, so the heads of a superstep are
+// compacted into the 64 lanes (rank = popcount of the head ballots below the lane, a 256-byte LDS buffer), counted,
+// prefix-maximised and gathered back to the positions; a scalar greedy walk over the eligibility masks marks the chosen
+// positions, which join the pending sequences in lanes (encode_seqs takes them a wavefront at a time).
+// A superstep holds at most 64 heads by construction: 256 positions if that many fit, else 128, else 64 (the scalar
+// model walks the same supersteps).
+//
+// What is counted here is instructions, not latencies: 18 wavefronts share a CU whose ONE scalar unit retires about an
+// instruction per cycle, and a vector instruction occupies its SIMD for 4 cycles whatever the number of active lanes;
+// measured, one more scalar instruction per superstep costs 13 cycles, one more vector instruction 6.  Hence the
+// compile-time superstep size (no masks for "step u is part of this superstep"), the hand-written walk, v_mbcnt's
+// accumulator operand, LDS addressed from 0 (the kernel checks), ...
+__device__ __attribute__((noinline)) void match_segment(const uint8_t* __restrict__ cand_t_, uint8_t* body_, uint32_t w_, uint32_t lane,
+                              uint32_t s0_, uint32_t s1_, uint32_t mfl_end_, uint32_t mend_, unsigned long long* prof_) {
+    const uint32_t w = uni(w_), s0 = uni(s0_), s1 = uni(s1_), mfl_end = uni(mfl_end_), mend = uni(mend_);
+    const g_u8* __restrict__ cand_t = uni_gptr<const g_u8>(cand_t_);
+    lds_u8* const lds = reinterpret_cast<lds_u8*>((uintptr_t)0);
+    lds_u8* const win = lds + L_WIN;
+    lds_u8* const stg = lds + L_STG + w * WORKER_LDS;
+    lds_u32* const cmp = (lds_u32*)(stg + STG_BYTES);             // compaction buffer: 64 x 4 B
+    lds_u32* const tmp = (lds_u32*)(stg + 192u);                  // second one: the staging buffer holds < FLUSH_AT bytes between calls of encode_seqs
+    static_assert(FLUSH_AT <= 192u && 192u + 256u <= STG_BYTES, "scratch inside the staging buffer");
+    EncState st;
+    st.fill = 0u; st.body_len = 0u; st.has = 0u; st.first_lit = 0u; st.first_ml = 0u; st.last_end = s0;
+    uint32_t cursor = s0, carry = 0u, dlast = 0u;
+    // sequences chosen but not encoded yet: lane k < npend holds the k-th
+    uint32_t psq = 0u, psp = 0u, npend = 0u;
+#ifdef LZ4W_PROF_STEPS      // tools: cycles per part of a superstep -> prof[8..13] (heads, compaction + lengths, scan, walk, merge + encode, supersteps)
+    uint64_t pt[5] = {0, 0, 0, 0, 0}, pn = 0, pt0 = __builtin_readcyclecounter();
+#define LZ4W_TICK(i) { const uint64_t t_ = __builtin_readcyclecounter(); pt[i] += t_ - pt0; pt0 = t_; }
+#elif defined(LZ4W_MARK)   // tools: phase boundaries visible in a -S listing
+#define LZ4W_TICK(i) asm volatile("; LZ4W_PHASE_END " #i);
+#else
+#define LZ4W_TICK(i)
+#endif
+    auto mbcnt = [&](uint64_t m, uint32_t base) -> uint32_t {      // bits of m below the lane + base
+        return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
     };
-    // cand[]: 16 bytes per lane and group of 8 steps (see index_window), fetched one group ahead.  The load is
-    // unconditional (the group behind the last one is still inside the workspace): a conditional load made hipcc wait
-    // for the data right where it was requested.  Positions at or behind the window's last match start (and with them
-    // everything behind a clipped segment end) carry distance 0 already: the indexer writes it.
-    u32x4 dn = *reinterpret_cast<const g_u32x4*>(cand_t + ((size_t)(s0 >> 9) * 64u + lane) * 16u);
-    for (uint32_t gb = s0; gb < s1; gb += 512u) {
-    u32x4 dc = dn;
-    dn = *reinterpret_cast<const g_u32x4*>(cand_t + ((size_t)((gb + 512u) >> 9) * 64u + lane) * 16u);
-    for (uint32_t B0 = gb; B0 < gb + 512u && B0 < s1; B0 += 256u) {
-        // the four steps of this 256-block
-        const uint32_t dq0 = dc.x & 0xFFFFu, dq1 = dc.x >> 16, dq2 = dc.y & 0xFFFFu, dq3 = dc.y >> 16;
-        dc.x = dc.z; dc.y = dc.w;
-        for (uint32_t j0 = 0u; j0 < 4u && B0 + 64u * j0 < s1;) {
-            const uint32_t b = B0 + 64u * j0;
-            const uint32_t maxs = j0 == 0u ? 4u : (j0 == 2u ? 2u : 1u);       // steps an aligned superstep may span from here
-            // t_u = distances of step u of this superstep
-            const uint32_t t0 = j0 == 0u ? dq0 : (j0 == 1u ? dq1 : (j0 == 2u ? dq2 : dq3));
-            const uint32_t t1 = j0 == 0u ? dq1 : dq3;
-            const uint32_t t2 = dq2, t3 = dq3;
-            LZ4W_TICK(4)
-#ifdef LZ4W_EXP_PAD_VALU     // tools: what does one more vector / scalar / LDS instruction per superstep cost?
-            { uint32_t pad_ = lane; _Pragma("unroll") for (int i_ = 0; i_ < LZ4W_EXP_PAD_VALU; ++i_) asm volatile("v_add_u32 %0, 1, %0" : "+v"(pad_)); asm volatile("" :: "v"(pad_)); }
+    auto ld4 = [&](uint32_t pos) -> uint32_t {                     // 4 bytes at any position from two aligned dwords
+        const lds_u32* ap = (const lds_u32*)(win + (pos & ~3u));
+        return __builtin_amdgcn_alignbyte(ap[1], ap[0], pos & 3u);
+    };
+    auto first_diff = [](const u32x4& va, const u32x4& vc) -> uint32_t {   // index of the first differing bit, 128 if none
+        const uint32_t f0 = ffbl(va.x ^ vc.x), f1 = ffbl(va.y ^ vc.y), f2 = ffbl(va.z ^ vc.z), f3 = ffbl(va.w ^ vc.w);   // 0xFFFFFFFF: equal
+        return umin3(umin3(f0, f1 | 32u, f2 | 64u), f3 | 96u, 128u);        // f < 32 or all ones: "or" is "add" or keeps "none"
+    };
+
+    // One superstep of NS steps at b (a multiple of 64 NS); t_u = distances of step u.  false: more than 64 heads, nothing
+    // was changed, the caller halves.
+    auto superstep = [&](auto nsc, const uint32_t b, const uint32_t t0, const uint32_t t1, const uint32_t t2, const uint32_t t3) -> bool {
+        constexpr uint32_t NS = decltype(nsc)::value;
+        LZ4W_TICK(4)
+#ifdef LZ4W_EXP_PAD_VALU     // tools: what does one more vector / scalar instruction per superstep cost?
+        { uint32_t pad_ = lane; _Pragma("unroll") for (int i_ = 0; i_ < LZ4W_EXP_PAD_VALU; ++i_) asm volatile("v_add_u32 %0, 1, %0" : "+v"(pad_)); asm volatile("" :: "v"(pad_)); }
 #endif
 #ifdef LZ4W_EXP_PAD_SALU
-            { uint32_t pad_ = s0; _Pragma("unroll") for (int i_ = 0; i_ < LZ4W_EXP_PAD_SALU; ++i_) asm volatile("s_add_u32 %0, %0, 1" : "+s"(pad_) :: "scc"); asm volatile("" :: "s"(pad_)); }
+        { uint32_t pad_ = s0; _Pragma("unroll") for (int i_ = 0; i_ < LZ4W_EXP_PAD_SALU; ++i_) asm volatile("s_add_u32 %0, %0, 1" : "+s"(pad_) :: "scc"); asm volatile("" :: "s"(pad_)); }
 #endif
-            const uint32_t cend = carry >> 16;
-            {
-                const uint32_t e1m = b + 64u * maxs < s1 ? b + 64u * maxs : s1;
-                if (cursor >= e1m && cend >= e1m - 1u + SKIPD) {      // everything here lies deep inside a match already taken
-                    const uint32_t tl = maxs == 4u ? t3 : (maxs == 2u ? t1 : t0);
-                    dlast = rdlane(tl, 63u);
-                    j0 += maxs;
-                    continue;
-                }
-            }
-            // heads of the (up to) four steps: the distance changes, and the candidate's first 4 bytes equal the position's
-            // (both read as aligned dword pairs: an unaligned LDS access costs a cycle per active lane)
-            const uint32_t p0 = b + lane, p1 = p0 + 64u, p2 = p0 + 128u, p3 = p0 + 192u;
-            const uint32_t pv0 = dpp_wave_shr1(t0, dlast);
-            const uint32_t pv1 = dpp_wave_shr1(t1, rdlane(t0, 63u));
-            const uint32_t pv2 = dpp_wave_shr1(t2, rdlane(t1, 63u));
-            const uint32_t pv3 = dpp_wave_shr1(t3, rdlane(t2, 63u));
-            bool k0 = (t0 != 0u) & (t0 != pv0);
-            bool k1 = (maxs > 1u) & (t1 != 0u) & (t1 != pv1);
-            bool k2 = (maxs > 2u) & (t2 != 0u) & (t2 != pv2);
-            bool k3 = (maxs > 2u) & (t3 != 0u) & (t3 != pv3);
-            if (cend >= b + SKIPD) {                                 // positions buried >= SKIPD deep in the running best match
-                const uint32_t T = cend - SKIPD;                      // p <= T: buried
-                k0 &= p0 > T; k1 &= p1 > T; k2 &= p2 > T; k3 &= p3 > T;
-            }
-            // all eight 4-byte reads are issued before the first compare (one LDS round trip, not four); lanes without a
-            // candidate read something harmless.  Own side: dwords at b + 64 u + (lane & ~3), one address for all four steps.
-            const lds_u32* own = (const lds_u32*)(W.win + (b + lane4));
-            const uint32_t a0 = __builtin_amdgcn_alignbyte(own[1], own[0], lane3), a1 = __builtin_amdgcn_alignbyte(own[17], own[16], lane3),
-                           a2 = __builtin_amdgcn_alignbyte(own[33], own[32], lane3), a3 = __builtin_amdgcn_alignbyte(own[49], own[48], lane3);
-            auto ld4 = [&](uint32_t pos) -> uint32_t {
-                const lds_u32* ap = (const lds_u32*)(W.win + (pos & ~3u));
-                return __builtin_amdgcn_alignbyte(ap[1], ap[0], pos & 3u);
-            };
-            const uint32_t g0 = ld4(p0 - t0), g1 = ld4(p1 - t1), g2 = ld4(p2 - t2), g3 = ld4(p3 - t3);
-            const bool h0 = k0 & (a0 == g0), h1 = k1 & (a1 == g1), h2 = k2 & (a2 == g2), h3 = k3 & (a3 == g3);
-            const uint64_t m0 = __builtin_amdgcn_ballot_w64(h0), m1 = __builtin_amdgcn_ballot_w64(h1),
-                           m2 = __builtin_amdgcn_ballot_w64(h2), m3 = __builtin_amdgcn_ballot_w64(h3);
-            const uint32_t c0 = (uint32_t)__builtin_popcountll(m0), c1 = (uint32_t)__builtin_popcountll(m1),
-                           c2 = (uint32_t)__builtin_popcountll(m2), c3 = (uint32_t)__builtin_popcountll(m3);
-            // the largest superstep that holds at most 64 heads
-            uint32_t ns = maxs, H = c0 + c1 + c2 + c3;
-            if (H > 64u && ns == 4u) { ns = 2u; H = c0 + c1; }
-            if (H > 64u && ns == 2u) { ns = 1u; H = c0; }
-            const uint32_t e1 = b + 64u * ns < s1 ? b + 64u * ns : s1;
-            const uint64_t M0 = m0, M1 = ns > 1u ? m1 : 0ull, M2 = ns > 2u ? m2 : 0ull, M3 = ns > 2u ? m3 : 0ull;
-            const uint32_t b1 = c0, b2 = c0 + c1, b3 = c0 + c1 + c2;             // heads before step u
-            {
-                const uint32_t tl = ns == 4u ? t3 : (ns == 2u ? t1 : t0);
-                dlast = rdlane(tl, 63u);
-            }
-            j0 += ns;
-            LZ4W_TICK(0)
-            if (H == 0u && cursor >= e1) continue;               // no head, nothing to select: the running best is unchanged
-            // compaction: head of rank r -> lane r, as (position << 16 | distance).  v_mbcnt adds the heads of the earlier
-            // steps for free (its accumulator operand).
-            auto mbcnt = [&](uint64_t m, uint32_t base) -> uint32_t {
-                return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
-            };
-            const uint32_t r0 = mbcnt(M0, 0u), r1 = mbcnt(M1, b1), r2 = mbcnt(M2, b2), r3 = mbcnt(M3, b3);   // heads before this position
-            const bool hh0 = __builtin_amdgcn_inverse_ballot_w64(M0), hh1 = __builtin_amdgcn_inverse_ballot_w64(M1),
-                       hh2 = __builtin_amdgcn_inverse_ballot_w64(M2), hh3 = __builtin_amdgcn_inverse_ballot_w64(M3);
-            if (hh0) cmp[r0] = (p0 << 16) | t0;
-            if (hh1) cmp[r1] = (p1 << 16) | t1;
-            if (hh2) cmp[r2] = (p2 << 16) | t2;
-            if (hh3) cmp[r3] = (p3 << 16) | t3;
-            const bool isH = lane < H;
-            uint32_t hv = 0u;
-            if (isH) hv = *cmp_lane;
-            const uint32_t p = hv >> 16, d = hv & 0xFFFFu;
-            // true match lengths of the heads (their first 4 bytes are known to match)
-            uint32_t lim = __builtin_elementwise_sub_sat(mend, p);
-            lim = lim < CAP ? lim : CAP;
-            uint32_t k = 4u;
-            bool act = isH & (lim > 4u);
-            auto first_diff = [](const u32x4& va, const u32x4& vc) -> uint32_t {   // index of the first differing bit, >= 128 if none
-                const uint32_t f0 = ffbl(va.x ^ vc.x), f1 = ffbl(va.y ^ vc.y), f2 = ffbl(va.z ^ vc.z), f3 = ffbl(va.w ^ vc.w);   // 0xFFFFFFFF: equal
-                return umin3(umin3(f0, f1 | 32u, f2 | 64u), f3 | 96u, 128u);        // f < 32 or all ones: "or" is "add" or keeps "none"
-            };
+        const uint32_t cend = carry >> 16;
+        const uint32_t e1 = b + 64u * NS < s1 ? b + 64u * NS : s1;
+        const uint32_t tl = NS == 4u ? t3 : (NS == 2u ? t1 : t0);
+        if (cursor >= e1 && cend >= e1 - 1u + SKIPD) {            // everything here lies deep inside a match already taken
+            dlast = rdlane(tl, 63u);
+            return true;
+        }
+        // heads: the distance changes, and the candidate's first 4 bytes equal the position's (both read as aligned dword
+        // pairs: an unaligned LDS access costs a cycle per active lane).  Positions at or behind the window's last match
+        // start (and with them everything behind a clipped segment end) carry distance 0: the indexer writes it.
+        const uint32_t p0 = b + lane, p1 = p0 + 64u, p2 = p0 + 128u, p3 = p0 + 192u;
+        bool k0 = (t0 != 0u) & (t0 != dpp_wave_shr1(t0, dlast)), k1 = false, k2 = false, k3 = false;
+        if (NS > 1u) k1 = (t1 != 0u) & (t1 != dpp_wave_shr1(t1, rdlane(t0, 63u)));
+        if (NS > 2u) {
+            k2 = (t2 != 0u) & (t2 != dpp_wave_shr1(t2, rdlane(t1, 63u)));
+            k3 = (t3 != 0u) & (t3 != dpp_wave_shr1(t3, rdlane(t2, 63u)));
+        }
+        if (cend >= b + SKIPD) {                                 // positions buried >= SKIPD deep in the running best match
+            const uint32_t T = cend - SKIPD;                      // p <= T: buried
+            k0 &= p0 > T; k1 &= p1 > T; k2 &= p2 > T; k3 &= p3 > T;
+        }
+        // all 4-byte reads are issued before the first compare (one LDS round trip); lanes without a candidate read
+        // something harmless.  Own side: dwords at b + 64 u + (lane & ~3), one address for all the steps.
+        const uint32_t lane3 = lane & 3u;                        // (recomputed per superstep: registers that live across the call of encode_seqs are scarce)
+        const lds_u32* own = (const lds_u32*)(win + (b + (lane & ~3u)));
+        uint32_t a0 = 0u, a1 = 0u, a2 = 0u, a3 = 0u, g0 = 1u, g1 = 1u, g2 = 1u, g3 = 1u;
+        a0 = __builtin_amdgcn_alignbyte(own[1], own[0], lane3);
+        if (NS > 1u) a1 = __builtin_amdgcn_alignbyte(own[17], own[16], lane3);
+        if (NS > 2u) { a2 = __builtin_amdgcn_alignbyte(own[33], own[32], lane3); a3 = __builtin_amdgcn_alignbyte(own[49], own[48], lane3); }
+        g0 = ld4(p0 - t0);
+        if (NS > 1u) g1 = ld4(p1 - t1);
+        if (NS > 2u) { g2 = ld4(p2 - t2); g3 = ld4(p3 - t3); }
+        const uint64_t M0 = __builtin_amdgcn_ballot_w64(k0 & (a0 == g0)), M1 = __builtin_amdgcn_ballot_w64(k1 & (a1 == g1)),
+                       M2 = __builtin_amdgcn_ballot_w64(k2 & (a2 == g2)), M3 = __builtin_amdgcn_ballot_w64(k3 & (a3 == g3));
+        const uint32_t c0 = (uint32_t)__builtin_popcountll(M0), c1 = (uint32_t)__builtin_popcountll(M1),
+                       c2 = (uint32_t)__builtin_popcountll(M2), c3 = (uint32_t)__builtin_popcountll(M3);
+        const uint32_t H = c0 + c1 + c2 + c3;
+        if (NS > 1u && H > 64u) return false;
+        dlast = rdlane(tl, 63u);
+        LZ4W_TICK(0)
+        if (H == 0u && cursor >= e1) return true;                // no head, nothing to select: the running best is unchanged
+        // compaction: head of rank r -> lane r, as (position << 16 | distance); v_mbcnt adds the heads of the earlier steps
+        const uint32_t r0 = mbcnt(M0, 0u), r1 = mbcnt(M1, c0), r2 = mbcnt(M2, c0 + c1), r3 = mbcnt(M3, c0 + c1 + c2);   // heads before this position
+        const bool hh0 = __builtin_amdgcn_inverse_ballot_w64(M0), hh1 = __builtin_amdgcn_inverse_ballot_w64(M1),
+                   hh2 = __builtin_amdgcn_inverse_ballot_w64(M2), hh3 = __builtin_amdgcn_inverse_ballot_w64(M3);
+        if (hh0) cmp[r0] = (p0 << 16) | t0;
+        if (NS > 1u) if (hh1) cmp[r1] = (p1 << 16) | t1;
+        if (NS > 2u) { if (hh2) cmp[r2] = (p2 << 16) | t2; if (hh3) cmp[r3] = (p3 << 16) | t3; }
+        const bool isH = lane < H;
+        uint32_t hv = 0u;
+        if (isH) hv = cmp[lane];
+        const uint32_t p = hv >> 16, d = hv & 0xFFFFu;
+        // true match lengths of the heads (their first 4 bytes are known to match)
+        uint32_t lim = __builtin_elementwise_sub_sat(mend, p);
+        lim = lim < CAP ? lim : CAP;
+        uint32_t k = 4u;
+        bool act = isH & (lim > 4u);
 #ifdef LZ4W_EXP_NOLEN
-            act = false;
+        act = false;
 #endif
-            if (__builtin_amdgcn_ballot_w64(act) != 0ull) {
-                if (act) {                                          // 16 bytes, branch-free: most candidates end here
-                    const lds_u8* ap = W.win + p + 4u;
-                    u32x4 va, vc;
-                    __builtin_memcpy(&va, (const void*)ap, 16);
-                    __builtin_memcpy(&vc, (const void*)(ap - d), 16);
-                    const uint32_t bits = first_diff(va, vc);
-                    k = 4u + (bits >> 3);
-                    act = (bits == 128u) & (k < lim);
+        if (__builtin_amdgcn_ballot_w64(act) != 0ull) {
+            if (act) {                                          // 16 bytes, branch-free: most candidates end here
+                const lds_u8* ap = win + p + 4u;
+                u32x4 va, vc;
+                __builtin_memcpy(&va, (const void*)ap, 16);
+                __builtin_memcpy(&vc, (const void*)(ap - d), 16);
+                const uint32_t bits = first_diff(va, vc);
+                k = 4u + (bits >> 3);
+                act = (bits == 128u) & (k < lim);
+            }
+            while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
+                if (act) {                                      // 32 bytes per further round
+                    const lds_u8* ap = win + p + k;
+                    u32x4 va0, vc0, va1, vc1;
+                    __builtin_memcpy(&va0, (const void*)ap, 16);
+                    __builtin_memcpy(&vc0, (const void*)(ap - d), 16);
+                    __builtin_memcpy(&va1, (const void*)(ap + 16), 16);
+                    __builtin_memcpy(&vc1, (const void*)(ap - d + 16), 16);
+                    const uint32_t d0 = first_diff(va0, vc0), d1 = first_diff(va1, vc1);
+                    const uint32_t bits = d0 < 128u ? d0 : 128u + d1;
+                    k += bits >> 3;
+                    act = (bits == 256u) & (k < lim);
                 }
-                while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
-                    if (act) {                                      // 32 bytes per further round
-                        const lds_u8* ap = W.win + p + k;
-                        u32x4 va0, vc0, va1, vc1;
-                        __builtin_memcpy(&va0, (const void*)ap, 16);
-                        __builtin_memcpy(&vc0, (const void*)(ap - d), 16);
-                        __builtin_memcpy(&va1, (const void*)(ap + 16), 16);
-                        __builtin_memcpy(&vc1, (const void*)(ap - d + 16), 16);
-                        const uint32_t d0 = first_diff(va0, vc0), d1 = first_diff(va1, vc1);
-                        const uint32_t bits = d0 < 128u ? d0 : 128u + d1;
-                        k += bits >> 3;
-                        act = (bits == 256u) & (k < lim);
-                    }
-                }
             }
-            k = k < lim ? k : lim;
-            LZ4W_TICK(1)
-            const uint32_t own_e = (isH & (k >= 4u)) ? hv + (k << 16) : 0u;      // (p + k) << 16 | d
-            // bestv[r]: the match that reaches furthest among heads 0..r and everything before the superstep;
-            // bestsh[r]: the same before head r, i.e. with r heads passed
-            uint32_t bestv = wave_incl_max(own_e);
-            bestv = bestv > carry ? bestv : carry;
-            const uint32_t bestsh = dpp_wave_shr1(bestv, carry);
-            carry = rdlane(bestv, 63u);
-            // back to positions: every position takes the best of the heads at or before it (a gather by rank), then the
-            // eligibility mask of each step: a match of >= 4 that does not yield to the next position (one-step lazy
-            // evaluation: the successor reaches further by more than a byte; the last position of a superstep has none)
-            auto best_at = [&](uint32_t rbefore, bool hd) -> uint32_t {
-                const uint32_t ri = rbefore + (hd ? 1u : 0u);          // <= 64; 64 (only with 64 heads) is patched below
-                return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ri << 2), (int)bestsh);
-            };
-            uint32_t q0 = best_at(r0, hh0), q1 = best_at(r1, hh1), q2 = best_at(r2, hh2), q3 = best_at(r3, hh3);
-            if (H == 64u) {                                          // rank 64 = all heads passed: the new running best
-                q0 = r0 + (hh0 ? 1u : 0u) >= 64u ? carry : q0;
-                q1 = r1 + (hh1 ? 1u : 0u) >= 64u ? carry : q1;
-                q2 = r2 + (hh2 ? 1u : 0u) >= 64u ? carry : q2;
-                q3 = r3 + (hh3 ? 1u : 0u) >= 64u ? carry : q3;
-            }
-            const uint32_t e0 = q0 >> 16, ee1 = q1 >> 16, ee2 = q2 >> 16, ee3 = q3 >> 16;
-            auto elig = [&](uint32_t pp, uint32_t e, uint32_t enext) -> bool {
-                return (e >= pp + 4u) & !(enext > e + 1u);
-            };
-            bool g0e = elig(p0, e0, dpp_wave_shl1(e0, ns > 1u ? rdlane(ee1, 0u) : 0u));
-            bool g1e = elig(p1, ee1, dpp_wave_shl1(ee1, ns > 2u ? rdlane(ee2, 0u) : 0u));
-            bool g2e = elig(p2, ee2, dpp_wave_shl1(ee2, rdlane(ee3, 0u)));
-            bool g3e = elig(p3, ee3, dpp_wave_shl1(ee3, 0u));
-            const uint32_t e1c = e1 < mfl_end ? e1 : mfl_end;
-            if (e1c < b + 64u * ns) {                                // the segment's or the block's last positions
-                g0e &= p0 < e1c; g1e &= p1 < e1c; g2e &= p2 < e1c; g3e &= p3 < e1c;
-            }
-            const uint64_t em0 = __builtin_amdgcn_ballot_w64(g0e);
-            const uint64_t em1 = ns > 1u ? __builtin_amdgcn_ballot_w64(g1e) : 0ull;
-            const uint64_t em2 = ns > 2u ? __builtin_amdgcn_ballot_w64(g2e) : 0ull;
-            const uint64_t em3 = ns > 2u ? __builtin_amdgcn_ballot_w64(g3e) : 0ull;
-            LZ4W_TICK(2)
-            // ---- greedy walk (scalar): the first eligible position at or behind the cursor, step by step.  The loop only
-            // marks the chosen positions (one bit each) and hops to the end of the chosen match: a handful of scalar
-            // instructions per sequence; everything else about a sequence is known to its position's lane already ----
-            uint64_t S0 = 0ull, S1 = 0ull, S2 = 0ull, S3 = 0ull;
-            const uint32_t anchor0 = anchor;
-            // Scalar instructions are the scarcest resource of this kernel (one scalar unit serves all the wavefronts of the
-            // CU), so the loop is written out: 5 scalar instructions, 2 branches and a v_readlane per sequence.
-            // er = end of the position's best match relative to the step's base (>= 64: the next sequence starts behind this step).
-            auto walk = [&](uint64_t em, uint32_t er, uint32_t base, uint64_t& S) {
-                if (cursor >= base + 64u) return;
-                uint32_t c;                                          // (written as max - base hipcc forms a saturating subtraction, a vector instruction)
-                asm("s_max_u32 %0, %1, %2" : "=s"(c) : "s"(cursor), "s"(base) : "scc");
-                c -= base;
-                uint64_t m; uint32_t t;
-                asm volatile(
-                    "s_lshr_b64 %[m], %[em], %[c]\n\t"
-                    "s_cbranch_scc0 1f\n"
-                    "0:\n\t"
-                    "s_ff1_i32_b64 %[t], %[m]\n\t"
-                    "s_add_u32 %[t], %[t], %[c]\n\t"
-                    "s_bitset1_b64 %[S], %[t]\n\t"
-                    "v_readlane_b32 %[c], %[er], %[t]\n\t"
-                    "s_cmp_lt_u32 %[c], 64\n\t"
-                    "s_cbranch_scc0 1f\n\t"
-                    "s_lshr_b64 %[m], %[em], %[c]\n\t"
-                    "s_cbranch_scc1 0b\n"
-                    "1:"
-                    : [m] "=&s"(m), [t] "=&s"(t), [c] "+s"(c), [S] "+s"(S)
-                    : [em] "s"(em), [er] "v"(er)
-                    : "scc");
-                if (S != 0ull) cursor = anchor = base + c;          // c = the last chosen match's end when anything was chosen
-            };
-            const uint32_t er0 = e0 - b, er1 = ee1 - (b + 64u), er2 = ee2 - (b + 128u), er3 = ee3 - (b + 192u);
+        }
+        k = k < lim ? k : lim;
+        LZ4W_TICK(1)
+        const uint32_t own_e = (isH & (k >= 4u)) ? hv + (k << 16) : 0u;      // (p + k) << 16 | d
+        // bestv[r]: the match that reaches furthest among heads 0..r and everything before the superstep;
+        // bestsh[r]: the same before head r, i.e. with r heads passed
+        uint32_t bestv = wave_incl_max(own_e);
+        bestv = bestv > carry ? bestv : carry;
+        const uint32_t bestsh = dpp_wave_shr1(bestv, carry);
+        carry = rdlane(bestv, 63u);
+        // back to positions: every position takes the best of the heads at or before it (a gather by rank), then the
+        // eligibility mask of each step: a match of >= 4 that does not yield to the next position (one-step lazy
+        // evaluation: the successor reaches further by more than a byte; the last position of a superstep has none)
+        auto best_at = [&](uint32_t rbefore, bool hd) -> uint32_t {
+            const uint32_t ri = rbefore + (hd ? 1u : 0u);          // <= 64; 64 (only with 64 heads) is patched below
+            return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ri << 2), (int)bestsh);
+        };
+        uint32_t q0 = best_at(r0, hh0), q1 = 0u, q2 = 0u, q3 = 0u;
+        if (NS > 1u) q1 = best_at(r1, hh1);
+        if (NS > 2u) { q2 = best_at(r2, hh2); q3 = best_at(r3, hh3); }
+        if (H == 64u) {                                          // rank 64 = all heads passed: the new running best
+            q0 = r0 + (hh0 ? 1u : 0u) >= 64u ? carry : q0;
+            q1 = r1 + (hh1 ? 1u : 0u) >= 64u ? carry : q1;
+            q2 = r2 + (hh2 ? 1u : 0u) >= 64u ? carry : q2;
+            q3 = r3 + (hh3 ? 1u : 0u) >= 64u ? carry : q3;
+        }
+        const uint32_t e0 = q0 >> 16, ee1 = q1 >> 16, ee2 = q2 >> 16, ee3 = q3 >> 16;
+        auto elig = [&](uint32_t pp, uint32_t e, uint32_t enext) -> bool {
+            return (e >= pp + 4u) & !(enext > e + 1u);
+        };
+        bool g0e = elig(p0, e0, dpp_wave_shl1(e0, NS > 1u ? rdlane(ee1, 0u) : 0u)), g1e = false, g2e = false, g3e = false;
+        if (NS > 1u) g1e = elig(p1, ee1, dpp_wave_shl1(ee1, NS > 2u ? rdlane(ee2, 0u) : 0u));
+        if (NS > 2u) { g2e = elig(p2, ee2, dpp_wave_shl1(ee2, rdlane(ee3, 0u))); g3e = elig(p3, ee3, dpp_wave_shl1(ee3, 0u)); }
+        const uint32_t e1c = e1 < mfl_end ? e1 : mfl_end;
+        if (e1c < b + 64u * NS) {                                // the segment's or the block's last positions
+            g0e &= p0 < e1c; g1e &= p1 < e1c; g2e &= p2 < e1c; g3e &= p3 < e1c;
+        }
+        const uint64_t em0 = __builtin_amdgcn_ballot_w64(g0e), em1 = __builtin_amdgcn_ballot_w64(g1e),
+                       em2 = __builtin_amdgcn_ballot_w64(g2e), em3 = __builtin_amdgcn_ballot_w64(g3e);
+        LZ4W_TICK(2)
+        // ---- greedy walk (scalar): the first eligible position at or behind the cursor, step by step.  The loop only marks
+        // the chosen positions (one bit each) and hops to the end of the chosen match: 5 scalar instructions, 2 branches and a
+        // v_readlane per sequence, written out because the scalar unit is the bottleneck.  cb = cursor - b;
+        // er = end of the position's best match relative to its step's base (>= 64: the next sequence starts behind the step) ----
+        uint64_t S0 = 0ull, S1 = 0ull, S2 = 0ull, S3 = 0ull;
+        uint32_t cb = cursor - b;
+        auto walk = [&](auto offc, uint64_t em, uint32_t e, uint64_t& S, uint32_t& cbr) {
+            constexpr uint32_t OFF = decltype(offc)::value;
+            const uint32_t er = e - (b + OFF);
+            uint64_t m; uint32_t t, c;
+            asm volatile(
+                "s_max_u32 %[c], %[cb], %[off]\n\t"
+                "s_sub_u32 %[c], %[c], %[off]\n\t"
+                "s_cmp_lt_u32 %[c], 64\n\t"
+                "s_cbranch_scc0 2f\n\t"
+                "s_lshr_b64 %[m], %[em], %[c]\n\t"
+                "s_cbranch_scc0 1f\n"
+                "0:\n\t"
+                "s_ff1_i32_b64 %[t], %[m]\n\t"
+                "s_add_u32 %[t], %[t], %[c]\n\t"
+                "s_bitset1_b64 %[S], %[t]\n\t"
+                "v_readlane_b32 %[c], %[er], %[t]\n\t"
+                "s_cmp_lt_u32 %[c], 64\n\t"
+                "s_cbranch_scc0 1f\n\t"
+                "s_lshr_b64 %[m], %[em], %[c]\n\t"
+                "s_cbranch_scc1 0b\n"
+                "1:\n\t"
+                "s_add_u32 %[cb], %[c], %[off]\n"
+                "2:"
+                : [m] "=&s"(m), [t] "=&s"(t), [c] "=&s"(c), [S] "+s"(S), [cb] "+s"(cbr)
+                : [em] "s"(em), [er] "v"(er), [off] "n"(OFF)
+                : "scc");
+        };
 #ifndef LZ4W_EXP_NOWALK
-            walk(em0, er0, b, S0);
-            if (ns > 1u) walk(em1, er1, b + 64u, S1);
-            if (ns > 2u) { walk(em2, er2, b + 128u, S2); walk(em3, er3, b + 192u, S3); }
+        walk(UConst<0u>{}, em0, e0, S0, cb);
+        if (NS > 1u) walk(UConst<64u>{}, em1, ee1, S1, cb);
+        if (NS > 2u) { walk(UConst<128u>{}, em2, ee2, S2, cb); walk(UConst<192u>{}, em3, ee3, S3, cb); }
 #else
-            asm volatile("" :: "s"(em0), "s"(em1), "s"(em2), "s"(em3), "v"(q0), "v"(q1), "v"(q2), "v"(q3));
+        asm volatile("" :: "s"(em0), "s"(em1), "s"(em2), "s"(em3), "v"(q0), "v"(q1), "v"(q2), "v"(q3));
 #endif
-            cursor = cursor > e1 ? cursor : e1;
-            LZ4W_TICK(3)
+        cursor = b + cb;
+        cursor = cursor > e1 ? cursor : e1;
+        LZ4W_TICK(3)
 #ifdef LZ4W_PROF_STEPS
-            pn += 1;
+        pn += 1;
 #endif
-            const uint32_t n0 = (uint32_t)__builtin_popcountll(S0), n1 = (uint32_t)__builtin_popcountll(S1),
-                           n2 = (uint32_t)__builtin_popcountll(S2), n3 = (uint32_t)__builtin_popcountll(S3);
-            const uint32_t nsel = n0 + n1 + n2 + n3;
-            if (nsel == 0u) continue;
+        const uint32_t n0 = (uint32_t)__builtin_popcountll(S0), n1 = (uint32_t)__builtin_popcountll(S1),
+                       n2 = (uint32_t)__builtin_popcountll(S2), n3 = (uint32_t)__builtin_popcountll(S3);
+        const uint32_t nsel = n0 + n1 + n2 + n3;
+        if (nsel == 0u) return true;
 #ifdef LZ4W_EXP_NOENC
-            asm volatile("" :: "s"(S0), "s"(S1), "s"(S2), "s"(S3));
-            continue;
+        asm volatile("" :: "s"(S0), "s"(S1), "s"(S2), "s"(S3));
+        return true;
 #endif
-            // ---- the chosen sequences join the pending ones: lane k = k-th sequence not encoded yet (through LDS: best |
-            // position of the chosen positions by rank; the staging buffer holds < FLUSH_AT bytes here, its upper part is
-            // free).  Encoding costs the same instructions for 5 sequences as for 60, so it waits for a full wavefront. ----
-            if (npend + nsel > 64u) encode_pending();
-            if (npend == 0u) panchor = anchor0;
-            lds_u32* tmp = (lds_u32*)(W.stg + 192u);
-            static_assert(FLUSH_AT <= 192u && 192u + 256u <= STG_BYTES, "scratch inside the staging buffer");
-            if (__builtin_amdgcn_inverse_ballot_w64(S0)) { const uint32_t r = mbcnt(S0, npend); cmp[r] = q0; tmp[r] = p0; }
-            if (__builtin_amdgcn_inverse_ballot_w64(S1)) { const uint32_t r = mbcnt(S1, npend + n0); cmp[r] = q1; tmp[r] = p1; }
-            if (__builtin_amdgcn_inverse_ballot_w64(S2)) { const uint32_t r = mbcnt(S2, npend + n0 + n1); cmp[r] = q2; tmp[r] = p2; }
-            if (__builtin_amdgcn_inverse_ballot_w64(S3)) { const uint32_t r = mbcnt(S3, npend + n0 + n1 + n2); cmp[r] = q3; tmp[r] = p3; }
-            if ((lane >= npend) & (lane < npend + nsel)) { psq = cmp_lane[0]; psp = cmp_lane[(int)(192u - STG_BYTES) / 4]; }   // tmp[lane]: tmp = stg + 192, cmp = stg + STG_BYTES
-            npend += nsel;
+        // ---- the chosen sequences join the pending ones: lane k = k-th sequence not encoded yet (through LDS: best |
+        // position of the chosen positions by rank).  Encoding costs the same instructions for 5 sequences as for 60, so it
+        // waits for a full wavefront. ----
+        auto scatter = [&](uint32_t base) {                      // chosen position of rank r -> slot base + r
+            if (__builtin_amdgcn_inverse_ballot_w64(S0)) { const uint32_t r = mbcnt(S0, base); cmp[r] = q0; tmp[r] = p0; }
+            if (NS > 1u) if (__builtin_amdgcn_inverse_ballot_w64(S1)) { const uint32_t r = mbcnt(S1, base + n0); cmp[r] = q1; tmp[r] = p1; }
+            if (NS > 2u) {
+                if (__builtin_amdgcn_inverse_ballot_w64(S2)) { const uint32_t r = mbcnt(S2, base + n0 + n1); cmp[r] = q2; tmp[r] = p2; }
+                if (__builtin_amdgcn_inverse_ballot_w64(S3)) { const uint32_t r = mbcnt(S3, base + n0 + n1 + n2); cmp[r] = q3; tmp[r] = p3; }
+            }
+        };
+        if (npend + nsel > 64u) {
+            // no room: the new sequences go to registers first (the staging buffer is about to be used), the pending ones are
+            // encoded, the new ones become the pending ones.  Only two values live across the call.
+            scatter(0u);
+            uint32_t nq = 0u, np = 0u;
+            if (lane < nsel) { nq = cmp[lane]; np = tmp[lane]; }
+            st = encode_seqs(psq, psp, npend, w, body_, lane, 0u, st);
+            psq = nq; psp = np; npend = nsel;
+            return true;
+        }
+        scatter(npend);
+        if ((lane >= npend) & (lane < npend + nsel)) { psq = cmp[lane]; psp = tmp[lane]; }
+        npend += nsel;
+        return true;
+    };
+
+    // cand[]: 8 bytes per lane and 256-block (see index_window), fetched one block ahead.  The load is unconditional (the
+    // block behind the last one is still inside the workspace): a conditional load made hipcc wait for the data right
+    // where it was requested.
+    u32x2 dn = *reinterpret_cast<const g_u32x2*>(cand_t + ((s0 >> 8) * 512u + lane * 8u));
+    for (uint32_t B0 = s0; B0 < s1; B0 += 256u) {
+        // the four steps of this 256-block: as one superstep if it holds at most 64 heads, else in halves, else in quarters
+        const uint32_t dq0 = dn.x & 0xFFFFu, dq1 = dn.x >> 16, dq2 = dn.y & 0xFFFFu, dq3 = dn.y >> 16;
+        dn = *reinterpret_cast<const g_u32x2*>(cand_t + (((B0 >> 8) + 1u) * 512u + lane * 8u));
+        if (superstep(UConst<4u>{}, B0, dq0, dq1, dq2, dq3)) continue;
+#pragma unroll 1
+        for (uint32_t hf = 0u; hf < 2u; ++hf) {
+            const uint32_t bh = B0 + 128u * hf;
+            if (bh >= s1) break;
+            const uint32_t ta = hf ? dq2 : dq0, tb = hf ? dq3 : dq1;
+            if (superstep(UConst<2u>{}, bh, ta, tb, 0u, 0u)) continue;
+#pragma unroll 1
+            for (uint32_t qt = 0u; qt < 2u; ++qt) {
+                if (bh + 64u * qt >= s1) break;
+                superstep(UConst<1u>{}, bh + 64u * qt, qt ? tb : ta, 0u, 0u, 0u);
+            }
         }
     }
-    }
-    if (npend != 0u) encode_pending();
-    W.flush(true);
+    st = encode_seqs(psq, psp, npend, w, body_, lane, 1u, st);
 #ifdef LZ4W_PROF_STEPS
     if (prof_ && lane == 0u) {
         for (int i = 0; i < 5; ++i) atomicAdd(prof_ + 8 + i, (unsigned long long)pt[i]);
@@ -695,7 +730,7 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
 #endif
     if (lane == 0u) {
         lds_u32* mp = (lds_u32*)(lds + L_META) + 5u * w;
-        mp[0] = W.has; mp[1] = W.first_lit; mp[2] = W.first_ml; mp[3] = s1 - anchor; mp[4] = W.body_len;
+        mp[0] = st.has; mp[1] = st.first_lit; mp[2] = st.first_ml; mp[3] = s1 - st.last_end; mp[4] = st.body_len;
     }
 }
 
