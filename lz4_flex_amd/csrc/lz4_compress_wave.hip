@@ -161,28 +161,47 @@ __device__ __forceinline__ void chunk_wait(ChunkRegs& r) {
 template <bool FULL>
 __device__ __forceinline__ void index_chunk(const lds_u8* lp, lds_u16* tab, g_u8* __restrict__ cand_lane, uint32_t c, uint32_t act_n,
                                             uint32_t lane) {
+    // 8 steps at a time, in three passes, so that the wavefront sees two LDS round trips per 8 steps and not per step: (1) the
+    // 4-byte values of all 8 steps (nothing in the table can change them), (2) lookup + insert of step 0, 1, ... back to
+    // back (LDS executes a wavefront's operations in order: the lookup of step k + 1 sees the inserts of step k without any
+    // wait), (3) distances.  Written in one loop per step hipcc has to wait for each lookup before the next step's read.
 #pragma unroll
-    for (uint32_t g4 = 0; g4 < 4u; ++g4) {
-        uint32_t pk[2] = {0u, 0u};
+    for (uint32_t g8 = 0; g8 < 2u; ++g8) {
+        uint32_t h[8], e[8];
+        // the 4 bytes at offset 64 st + lane from two ALIGNED dwords: a byte-unaligned LDS access is executed one lane per
+        // cycle (64 cycles per instruction; tools/ubench_lds.hip), an aligned one in 2-4.  The eight reads are inline
+        // assembly so that they are issued together into eight register pairs (hipcc reused one pair and waited eight times).
+        uint64_t xr[8];
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; ++u) {
-            const uint32_t st = g4 * 4u + u;                    // step in the chunk: offsets 64 st + lane
-            const uint32_t p = c * CHUNK + st * 64u + lane;
-            // the 4 bytes at that offset from two ALIGNED dwords: a byte-unaligned LDS access is executed one lane per
-            // cycle (64 cycles per instruction; tools/ubench_lds.hip), an aligned one in 2-4
-            const lds_u32* ap = (const lds_u32*)(lp + st * 64u);
-            const uint32_t x = __builtin_amdgcn_alignbyte(ap[1], ap[0], lane & 3u);
-            const uint32_t h = (x * 2654435761u) >> (32u - HBITS);
-            uint32_t d = 0u;
-            if (FULL || p < act_n) {
-                const uint32_t e = tab[h];
-                tab[h] = (uint16_t)p;
-                d = (p - e) & 0xFFFFu;
-            }
-            pk[u >> 1] |= d << (16u * (u & 1u));
+        for (uint32_t u = 0; u < 8u; ++u)
+            asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(xr[u]) : "v"((uint32_t)(uintptr_t)lp), "n"((g8 * 8u + u) * 16u), "n"((g8 * 8u + u) * 16u + 1u) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]) :: "memory");
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) {
+            const uint32_t x = __builtin_amdgcn_alignbyte((uint32_t)(xr[u] >> 32), (uint32_t)xr[u], lane & 3u);
+            h[u] = (x * 2654435761u) >> (32u - HBITS);
         }
-        const u32x2 v = {pk[0], pk[1]};
-        *reinterpret_cast<g_u32x2*>(cand_lane + (size_t)(c * 4u + g4) * 512u) = v;      // group (4 c + g4), lane: (64 g + lane) * 8
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) {
+            const uint32_t p = c * CHUNK + (g8 * 8u + u) * 64u + lane;
+            e[u] = p;                                           // inactive position: distance 0
+            if (FULL || p < act_n) {
+                e[u] = tab[h[u]];
+                tab[h[u]] = (uint16_t)p;
+            }
+        }
+#pragma unroll
+        for (uint32_t g4 = 0; g4 < 2u; ++g4) {
+            uint32_t pk[2] = {0u, 0u};
+#pragma unroll
+            for (uint32_t v = 0; v < 4u; ++v) {
+                const uint32_t u = g4 * 4u + v;
+                const uint32_t p = c * CHUNK + (g8 * 8u + u) * 64u + lane;
+                pk[v >> 1] |= ((p - e[u]) & 0xFFFFu) << (16u * (v & 1u));
+            }
+            const u32x2 val = {pk[0], pk[1]};
+            *reinterpret_cast<g_u32x2*>(cand_lane + (size_t)(c * 4u + g8 * 2u + g4) * 512u) = val;      // block (4 c + ..), lane: (64 g + lane) * 8
+        }
     }
 }
 
