@@ -516,7 +516,9 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
         const uint32_t cend = carry >> 16;
         const uint32_t e1 = b + 64u * NS < s1 ? b + 64u * NS : s1;
         const uint32_t tl = NS == 4u ? t3 : (NS == 2u ? t1 : t0);
-        if (cursor >= e1 && cend >= e1 - 1u + SKIPD) {            // everything here lies deep inside a match already taken
+        // (one comparison: min(cursor, cend - (SKIPD - 1)) >= e1)
+        const uint32_t deep = (cend > SKIPD - 1u ? cend : SKIPD - 1u) - (SKIPD - 1u);
+        if ((cursor < deep ? cursor : deep) >= e1) {              // everything here lies deep inside a match already taken
             dlast = rdlane(tl, 63u);
             return true;
         }
@@ -524,15 +526,20 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
         // pairs: an unaligned LDS access costs a cycle per active lane).  Positions at or behind the window's last match
         // start (and with them everything behind a clipped segment end) carry distance 0: the indexer writes it.
         const uint32_t p0 = b + lane, p1 = p0 + 64u, p2 = p0 + 128u, p3 = p0 + 192u;
-        bool k0 = (t0 != 0u) & (t0 != dpp_wave_shr1(t0, dlast)), k1 = false, k2 = false, k3 = false;
-        if (NS > 1u) k1 = (t1 != 0u) & (t1 != dpp_wave_shr1(t1, rdlane(t0, 63u)));
+        // (conditions are kept as 64-bit lane masks: a bool that is changed under a branch makes hipcc materialise it in a
+        // VGPR and compare again)
+        auto bal = [](bool c) -> uint64_t { return __builtin_amdgcn_ballot_w64(c); };
+        uint64_t K0 = bal(t0 != 0u) & bal(t0 != dpp_wave_shr1(t0, dlast)), K1 = 0ull, K2 = 0ull, K3 = 0ull;
+        if (NS > 1u) K1 = bal(t1 != 0u) & bal(t1 != dpp_wave_shr1(t1, rdlane(t0, 63u)));
         if (NS > 2u) {
-            k2 = (t2 != 0u) & (t2 != dpp_wave_shr1(t2, rdlane(t1, 63u)));
-            k3 = (t3 != 0u) & (t3 != dpp_wave_shr1(t3, rdlane(t2, 63u)));
+            K2 = bal(t2 != 0u) & bal(t2 != dpp_wave_shr1(t2, rdlane(t1, 63u)));
+            K3 = bal(t3 != 0u) & bal(t3 != dpp_wave_shr1(t3, rdlane(t2, 63u)));
         }
         if (cend >= b + SKIPD) {                                 // positions buried >= SKIPD deep in the running best match
             const uint32_t T = cend - SKIPD;                      // p <= T: buried
-            k0 &= p0 > T; k1 &= p1 > T; k2 &= p2 > T; k3 &= p3 > T;
+            K0 &= bal(p0 > T);
+            if (NS > 1u) K1 &= bal(p1 > T);
+            if (NS > 2u) { K2 &= bal(p2 > T); K3 &= bal(p3 > T); }
         }
         // all 4-byte reads are issued before the first compare (one LDS round trip); lanes without a candidate read
         // something harmless.  Own side: dwords at b + 64 u + (lane & ~3), one address for all the steps.
@@ -545,8 +552,8 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
         g0 = ld4(p0 - t0);
         if (NS > 1u) g1 = ld4(p1 - t1);
         if (NS > 2u) { g2 = ld4(p2 - t2); g3 = ld4(p3 - t3); }
-        const uint64_t M0 = __builtin_amdgcn_ballot_w64(k0 & (a0 == g0)), M1 = __builtin_amdgcn_ballot_w64(k1 & (a1 == g1)),
-                       M2 = __builtin_amdgcn_ballot_w64(k2 & (a2 == g2)), M3 = __builtin_amdgcn_ballot_w64(k3 & (a3 == g3));
+        const uint64_t M0 = K0 & bal(a0 == g0), M1 = NS > 1u ? K1 & bal(a1 == g1) : 0ull,
+                       M2 = NS > 2u ? K2 & bal(a2 == g2) : 0ull, M3 = NS > 2u ? K3 & bal(a3 == g3) : 0ull;
         const uint32_t c0 = (uint32_t)__builtin_popcountll(M0), c1 = (uint32_t)__builtin_popcountll(M1),
                        c2 = (uint32_t)__builtin_popcountll(M2), c3 = (uint32_t)__builtin_popcountll(M3);
         const uint32_t H = c0 + c1 + c2 + c3;
@@ -610,32 +617,33 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
         // back to positions: every position takes the best of the heads at or before it (a gather by rank), then the
         // eligibility mask of each step: a match of >= 4 that does not yield to the next position (one-step lazy
         // evaluation: the successor reaches further by more than a byte; the last position of a superstep has none)
-        auto best_at = [&](uint32_t rbefore, bool hd) -> uint32_t {
-            const uint32_t ri = rbefore + (hd ? 1u : 0u);          // <= 64; 64 (only with 64 heads) is patched below
-            return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ri << 2), (int)bestsh);
+        auto incl_rank = [](uint32_t rbefore, uint64_t m) -> uint32_t {      // rbefore + (lane's bit of m): one v_addc with m as the carry-in
+            uint32_t ri; uint64_t co;
+            asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(ri), "=s"(co) : "v"(rbefore), "s"(m));
+            return ri;                                            // <= 64; 64 (only with 64 heads) is patched below
         };
-        uint32_t q0 = best_at(r0, hh0), q1 = 0u, q2 = 0u, q3 = 0u;
-        if (NS > 1u) q1 = best_at(r1, hh1);
-        if (NS > 2u) { q2 = best_at(r2, hh2); q3 = best_at(r3, hh3); }
+        auto best_at = [&](uint32_t ri) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ri << 2), (int)bestsh); };
+        const uint32_t ri0 = incl_rank(r0, M0), ri1 = incl_rank(r1, M1), ri2 = incl_rank(r2, M2), ri3 = incl_rank(r3, M3);
+        uint32_t q0 = best_at(ri0), q1 = 0u, q2 = 0u, q3 = 0u;
+        if (NS > 1u) q1 = best_at(ri1);
+        if (NS > 2u) { q2 = best_at(ri2); q3 = best_at(ri3); }
         if (H == 64u) {                                          // rank 64 = all heads passed: the new running best
-            q0 = r0 + (hh0 ? 1u : 0u) >= 64u ? carry : q0;
-            q1 = r1 + (hh1 ? 1u : 0u) >= 64u ? carry : q1;
-            q2 = r2 + (hh2 ? 1u : 0u) >= 64u ? carry : q2;
-            q3 = r3 + (hh3 ? 1u : 0u) >= 64u ? carry : q3;
+            q0 = ri0 >= 64u ? carry : q0;
+            q1 = ri1 >= 64u ? carry : q1;
+            q2 = ri2 >= 64u ? carry : q2;
+            q3 = ri3 >= 64u ? carry : q3;
         }
         const uint32_t e0 = q0 >> 16, ee1 = q1 >> 16, ee2 = q2 >> 16, ee3 = q3 >> 16;
-        auto elig = [&](uint32_t pp, uint32_t e, uint32_t enext) -> bool {
-            return (e >= pp + 4u) & !(enext > e + 1u);
+        auto elig = [&](uint32_t pp, uint32_t e, uint32_t enext) -> uint64_t {
+            return bal(e >= pp + 4u) & bal(enext <= e + 1u);
         };
-        bool g0e = elig(p0, e0, dpp_wave_shl1(e0, NS > 1u ? rdlane(ee1, 0u) : 0u)), g1e = false, g2e = false, g3e = false;
-        if (NS > 1u) g1e = elig(p1, ee1, dpp_wave_shl1(ee1, NS > 2u ? rdlane(ee2, 0u) : 0u));
-        if (NS > 2u) { g2e = elig(p2, ee2, dpp_wave_shl1(ee2, rdlane(ee3, 0u))); g3e = elig(p3, ee3, dpp_wave_shl1(ee3, 0u)); }
+        uint64_t em0 = elig(p0, e0, dpp_wave_shl1(e0, NS > 1u ? rdlane(ee1, 0u) : 0u)), em1 = 0ull, em2 = 0ull, em3 = 0ull;
+        if (NS > 1u) em1 = elig(p1, ee1, dpp_wave_shl1(ee1, NS > 2u ? rdlane(ee2, 0u) : 0u));
+        if (NS > 2u) { em2 = elig(p2, ee2, dpp_wave_shl1(ee2, rdlane(ee3, 0u))); em3 = elig(p3, ee3, dpp_wave_shl1(ee3, 0u)); }
         const uint32_t e1c = e1 < mfl_end ? e1 : mfl_end;
         if (e1c < b + 64u * NS) {                                // the segment's or the block's last positions
-            g0e &= p0 < e1c; g1e &= p1 < e1c; g2e &= p2 < e1c; g3e &= p3 < e1c;
+            em0 &= bal(p0 < e1c); em1 &= bal(p1 < e1c); em2 &= bal(p2 < e1c); em3 &= bal(p3 < e1c);
         }
-        const uint64_t em0 = __builtin_amdgcn_ballot_w64(g0e), em1 = __builtin_amdgcn_ballot_w64(g1e),
-                       em2 = __builtin_amdgcn_ballot_w64(g2e), em3 = __builtin_amdgcn_ballot_w64(g3e);
         LZ4W_TICK(2)
         // ---- greedy walk (scalar): the first eligible position at or behind the cursor, step by step.  The loop only marks
         // the chosen positions (one bit each) and hops to the end of the chosen match: 5 scalar instructions, 2 branches and a
@@ -647,6 +655,27 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
             constexpr uint32_t OFF = decltype(offc)::value;
             const uint32_t er = e - (b + OFF);
             uint64_t m; uint32_t t, c;
+            if constexpr (OFF == 0u) {
+                asm volatile(
+                    "s_cmp_lt_u32 %[cb], 64\n\t"
+                    "s_cbranch_scc0 2f\n\t"
+                    "s_lshr_b64 %[m], %[em], %[cb]\n\t"
+                    "s_cbranch_scc0 2f\n"
+                    "0:\n\t"
+                    "s_ff1_i32_b64 %[t], %[m]\n\t"
+                    "s_add_u32 %[t], %[t], %[cb]\n\t"
+                    "s_bitset1_b64 %[S], %[t]\n\t"
+                    "v_readlane_b32 %[cb], %[er], %[t]\n\t"
+                    "s_cmp_lt_u32 %[cb], 64\n\t"
+                    "s_cbranch_scc0 2f\n\t"
+                    "s_lshr_b64 %[m], %[em], %[cb]\n\t"
+                    "s_cbranch_scc1 0b\n"
+                    "2:"
+                    : [m] "=&s"(m), [t] "=&s"(t), [S] "+s"(S), [cb] "+s"(cbr)
+                    : [em] "s"(em), [er] "v"(er)
+                    : "scc");
+                return;
+            }
             asm volatile(
                 "s_max_u32 %[c], %[cb], %[off]\n\t"
                 "s_sub_u32 %[c], %[c], %[off]\n\t"
