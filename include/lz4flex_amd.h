@@ -282,6 +282,14 @@ int lz4flex_frame_assemble_device(const void *src_base, const uint64_t *src_off,
 int lz4flex_copy_batch_device(const void *src_base, const uint64_t *src_off, const uint32_t *len, void *dst_base,
                               const uint64_t *dst_off, uint32_t n, void *hip_stream);
 
+/* The block-header walk of FrameDecoder::read_block (src/frame/decompress.rs:231-247) for a frame in DEVICE memory: follows
+ * the BlockInfo words from header_len to the EndMark and writes, per block, the payload offset and the length word (high
+ * bit = stored uncompressed).  info (4 x u32, device): [0] blocks found, [1] 0 ok / 1 truncated frame / 2 BlockTooBig
+ * (a block longer than block_size, :242-247) / 3 more than max_blocks, [2..3] offset behind the EndMark.  Only the few
+ * result words travel to the host; the frame stays where it is. */
+int lz4flex_frame_walk_device(const void *frame, uint64_t frame_len, uint32_t header_len, int block_checksums, uint32_t block_size,
+                              uint32_t max_blocks, uint64_t *payload_off, uint32_t *len_word, uint32_t *info, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,7 +40,7 @@ WRITE_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
 READ_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
 
 # every symbol include/lz4flex_amd.h declares: name -> (restype, argtypes)
-_VP, _SZ, _I64, _I32, _U32 = C.c_void_p, C.c_size_t, C.c_int64, C.c_int, C.c_uint32
+_VP, _SZ, _I64, _I32, _U32, _U64 = C.c_void_p, C.c_size_t, C.c_int64, C.c_int, C.c_uint32, C.c_uint64
 SIGNATURES = {
     "lz4flex_ctx_create": (_I32, [C.POINTER(_VP), _I32]),
     "lz4flex_ctx_destroy": (None, [_VP]),
@@ -91,6 +91,7 @@ SIGNATURES = {
     "lz4flex_xxh32_batch_device": (_I32, [_VP, _VP, _VP, _U32, _U32, _VP, _VP]),
     "lz4flex_frame_assemble_device": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _U32, _I32, _VP, _VP, _VP, _VP]),
     "lz4flex_copy_batch_device": (_I32, [_VP, _VP, _VP, _VP, _VP, _U32, _VP]),
+    "lz4flex_frame_walk_device": (_I32, [_VP, _U64, _U32, _I32, _U32, _U32, _VP, _VP, _VP, _VP]),
 }
 
 _lib = None

@@ -726,6 +726,14 @@ int lz4flex_copy_batch_device(const void* src_base, const uint64_t* src_off, con
     return le == hipSuccess ? 0 : hip_fail(le, "copy batch launch");
 }
 
+int lz4flex_frame_walk_device(const void* frame, uint64_t frame_len, uint32_t header_len, int block_checksums, uint32_t block_size,
+                              uint32_t max_blocks, uint64_t* payload_off, uint32_t* len_word, uint32_t* info, void* hip_stream) {
+    if (!frame || !payload_off || !len_word || !info) return -LZ4FLEX_E_INVALID_ARG;
+    hipError_t le = launch_frame_walk((const uint8_t*)frame, frame_len, header_len, block_checksums ? 4u : 0u, block_size, max_blocks,
+                                      payload_off, len_word, info, (hipStream_t)hip_stream);
+    return le == hipSuccess ? 0 : hip_fail(le, "frame walk launch");
+}
+
 // ---- CompressTable / compress_into_with_table, src/block/compress.rs:710-766 --------------------------------------
 // The reference clears the table on every call: the handle only avoids re-allocating it and remembers its variant
 // (Small = u16 entries + 4-byte hash, Large = u32 entries + 5-byte hash; upgraded, never downgraded).  Here the handle

@@ -128,6 +128,36 @@ hipError_t launch_frame_assemble(const uint8_t* src_base, const uint64_t* src_of
     return hipGetLastError();
 }
 
+// The block-header walk of FrameDecoder::read_block (src/frame/decompress.rs:231-247) over a frame that lives in device
+// memory: one thread follows the chain of 4-byte BlockInfo words (each position depends on the previous length) and writes
+// payload offset / length-with-the-uncompressed-bit per block.  info[0] = blocks, info[1] = status (0 ok, 1 truncated,
+// 2 BlockTooBig, 3 more than max_blocks), info[2..3] = offset behind the EndMark.
+__global__ void frame_walk_kernel(const uint8_t* __restrict__ f, uint64_t n, uint32_t hdr, uint32_t tail, uint32_t block_size, uint32_t max_blocks,
+                                  uint64_t* __restrict__ off, uint32_t* __restrict__ len, uint32_t* __restrict__ info) {
+    if (threadIdx.x != 0u || blockIdx.x != 0u) return;
+    uint64_t p = hdr;
+    uint32_t k = 0u, st = 0u;
+    for (;;) {
+        if (p + 4u > n) { st = 1u; break; }
+        const uint32_t w = (uint32_t)f[p] | ((uint32_t)f[p + 1] << 8) | ((uint32_t)f[p + 2] << 16) | ((uint32_t)f[p + 3] << 24);
+        p += 4u;
+        if (w == 0u) break;                                   // EndMark
+        const uint32_t ln = w & 0x7FFFFFFFu;
+        if (ln > block_size) { st = 2u; break; }
+        if (p + ln + tail > n) { st = 1u; break; }
+        if (k >= max_blocks) { st = 3u; break; }
+        off[k] = p; len[k] = w; k += 1u;
+        p += (uint64_t)ln + tail;
+    }
+    info[0] = k; info[1] = st; info[2] = (uint32_t)p; info[3] = (uint32_t)(p >> 32);
+}
+
+hipError_t launch_frame_walk(const uint8_t* f, uint64_t n, uint32_t hdr, uint32_t tail, uint32_t block_size, uint32_t max_blocks, uint64_t* off,
+                             uint32_t* len, uint32_t* info, hipStream_t s) {
+    hipLaunchKernelGGL(frame_walk_kernel, dim3(1), dim3(64), 0, s, f, n, hdr, tail, block_size, max_blocks, off, len, info);
+    return hipGetLastError();
+}
+
 hipError_t launch_copy_batch(const uint8_t* src_base, const uint64_t* src_off, const uint32_t* len, uint8_t* dst_base, const uint64_t* dst_off,
                              uint32_t n, hipStream_t s) {
     if (n == 0u) return hipSuccess;

@@ -72,6 +72,8 @@ hipError_t launch_xxh32_batch(const uint8_t* base, const uint64_t* off, const ui
 hipError_t launch_frame_assemble(const uint8_t* src_base, const uint64_t* src_off, const uint32_t* in_len, const uint8_t* comp_base,
                                  const uint64_t* comp_off, const uint32_t* comp_len, uint32_t n, int block_checksums, uint8_t* seg,
                                  uint64_t* seg_off, uint64_t* pay_off, uint32_t* pay_len, uint32_t* sums, hipStream_t s);
+hipError_t launch_frame_walk(const uint8_t* f, uint64_t n, uint32_t hdr, uint32_t tail, uint32_t block_size, uint32_t max_blocks, uint64_t* off,
+                             uint32_t* len, uint32_t* info, hipStream_t s);
 hipError_t launch_copy_batch(const uint8_t* src_base, const uint64_t* src_off, const uint32_t* len, uint8_t* dst_base, const uint64_t* dst_off,
                              uint32_t n, hipStream_t s);
 

@@ -258,6 +258,37 @@ def walk_blocks(frame_host, header_len, block_checksums=False, block_size=None):
         p += ln + (4 if block_checksums else 0)
 
 
+def walk_blocks_device(frame, header_len, block_checksums, block_size):
+    """walk_blocks for a frame in device memory: the chain of block headers is followed by a kernel
+    (lz4flex_frame_walk_device); only 12 bytes per block come back to the host, not the frame."""
+    from . import _lib as L
+    from .frame import BlockTooBig
+    lib = L.load()
+    dev = frame.device
+    max_blocks = max(1024, 4 * (frame.numel() // block_size) + 16)      # grown below if the frame holds more (tiny blocks)
+    while True:
+        off = torch.empty(max_blocks, dtype=torch.int64, device=dev)
+        ln = torch.empty(max_blocks, dtype=torch.int32, device=dev)
+        info = torch.zeros(4, dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.lz4flex_frame_walk_device(frame.data_ptr(), frame.numel(), header_len, 1 if block_checksums else 0, block_size, max_blocks,
+                                           off.data_ptr(), ln.data_ptr(), info.data_ptr(), stream)
+        if rc != 0:
+            raise RuntimeError("lz4flex_frame_walk_device: %d %s" % (rc, L.last_error()))
+        n, st = (int(x) for x in info[:2].cpu().tolist())
+        if st == 3 and max_blocks < (1 << 26):
+            max_blocks *= 8
+            continue
+        break
+    if st == 2:
+        raise BlockTooBig()
+    if st != 0:
+        raise ValueError("truncated frame")
+    offs = off[:n].cpu().tolist()
+    words = (ln[:n].to(torch.int64) & 0xFFFFFFFF).cpu().tolist()
+    return [(int(o), int(w) & ~UNCOMPRESSED_BIT, bool(int(w) & UNCOMPRESSED_BIT)) for o, w in zip(offs, words)]
+
+
 def decompress_frame_sharded(frame, group=None, root=0, decompress_blocks=decompress_blocks_device, device=None,
                              xxh32_blocks=None):
     """`frame` (uint8 tensor) is needed on the root only.  The root walks the block headers, every rank
@@ -266,12 +297,14 @@ def decompress_frame_sharded(frame, group=None, root=0, decompress_blocks=decomp
     dev = frame.device if frame is not None else torch.device(device or "cpu")
     meta = [None]
     if rank == root:
-        host = frame.cpu().numpy()
-        fi = FrameInfo.read(bytes(host[:19]))                      # validates magic, version, flags, header checksum (header.rs:277-373)
+        fi = FrameInfo.read(bytes(frame[:19].cpu().numpy()))      # validates magic, version, flags, header checksum (header.rs:277-373)
         hdr_len = len(fi.write())
         if fi.legacy_frame or fi.block_mode != BlockMode.Independent or fi.content_checksum:
             raise ValueError("only Independent frames without a content checksum shard")
-        blocks, _end = walk_blocks(host, hdr_len, fi.block_checksums, fi.block_size.get_size())
+        if frame.is_cuda:
+            blocks = walk_blocks_device(frame, hdr_len, fi.block_checksums, fi.block_size.get_size())
+        else:
+            blocks, _end = walk_blocks(frame.numpy(), hdr_len, fi.block_checksums, fi.block_size.get_size())
         meta = [(blocks, int(fi.block_size), bool(fi.block_checksums))]
     if world > 1:
         dist.broadcast_object_list(meta, src=root, group=group)

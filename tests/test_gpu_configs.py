@@ -136,3 +136,23 @@ def test_xxh32_batch_device_and_checksummed_sharded_frame(mods):
     bad = fr.clone(); bad[-9] ^= 0x55          # corrupt the last block's checksum
     with pytest.raises(RuntimeError, match="BlockChecksumError"):
         sharded.decompress_frame_sharded(bad)
+
+
+def test_device_block_header_walk_equals_host_walk(mods):
+    """lz4flex_frame_walk_device (the sharded decoder's header walk, frame/decompress.rs:231-247) against the host walk: offsets,
+    lengths, stored-raw bits, with and without block checksums; truncated frames and BlockTooBig are reported, not walked."""
+    block, frame, sharded, W = mods
+    rng = np.random.default_rng(11)
+    data = bytes(W.log_stream(0, 300 * W.LINE * 16).numpy()) + rng.integers(0, 256, 200000, dtype=np.uint8).tobytes()   # compressible + stored blocks
+    for bc in (False, True):
+        fi = frame.FrameInfo(block_size=frame.BlockSize.Max64KB, block_checksums=bc)
+        fr = frame.compress_frame(data, fi)
+        hdr = len(fi.write())
+        want, end = sharded.walk_blocks(np.frombuffer(fr, dtype=np.uint8), hdr, bc, 65536)
+        dev = torch.frombuffer(bytearray(fr), dtype=torch.uint8).cuda()
+        got = sharded.walk_blocks_device(dev, hdr, bc, 65536)
+        assert got == want and any(r for _, _, r in got) and not all(r for _, _, r in got)
+        with pytest.raises(ValueError):
+            sharded.walk_blocks_device(dev[:len(fr) - 9].contiguous(), hdr, bc, 65536)
+        with pytest.raises(frame.BlockTooBig):
+            sharded.walk_blocks_device(dev, hdr, bc, 1000)

@@ -19,22 +19,25 @@ def main():
     ap.add_argument("--data", default="json")
     ap.add_argument("--prof", action="store_true")
     ap.add_argument("--dec", type=int, default=0, help="decompress_variant")
+    ap.add_argument("--block", type=int, default=65536, help="block size in bytes (config 4: --data log --block 4194304 --blocks 256)")
     args = ap.parse_args()
     import torch
     import oracle_api as O
     from lz4_flex_amd import _lib as L, workloads
     lib = L.load()
     dev = torch.device("cuda", 0)
-    n, B = args.blocks, 65536
+    n, B = args.blocks, args.block
     if args.data == "json":
         src = workloads.json_tiles(O.fixture_plain("compression_66k_JSON"), n * B, device=dev)
     elif args.data == "text":
         src = workloads.json_tiles(O.fixture_plain("compression_65k"), n * B, device=dev)
+    elif args.data == "log":
+        src = workloads.log_stream(0, n * B, device=dev)
     elif args.data == "zeros":
         src = torch.zeros(n * B, dtype=torch.uint8, device=dev)
     else:
         src = torch.randint(0, 256, (n * B,), dtype=torch.uint8, device=dev)
-    stride = 72128
+    stride = (20 + B * 110 // 100 + 63) // 64 * 64
     comp = torch.empty(n * stride, dtype=torch.uint8, device=dev)
     back = torch.empty(n * B, dtype=torch.uint8, device=dev)
     ar = torch.arange(n, dtype=torch.int64, device=dev)
@@ -55,7 +58,7 @@ def main():
 
     def comp_once():
         assert lib.lz4flex_compress_batch(ctx, p(src), p(in_off), p(in_len), None, n, p(comp), p(comp_off), p(cap), p(clen), p(st),
-                                          L.MEM_DEVICE, stream) == 0, L.last_error()
+                                          L.MEM_DEVICE | (L.MEM_BIG_BLOCKS if B > 65536 else 0), stream) == 0, L.last_error()
 
     def dec_once():
         assert lib.lz4flex_decompress_batch(ctx, p(comp), p(comp_off), p(clen), n, p(back), p(in_off), p(in_len), p(blen), p(bst),
