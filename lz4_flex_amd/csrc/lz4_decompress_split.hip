@@ -341,10 +341,7 @@ __global__ void __launch_bounds__(64 * (NB * G / 64 + 1)) lz4_decompress_split_k
 #ifdef LZ4FLEX_SPLIT_DEBUG
         p.dbg_ip = 0xFFFFFFFFu; p.dbg_w0 = 0u; p.dbg_w1 = 0u; p.dbg_kb = 0u;
 #endif
-        p.C0 = *reinterpret_cast<const u32x4*>(p.chunk_addr(0u));
-        p.C1 = *reinterpret_cast<const u32x4*>(p.chunk_addr(16u));
-        p.C2 = *reinterpret_cast<const u32x4*>(p.chunk_addr(32u));
-        p.N = *reinterpret_cast<const u32x4*>(p.chunk_addr(48u));
+        p.prime();
         __syncthreads();
         // the token chain is the critical path of the workgroup: the parser wavefront issues ahead of the copiers on its SIMD
         // (priority 0: 2.80 ms instead of 2.36 ms)

@@ -27,6 +27,12 @@ static inline uint32_t lz4_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
 #define LZ4_ANY(x) __any(x)
 #define lz4_alignbyte(hi, lo, sh) __builtin_amdgcn_alignbyte(hi, lo, sh)
 #endif
+// base + off for a base that is aligned to more than off can reach: an OR on the device (one v_and_or with the masking)
+#ifdef LZ4FLEX_HOST_SIM
+#define LZ4_ALIGNED_PLUS(base, off) ((base) + (off))
+#else
+#define LZ4_ALIGNED_PLUS(base, off) ((lds_u8*)(uintptr_t)((uint32_t)(uintptr_t)(base) | (uint32_t)(off)))
+#endif
 
 namespace lz4flex_dev {
 namespace v5 {
@@ -40,7 +46,9 @@ typedef uint32_t LZ4_LDS lds_u32;
 constexpr uint32_t OUT_SLACK = 32;
 constexpr uint32_t TAILB = 48;        // bytes of the block's end staged in LDS
 constexpr uint32_t TAIL_BUF = 80;     // + zero padding: a 24-byte window read at any tail position stays inside
-// LDS layout of one block: output buffer | record queue | head, tail | tail copy | sink
+constexpr uint32_t RING = 64;         // compressed bytes around the parse position, per block (+ 8 mirrored bytes behind it)
+constexpr uint32_t RING_BYTES = 80;
+// LDS layout of one block: output buffer | record queue | head, tail | tail copy | sink | ring (64 B aligned)
 template <uint32_t OUT_CAP_, uint32_t OUT_H_, uint32_t QD_>
 struct Layout {
     static constexpr uint32_t QD = QD_;             // records per queue (power of two)
@@ -51,16 +59,17 @@ struct Layout {
     static constexpr uint32_t CTL_OFF = Q_OFF + 16u * QD;   // head, tail
     static constexpr uint32_t TAIL_OFF = CTL_OFF + 16u;
     static constexpr uint32_t SINK_OFF = TAIL_OFF + TAIL_BUF;   // 16 bytes nobody reads: target of the parser's record store when it has nothing to push
-    static constexpr uint32_t BLK_LDS = SINK_OFF + 16u;
-    static_assert(BLK_LDS % 16 == 0 && OUT_H % 16 == 0 && (QD & (QD - 1u)) == 0 && QD >= 8, "layout");
+    static constexpr uint32_t RING_OFF = (SINK_OFF + 16u + 63u) & ~63u;
+    static constexpr uint32_t BLK_LDS = (RING_OFF + RING_BYTES + 63u) & ~63u;   // a multiple of 64: every block's ring is 64 B aligned
+    static_assert(BLK_LDS % 64 == 0 && RING_OFF % 64 == 0 && OUT_H % 16 == 0 && (QD & (QD - 1u)) == 0 && QD >= 8, "layout");
     static_assert(FLUSH_AT >= 4u * 32u + 64u + 64u, "a write-back must leave room for an iteration's pieces");
 };
-using LayoutBig = Layout<2080, 512, 16>;     // 2 448 B per block: 64 blocks = one workgroup per CU
-using LayoutSmall = Layout<1040, 256, 8>;    // 1 280 B per block: two 64-block workgroups per CU (an option; measured no faster, see launch_decompress_split)
-static_assert(LayoutBig::BLK_LDS == 2448 && LayoutBig::FLUSH_AT == 760 && LayoutSmall::BLK_LDS == 1280, "LDS per block");
+using LayoutBig = Layout<1984, 512, 16>;     // 2 496 B per block: 64 blocks = one workgroup per CU (156 KiB of its 160 KiB of LDS)
+using LayoutSmall = Layout<1024, 256, 8>;    // 1 408 B per block (host simulation of a short queue; not launched)
+static_assert(LayoutBig::BLK_LDS == 2496 && LayoutBig::FLUSH_AT == 712 && LayoutSmall::BLK_LDS == 1408, "LDS per block");
 // the default layout's constants at namespace level (host simulation, tools)
 constexpr uint32_t QD = LayoutBig::QD, OUT_H = LayoutBig::OUT_H, OUT_CAP = LayoutBig::OUT_CAP, FLUSH_AT = LayoutBig::FLUSH_AT;
-constexpr uint32_t Q_OFF = LayoutBig::Q_OFF, CTL_OFF = LayoutBig::CTL_OFF, TAIL_OFF = LayoutBig::TAIL_OFF, SINK_OFF = LayoutBig::SINK_OFF;
+constexpr uint32_t Q_OFF = LayoutBig::Q_OFF, CTL_OFF = LayoutBig::CTL_OFF, TAIL_OFF = LayoutBig::TAIL_OFF, SINK_OFF = LayoutBig::SINK_OFF, RING_OFF = LayoutBig::RING_OFF;
 constexpr uint32_t BLK_LDS = LayoutBig::BLK_LDS;
 constexpr uint32_t PF_AHEAD = 512;    // compressed bytes kept warm ahead of the records being copied
 
@@ -100,9 +109,9 @@ struct QueueT {
 // =====================================================================================================
 template <class L>
 struct ParserT {
-    static constexpr uint32_t QD = L::QD, Q_OFF = L::Q_OFF, CTL_OFF = L::CTL_OFF, TAIL_OFF = L::TAIL_OFF, SINK_OFF = L::SINK_OFF;
+    static constexpr uint32_t QD = L::QD, Q_OFF = L::Q_OFF, CTL_OFF = L::CTL_OFF, TAIL_OFF = L::TAIL_OFF, SINK_OFF = L::SINK_OFF, RING_OFF = L::RING_OFF;
     const uint8_t* gin;      // compressed block
-    const uint8_t* gal;      // gin rounded down to 4 bytes: the register window lives in this "aligned space"
+    const uint8_t* gal;      // gin rounded down to 4 bytes: the ring holds bytes of this "aligned space"
     uint32_t A;              // gin - gal
     uint32_t ilen, cap;
     uint32_t ip, op;
@@ -114,11 +123,15 @@ struct ParserT {
     uint32_t qtail;
     uint32_t tstart;         // the LDS tail copy holds compressed positions [tstart, ilen)
     QueueT<L> q;
-    // register window: stream bytes [base, base + 48) of the aligned space, N = the chunk at base + 48
-    uint32_t base;
+    // The compressed bytes around the parse position live in a 64-byte LDS ring per block: bytes [vhi - 64, vhi) of the
+    // aligned space, byte x at ring offset x & 63 (the first 8 bytes are mirrored behind the ring, so a dword pair never
+    // wraps).  N = the 16-byte chunk at vhi, in flight from the previous step.  Round 1 kept a 48-byte window in
+    // registers: sliding it and selecting 24 bytes at a per-lane offset cost ~85 of a step's 172 instructions; two aligned
+    // LDS reads at computed addresses cost 10.
+    uint32_t vhi;
     uint32_t rare_below;     // matches with a smaller offset are marked R_RARE (the copier moves this many bytes per lane)
     uint32_t climit;         // start of the last chunk that lies entirely inside the block (loads are clamped to it)
-    u32x4 C0, C1, C2, N;
+    u32x4 N;
 #ifdef LZ4FLEX_SPLIT_DEBUG
     uint32_t dbg_ip, dbg_w0, dbg_w1, dbg_kb;   // state at the first sequence that left the fast path
 #endif
@@ -142,7 +155,22 @@ struct ParserT {
         gal = any ? g - A : g_pad;
         climit = any ? ((n + A) & ~15u) - 16u : 0u;
         tstart = n > TAILB ? n - TAILB : 0u;
-        base = 0u;
+        vhi = 0u;
+    }
+    LZ4_FN lds_u8* ring() const { return q.blk + RING_OFF; }
+    LZ4_FN void ring_put(const u32x4& c) {                  // the chunk at vhi enters the ring
+        const uint32_t slot = vhi & (RING - 1u);
+        *reinterpret_cast<lds_vu128*>(LZ4_ALIGNED_PLUS(ring(), slot)) = c;
+        if (slot == 0u) {
+            *reinterpret_cast<lds_vu32*>(ring() + RING) = c.x;
+            *reinterpret_cast<lds_vu32*>(ring() + RING + 4u) = c.y;
+        }
+        vhi += 16u;
+    }
+    // fill the ring with the block's first 64 bytes, request the chunk behind them
+    LZ4_FN void prime() {
+        for (uint32_t c = 0u; c < RING; c += 16u) ring_put(*reinterpret_cast<const u32x4*>(chunk_addr(c)));
+        N = *reinterpret_cast<const u32x4*>(chunk_addr(vhi));
     }
     LZ4_FN const uint8_t* chunk_addr(uint32_t c) const { return gal + (c < climit ? c : climit); }
     LZ4_FN uint32_t rd8(uint32_t pos) const {   // pos < ilen
@@ -224,7 +252,9 @@ struct ParserT {
 
     // One step = window() ; [patch_tail() if any lane of the wave reads its tail copy] ; parse() ; [exact_step() for
     // lanes whose sequence left the fast path].
-    uint32_t qhead_, k_, sh_, D0, D1, D2, D3, D4, D5;   // carried from window() to parse()
+    uint32_t qhead_, ahead_, rel_;     // carried from window() to parse()
+    const lds_u8* a_;                  // LDS address of the dword that holds the byte at ip
+    uint32_t sh_;
     bool tailmode, slow;
 
     LZ4_FN void step() {
@@ -237,44 +267,33 @@ struct ParserT {
     }
     LZ4_FN void window() {
         qhead_ = q.head();
-        // ---- register window: take the chunk that was in flight, slide by at most one chunk, fetch the next one
+        // ---- ring: take the chunk that was in flight if its slot lies before the parse position, fetch the next one
         const uint32_t ipa = ip + A;
-        uint32_t k = ipa - base;
-        const bool slide = k - 16u < 48u;        // 16 <= k < 64
-        const bool rebase = k >= 64u;            // a long literal run was skipped: restart three chunks before the target
-        if (slide) { C0 = C1; C1 = C2; C2 = N; }
-        base = rebase ? (ipa & ~15u) - 48u : (slide ? base + 16u : base);
-        N = *reinterpret_cast<const u32x4*>(chunk_addr(base + 48u));
-        k = ipa - base;
-        k_ = k;
+        const uint32_t ipa4 = ipa & ~3u;
+        const bool rebase = (int32_t)(ipa - vhi) >= 16;      // a long literal run led behind the chunk in flight: restart at the target (the steps until the ring is full again do not parse)
+        const bool slide = !rebase && (int32_t)(ipa4 - (vhi - 48u)) >= 0;   // slot [vhi - 64, vhi - 48) is behind the dwords at ip
+        if (slide) ring_put(N);
+        vhi = rebase ? (ipa & ~15u) : vhi;
+        N = *reinterpret_cast<const u32x4*>(chunk_addr(vhi));
+        ahead_ = vhi - ipa;                                  // valid bytes from ip on (signed)
         tailmode = ip + 48u > ilen;
-        // ---- 24 bytes at ip: D0..D5 dwords -> W0..W4
-        const uint32_t i = (k >> 2) & 3u;
-        const uint32_t m0 = 0u - (i & 1u), m1 = 0u - (i >> 1);   // 4-way selects on the two index bits, no control flow
-        D0 = sel4(m0, m1, C0.x, C0.y, C0.z, C0.w);
-        D1 = sel4(m0, m1, C0.y, C0.z, C0.w, C1.x);
-        D2 = sel4(m0, m1, C0.z, C0.w, C1.x, C1.y);
-        D3 = sel4(m0, m1, C0.w, C1.x, C1.y, C1.z);
-        D4 = sel4(m0, m1, C1.x, C1.y, C1.z, C1.w);
-        D5 = sel4(m0, m1, C1.y, C1.z, C1.w, C2.x);
-        sh_ = k & 3u;
+        a_ = LZ4_ALIGNED_PLUS(ring(), ipa4 & (RING - 1u));
+        sh_ = ipa & 3u;
+        rel_ = 0u;
     }
-    // lanes within 48 bytes of their block's end take the 24-byte window from the LDS tail copy instead
+    // lanes within 48 bytes of their block's end read the LDS tail copy instead of the ring
     LZ4_FN void patch_tail() {
-        const uint32_t rel = tailmode ? ip - tstart : 0u;
-        const lds_u32* tw = reinterpret_cast<const lds_u32*>(q.blk + TAIL_OFF + (rel & ~3u));
-        const uint32_t t0 = tw[0], t1 = tw[1], t2 = tw[2], t3 = tw[3], t4 = tw[4], t5 = tw[5];
-        D0 = tailmode ? t0 : D0; D1 = tailmode ? t1 : D1; D2 = tailmode ? t2 : D2;
-        D3 = tailmode ? t3 : D3; D4 = tailmode ? t4 : D4; D5 = tailmode ? t5 : D5;
-        sh_ = tailmode ? (rel & 3u) : sh_;
+        rel_ = tailmode ? ip - tstart : 0u;
+        a_ = tailmode ? q.blk + TAIL_OFF + (rel_ & ~3u) : a_;
+        sh_ = tailmode ? (rel_ & 3u) : sh_;
+    }
+    LZ4_FN uint32_t rd4(const lds_u8* a, uint32_t sh) const {      // 4 bytes at byte sh of the dword pair at a
+        const lds_u32* w = reinterpret_cast<const lds_u32*>(a);
+        return lz4_alignbyte(w[1], w[0], sh);
     }
     LZ4_FN void parse() {
-        const uint32_t qhead = qhead_, k = k_, sh = sh_;
-        const uint32_t W0 = lz4_alignbyte(D1, D0, sh);
-        const uint32_t W1 = lz4_alignbyte(D2, D1, sh);
-        const uint32_t W2 = lz4_alignbyte(D3, D2, sh);
-        const uint32_t W3 = lz4_alignbyte(D4, D3, sh);
-        const uint32_t W4 = lz4_alignbyte(D5, D4, sh);
+        const uint32_t qhead = qhead_;
+        const uint32_t W0 = rd4(a_, sh_);
         // ---- token (or the synthetic one left by a long literal run), literal length with at most one extension byte
         const uint32_t tokb = tok_over != 0u ? tok_over : W0;
         const uint32_t lc = (tokb >> 4) & 15u;
@@ -282,12 +301,17 @@ struct ParserT {
         const uint32_t lc15 = lc == 15u ? 1u : 0u;
         const uint32_t lit = lc + (lc15 ? (W0 >> 8) & 0xFFu : 0u);       // 270 = the extension continues (exact path)
         const uint32_t pos_off = 1u + lc15 + lit;                         // window index of the offset
-        // ---- offset and match-length extension at window index pos_off (used when pos_off <= 17)
-        const uint32_t wi = pos_off >> 2;
-        const uint32_t n0 = 0u - (wi & 1u), n1 = 0u - ((wi >> 1) & 1u), n2 = 0u - ((wi >> 2) & 1u);
-        const uint32_t lo = bfi(n2, W4, bfi(n1, bfi(n0, W3, W2), bfi(n0, W1, W0)));
-        const uint32_t hi = bfi(n2, 0u, bfi(n1, bfi(n0, W4, W3), bfi(n0, W2, W1)));
-        const uint32_t t = lz4_alignbyte(hi, lo, pos_off & 3u);
+        // ---- offset and match-length extension, pos_off bytes behind ip (used when pos_off <= 17: inside the 24 valid bytes)
+        const uint32_t po = pos_off < 20u ? pos_off : 20u;                   // (a longer run is not read here: keep the address inside the buffers)
+        const uint32_t x2 = ip + A + po;
+        const lds_u8* b = LZ4_ALIGNED_PLUS(ring(), x2 & (RING - 4u));
+        uint32_t shb = x2 & 3u;
+        if (LZ4_ANY(tailmode)) {
+            const uint32_t r2 = rel_ + po;
+            b = tailmode ? q.blk + TAIL_OFF + (r2 & ~3u) : b;
+            shb = tailmode ? (r2 & 3u) : shb;
+        }
+        const uint32_t t = rd4(b, shb);
         const uint32_t offset = t & 0xFFFFu;
         const uint32_t ee = mlc == 15u ? (t >> 16) & 0xFFu : 0u;          // 255 = the extension continues (exact path)
         const uint32_t ml = 4u + mlc + ee;
@@ -297,7 +321,7 @@ struct ParserT {
         const uint32_t mstart = op + lit;
         // ---- classify.  Every condition is a signed slack (>= 0 holds), folded with min: sizes are below 2 GiB, larger
         // values only send a sequence to the exact path.  decompress.rs:334-408 in one go for the plain sequence:
-        const int32_t common = imin3((int32_t)(0u - done), tailmode ? 0 : (int32_t)(15u - k),          // live, window holds ip
+        const int32_t common = imin3((int32_t)(0u - done), tailmode ? 0 : (int32_t)(ahead_ - 24u),      // live, the ring holds 24 bytes from ip on
                                      (int32_t)(QD - 3u - (qtail - qhead)));                              // queue has room
         const int32_t short_s = imin3(imin3((int32_t)(ilen - 1u - seq_end),                              // a byte follows the sequence
                                             (int32_t)(mstart - offset), (int32_t)(offset - 1u)),         // 1 <= offset <= output so far
@@ -311,10 +335,10 @@ struct ParserT {
         slow = common >= 0 && !is_short && !is_long;
 #ifdef LZ4FLEX_PROFILE_PHASES
         pr_steps += done == 0u; pr_noroom += done == 0u && (int32_t)(QD - 3u - (qtail - qhead)) < 0;
-        pr_bubble += done == 0u && !tailmode && k >= 16u; pr_slow += slow; pr_pushed += (is_short | is_long);
+        pr_bubble += done == 0u && !tailmode && (int32_t)(ahead_ - 24u) < 0; pr_slow += slow; pr_pushed += (is_short | is_long);
 #endif
 #ifdef LZ4FLEX_SPLIT_DEBUG
-        if (slow && dbg_ip == 0xFFFFFFFFu) { dbg_ip = ip; dbg_w0 = W0; dbg_w1 = W1; dbg_kb = (k << 24) | (base & 0xFFFFFFu); }
+        if (slow && dbg_ip == 0xFFFFFFFFu) { dbg_ip = ip; dbg_w0 = W0; dbg_w1 = t; dbg_kb = (ahead_ << 24) | (vhi & 0xFFFFFFu); }
 #endif
         // ---- commit
         push_if(is_short | is_long, lit_src, lit, is_short ? ml : 0u, is_short ? (offset | (offset < rare_below ? R_RARE << 16 : 0u)) : 0u);

@@ -34,10 +34,7 @@ static int sim_run(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t ca
     p.cap = cap;
     for (uint32_t i = 0; i < TAIL_BUF; ++i) lds[TAIL_OFF + i] = (p.tstart + i < in_len) ? gin[p.tstart + i] : 0;
     p.ip = 0; p.op = 0; p.tok_over = 0; p.qtail = 0; p.status = 0; p.expected = 0; p.done = 0;
-    memcpy(&p.C0, p.chunk_addr(0), 16);
-    memcpy(&p.C1, p.chunk_addr(16), 16);
-    memcpy(&p.C2, p.chunk_addr(32), 16);
-    memcpy(&p.N, p.chunk_addr(48), 16);
+    p.prime();
     if (in_len == 0) p.fail(LZ4FLEX_DEV_E_EXPECTED_ANOTHER_BYTE);
     uint32_t head = 0, op = 0, recs = 0, steps = 0;
     bool finished = false;
