@@ -357,11 +357,18 @@ __global__ void __launch_bounds__(64 * (NB * G / 64 + 1)) lz4_decompress_split_k
 #else
         // A lane only finishes (or fails) inside exact_step, so the hot loop below needs no "done" test and no slow-path
         // code: it runs fast steps until some lane's sequence leaves the fast path.
+        // Only a few lanes at a time are within 48 bytes of their block's end (and read the tail copy instead of the ring):
+        // the step without any such lane carries no code for it.
         while (!__all(p.done != 0u)) {
             do {
                 p.window();
-                if (__any(p.tailmode)) p.patch_tail();
-                p.parse();
+                if (__any(p.tailmode)) {
+                    asm volatile("" ::: "memory");        // keep this a branch: hipcc otherwise merges both bodies into one with selects
+                    p.patch_tail();
+                    p.template parse<true>();
+                } else {
+                    p.template parse<false>();
+                }
             } while (!__any(p.slow));
             if (p.slow) p.exact_step();
         }

@@ -259,8 +259,7 @@ struct ParserT {
 
     LZ4_FN void step() {
         window();
-        if (LZ4_ANY(tailmode)) patch_tail();
-        parse();
+        if (LZ4_ANY(tailmode)) { patch_tail(); parse<true>(); } else parse<false>();
         if (LZ4_ANY(slow)) {
             if (slow) exact_step();
         }
@@ -276,7 +275,7 @@ struct ParserT {
         vhi = rebase ? (ipa & ~15u) : vhi;
         N = *reinterpret_cast<const u32x4*>(chunk_addr(vhi));
         ahead_ = vhi - ipa;                                  // valid bytes from ip on (signed)
-        tailmode = ip + 48u > ilen;
+        tailmode = (ip + 48u > ilen) & (done == 0u);         // (a finished lane reads whatever its ring holds: nothing of it is used)
         a_ = LZ4_ALIGNED_PLUS(ring(), ipa4 & (RING - 1u));
         sh_ = ipa & 3u;
         rel_ = 0u;
@@ -291,6 +290,8 @@ struct ParserT {
         const lds_u32* w = reinterpret_cast<const lds_u32*>(a);
         return lz4_alignbyte(w[1], w[0], sh);
     }
+    // TAIL: some lane of the wavefront reads its tail copy (patch_tail() has run); false: every lane reads its ring
+    template <bool TAIL>
     LZ4_FN void parse() {
         const uint32_t qhead = qhead_;
         const uint32_t W0 = rd4(a_, sh_);
@@ -306,7 +307,7 @@ struct ParserT {
         const uint32_t x2 = ip + A + po;
         const lds_u8* b = LZ4_ALIGNED_PLUS(ring(), x2 & (RING - 4u));
         uint32_t shb = x2 & 3u;
-        if (LZ4_ANY(tailmode)) {
+        if (TAIL) {
             const uint32_t r2 = rel_ + po;
             b = tailmode ? q.blk + TAIL_OFF + (r2 & ~3u) : b;
             shb = tailmode ? (r2 & 3u) : shb;
@@ -321,7 +322,7 @@ struct ParserT {
         const uint32_t mstart = op + lit;
         // ---- classify.  Every condition is a signed slack (>= 0 holds), folded with min: sizes are below 2 GiB, larger
         // values only send a sequence to the exact path.  decompress.rs:334-408 in one go for the plain sequence:
-        const int32_t common = imin3((int32_t)(0u - done), tailmode ? 0 : (int32_t)(ahead_ - 24u),      // live, the ring holds 24 bytes from ip on
+        const int32_t common = imin3((int32_t)(0u - done), (TAIL && tailmode) ? 0 : (int32_t)(ahead_ - 24u),   // live, the ring holds 24 bytes from ip on
                                      (int32_t)(QD - 3u - (qtail - qhead)));                              // queue has room
         const int32_t short_s = imin3(imin3((int32_t)(ilen - 1u - seq_end),                              // a byte follows the sequence
                                             (int32_t)(mstart - offset), (int32_t)(offset - 1u)),         // 1 <= offset <= output so far

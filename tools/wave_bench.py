@@ -91,6 +91,18 @@ def main():
         print("wave decoder, cycles per window: " + ", ".join("%s=%.0f" % (a_, x / nw) for a_, x in zip(names, v)) +
               "; per window: sequences %.1f, phase-B matches %.1f (easy %.1f), far-LP %.1f, near-LP %.1f; windows %d" %
               (v[9] / nw, v[10] / nw, v[11] / nw, v[12] / nw, v[13] / nw, v[8]), flush=True)
+    if hasattr(lib, "lz4flex_debug_phase_split"):          # -DLZ4FLEX_PROFILE_PHASES variant build
+        lib.lz4flex_debug_phase_split.argtypes = [C.c_void_p, C.c_int]
+        v = (C.c_ulonglong * 16)()
+        lib.lz4flex_debug_phase_split(None, 1)
+        dec_once(); torch.cuda.synchronize()
+        lib.lz4flex_debug_phase_split(v, 0)
+        v = list(v)
+        pw = max(n // 64, 1)
+        print("split decoder: parser wave cycles %.0f, steps per parser %.0f (%.0f cycles per step); lane steps: live %d, queue full %.1f%%, "
+              "ring not ready %.1f%%, exact path %.2f%%, records %d; copier wave cycles %.0f, iterations %.0f, write-backs %.0f, cycles in write-backs %.0f" %
+              (v[0] / pw, v[1] / pw, v[0] / max(v[1], 1), v[2], 100.0 * v[3] / max(v[2], 1), 100.0 * v[4] / max(v[2], 1), 100.0 * v[5] / max(v[2], 1), v[6],
+               v[8] / (8 * pw), v[9] / (8 * pw), v[10] / (8 * pw), v[14] / (8 * pw)), flush=True)
     tc, td = [], []
     for _ in range(args.reps):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
