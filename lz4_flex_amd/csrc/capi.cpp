@@ -63,7 +63,10 @@ static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressA
     // by batch shape: up to ~6 000 blocks the wave decoder (a wavefront per block: a block is done in a third of the time the
     // split decoder's serial chain needs, and blocks larger than 64 KiB stay tolerable); larger batches have enough blocks
     // to fill the chip with one chain per lane, which costs half the instructions per byte
-    const int v = c->dec_variant != 0 ? c->dec_variant : (a.n <= 6144u ? 5 : (a.n > 20480u ? 3 : 4));
+    // round 2 (tools/wave_bench.py --dec, JSON tiles; ms for 1 024 / 4 096 / 6 144 / 8 192 / 16 384 / 32 768 blocks): wave 0.74 / 1.01 /
+    // 1.64 / 1.95 / 3.8 / 7.3, split 1.31 / 1.31 / 1.52 / 1.55 / 1.92 / 3.86, pipelined 2.43 / 2.54 / 2.62 / 2.59 / 2.9 / 4.15: the
+    // pipelined kernel is no longer chosen
+    const int v = c->dec_variant != 0 ? c->dec_variant : (a.n <= 5120u ? 5 : 4);
     if (v == 5) {
         // one block per wavefront; blocks it marks (errors, sinks too small) are decoded again in the reference's order
         constexpr int32_t REDO = 0x7F000001;

@@ -290,13 +290,24 @@ struct Copier {
 // (half the copier wavefronts, each alone on its SIMD) 4.35 ms; two or four blocks per parser lane (independent
 // chains in one instruction stream) 2.94 / 14.4 ms: the compiler serialises them and the wider parser starves the
 // copiers that share its SIMD.  Only G = 8, WB = 4 is instantiated.
+// Wavefronts of a workgroup are dealt to the four SIMDs in turn.  With eight copier wavefronts (ISO) the workgroup is launched
+// with twelve: wavefront 3 is the parser and 7, 10, 11 end at once, so the parser -- the serial chain everything waits for --
+// has SIMD 3 to itself instead of sharing an issue port with two copiers.
+template <uint32_t CW> constexpr bool split_iso() { return CW == 8u; }
+template <uint32_t CW> constexpr uint32_t split_waves() { return split_iso<CW>() ? 12u : CW + 1u; }
+
 template <class L, uint32_t NB, uint32_t G, uint32_t WB>
-__global__ void __launch_bounds__(64 * (NB * G / 64 + 1)) lz4_decompress_split_kernel(DecompressArgs a) {
+__global__ void __launch_bounds__(64 * split_waves<NB * G / 64>()) lz4_decompress_split_kernel(DecompressArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
     constexpr uint32_t CW = NB * G / 64u;
     static_assert(NB <= 64 && (NB * G) % 64 == 0, "geometry");
-    const uint32_t wave = threadIdx.x / 64u;
+    const uint32_t pw = threadIdx.x / 64u;
+    uint32_t wave = pw;                                    // role: < CW copier, == CW parser
+    if (split_iso<CW>()) {
+        if (pw == 7u || pw >= 10u) return;                 // (finished wavefronts do not count at the barrier)
+        wave = pw == 3u ? CW : (pw < 3u ? pw : (pw < 7u ? pw - 1u : pw - 2u));
+    }
     const uint32_t lane = threadIdx.x % 64u;
     const uint32_t first = blockIdx.x * NB;
     if (wave < CW) {
@@ -405,7 +416,7 @@ static hipError_t launch_cfg(const DecompressArgs& a, hipStream_t s) {
             have |= bit;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * (NB * G / 64u + 1u)), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * split_waves<NB * G / 64u>()), lds, s, a);
     return hipGetLastError();
 }
 
