@@ -294,7 +294,10 @@ struct Copier {
 // with twelve: wavefront 3 is the parser and 7, 10, 11 end at once, so the parser -- the serial chain everything waits for --
 // has SIMD 3 to itself instead of sharing an issue port with two copiers.
 template <uint32_t CW> constexpr bool split_iso() { return CW == 8u; }
-template <uint32_t CW> constexpr uint32_t split_waves() { return split_iso<CW>() ? 12u : CW + 1u; }
+#ifndef LZ4S_ISO_WAVES
+#define LZ4S_ISO_WAVES 12
+#endif
+template <uint32_t CW> constexpr uint32_t split_waves() { return split_iso<CW>() ? (uint32_t)LZ4S_ISO_WAVES : CW + 1u; }
 
 template <class L, uint32_t NB, uint32_t G, uint32_t WB>
 __global__ void __launch_bounds__(64 * split_waves<NB * G / 64>()) lz4_decompress_split_kernel(DecompressArgs a) {
@@ -305,8 +308,15 @@ __global__ void __launch_bounds__(64 * split_waves<NB * G / 64>()) lz4_decompres
     const uint32_t pw = threadIdx.x / 64u;
     uint32_t wave = pw;                                    // role: < CW copier, == CW parser
     if (split_iso<CW>()) {
+#if LZ4S_ISO_WAVES == 12
         if (pw == 7u || pw >= 10u) return;                 // (finished wavefronts do not count at the barrier)
         wave = pw == 3u ? CW : (pw < 3u ? pw : (pw < 7u ? pw - 1u : pw - 2u));
+#elif LZ4S_ISO_WAVES == 9      // experiment: the parser shares SIMD 3 with one copier
+        wave = pw == 3u ? CW : (pw < 3u ? pw : pw - 1u);
+#elif LZ4S_ISO_WAVES == 10     // experiment: parser + wavefront 7 idle: SIMDs 0, 1, 2 carry 3, 3, 2 copiers (as 12) 
+        if (pw == 7u) return;
+        wave = pw == 3u ? CW : (pw < 3u ? pw : (pw < 7u ? pw - 1u : pw - 2u));
+#endif
     }
     const uint32_t lane = threadIdx.x % 64u;
     const uint32_t first = blockIdx.x * NB;
