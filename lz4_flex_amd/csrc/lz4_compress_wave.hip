@@ -56,6 +56,8 @@ __host__ __device__ constexpr uint32_t seg_lo(uint32_t w) { return 512u * ((GROU
 constexpr uint32_t SEG = seg_lo(1u) > WINDOW / WORKERS ? seg_lo(1u) : 512u * ((GROUPS + WORKERS - 1u) / WORKERS);   // longest segment
 constexpr uint32_t CAP = 1024u;           // longest match a head counts
 constexpr uint32_t SKIPD = 64u;           // a position buried this deep in a running match is not evaluated
+constexpr uint32_t LONGK = 84u;           // heads that match this far ...
+constexpr uint32_t NEARP = 20u;           // ... and start within this many positions of the previous such head stop counting there
 constexpr uint32_t HBITS = 12u;
 constexpr uint32_t THREADS = 64u * (WORKERS + 1u);
 constexpr uint32_t STG_BYTES = 448u;      // per worker: encoded sequences waiting for a 16 B-per-lane flush
@@ -590,7 +592,20 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
                 k = 4u + (bits >> 3);
                 act = (bits == 128u) & (k < lim);
             }
-            while (__builtin_amdgcn_ballot_w64(act) != 0ull) {
+            for (uint32_t rounds = 0u; __builtin_amdgcn_ballot_w64(act) != 0ull; ++rounds) {
+                if (rounds == 2u) {
+                    // Heads still matching after LONGK bytes.  In a run (zeros, a repeated record) EVERY position is one, and 64
+                    // lanes reading unaligned to the cap keep the LDS pipe busy for 16 ms per GiB: a head followed within NEARP
+                    // positions by another such head stays at LONGK bytes (it starts just before a match that is at least as
+                    // long as it is known to be); the last one of such a group goes on.
+                    static_assert(LONGK == 4u + 16u + 2u * 32u, "the check sits behind the third compare round");
+                    const uint64_t am = __builtin_amdgcn_ballot_w64(act);
+                    const uint64_t above = (am >> lane) >> 1;                                      // active lanes behind this one, bit 0 = lane + 1
+                    const uint32_t next = lane + 1u + ctz64(above | (1ull << 63));                 // the next active lane (anything if none)
+                    const uint32_t pn = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((next & 63u) << 2), (int)p);
+                    act = act & ((above == 0ull) | (pn - p > NEARP));
+                    if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
+                }
                 if (act) {                                      // 32 bytes per further round
                     const lds_u8* ap = win + p + k;
                     u32x4 va0, vc0, va1, vc1;

@@ -29,6 +29,8 @@
 #define WAVE 64
 #define HBITS 12
 #define WINDOW 65536u
+#define LONGK 84u
+#define NEARP 20u
 
 typedef struct {
     uint32_t nseg;   /* segments per 64 KiB window (the kernel's worker wavefronts); boundaries are multiples of 512 */
@@ -112,18 +114,31 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
                 }
             }
             const uint32_t cnt = e1 - b;
-            /* heads and their own ends */
+            /* heads and their own lengths */
+            uint32_t klen[256];
+            uint8_t is_long[256];
             for (uint32_t i = 0; i < cnt; i++) {
                 const uint32_t p = b + i;
-                own[i] = 0;
+                own[i] = 0; klen[i] = 0; is_long[i] = 0;
                 if (!is_head(in, n, d, P, wbase, s0, s1, carry, p)) continue;
                 const uint32_t dp = d[p];
                 uint32_t lim = (mend > p) ? mend - p : 0;
                 if (lim > P->cap) lim = P->cap;
                 uint32_t k = 0;
                 while (k < lim && in[p + k] == in[p - dp + k]) k++;
-                if (k >= 4) own[i] = ((p - wbase + k) << 16) | dp;
+                klen[i] = k;
+                is_long[i] = (k >= LONGK && lim > LONGK);            /* still matching at the check behind the third compare round */
             }
+            /* a head that still matches after LONGK bytes and is followed within NEARP positions by another such head of the
+             * superstep stops counting there (runs: every position would count to the cap); the last one of a group goes on */
+            uint32_t next_long = 0xFFFFFFFFu;
+            for (uint32_t i = cnt; i-- > 0;) {
+                if (!is_long[i]) continue;
+                if (next_long != 0xFFFFFFFFu && next_long - i <= NEARP) klen[i] = LONGK;
+                next_long = i;
+            }
+            for (uint32_t i = 0; i < cnt; i++)
+                if (klen[i] >= 4) own[i] = ((b + i - wbase + klen[i]) << 16) | d[b + i];
             /* prefix maximum, carried across supersteps */
             uint32_t run = carry;
             for (uint32_t i = 0; i < cnt; i++) { if (own[i] > run) run = own[i]; best[i] = run; }
