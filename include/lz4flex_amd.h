@@ -196,7 +196,8 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  *   reference's exact bytes (src/block/compress.rs:318-489 restated; about 3x slower).  Blocks with a dictionary / prefix
  *   and Linked frames always use the exact encoder.  Environment: LZ4FLEX_COMPRESS_MODE=exact|fast.
  * Kernel selection, for measurements only (every choice produces the same bytes / lengths / error variants):
- * "decompress_variant": 0 = by batch size (default), 5 = one block per wavefront (lz4_decompress_wave.hip), 4 = parser /
+ * "decompress_variant": 0 = by batch size (default), 5 = one block per wavefront (lz4_decompress_wave.hip), 6 = the same with a
+ *   parser and an executor wavefront per block (few, large blocks), 4 = parser /
  *   copier split decoder, 3 = pipelined LDS-staged decoder (with "decompress_geometry" -1 / 0 / 1 = by batch size /
  *   8 lanes x 4 B / 4 lanes x 8 B per block), 1 = decoder whose window lives in HBM/L2 (always used for dictionary /
  *   prefix blocks); "decompress_blocks_per_wg" (variant 4: 0 = by batch size, 8/16/32/64); "decompress_lanes"

@@ -66,11 +66,14 @@ static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressA
     // round 2 (tools/wave_bench.py --dec, JSON tiles; ms for 1 024 / 4 096 / 6 144 / 8 192 / 16 384 / 32 768 blocks): wave 0.74 / 1.01 /
     // 1.64 / 1.95 / 3.8 / 7.3, split 1.31 / 1.31 / 1.52 / 1.55 / 1.92 / 3.86, pipelined 2.43 / 2.54 / 2.62 / 2.59 / 2.9 / 4.15: the
     // pipelined kernel is no longer chosen
-    const int v = c->dec_variant != 0 ? c->dec_variant : (a.n <= 5120u ? 5 : 4);
-    if (v == 5) {
-        // one block per wavefront; blocks it marks (errors, sinks too small) are decoded again in the reference's order
+    // up to 2 304 blocks (nine pairs of wavefronts per CU) the wave decoder runs with a parser and an executor wavefront per
+    // block: 256 / 1 024 / 2 048 blocks 0.45 / 0.52 / 0.65 ms against 0.73 / 0.75 / 0.82 with one wavefront
+    const int v = c->dec_variant != 0 ? c->dec_variant : (a.n <= 2304u ? 6 : (a.n <= 5120u ? 5 : 4));
+    if (v == 5 || v == 6) {
+        // one block per wavefront (6: per pair of wavefronts); blocks it marks (errors, sinks too small) are decoded again in
+        // the reference's order
         constexpr int32_t REDO = 0x7F000001;
-        hipError_t e = launch_decompress_wave(a, REDO, s);
+        hipError_t e = v == 6 ? launch_decompress_wave_pair(a, REDO, s) : launch_decompress_wave(a, REDO, s);
         if (e != hipSuccess) return e;
         DecompressArgs r = a;
         r.only_status = REDO;
@@ -183,7 +186,7 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
     c->device = device;
     if (const char* e = getenv("LZ4FLEX_COMPRESS_MODE")) c->comp_mode = (!strcmp(e, "exact") || !strcmp(e, "1")) ? 1 : 0;
     if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v == 1 || v == 3) c->comp_variant = v; }
-    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v == 0 || v == 1 || v == 3 || v == 4 || v == 5) c->dec_variant = v; }
+    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v == 0 || v == 1 || (v >= 3 && v <= 6)) c->dec_variant = v; }
     if (const char* e = getenv("LZ4FLEX_DECOMPRESS_GEOMETRY")) { const int v = atoi(e); if (v >= -1 && v <= 1) c->dec_geometry = v; }
     int prev = 0;
     (void)hipGetDevice(&prev);
@@ -243,7 +246,7 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "decompress_variant")) {
-        if (value != 0 && value != 1 && value != 3 && value != 4 && value != 5) return -LZ4FLEX_E_INVALID_ARG;
+        if (value != 0 && value != 1 && (value < 3 || value > 6)) return -LZ4FLEX_E_INVALID_ARG;
         c->dec_variant = value;
         return 0;
     }

@@ -216,6 +216,9 @@ struct Win {
     bool ok, done, stop_cx;               // uniform: regular so far; the block's last sequence is inside; exact_token comes next
 };
 
+// FARLOADS: request the sources of far matches here (the single-wavefront kernel: the window is executed by this wavefront
+// after the previous one); false: the executing wavefront requests them itself (request_far), W.lpf = "far" only
+template <bool FARLOADS>
 __device__ __forceinline__ Win parse_window(Dec& D, uint32_t ip, uint32_t op0) {
     Win W;
     LZ4D_T0
@@ -292,10 +295,10 @@ __device__ __forceinline__ Win parse_window(Dec& D, uint32_t ip, uint32_t op0) {
     auto crosses = [](uint32_t pos, uint32_t n) -> bool { return (pos & RM) + n > RB; };
     W.lpl = tk & (lit != 0u) & (lit <= 16u) & !crosses(o, 16u);
     const bool far = mt & (sm + mlen <= W.near_lo);            // source older than the ring: read it from the output
-    W.lpf = W.ok & far & (mlen <= 32u) & !crosses(dm, 32u);
+    W.lpf = FARLOADS ? (W.ok & far & (mlen <= 32u) & !crosses(dm, 32u)) : far;
     W.lpn = mt & !far & (sm >= W.near_lo) & (sm + mlen <= op0) & (mlen <= 64u) & !crosses(sm, mlen + 15u) & !crosses(dm, mlen + 15u);
     W.f0 = u32x4{0u, 0u, 0u, 0u}; W.f1 = W.f0;
-    if (W.lpf) {                                               // requested now, written when the window is executed
+    if (FARLOADS && W.lpf) {                                   // requested now, written when the window is executed
         __builtin_memcpy(&W.f0, (const void*)(D.out + sm), 16);
         __builtin_memcpy(&W.f1, (const void*)(D.out + sm + 16u), 16);
     }
@@ -375,20 +378,20 @@ __global__ void __launch_bounds__(64 * WPB) lz4_decompress_wave_kernel(Decompres
     bool ok = D.ilen != 0u, done = false;
     uint32_t ip = 0u;
     if (ok) {
-        Win A = parse_window(D, 0u, 0u);
+        Win A = parse_window<true>(D, 0u, 0u);
         for (;;) {
             if (!A.ok) { ok = false; break; }
             const uint32_t ip_next = ip + A.adv;
             const bool pipe = !A.done && !A.stop_cx;
             Win B = A;
-            if (pipe) B = parse_window(D, ip_next, A.op0 + A.T);   // the next window's loads are in flight while this one is executed
+            if (pipe) B = parse_window<true>(D, ip_next, A.op0 + A.T);   // the next window's loads are in flight while this one is executed
             exec_window(D, A);
             ip = ip_next;
             if (A.done) { done = true; break; }
             if (A.stop_cx) {
                 ok = exact_token(D, ip, done);
                 if (!ok || done) break;
-                A = parse_window(D, ip, D.op);
+                A = parse_window<true>(D, ip, D.op);
                 continue;
             }
             A = B;
@@ -407,6 +410,169 @@ __global__ void __launch_bounds__(64 * WPB) lz4_decompress_wave_kernel(Decompres
     }
 }
 
+// =====================================================================================================================
+// Two wavefronts per block: a PARSER (parse_window: the token chain, placement, classification) and an EXECUTOR
+// (exec_window: the copies, the write-back, exact_token), coupled by a queue of window descriptors in LDS.  A block costs the
+// same per byte whatever its size (one wavefront: 80 MB/s), so for batches of few, large blocks -- fewer wavefronts than
+// the chip has SIMDs -- the chain itself is what can be shortened: the two halves of a window's work overlap.
+// Every wait is bounded: a wavefront that gives up marks the block for the reference-order kernel (as any irregularity).
+// =====================================================================================================================
+constexpr uint32_t NQ = 4u;                          // window descriptors in flight
+constexpr uint32_t P_DESC = RB + IB + IB_PAD;        // per lane and window: {lit | mlen << 9 | flags << 18, ls, offs, o}, the 16 literal bytes
+constexpr uint32_t P_HDR = P_DESC + NQ * 2048u;      // per window: {op0, T, near_lo, adv}, {flags, ip behind the window, -, -}
+constexpr uint32_t P_CTL = P_HDR + NQ * 32u;         // tail (parser), head (executor), resume sequence / ip / op / flags, abort
+constexpr uint32_t PAIR_LDS = P_CTL + 32u;
+constexpr uint32_t SPIN_LIMIT = 1u << 22;            // x s_sleep(1) = 64 clocks: a quarter of a second
+typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+
+__device__ __forceinline__ void put_window(lds_u8* lds, uint32_t slot, const Win& W, uint32_t ip_next, uint32_t lane) {
+    const uint32_t fl = (W.tk ? 1u : 0u) | (W.mt ? 2u : 0u) | (W.lpl ? 4u : 0u) | (W.lpn ? 8u : 0u) | (W.lpf ? 16u : 0u);
+    lds_u32x4* d = (lds_u32x4*)(lds + P_DESC + slot * 2048u + lane * 32u);
+    d[0] = u32x4{W.lit | (W.mlen << 9) | (fl << 18), W.ls, W.offs, W.o};
+    d[1] = W.lv;
+    if (lane == 0u) {
+        lds_u32x4* h = (lds_u32x4*)(lds + P_HDR + slot * 32u);
+        h[0] = u32x4{W.op0, W.T, W.near_lo, W.adv};
+        h[1] = u32x4{(W.ok ? 1u : 0u) | (W.done ? 2u : 0u) | (W.stop_cx ? 4u : 0u), ip_next, 0u, 0u};
+    }
+}
+__device__ __forceinline__ Win get_window(const lds_u8* lds, uint32_t slot, uint32_t lane, uint32_t& ip_next) {
+    Win W;
+    const lds_u32x4* d = (const lds_u32x4*)(lds + P_DESC + slot * 2048u + lane * 32u);
+    const u32x4 a = d[0];
+    W.lv = d[1];
+    const lds_u32x4* h = (const lds_u32x4*)(lds + P_HDR + slot * 32u);
+    const u32x4 h0 = h[0], h1 = h[1];
+    W.lit = a.x & 511u; W.mlen = (a.x >> 9) & 511u;
+    const uint32_t fl = a.x >> 18;
+    W.tk = fl & 1u; W.mt = fl & 2u; W.lpl = fl & 4u; W.lpn = fl & 8u;
+    W.ls = a.y; W.offs = a.z; W.o = a.w;
+    W.op0 = uni(h0.x); W.T = uni(h0.y); W.near_lo = uni(h0.z); W.adv = uni(h0.w);
+    const uint32_t hf = uni(h1.x);
+    W.ok = hf & 1u; W.done = hf & 2u; W.stop_cx = hf & 4u;
+    ip_next = uni(h1.y);
+    // a far match (source older than the ring) is written lane-parallel if it is short and does not wrap; its source is
+    // requested by request_far
+    const uint32_t dm = W.o + W.lit;
+    W.lpf = W.ok && (fl & 16u) && (W.mlen <= 32u) && ((dm & RM) + 32u <= RB);
+    W.f0 = u32x4{0u, 0u, 0u, 0u}; W.f1 = W.f0;
+    return W;
+}
+__device__ __forceinline__ void request_far(const Dec& D, Win& W) {
+    if (W.lpf) {
+        const uint32_t sm = W.o + W.lit - W.offs;
+        __builtin_memcpy(&W.f0, (const void*)(D.out + sm), 16);
+        __builtin_memcpy(&W.f1, (const void*)(D.out + sm + 16u), 16);
+    }
+}
+
+__global__ void __launch_bounds__(128) lz4_decompress_wave_pair_kernel(DecompressArgs a, int32_t redo_code) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t pair_lds[];
+    lds_u8* lds = (lds_u8*)pair_lds;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t role = uni(threadIdx.x >> 6);          // 0 parser, 1 executor
+    const uint32_t b = blockIdx.x;
+    if (b >= a.n) return;
+    lds_vu32* ctl = (lds_vu32*)(lds + P_CTL);             // [0] tail, [1] head, [2] resume seq, [3] ip, [4] op, [5] flags (1 done, 2 failed), [6] abort
+    if (threadIdx.x < 8u) ctl[threadIdx.x] = 0u;
+    __syncthreads();
+    Dec D;
+    D.in = (const g_u8*)(a.in_base + a.in_off[b]);
+    D.out = (g_u8*)(a.out_base + a.out_off[b]);
+    D.ring = lds;
+    D.ibuf = lds + RB;
+    D.ilen = a.in_len[b];
+    D.cap = a.out_cap[b];
+    D.lane = lane;
+    D.op = 0u; D.F = 0u;
+    D.ib0 = 0xFFFF0000u;
+    if (D.ilen == 0u) {                                     // decompress.rs:207-209: the reference-order kernel reports it
+        if (threadIdx.x == 0u) { a.status[b] = redo_code; a.out_len[b] = 0u; }
+        return;
+    }
+    auto fence = []() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); };
+    if (role == 0u) {
+        // ---- parser ------------------------------------------------------------------------------------------------
+        uint32_t ip = 0u, op0 = 0u, tail = 0u, seq = 0u;
+        for (;;) {
+            uint32_t spins = 0u;
+            while (tail - ctl[1] >= NQ && ctl[6] == 0u && ++spins < SPIN_LIMIT) __builtin_amdgcn_s_sleep(1);
+            if (ctl[6] != 0u) break;
+            if (spins >= SPIN_LIMIT) { if (lane == 0u) ctl[6] = 1u; break; }
+            const Win W = parse_window<false>(D, ip, op0);
+            put_window(lds, tail & (NQ - 1u), W, ip + W.adv, lane);
+            fence();
+            tail += 1u;
+            if (lane == 0u) ctl[0] = tail;
+            if (!W.ok || W.done) break;
+            ip += W.adv;
+            op0 += W.T;
+            if (W.stop_cx) {                                  // the executor decodes one sequence of any shape, then tells where to go on
+                seq += 1u;
+                spins = 0u;
+                while (ctl[2] != seq && ctl[6] == 0u && ++spins < SPIN_LIMIT) __builtin_amdgcn_s_sleep(1);
+                if (ctl[6] != 0u) break;
+                if (spins >= SPIN_LIMIT) { if (lane == 0u) ctl[6] = 1u; break; }
+                fence();
+                if (ctl[5] != 0u) break;                      // the block ended or failed inside that sequence
+                ip = ctl[3];
+                op0 = ctl[4];
+            }
+        }
+        return;
+    }
+    // ---- executor ------------------------------------------------------------------------------------------------------
+    bool ok = true, done = false, have_next = false;
+    uint32_t head = 0u, seq = 0u, ipn = 0u, ipn_next = 0u;
+    Win A, B;
+    for (;;) {
+        if (have_next) { A = B; ipn = ipn_next; have_next = false; }
+        else {
+            uint32_t spins = 0u;
+            while (ctl[0] == head && ctl[6] == 0u && ++spins < SPIN_LIMIT) __builtin_amdgcn_s_sleep(1);
+            if (ctl[6] != 0u || spins >= SPIN_LIMIT) { ok = false; break; }
+            fence();
+            A = get_window(lds, head & (NQ - 1u), lane, ipn);
+            request_far(D, A);
+        }
+        if (!A.ok) { ok = false; break; }
+        if (!A.done && !A.stop_cx && ctl[0] - head >= 2u) {    // the window behind it is parsed already: its far sources travel while this one is executed
+            fence();
+            B = get_window(lds, (head + 1u) & (NQ - 1u), lane, ipn_next);
+            request_far(D, B);
+            have_next = true;
+        }
+        exec_window(D, A);
+        head += 1u;
+        if (lane == 0u) ctl[1] = head;
+        if (A.done) { done = true; break; }
+        if (A.stop_cx) {
+            uint32_t ip = ipn;
+            ok = exact_token(D, ip, done);
+            seq += 1u;
+            if (lane == 0u) { ctl[3] = ip; ctl[4] = D.op; ctl[5] = (done ? 1u : 0u) | (ok ? 0u : 2u); }
+            fence();
+            if (lane == 0u) ctl[2] = seq;
+            if (!ok || done) break;
+        }
+    }
+    if (ok && done) {
+        D.finish();
+        if (lane == 0u) {
+            a.status[b] = 0;
+            a.out_len[b] = D.op;
+            if (a.detail) { a.detail[2u * b] = 0u; a.detail[2u * b + 1u] = 0u; }
+        }
+    } else {
+        if (lane == 0u) {
+            ctl[6] = 1u;                      // (the parser may be waiting for a slot)
+            a.status[b] = redo_code;          // decoded again, with the reference's check order, by lz4_decompress_blocks_kernel
+            a.out_len[b] = 0u;
+        }
+    }
+}
+
 }  // namespace wdec
 
 // Blocks without dictionary / prefix.  Irregular blocks get status `redo_code`; the caller runs launch_decompress with
@@ -416,6 +582,14 @@ hipError_t launch_decompress_wave(const DecompressArgs& a, int32_t redo_code, hi
     if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;
     const uint32_t grid = (a.n + wdec::WPB - 1u) / wdec::WPB;
     hipLaunchKernelGGL(wdec::lz4_decompress_wave_kernel, dim3(grid), dim3(64u * wdec::WPB), 0, s, a, redo_code);
+    return hipGetLastError();
+}
+
+// The same contract with two wavefronts per block (see above): for batches with fewer blocks than the chip has SIMDs.
+hipError_t launch_decompress_wave_pair(const DecompressArgs& a, int32_t redo_code, hipStream_t s) {
+    if (a.n == 0u) return hipSuccess;
+    if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(wdec::lz4_decompress_wave_pair_kernel, dim3(a.n), dim3(128), wdec::PAIR_LDS, s, a, redo_code);
     return hipGetLastError();
 }
 

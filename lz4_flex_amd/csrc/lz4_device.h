@@ -49,6 +49,7 @@ hipError_t launch_decompress_pipe(const DecompressArgs& a, hipStream_t s, int ab
 // one block per wavefront (lz4_decompress_wave.hip); irregular blocks are left with status redo_code for a second pass of
 // launch_decompress (only_status = redo_code), which decodes them in the reference's check order
 hipError_t launch_decompress_wave(const DecompressArgs& a, int32_t redo_code, hipStream_t s);
+hipError_t launch_decompress_wave_pair(const DecompressArgs& a, int32_t redo_code, hipStream_t s);
 hipError_t launch_decompress_split(const DecompressArgs& a, hipStream_t s, int blocks_per_wg = 0);   // parser / copier wavefronts, no dict/prefix
 hipError_t launch_compress(const CompressArgs& a, int variant, hipStream_t s);
 // throughput ("wave") encoder, lz4_compress_wave.hip: persistent workgroups, `workspace` holds
