@@ -309,6 +309,12 @@ __device__ __forceinline__ Win parse_window(Dec& D, uint32_t ip, uint32_t op0) {
 
 __device__ __forceinline__ void exec_window(Dec& D, const Win& W) {
     LZ4D_T0
+#ifdef LZ4D_EXP_NOEXEC      // tools: the parser's share of a window (the output is wrong)
+    asm volatile("" :: "v"(W.lv), "v"(W.f0), "v"(W.f1), "v"(W.o), "v"(W.lit), "v"(W.mlen), "v"(W.offs));
+    D.op = W.op0 + W.T;
+    if (D.op - D.F >= FLUSH_AT) D.flush();
+    return;
+#endif
     const uint32_t dm = W.o + W.lit, sm = dm - W.offs;
     // ---- phase A: lane = sequence --------------------------------------------------------------------------------------
     if (W.lpl) write_exact16(D.ring + (W.o & RM), W.lv, W.lit);
