@@ -56,6 +56,9 @@ __host__ __device__ constexpr uint32_t seg_lo(uint32_t w) { return 512u * ((GROU
 constexpr uint32_t SEG = seg_lo(1u) > WINDOW / WORKERS ? seg_lo(1u) : 512u * ((GROUPS + WORKERS - 1u) / WORKERS);   // longest segment
 constexpr uint32_t CAP = 1024u;           // longest match a head counts
 constexpr uint32_t SKIPD = 64u;           // a position buried this deep in a running match is not evaluated
+constexpr uint32_t CARRY_SLOTS = 16u;        // per block: a ring of {out_pos, pend, window} records, one cache line each
+constexpr uint32_t CARRY_DWORDS = CARRY_SLOTS * 16u;
+constexpr uint32_t CARRY_SPINS = 1u << 18;   // x (s_sleep(16) + a load from L2): a good fraction of a second for another workgroup's window
 constexpr uint32_t LONGK = 84u;           // heads that match this far ...
 constexpr uint32_t NEARP = 20u;           // ... and start within this many positions of the previous such head stop counting there
 constexpr uint32_t HBITS = 12u;
@@ -840,7 +843,7 @@ __device__ __forceinline__ void put_len_header(g_u8* dst, uint32_t lit, uint32_t
 // Place segment w of the current window (after the barrier: every worker's SegMeta is final).
 __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8_t* __restrict__ gin_, uint32_t blk_len_, uint32_t win_idx_, bool last_win_,
                               uint32_t wl_, const uint8_t* body_, uint8_t* gout_, uint32_t carry_slot_, uint32_t w_, uint32_t lane,
-                              uint32_t* out_len_, int32_t* status_) {
+                              uint32_t* out_len_, int32_t* status_, uint32_t* gcarry_, uint32_t iter_) {
     const g_u8* __restrict__ gin = uni_gptr<const g_u8>(gin_);
     const g_u8* body = uni_gptr<const g_u8>(body_);
     g_u8* gout = uni_gptr<g_u8>(gout_);
@@ -850,8 +853,44 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
     const bool last_win = uni((uint32_t)last_win_) != 0u;
     const lds_u32* mp = (const lds_u32*)(lds + L_META);
     lds_u32* cp = (lds_u32*)(lds + L_META) + 5u * WORKERS;          // BlkCarry[2]
-    uint32_t out_pos = 0u, pend = 0u;
-    if (win_idx != 0u) { out_pos = cp[2u * (carry_slot ^ 1u)]; pend = cp[2u * (carry_slot ^ 1u) + 1u]; }
+    // Where this window's output starts and how many literals the block has pending: from the previous window, which this
+    // workgroup placed itself (LDS) or, when the windows of a block are dealt to different workgroups (gcarry: a ring of
+    // {out_pos, pend, window} records per block in the workspace), another one did -- that wait is bounded, a window that gives
+    // up poisons the rest of its block (pend bit 31) and the block reports a device failure.
+    g_u32* gcarry = uni_gptr<g_u32>(gcarry_);
+    uint32_t out_pos = 0u, pend = 0u, poisoned = 0u;
+    if (win_idx != 0u) {
+        if (gcarry != nullptr) {
+            // ONE wavefront of the workgroup polls global memory (with all eight of all 512 workgroups polling the same few
+            // cache lines the carry took 60 microseconds per window to get through); the others wait for it in LDS
+            const uint32_t iter = uni(iter_);
+            typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
+            lds_vu32* box = (lds_vu32*)(lds + L_META) + 5u * WORKERS + 8u;     // {out_pos, pend | poisoned << 31, iteration}
+            if (w == WORKERS - 1u) {
+                g_u32* sl = gcarry + 16u * (win_idx & (CARRY_SLOTS - 1u));
+                uint32_t spins = 0u;
+                while (__hip_atomic_load(sl + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != win_idx && ++spins < CARRY_SPINS) __builtin_amdgcn_s_sleep(16);
+                out_pos = __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pend = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (spins >= CARRY_SPINS) pend = 0x80000000u;
+                if (lane == 0u) { box[0] = out_pos; box[1] = pend; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0u) box[2] = iter;
+            } else {
+                uint32_t spins = 0u;
+                while (box[2] != iter && ++spins < (CARRY_SPINS << 4)) __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                out_pos = box[0];
+                pend = spins >= (CARRY_SPINS << 4) ? 0x80000000u : box[1];
+            }
+            poisoned = pend >> 31;
+            pend &= 0x7FFFFFFFu;
+            if (poisoned) { out_pos = 0u; pend = 0u; }
+            out_pos = uni(out_pos); pend = uni(pend); poisoned = uni(poisoned);
+        } else {
+            out_pos = cp[2u * (carry_slot ^ 1u)]; pend = cp[2u * (carry_slot ^ 1u) + 1u];
+        }
+    }
     auto seg_len = [&](uint32_t j) -> uint32_t {
         const uint32_t lo = seg_lo(j) < wl ? seg_lo(j) : wl, hi = seg_lo(j + 1u) < wl ? seg_lo(j + 1u) : wl;
         return hi - lo;
@@ -868,6 +907,22 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
     }
     const uint32_t sl = seg_len(w);
     const uint32_t abs0 = win_idx * WINDOW + seg_lo(w);            // block-relative start of this segment
+    if (gcarry != nullptr && w == WORKERS - 1u && !last_win && lane == 0u) {
+        // the next window's carry depends on sizes only: hand it on BEFORE the bytes are copied (the windows of a block form a
+        // chain through global memory; with the copies inside it a block advanced one window per 4 microseconds)
+        uint32_t eo = out_pos, ep = pend;
+        if (mp[5u * w] != 0u) {
+            const uint32_t L = pend + mp[5u * w + 1u];
+            eo += 1u + len_ext_bytes(L) + L + mp[5u * w + 4u];
+            ep = mp[5u * w + 3u];
+        } else {
+            ep += sl;
+        }
+        g_u32* so = gcarry + 16u * ((win_idx + 1u) & (CARRY_SLOTS - 1u));
+        __hip_atomic_store(so, eo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(so + 1, ep | (poisoned << 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(so + 2, win_idx + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (mp[5u * w] != 0u) {
         const uint32_t fl = mp[5u * w + 1u], L = pend + fl, ml = mp[5u * w + 2u] - 4u, bl = mp[5u * w + 4u];
         put_len_header(gout + out_pos, L, ml < 15u ? ml : 15u, lane);
@@ -887,7 +942,7 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
             out_pos += 1u + len_ext_bytes(pend);
             copy_bytes(gout + out_pos, gin + (blk_len - pend), pend, lane);
             out_pos += pend;
-            if (lane == 0u) { *out_len = out_pos; *status = 0; }
+            if (lane == 0u) { *out_len = poisoned ? 0u : out_pos; *status = poisoned ? 66 /* LZ4FLEX_E_HIP: a window never got its carry */ : 0; }
         } else if (lane == 0u) {
             cp[2u * carry_slot] = out_pos;
             cp[2u * carry_slot + 1u] = pend;
@@ -942,17 +997,37 @@ __device__ __forceinline__ void item_load(const CompressArgs& a, Item& it) {
     const uint64_t need = 20ull + (uint64_t)len * 110ull / 100ull;   // get_maximum_output_size, compress.rs:588-590
     if ((uint64_t)cap < need) { it.skip = 1u; it.nwin = 1u; }
 }
-__device__ __forceinline__ void item_next(const CompressArgs& a, Item& it) {
+// Two ways of dealing work to the persistent workgroups.  Block mode: workgroup g owns blocks g, g + G, ... and walks
+// their windows in order (the carry between windows stays in LDS).  Window mode (fewer blocks than workgroups -- few, large
+// blocks; one 1 GiB block would otherwise be one workgroup's 16 384 windows): workgroup g joins the team of block g mod n
+// and draws that block's windows from the block's atomic counter (a team of one draws them in order; a drawn window is
+// always held by a running workgroup, so the wait for the previous window's carry cannot deadlock whatever is resident);
+// when its block has no windows left it moves on to the next block that has.
+__device__ __forceinline__ void item_next_block(const CompressArgs& a, Item& it) {
     if (it.win + 1u < it.nwin) { it.win += 1u; return; }
     it.blk += gridDim.x;
     item_load(a, it);
+}
+// window mode, one thread: the next window for this workgroup, starting the search at block b0 -> {block, window} (block == n: none)
+__device__ __forceinline__ void item_draw(const CompressArgs& a, uint32_t* wctr, uint32_t b0, uint32_t& ob, uint32_t& ow) {
+    const uint32_t n = a.n;
+    uint32_t b = b0;
+    for (uint32_t t = 0; t < n; ++t) {
+        Item q;
+        q.blk = b;
+        item_load(a, q);
+        const uint32_t w = atomicAdd(wctr + b, 1u);
+        if (w < q.nwin) { ob = b; ow = w; return; }
+        b = b + 1u == n ? 0u : b + 1u;
+    }
+    ob = n; ow = 0u;
 }
 
 // prof (nullable, tools only): cycle sums per role, [0] indexer busy, [1] indexer at barriers, [2] workers matching,
 // [3] workers at the barrier behind matching, [4] placing, [5] loading the next window, [6] at the barrier behind loading,
 // [7] windows
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) lz4_compress_wave_kernel(const CompressArgs a, uint8_t* __restrict__ ws,
-                                                                    unsigned long long* __restrict__ prof) {
+                                                                    uint32_t* __restrict__ carry, unsigned long long* __restrict__ prof) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
     if ((uint32_t)(uintptr_t)lds != 0u) __builtin_trap();        // match_segment addresses LDS from 0 (no static LDS in this kernel)
@@ -962,11 +1037,30 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
     uint8_t* slots = my_ws;                                        // two cand[] slots
     uint8_t* bodies = my_ws + 2u * SLOT_BYTES;
 
-    Item it;
-    it.blk = blockIdx.x;
-    item_load(a, it);
+    const bool wmode = carry != nullptr;                          // windows (not blocks) are dealt to the workgroups
+    lds_u32* giq = (lds_u32*)(lds + L_META) + 5u * WORKERS + 4u;   // window mode: item indices drawn by thread 0
+    uint32_t* wctr = wmode ? carry + CARRY_DWORDS * (size_t)a.n : nullptr;   // per-block window counters behind the carry slots
+    Item it, ix;                                                  // the window being matched; the next one (the indexer runs one window ahead)
+    if (threadIdx.x == 0u) giq[6] = 0u;                           // place_segment's mailbox: no iteration yet
+    if (wmode) {
+        if (threadIdx.x == 0u) {
+            uint32_t b = a.n, wn = 0u;
+            item_draw(a, wctr, blockIdx.x % a.n, b, wn);
+            giq[0] = b; giq[1] = wn;
+        }
+        __syncthreads();
+        it.blk = giq[0];
+        item_load(a, it);
+        it.win = giq[1];
+        ix.blk = a.n;                                             // drawn behind the prologue (see there)
+        item_load(a, ix);
+    } else {
+        it.blk = blockIdx.x;
+        item_load(a, it);
+        ix = it;
+        item_next_block(a, ix);
+    }
     if (it.blk >= a.n) return;
-    Item ix = it;                                                 // the indexer runs one window ahead
     uint32_t k = 0u;
 
     auto win_len = [](const Item& t) -> uint32_t {
@@ -998,15 +1092,29 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
         }
     };
     // prologue: cand[] of the first window, the first window into LDS
-    if (w == WORKERS) { do_index(ix, 0u); item_next(a, ix); tick(0u); }
+    if (w == WORKERS) { do_index(it, 0u); tick(0u); }
     else { do_load(it); tick(5u); }
     __syncthreads();
     tick(w == WORKERS ? 1u : 6u);
+    if (wmode) {
+        // The second window is drawn only now, a prologue later: drawn in a row with the first, a workgroup would hold two
+        // CONSECUTIVE windows of a block, and every window of the block would wait for the one before it to be matched.
+        if (threadIdx.x == 0u) {
+            uint32_t b2 = a.n, w2 = 0u;
+            item_draw(a, wctr, it.blk, b2, w2);
+            giq[2] = b2; giq[3] = w2;
+        }
+        __syncthreads();
+        ix.blk = giq[2];
+        item_load(a, ix);
+        ix.win = giq[3];
+        __syncthreads();                                          // (giq[2..3] are written again in the loop)
+    }
     for (;;) {
         const uint32_t wl = win_len(it);
         const bool last_win = it.win + 1u == it.nwin;
         if (w == WORKERS) {
-            if (ix.blk < a.n) { do_index(ix, (k + 1u) & 1u); item_next(a, ix); }
+            if (ix.blk < a.n) do_index(ix, (k + 1u) & 1u);
         } else if (!it.skip) {
             const uint32_t base = it.win * WINDOW;
             const uint32_t s0 = seg_lo(w) < wl ? seg_lo(w) : wl;
@@ -1022,17 +1130,23 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
         tick(w == WORKERS ? 0u : 2u);
         __syncthreads();
         tick(w == WORKERS ? 1u : 3u);
+        if (wmode && threadIdx.x == 0u) {                          // the window behind ix
+            uint32_t b2 = a.n, w2 = 0u;
+            if (ix.blk < a.n) item_draw(a, wctr, ix.blk, b2, w2);
+            giq[2] = b2; giq[3] = w2;
+        }
         if (w != WORKERS) {
             if (it.skip) {
                 if (threadIdx.x == 0u) { a.out_len[it.blk] = 0u; a.status[it.blk] = LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL; }
             } else {
                 place_segment(lds, a.in_base + it.in_off, it.len, it.win, last_win, wl, bodies + (size_t)w * BODY_STRIDE,
-                              a.out_base + a.out_off[it.blk], k & 1u, w, lane, a.out_len + it.blk, a.status + it.blk);
+                              a.out_base + a.out_off[it.blk], k & 1u, w, lane, a.out_len + it.blk, a.status + it.blk,
+                              wmode ? carry + CARRY_DWORDS * (size_t)it.blk : nullptr, k + 1u);
             }
         }
         tick(w == WORKERS ? 1u : 4u);
         if (prof && threadIdx.x == 0u) atomicAdd(prof + 7, 1ull);
-        item_next(a, it);
+        it = ix;
         k += 1u;
         if (it.blk >= a.n) {
             if (prof && lane == 0u)
@@ -1044,12 +1158,16 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
         tick(w == WORKERS ? 1u : 5u);
         __syncthreads();
         tick(w == WORKERS ? 1u : 6u);
+        if (wmode) { ix.blk = giq[2]; item_load(a, ix); ix.win = giq[3]; }
+        else item_next_block(a, ix);
     }
 }
 
 }  // namespace wave
 
-size_t compress_wave_workspace_bytes(int n_workgroups) { return (size_t)n_workgroups * wave::WS_BYTES; }
+// cand[] slots and segment bodies per workgroup, then the window-carry ring and window counter per block for batches of fewer
+// blocks than workgroups
+size_t compress_wave_workspace_bytes(int n_workgroups) { return (size_t)n_workgroups * (wave::WS_BYTES + wave::CARRY_DWORDS * 4u + 4u); }
 
 hipError_t launch_compress_wave(const CompressArgs& a, void* workspace, int n_workgroups, hipStream_t s, unsigned long long* prof) {
     if (a.n == 0u) return hipSuccess;
@@ -1064,8 +1182,16 @@ hipError_t launch_compress_wave(const CompressArgs& a, void* workspace, int n_wo
         if (e != hipSuccess) return e;
         have |= bit;
     }
-    const uint32_t grid = a.n < (uint32_t)n_workgroups ? a.n : (uint32_t)n_workgroups;
-    hipLaunchKernelGGL(wave::lz4_compress_wave_kernel, dim3(grid), dim3(wave::THREADS), wave::LDS_BYTES, s, a, (uint8_t*)workspace, prof);
+    // fewer blocks than workgroups: windows, not blocks, are dealt out (see item_seek); the carry slots and the item counter
+    // behind the per-workgroup workspaces start at zero
+    uint32_t* carry = nullptr;
+    if (a.n < (uint32_t)n_workgroups) {
+        carry = (uint32_t*)((uint8_t*)workspace + (size_t)n_workgroups * wave::WS_BYTES);
+        const hipError_t e = hipMemsetAsync(carry, 0, (size_t)a.n * (wave::CARRY_DWORDS * 4u + 4u), s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(wave::lz4_compress_wave_kernel, dim3((uint32_t)n_workgroups), dim3(wave::THREADS), wave::LDS_BYTES, s, a,
+                       (uint8_t*)workspace, carry, prof);
     return hipGetLastError();
 }
 
