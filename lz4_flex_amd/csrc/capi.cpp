@@ -57,15 +57,12 @@ struct lz4flex_ctx {
 
 // the decoders for blocks without dictionary / prefix
 static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressArgs& a, hipStream_t s) {
-    // 0: by batch size (tools/dec_geometry.py on the configs[1] workload: split 1.69 / 1.80 / 2.36 ms for 1 024 / 8 192 /
-    // 16 384 blocks against 2.39 / 2.55 / 2.93 ms pipelined; above one split round per CU the 4-lane pipelined geometry
-    // holds twice the blocks per CU: 32 768 blocks 4.19 ms against 4.60 ms)
-    // by batch shape: up to ~6 000 blocks the wave decoder (a wavefront per block: a block is done in a third of the time the
+    // 0: by batch shape.  Up to ~5 000 blocks the wave decoder (a wavefront per block: a block is done in half the time the
     // split decoder's serial chain needs, and blocks larger than 64 KiB stay tolerable); larger batches have enough blocks
-    // to fill the chip with one chain per lane, which costs half the instructions per byte
-    // round 2 (tools/wave_bench.py --dec, JSON tiles; ms for 1 024 / 4 096 / 6 144 / 8 192 / 16 384 / 32 768 blocks): wave 0.74 / 1.01 /
-    // 1.64 / 1.95 / 3.8 / 7.3, split 1.31 / 1.31 / 1.52 / 1.55 / 1.92 / 3.86, pipelined 2.43 / 2.54 / 2.62 / 2.59 / 2.9 / 4.15: the
-    // pipelined kernel is no longer chosen
+    // to fill the chip with one chain per lane, which costs half the instructions per byte.  tools/wave_bench.py --dec, JSON
+    // tiles, ms for 1 024 / 4 096 / 6 144 / 8 192 / 16 384 / 32 768 blocks: wave 0.74 / 1.01 / 1.64 / 1.95 / 3.8 / 7.3, split
+    // 1.31 / 1.31 / 1.52 / 1.55 / 1.79 / 3.86, pipelined (round 1's choice above 20 480) 2.43 / 2.54 / 2.62 / 2.59 / 2.9 / 4.15:
+    // no longer chosen.
     // up to 2 304 blocks (nine pairs of wavefronts per CU) the wave decoder runs with a parser and an executor wavefront per
     // block: 256 / 1 024 / 2 048 blocks 0.45 / 0.52 / 0.65 ms against 0.73 / 0.75 / 0.82 with one wavefront
     const int v = c->dec_variant != 0 ? c->dec_variant : (a.n <= 2304u ? 6 : (a.n <= 5120u ? 5 : 4));

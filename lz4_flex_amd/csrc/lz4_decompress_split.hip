@@ -9,9 +9,10 @@
 //   * PARSER wavefront: ONE LANE PER BLOCK (up to 64 blocks).  A lane walks its block's token chain
 //     (token, literal length, offset, match length: decompress.rs:244-332,377-391) with every bounds check of
 //     the reference, and pushes {literal source, literal length, match length, offset} records into the
-//     block's LDS queue.  It never touches the output.  The compressed stream is kept in a 48-byte REGISTER
-//     window per lane (three 16-byte chunks + one chunk in flight), so no memory round trip sits on the chain;
-//     the last 48 bytes of a block are staged in LDS (zero padded) so that nothing is read behind the block.
+//     block's LDS queue.  It never touches the output.  The compressed bytes around the parse position sit in a 64-byte
+//     LDS RING per block (16-byte chunks enter it from a register loaded one step earlier; round 1 kept a 48-byte register
+//     window, whose sliding and per-lane byte selection was half of a step's instructions); the last 48 bytes of a block
+//     are staged in LDS (zero padded) so that nothing is read behind the block.
 //     Everything that is not a plain sequence (255-chains, errors, the block's last sequence) goes through an
 //     exact byte-wise path that follows decompress.rs line by line.
 //   * COPIER wavefronts: G = 8 lanes per block as before.  A group pops records and executes them as 32-byte
@@ -22,12 +23,12 @@
 //     compressed stream ahead of the parser, which keeps the parser's chunk loads out of HBM latency.
 //
 // The parser is per-lane scalar code: lz4_split_parser.h also compiles for the host (tests/sim/), where it is checked
-// against the oracle.  Measurements, the instruction-issue model that bounds the kernel and the variants that were
-// tried and dropped: DESIGN.md section 5.1.1.
+// against the oracle.  Measurements, what bounds the kernel and the variants that were tried and dropped: DESIGN.md
+// section 5.2.
 //
-// LDS per block (LayoutBig): 2 080 B output buffer + 16 x 16 B queue + 16 B head/tail + 80 B tail copy + 16 B sink =
-// 2 448 B; 64 blocks = 153 KiB of the CU's 160 KiB.  LayoutSmall (1 040 B buffer with 256 B of history, 8 records) is
-// 1 280 B: two 64-block workgroups per CU (an option that measured no faster, see launch_decompress_split).
+// LDS per block (LayoutBig): 1 984 B output buffer + 16 x 16 B queue + 16 B head/tail + 80 B tail copy + 16 B sink, then
+// (64 B aligned) the 80 B ring = 2 496 B; 64 blocks = 156 KiB of the CU's 160 KiB.  LayoutSmall (1 024 B buffer, 8
+// records) only exists for the host simulation of a short queue.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -432,10 +433,8 @@ static hipError_t launch_cfg(const DecompressArgs& a, hipStream_t s) {
 
 }  // namespace v5
 
-// blocks_per_wg: 8, 16, 32 or 64 (0 = the largest that still gives every CU a workgroup); + 256: the small LDS layout
-// (1 280 B per block: two 64-block workgroups per CU).  Measured at 32 768 blocks: 4.28 ms against 4.56 ms for two
-// rounds of the big layout and 4.17 ms for the pipelined 4-lane geometry (which capi.cpp picks above 20 480 blocks);
-// at 16 384 blocks 2.74 ms against 2.39 ms (twice the write-backs, more far loads) -- kept as an option, never chosen.
+// blocks_per_wg: 8, 16, 32 or 64 (0 = the largest that still gives every CU a workgroup).  Round 2, JSON tiles: 4 096 blocks
+// (16 per workgroup) 1.31 ms, 8 192 (32) 1.55, 16 384 (64) 1.79, 32 768 (two rounds) 3.86.
 hipError_t launch_decompress_split(const DecompressArgs& a, hipStream_t s, int blocks_per_wg) {
     if (a.n == 0u) return hipSuccess;
     if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;   // dictionary / prefix: v1 kernel

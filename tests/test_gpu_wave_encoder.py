@@ -130,3 +130,38 @@ def test_wave_encoder_output_too_small(blk):
     ol, st = blk.compress_batch(src, [0, len(data)], [len(data), len(data)], outb, [0, 2048], [10, 2048])
     assert st.tolist() == [L.E_OUTPUT_TOO_SMALL, 0] and bytes(outb[:10]) == b"\xEE" * 10
     assert O.decompress(bytes(outb[2048:2048 + int(ol[1])]), len(data)) == ("ok", data)
+
+
+def test_wave_encoder_few_large_blocks_window_mode(blk):
+    """fewer blocks than persistent workgroups: the windows of a block are dealt to different workgroups and the output position
+    travels between them through the workspace.  Ragged sizes (one window ... 90 windows), an empty block, a block whose sink
+    is too small in the middle; every block == model, decodes with the oracle; twice (the carry ring and counters are reset)"""
+    from lz4_flex_amd import _lib as L
+    lib = L.load()
+    rnd = random.Random(17)
+    j = O.fixture_plain("compression_66k_JSON")
+    t = O.fixture_plain("compression_65k")
+    sizes = [5 * 1048576 + 123, 70000, 0, 3 * 65536, 1500000, 65536, 12, 90 * 65536 + 7, 200001]
+    blocks = []
+    for k, n in enumerate(sizes):
+        src = (j if k % 2 else t)
+        ph = rnd.randrange(len(src))
+        reps = n // len(src) + 3
+        blocks.append((src * reps)[ph:ph + n])
+    src_buf = np.frombuffer(b"".join(blocks), dtype=np.uint8).copy()
+    in_len = [len(b) for b in blocks]
+    in_off = [int(x) for x in np.concatenate([[0], np.cumsum(in_len)[:-1]])]
+    cap = [O.max_out(n) for n in in_len]
+    cap[4] = 1000                                                      # OutputTooSmall for block 4, decided up front
+    out_off = [int(x) for x in np.concatenate([[0], np.cumsum(cap)[:-1]])]
+    for rep in range(2):
+        outb = np.full(sum(cap) + 64, 0xEE, dtype=np.uint8)
+        ol, st = blk.compress_batch(src_buf, in_off, in_len, outb, out_off, cap)
+        assert st.tolist() == [0, 0, 0, 0, L.E_OUTPUT_TOO_SMALL, 0, 0, 0, 0]
+        for k, b in enumerate(blocks):
+            if k == 4:
+                assert bytes(outb[out_off[k]:out_off[k] + cap[k]]) == b"\xEE" * cap[k]
+                continue
+            got = bytes(outb[out_off[k]:out_off[k] + int(ol[k])])
+            assert got == W.compress(b), (k, len(b))
+            assert O.decompress(got, len(b)) == ("ok", b), k
