@@ -1012,7 +1012,10 @@ __device__ __forceinline__ void item_next_block(const CompressArgs& a, Item& it)
 __device__ __forceinline__ void item_draw(const CompressArgs& a, uint32_t* wctr, uint32_t b0, uint32_t& ob, uint32_t& ow) {
     const uint32_t n = a.n;
     uint32_t b = b0;
-    for (uint32_t t = 0; t < n; ++t) {
+    // (its own block, then a few behind it: every block has workgroups that start at it and stay until it is done, so giving up
+    // early loses no work -- and with many small blocks a workgroup without work would otherwise try them all, 2 us each)
+    const uint32_t tries = n < 8u ? n : 8u;
+    for (uint32_t t = 0; t < tries; ++t) {
         Item q;
         q.blk = b;
         item_load(a, q);
