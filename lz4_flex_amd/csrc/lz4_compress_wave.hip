@@ -60,7 +60,8 @@ constexpr uint32_t CARRY_SLOTS = 16u;        // per block: a ring of {out_pos, p
 constexpr uint32_t CARRY_DWORDS = CARRY_SLOTS * 16u;
 constexpr uint32_t CARRY_SPINS = 1u << 18;   // x (s_sleep(16) + a load from L2): a good fraction of a second for another workgroup's window
 constexpr uint32_t LONGK = 84u;           // heads that match this far ...
-constexpr uint32_t NEARP = 20u;           // ... and start within this many positions of the previous such head stop counting there
+constexpr uint32_t NEARP = 20u;           // ... and are followed within this many positions by another such head stop counting there ...
+constexpr uint32_t LONGN = 8u;            // ... when the superstep holds at least this many of them
 constexpr uint32_t HBITS = 12u;
 constexpr uint32_t THREADS = 64u * (WORKERS + 1u);
 constexpr uint32_t STG_BYTES = 448u;      // per worker: encoded sequences waiting for a 16 B-per-lane flush
@@ -603,11 +604,13 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
                     // long as it is known to be); the last one of such a group goes on.
                     static_assert(LONGK == 4u + 16u + 2u * 32u, "the check sits behind the third compare round");
                     const uint64_t am = __builtin_amdgcn_ballot_w64(act);
+                    if ((uint32_t)__builtin_popcountll(am) >= LONGN) {       // (a handful of long matches is ordinary data: no check)
                     const uint64_t above = (am >> lane) >> 1;                                      // active lanes behind this one, bit 0 = lane + 1
                     const uint32_t next = lane + 1u + ctz64(above | (1ull << 63));                 // the next active lane (anything if none)
                     const uint32_t pn = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((next & 63u) << 2), (int)p);
                     act = act & ((above == 0ull) | (pn - p > NEARP));
                     if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
+                    }
                 }
                 if (act) {                                      // 32 bytes per further round
                     const lds_u8* ap = win + p + k;

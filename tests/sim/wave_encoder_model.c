@@ -31,6 +31,7 @@
 #define WINDOW 65536u
 #define LONGK 84u
 #define NEARP 20u
+#define LONGN 8u
 
 typedef struct {
     uint32_t nseg;   /* segments per 64 KiB window (the kernel's worker wavefronts); boundaries are multiples of 512 */
@@ -131,8 +132,9 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
             }
             /* a head that still matches after LONGK bytes and is followed within NEARP positions by another such head of the
              * superstep stops counting there (runs: every position would count to the cap); the last one of a group goes on */
-            uint32_t next_long = 0xFFFFFFFFu;
-            for (uint32_t i = cnt; i-- > 0;) {
+            uint32_t next_long = 0xFFFFFFFFu, n_long = 0;
+            for (uint32_t i = 0; i < cnt; i++) n_long += is_long[i];
+            for (uint32_t i = cnt; n_long >= LONGN && i-- > 0;) {     /* (a handful of long matches is ordinary data: left alone) */
                 if (!is_long[i]) continue;
                 if (next_long != 0xFFFFFFFFu && next_long - i <= NEARP) klen[i] = LONGK;
                 next_long = i;
