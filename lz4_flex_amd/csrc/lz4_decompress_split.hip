@@ -294,10 +294,10 @@ struct Copier {
 // Wavefronts of a workgroup are dealt to the four SIMDs in turn.  With eight copier wavefronts (ISO) the workgroup is launched
 // with twelve: wavefront 3 is the parser and 7, 10, 11 end at once, so the parser -- the serial chain everything waits for --
 // has SIMD 3 to itself instead of sharing an issue port with two copiers.
-template <uint32_t CW> constexpr bool split_iso() { return CW == 8u; }
 #ifndef LZ4S_ISO_WAVES
 #define LZ4S_ISO_WAVES 12
 #endif
+template <uint32_t CW> constexpr bool split_iso() { return CW == 8u && LZ4S_ISO_WAVES != 0; }
 template <uint32_t CW> constexpr uint32_t split_waves() { return split_iso<CW>() ? (uint32_t)LZ4S_ISO_WAVES : CW + 1u; }
 
 template <class L, uint32_t NB, uint32_t G, uint32_t WB>

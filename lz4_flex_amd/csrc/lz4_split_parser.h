@@ -341,13 +341,45 @@ struct ParserT {
 #ifdef LZ4FLEX_SPLIT_DEBUG
         if (slow && dbg_ip == 0xFFFFFFFFu) { dbg_ip = ip; dbg_w0 = W0; dbg_w1 = t; dbg_kb = (ahead_ << 24) | (vhi & 0xFFFFFFu); }
 #endif
+        // ---- a second sequence in the same step, when both are plain short ones (the usual case): the block's token chain is
+        // what the whole kernel waits for (its longest block), and the second sequence's token can be read as soon as the
+        // first one's length bytes are known -- three dependent LDS round trips for two sequences instead of four, and a
+        // step's fixed instructions once.  Needs 44 valid bytes in the ring, room for a second record, and the second
+        // sequence itself away from the block's tail copy; anything else is simply left to the next step.
+        bool two = false;
+        uint32_t lit_src2 = 0u, lit2 = 0u, ml2 = 0u, offset2 = 0u, seq_end2 = 0u, op_end2 = 0u;
+        if (!TAIL) {
+            const uint32_t ip1 = seq_end, op1 = mstart + ml;
+            const uint32_t xa = ip1 + A;
+            const uint32_t V0 = rd4(LZ4_ALIGNED_PLUS(ring(), xa & (RING - 4u)), xa & 3u);
+            const uint32_t lcb = (V0 >> 4) & 15u, mlcb = V0 & 15u;
+            const uint32_t l15 = lcb == 15u ? 1u : 0u;
+            lit2 = lcb + (l15 ? (V0 >> 8) & 0xFFu : 0u);
+            const uint32_t pob = 1u + l15 + lit2;
+            const uint32_t xb = xa + (pob < 20u ? pob : 20u);
+            const uint32_t t2 = rd4(LZ4_ALIGNED_PLUS(ring(), xb & (RING - 4u)), xb & 3u);
+            offset2 = t2 & 0xFFFFu;
+            const uint32_t ee2 = mlcb == 15u ? (t2 >> 16) & 0xFFu : 0u;
+            ml2 = 4u + mlcb + ee2;
+            lit_src2 = ip1 + 1u + l15;
+            const uint32_t lit_end2 = lit_src2 + lit2;
+            seq_end2 = lit_end2 + 2u + (mlcb == 15u ? 1u : 0u);
+            const uint32_t mstart2 = op1 + lit2;
+            op_end2 = mstart2 + ml2;
+            const int32_t s2 = imin3(imin3((int32_t)(ilen - 1u - seq_end2), (int32_t)(mstart2 - offset2), (int32_t)(offset2 - 1u)),
+                                     imin3((int32_t)(cap - mstart2 - ml2), (int32_t)(17u - pob), (int32_t)(254u - ee2)),
+                                     imin3(short_s, imin3((int32_t)(ahead_ - 44u), (int32_t)(QD - 4u - (qtail - qhead)), (int32_t)(ilen - 48u - ip1)), 0));
+            two = s2 >= 0;
+        }
         // ---- commit
         push_if(is_short | is_long, lit_src, lit, is_short ? ml : 0u, is_short ? (offset | (offset < rare_below ? R_RARE << 16 : 0u)) : 0u);
+        if (!TAIL) push_if(two, lit_src2, lit2, ml2, offset2 | (offset2 < rare_below ? R_RARE << 16 : 0u));
         // is_short and is_long exclude each other; one select per case (a nested ?: chain here became exec-mask branches)
         uint32_t ip2 = is_short ? seq_end : ip, op2 = is_short ? mstart + ml : op, to2 = is_short ? 0u : tok_over;
         ip = is_long ? lit_end - 1u : ip2;
         op = is_long ? mstart : op2;
         tok_over = is_long ? (0x100u | mlc) : to2;
+        if (!TAIL) { ip = two ? seq_end2 : ip; op = two ? op_end2 : op; }
     }
 };
 using Queue = QueueT<LayoutBig>;
