@@ -198,8 +198,7 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  * Kernel selection, for measurements only (every choice produces the same bytes / lengths / error variants):
  * "decompress_variant": 0 = by batch size (default), 5 = one block per wavefront (lz4_decompress_wave.hip), 6 = the same with a
  *   parser and an executor wavefront per block (few, large blocks), 4 = parser /
- *   copier split decoder, 3 = pipelined LDS-staged decoder (with "decompress_geometry" -1 / 0 / 1 = by batch size /
- *   8 lanes x 4 B / 4 lanes x 8 B per block), 1 = decoder whose window lives in HBM/L2 (always used for dictionary /
+ *   copier split decoder, 1 = decoder whose window lives in HBM/L2 (always used for dictionary /
  *   prefix blocks); "decompress_blocks_per_wg" (variant 4: 0 = by batch size, 8/16/32/64); "decompress_lanes"
  *   (8/16/32/64, variant 1); exact encoder: "compress_lanes" (8/16 lanes of a wavefront per block), "compress_variant"
  *   (1 = group encoder + emitter wavefront, 3 = group encoder alone). */

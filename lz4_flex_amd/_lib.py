@@ -108,7 +108,7 @@ def load():
         raise ImportError(
             "lz4_flex_amd: %s is missing. Build it with `python -m lz4_flex_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
-    if not os.environ.get("LZ4FLEX_NO_TORCH"):   # torch-free tools (tools/dec_geometry.py) load libamdhip64 themselves
+    if not os.environ.get("LZ4FLEX_NO_TORCH"):   # torch-free tools load libamdhip64 themselves
         try:
             import torch  # noqa: F401  (HIP runtime unification; plumbing only)
         except Exception:

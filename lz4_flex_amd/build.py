@@ -114,7 +114,9 @@ def build_variant(name, extra_flags):
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
     lib = os.path.join(vdir, "liblz4flex_amd.so")
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, stdout=subprocess.PIPE,
+    # -Bsymbolic: the variant calls its OWN launchers even when another build of the library is loaded in the same process
+    # (tools/dec_variants.py times several variants in one run)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", lib] + objs, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))

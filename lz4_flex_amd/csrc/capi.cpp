@@ -51,8 +51,7 @@ struct lz4flex_ctx {
     unsigned long long* wave_prof = nullptr;   // tools: per-role cycle counters of the wave encoder (lz4flex_debug_wave_prof)
     int wave_wgs = 0;
     int dec_blocks_per_wg = 0;    // split decoder: blocks per workgroup (8/16/32/64), 0 = by batch size
-    int dec_geometry = -1;        // pipelined decoder geometry (lz4_decompress_lds.hip launch_decompress_pipe): -1 by batch size, 0 = 8 lanes x 4 B, 1 = 4 lanes x 8 B
-    int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 2 = LDS-staged generic loop, 3 = LDS-staged pipelined (lz4_decompress_lds.hip), 4 = parser / copier split (lz4_decompress_split.hip)
+    int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 4 = parser / copier split (lz4_decompress_split.hip), 5 / 6 = a wavefront / a pair of wavefronts per block (lz4_decompress_wave.hip)
 };
 
 // the decoders for blocks without dictionary / prefix
@@ -61,8 +60,7 @@ static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressA
     // split decoder's serial chain needs, and blocks larger than 64 KiB stay tolerable); larger batches have enough blocks
     // to fill the chip with one chain per lane, which costs half the instructions per byte.  tools/wave_bench.py --dec, JSON
     // tiles, ms for 1 024 / 4 096 / 6 144 / 8 192 / 16 384 / 32 768 blocks: wave 0.74 / 1.01 / 1.64 / 1.95 / 3.8 / 7.3, split
-    // 1.31 / 1.31 / 1.52 / 1.55 / 1.79 / 3.86, pipelined (round 1's choice above 20 480) 2.43 / 2.54 / 2.62 / 2.59 / 2.9 / 4.15:
-    // no longer chosen.
+    // 1.31 / 1.31 / 1.52 / 1.55 / 1.79 / 3.86 (round 1's pipelined decoder 2.43 / 2.54 / 2.62 / 2.59 / 2.9 / 4.15: deleted).
     // up to 2 304 blocks (nine pairs of wavefronts per CU) the wave decoder runs with a parser and an executor wavefront per
     // block: 256 / 1 024 / 2 048 blocks 0.45 / 0.52 / 0.65 ms against 0.73 / 0.75 / 0.82 with one wavefront
     const int v = c->dec_variant != 0 ? c->dec_variant : (a.n <= 2304u ? 6 : (a.n <= 5120u ? 5 : 4));
@@ -76,8 +74,7 @@ static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressA
         r.only_status = REDO;
         return launch_decompress(r, c->dec_lanes, s);
     }
-    if (v == 4) return launch_decompress_split(a, s, c->dec_blocks_per_wg);
-    return launch_decompress_pipe(a, s, 0, c->dec_geometry);
+    return launch_decompress_split(a, s, c->dec_blocks_per_wg);
 }
 
 // Reference-exact encoder, MEM_DEVICE batches without LZ4FLEX_MEM_BIG_BLOCKS: the u16-table kernel is only right for blocks
@@ -183,8 +180,7 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
     c->device = device;
     if (const char* e = getenv("LZ4FLEX_COMPRESS_MODE")) c->comp_mode = (!strcmp(e, "exact") || !strcmp(e, "1")) ? 1 : 0;
     if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v == 1 || v == 3) c->comp_variant = v; }
-    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v == 0 || v == 1 || (v >= 3 && v <= 6)) c->dec_variant = v; }
-    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_GEOMETRY")) { const int v = atoi(e); if (v >= -1 && v <= 1) c->dec_geometry = v; }
+    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v == 0 || v == 1 || (v >= 4 && v <= 6)) c->dec_variant = v; }
     int prev = 0;
     (void)hipGetDevice(&prev);
     e = hipSetDevice(device);
@@ -243,13 +239,8 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "decompress_variant")) {
-        if (value != 0 && value != 1 && (value < 3 || value > 6)) return -LZ4FLEX_E_INVALID_ARG;
+        if (value != 0 && value != 1 && (value < 4 || value > 6)) return -LZ4FLEX_E_INVALID_ARG;
         c->dec_variant = value;
-        return 0;
-    }
-    if (!strcmp(key, "decompress_geometry")) {
-        if (value < -1 || value > 1) return -LZ4FLEX_E_INVALID_ARG;
-        c->dec_geometry = value;
         return 0;
     }
     if (!strcmp(key, "compress_variant")) {

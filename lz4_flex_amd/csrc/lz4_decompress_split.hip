@@ -2,9 +2,9 @@
 //
 // Same contract as lz4_decompress.hip (reference src/block/decompress.rs:201-449: result bytes, byte count,
 // error variant and OutputTooSmall{expected,actual}, unsafe-flavour check order), blocks without dictionary /
-// prefix.  What the pipelined decoder (lz4_decompress_lds.hip) spends its issue slots on is the token parse:
-// 8 lanes own a block and all 8 run the same parse (116 VALU + 75 SALU per step) to produce ONE sequence.  Here the two
-// halves of the reference loop run in different wavefronts of a workgroup:
+// prefix.  What round 1's pipelined decoder (8 lanes per block, deleted) spent its issue slots on was the token parse:
+// all 8 lanes ran the same parse (116 VALU + 75 SALU per step) to produce ONE sequence.  Here the two halves of the
+// reference loop run in different wavefronts of a workgroup:
 //
 //   * PARSER wavefront: ONE LANE PER BLOCK (up to 64 blocks).  A lane walks its block's token chain
 //     (token, literal length, offset, match length: decompress.rs:244-332,377-391) with every bounds check of
@@ -15,12 +15,13 @@
 //     are staged in LDS (zero padded) so that nothing is read behind the block.
 //     Everything that is not a plain sequence (255-chains, errors, the block's last sequence) goes through an
 //     exact byte-wise path that follows decompress.rs line by line.
-//   * COPIER wavefronts: G = 8 lanes per block as before.  A group pops records and executes them as 32-byte
-//     pieces on the LDS output buffer of lz4_decompress_lds.hip (512 B of history, 16 B/lane coalesced
-//     write-back): literal pieces and far match pieces are global loads issued three steps before their bytes
-//     are needed, near matches are LDS -> LDS.  Once per 4-step iteration a group snapshots the queue's tail,
-//     publishes its head, checks the buffer space for four pieces and touches the next 128-byte line of the
-//     compressed stream ahead of the parser, which keeps the parser's chunk loads out of HBM latency.
+//   * COPIER wavefronts: a group of G lanes per block (large batches: 4 lanes x 16 bytes, four wavefronts for 64 blocks;
+//     smaller ones: 8 lanes x 4 bytes).  A group pops records and executes them as pieces of up to G x WB bytes on the LDS
+//     block's LDS output buffer (512 B of history, 16 B/lane coalesced write-back): literal pieces and far
+//     match pieces are global loads issued three steps before their bytes are needed, near matches are LDS -> LDS.  Every
+//     4 steps a group snapshots the queue's tail and publishes its head; once per iteration it checks the buffer space for
+//     the iteration's pieces and touches the next 128-byte line of the compressed stream ahead of the parser, which keeps
+//     the parser's chunk loads out of HBM latency.
 //
 // The parser is per-lane scalar code: lz4_split_parser.h also compiles for the host (tests/sim/), where it is checked
 // against the oracle.  Measurements, what bounds the kernel and the variants that were tried and dropped: DESIGN.md
@@ -50,12 +51,14 @@ namespace v5 {
 // =====================================================================================================
 template <uint32_t WB> struct Word;
 template <> struct Word<4> { using type = uint32_t; };
-template <> struct Word<8> { using type = uint2; };
+template <> struct Word<16> { using type = u32x4; };
 
-// G lanes per block, WB bytes per lane and piece; L = the block's LDS layout
-template <class L, uint32_t G, uint32_t WB>
+// G lanes per block, WB bytes per lane and piece, NS pieces in flight (a piece's global load is issued NS - 1 steps before its
+// bytes are stored); L = the block's LDS layout
+template <class L, uint32_t G, uint32_t WB, uint32_t NS>
 struct Copier {
     static constexpr uint32_t PIECE = G * WB;
+    static_assert((WB == 4u || WB == 16u) && NS >= 2u && NS * PIECE + 64u + 64u <= L::FLUSH_AT && PIECE <= L::OUT_H, "geometry");
     static constexpr uint32_t OUT_CAP = L::OUT_CAP, OUT_H = L::OUT_H, FLUSH_AT = L::FLUSH_AT, TAIL_OFF = L::TAIL_OFF;
     using word_t = typename Word<WB>::type;
     const uint8_t* gin;
@@ -167,14 +170,17 @@ struct Copier {
         }
     }
 
-    // Once per 4-step iteration: snapshot the queue's tail (records below it are complete), publish the head, make
-    // sure four pieces fit into the output buffer, touch the next line of the compressed stream ahead of the parser.
-    __device__ __forceinline__ void iteration_begin() {
+    // Every 4 steps: snapshot the queue's tail (records below it are complete), publish the head.
+    __device__ __forceinline__ void snapshot() {
         snap = q.tail();
         e = q.get(head);   // re-read AFTER the snapshot: the copy fetched at the end of the last step may predate the record
         if (g == 0u && head != head_pub) q.set_head(head);
         head_pub = head;
-        if ((done | blocked) == 0u && out_space() < 4u * PIECE + 64u) blocked = K_MAINT;
+    }
+    // Once per NS-step iteration: make sure NS pieces fit into the output buffer, touch the next line of the compressed
+    // stream ahead of the parser.
+    __device__ __forceinline__ void iteration_begin() {
+        if ((done | blocked) == 0u && out_space() < NS * PIECE + 64u) blocked = K_MAINT;
         pf_acc += pf_v;                                   // the touch issued one iteration ago (long complete)
         const bool pf = pf_next < lit_src + PF_AHEAD;
         const uint32_t pos = pf_next + (128u / G) * g;
@@ -195,20 +201,34 @@ struct Copier {
         e = q.get(head);                                  // next record (complete iff head != snap); its latency overlaps this step
         const bool go = ok && kind == 0u;
         const bool isl = lit_rem != 0u;
-        const uint32_t pm = moff >= PIECE ? PIECE : (moff & ~(WB - 1u));
+        // a match piece never reads bytes of its own: whole words up to the offset, or (words wider than 4 bytes) the offset's
+        // bytes in the group's first lane.  Offsets below 4 are R_RARE records.
+        const uint32_t pm = moff >= PIECE ? PIECE : ((WB == 4u || moff >= WB) ? (moff & ~(WB - 1u)) : moff);
         const uint32_t rem = isl ? lit_rem : ml_rem;
         const uint32_t lim = isl ? PIECE : pm;
         const uint32_t n = go ? (rem < lim ? rem : lim) : 0u;
         const uint32_t msrc = op - moff;
+#ifdef LZ4S_EXP_NOFAR    // timing experiments only (tools; the output is wrong): far matches read LDS like near ones
+        const bool far = false;
+#else
         const bool far = !isl && msrc < L0;
+#endif
         // one load per step and lane: literal bytes, far match bytes (already written back: msrc + PIECE <= L0 + PIECE - 1 < F),
         // or nothing useful (position 0).  Literal positions are clamped so that no lane reads behind the block.
         const uint32_t lpos = lit_src + WB * g;
         const uint32_t off = isl ? (lpos < ilen_w ? lpos : ilen_w) : (far ? msrc + WB * g : 0u);
+#ifdef LZ4S_EXP_NOGLOB   // ... no global load at all in a step
+        s.v = word_t{}; asm volatile("" :: "v"(off));
+#else
         s.v = ldw((isl ? gin_ld : gout_ld) + off);
+#endif
         s.n = n;
         s.dst = op - L0;
+#ifdef LZ4S_EXP_NOFAR
+        s.msrc = (msrc - L0) & 1023u;
+#else
         s.msrc = far ? 0u : msrc - L0;                    // LDS source (always read; 0 when unused)
+#endif
         s.glob = (isl || far) ? 1u : 0u;
         lit_src = isl ? lit_src + n : lit_src;
         lit_rem = isl ? lit_rem - n : lit_rem;
@@ -219,6 +239,10 @@ struct Copier {
 #endif
     }
     __device__ __forceinline__ void be_step(const Slot& s) {
+#ifdef LZ4S_EXP_NOBE     // ... no LDS traffic in the back end
+        asm volatile("" :: "v"(s.n), "v"(s.dst), "v"(s.msrc), "v"(s.glob), "v"(s.v));
+        return;
+#endif
         word_t x;
         __builtin_memcpy(&x, (const void*)(lout + (s.glob ? 0u : s.msrc) + WB * g), WB);
         if (s.glob) x = s.v;
@@ -240,7 +264,7 @@ struct Copier {
         blocked = K_NONE;
     }
     __device__ __forceinline__ void run() {
-        Slot s0, s1, s2, s3;
+        Slot sl[NS];
 #ifdef LZ4FLEX_PROFILE_PHASES
         pr_piece = pr_idle = pr_blocked = 0u;
         const unsigned long long t_begin = __builtin_readcyclecounter();
@@ -249,21 +273,23 @@ struct Copier {
 #endif
         if (__all(done != 0u)) return;   // a wavefront without blocks (batch tail)
         for (;;) {
-            s1.n = 0u; s1.dst = 0u; s1.msrc = 0u; s1.glob = 0u; s1.v = word_t{};
-            s2 = s1; s3 = s1;
+#pragma unroll
+            for (uint32_t k = 1u; k < NS; ++k) { sl[k].n = 0u; sl[k].dst = 0u; sl[k].msrc = 0u; sl[k].glob = 0u; sl[k].v = word_t{}; }
             do {
                 const uint32_t before = head + op;
-                iteration_begin();
-                fe_step(s0); be_step(s1);
-                fe_step(s1); be_step(s2);
-                fe_step(s2); be_step(s3);
-                fe_step(s3); be_step(s0);
+#pragma unroll
+                for (uint32_t k = 0u; k < NS; ++k) {
+                    if (k % 4u == 0u) snapshot();
+                    if (k == 0u) iteration_begin();
+                    fe_step(sl[k]); be_step(sl[(k + 1u) % NS]);
+                }
                 if (!__any(head + op != before)) __builtin_amdgcn_s_sleep(2);   // nothing to do in the whole wave: yield issue slots
 #ifdef LZ4FLEX_PROFILE_PHASES
                 iters++;
 #endif
             } while (!__any(blocked != K_NONE));
-            be_step(s1); be_step(s2); be_step(s3);
+#pragma unroll
+            for (uint32_t k = 1u; k < NS; ++k) be_step(sl[k]);
 #ifdef LZ4FLEX_PROFILE_PHASES
             const unsigned long long ts = __builtin_readcyclecounter();
 #endif
@@ -285,30 +311,44 @@ struct Copier {
     }
 };
 
-// NB blocks per workgroup: NB*G/64 copier wavefronts followed by the parser wavefront (NB lanes in use).  G copier lanes
-// per block move WB bytes each per piece.
-// Measured on the configs[1] workload (tools/dec_geometry.py --split, 16 384 blocks): G = 8 x 4 B 2.36 ms; G = 4 x 8 B
-// (half the copier wavefronts, each alone on its SIMD) 4.35 ms; two or four blocks per parser lane (independent
-// chains in one instruction stream) 2.94 / 14.4 ms: the compiler serialises them and the wider parser starves the
-// copiers that share its SIMD.  Only G = 8, WB = 4 is instantiated.
-// Wavefronts of a workgroup are dealt to the four SIMDs in turn.  With eight copier wavefronts (ISO) the workgroup is launched
-// with twelve: wavefront 3 is the parser and 7, 10, 11 end at once, so the parser -- the serial chain everything waits for --
-// has SIMD 3 to itself instead of sharing an issue port with two copiers.
+// NB blocks per workgroup: NB*G/64 copier wavefronts and the parser wavefront (NB lanes in use).  G copier lanes per
+// block move WB bytes each per piece, NS pieces are in flight.
+// Measured on the configs[1] workload (tools/dec_variants.py, 16 384 blocks, same run, ms): 8 x 4 B 1.75; 8 x 16 B 1.83;
+// 4 x 16 B 1.65 (NS = 3 / 4 / 6 / 8: 1.69 / 1.65 / 1.70 / 1.69); 2 x 16 B 1.71.  A 16-byte word costs the instructions of
+// a 4-byte one, the pieces are twice as long (13 % fewer of them: most are cut by the sequence, not by the piece size) and
+// half the copier wavefronts issue them.  8-byte words (8 x 8 B 4.0, 4 x 8 B 4.4) are not an option: an unaligned 8-byte
+// LDS access is several times slower than a 4- or a 16-byte one.  Two or four blocks per parser lane (independent chains
+// in one instruction stream) 2.94 / 14.4 ms (round 1): the compiler serialises them.
+// Wavefronts of a workgroup are dealt to the four SIMDs in turn, and the parser -- the serial chain everything waits for --
+// gets SIMD 3 to itself: with eight copier wavefronts (8 x 4 B; ISO) the workgroup is launched with twelve, wavefront 3 is
+// the parser and 7, 10, 11 end at once; with four (4 x 16 B) it is launched with eight, the copiers are wavefronts 0, 1, 2, 4
+// and 5, 6, 7 end at once; with two, wavefronts 0, 1 of four.
 #ifndef LZ4S_ISO_WAVES
 #define LZ4S_ISO_WAVES 12
 #endif
-template <uint32_t CW> constexpr bool split_iso() { return CW == 8u && LZ4S_ISO_WAVES != 0; }
-template <uint32_t CW> constexpr uint32_t split_waves() { return split_iso<CW>() ? (uint32_t)LZ4S_ISO_WAVES : CW + 1u; }
+template <uint32_t CW, uint32_t G> constexpr bool split_iso() { return G == 8u && CW == 8u && LZ4S_ISO_WAVES != 0; }
+template <uint32_t CW, uint32_t G> constexpr uint32_t split_waves() {
+    if (G != 8u) return CW == 4u ? 8u : (CW == 2u ? 4u : CW + 1u);
+    return split_iso<CW, G>() ? (uint32_t)LZ4S_ISO_WAVES : CW + 1u;
+}
 
-template <class L, uint32_t NB, uint32_t G, uint32_t WB>
-__global__ void __launch_bounds__(64 * split_waves<NB * G / 64>()) lz4_decompress_split_kernel(DecompressArgs a) {
+template <class L, uint32_t NB, uint32_t G, uint32_t WB, uint32_t NS>
+__global__ void __launch_bounds__((64 * split_waves<NB * G / 64, G>())) lz4_decompress_split_kernel(DecompressArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
     constexpr uint32_t CW = NB * G / 64u;
     static_assert(NB <= 64 && (NB * G) % 64 == 0, "geometry");
     const uint32_t pw = threadIdx.x / 64u;
     uint32_t wave = pw;                                    // role: < CW copier, == CW parser
-    if (split_iso<CW>()) {
+    if (G != 8u) {
+        if (CW == 4u) {
+            if (pw >= 5u) return;
+            wave = pw == 3u ? CW : (pw < 3u ? pw : 3u);
+        } else if (CW == 2u) {
+            if (pw == 2u) return;
+            wave = pw == 3u ? CW : pw;
+        }
+    } else if (split_iso<CW, G>()) {
 #if LZ4S_ISO_WAVES == 12
         if (pw == 7u || pw >= 10u) return;                 // (finished wavefronts do not count at the barrier)
         wave = pw == 3u ? CW : (pw < 3u ? pw : (pw < 7u ? pw - 1u : pw - 2u));
@@ -326,7 +366,7 @@ __global__ void __launch_bounds__(64 * split_waves<NB * G / 64>()) lz4_decompres
         const uint32_t j = wave * (64u / G) + lane / G;
         const uint32_t b = first + j;
         const bool valid = b < a.n;
-        Copier<L, G, WB> c;
+        Copier<L, G, WB, NS> c;
         constexpr uint32_t BLK_LDS = L::BLK_LDS, TAIL_OFF = L::TAIL_OFF;
         c.g = lane % G;
         c.lout = lds + j * BLK_LDS;
@@ -343,7 +383,7 @@ __global__ void __launch_bounds__(64 * split_waves<NB * G / 64>()) lz4_decompres
         c.gin_ld = c.ilen >= WB ? c.gin : g_pad;
         c.ilen_w = c.ilen >= WB ? c.ilen - WB : 0u;
         c.gout_ld = (valid && a.out_cap[b] >= WB) ? c.gout : g_pad;
-        c.blocked = Copier<L, G, WB>::K_NONE;
+        c.blocked = Copier<L, G, WB, NS>::K_NONE;
         c.done = valid ? 0u : 1u;
         __syncthreads();
         c.run();
@@ -355,7 +395,8 @@ __global__ void __launch_bounds__(64 * split_waves<NB * G / 64>()) lz4_decompres
         ParserT<L> p;
         p.q.blk = lds + (j < NB ? j : 0u) * L::BLK_LDS;
         p.init_window(valid ? a.in_base + a.in_off[b] : g_pad, valid ? a.in_len[b] : 0u);
-        p.rare_below = WB;
+        p.rare_below = 4u;           // the copier cuts match pieces at the offset (words, or the offset's bytes in one lane)
+        p.lit_slack = WB - 1u;
         p.cap = valid ? a.out_cap[b] : 0u;
         p.ip = 0u; p.op = 0u; p.tok_over = 0u; p.qtail = 0u;
         p.status = 0; p.expected = 0u;
@@ -411,11 +452,11 @@ __global__ void __launch_bounds__(64 * split_waves<NB * G / 64>()) lz4_decompres
     }
 }
 
-template <class L, uint32_t NB, uint32_t G, uint32_t WB>
+template <class L, uint32_t NB, uint32_t G, uint32_t WB, uint32_t NS>
 static hipError_t launch_cfg(const DecompressArgs& a, hipStream_t s) {
     const uint32_t grid = (a.n + NB - 1u) / NB;
     const size_t lds = (size_t)NB * L::BLK_LDS;
-    auto kern = lz4_decompress_split_kernel<L, NB, G, WB>;
+    auto kern = lz4_decompress_split_kernel<L, NB, G, WB, NS>;
     if (lds > 65536u) {   // the attribute is per device: remember which devices have it (per instantiation)
         static unsigned long long have = 0ull;   // benign race: setting it twice is harmless
         int dev = 0;
@@ -427,11 +468,22 @@ static hipError_t launch_cfg(const DecompressArgs& a, hipStream_t s) {
             have |= bit;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * split_waves<NB * G / 64u>()), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64u * split_waves<NB * G / 64u, G>()), lds, s, a);
     return hipGetLastError();
 }
 
 }  // namespace v5
+
+// geometry of the 64-blocks-per-workgroup launch (the large batches): copier lanes per block, bytes per lane, pieces in flight
+#ifndef LZ4S_G
+#define LZ4S_G 4
+#endif
+#ifndef LZ4S_WB
+#define LZ4S_WB 16
+#endif
+#ifndef LZ4S_NS
+#define LZ4S_NS 4
+#endif
 
 // blocks_per_wg: 8, 16, 32 or 64 (0 = the largest that still gives every CU a workgroup).  Round 2, JSON tiles: 4 096 blocks
 // (16 per workgroup) 1.31 ms, 8 192 (32) 1.55, 16 384 (64) 1.79, 32 768 (two rounds) 3.86.
@@ -441,10 +493,10 @@ hipError_t launch_decompress_split(const DecompressArgs& a, hipStream_t s, int b
     if (blocks_per_wg == 0)
         blocks_per_wg = a.n >= 64u * 256u ? 64 : (a.n >= 32u * 256u ? 32 : (a.n >= 16u * 256u ? 16 : 8));
     switch (blocks_per_wg) {
-        case 64: return v5::launch_cfg<v5::LayoutBig, 64, 8, 4>(a, s);
-        case 32: return v5::launch_cfg<v5::LayoutBig, 32, 8, 4>(a, s);
-        case 16: return v5::launch_cfg<v5::LayoutBig, 16, 8, 4>(a, s);
-        case 8: return v5::launch_cfg<v5::LayoutBig, 8, 8, 4>(a, s);
+        case 64: return v5::launch_cfg<v5::LayoutBig, 64, LZ4S_G, LZ4S_WB, LZ4S_NS>(a, s);
+        case 32: return v5::launch_cfg<v5::LayoutBig, 32, 8, 4, 4>(a, s);
+        case 16: return v5::launch_cfg<v5::LayoutBig, 16, 8, 4, 4>(a, s);
+        case 8: return v5::launch_cfg<v5::LayoutBig, 8, 8, 4, 4>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

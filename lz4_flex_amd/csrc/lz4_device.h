@@ -45,7 +45,6 @@ struct CompressArgs {
 };
 
 hipError_t launch_decompress(const DecompressArgs& a, int lanes_per_block, hipStream_t s);
-hipError_t launch_decompress_pipe(const DecompressArgs& a, hipStream_t s, int ablate = 0, int geometry = -1);  // pipelined LDS variant
 // one block per wavefront (lz4_decompress_wave.hip); irregular blocks are left with status redo_code for a second pass of
 // launch_decompress (only_status = redo_code), which decodes them in the reference's check order
 hipError_t launch_decompress_wave(const DecompressArgs& a, int32_t redo_code, hipStream_t s);

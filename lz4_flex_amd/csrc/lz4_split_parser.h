@@ -15,7 +15,14 @@
 #define LZ4_LDS
 #define LZ4_FN inline
 #define LZ4_COLD_FN inline
-#define LZ4_ANY(x) (x)
+// one lane per run on the host: "some other lane of the wavefront wants this path" is simulated by a coin (0 = never)
+static uint32_t lz4_sim_chaos_state = 0u;
+static inline bool lz4_sim_chaos() {
+    if (lz4_sim_chaos_state == 0u) return false;
+    lz4_sim_chaos_state = lz4_sim_chaos_state * 1664525u + 1013904223u;
+    return (lz4_sim_chaos_state >> 29) == 0u;
+}
+#define LZ4_ANY(x) ((x) || lz4_sim_chaos())
 static inline uint32_t lz4_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (sh & 3u)));
 }
@@ -62,11 +69,11 @@ struct Layout {
     static constexpr uint32_t RING_OFF = (SINK_OFF + 16u + 63u) & ~63u;
     static constexpr uint32_t BLK_LDS = (RING_OFF + RING_BYTES + 63u) & ~63u;   // a multiple of 64: every block's ring is 64 B aligned
     static_assert(BLK_LDS % 64 == 0 && RING_OFF % 64 == 0 && OUT_H % 16 == 0 && (QD & (QD - 1u)) == 0 && QD >= 8, "layout");
-    static_assert(FLUSH_AT >= 4u * 32u + 64u + 64u, "a write-back must leave room for an iteration's pieces");
 };
 using LayoutBig = Layout<1984, 512, 16>;     // 2 496 B per block: 64 blocks = one workgroup per CU (156 KiB of its 160 KiB of LDS)
+static_assert(LayoutBig::BLK_LDS == 2496 && LayoutBig::FLUSH_AT == 712, "LDS per block");
 using LayoutSmall = Layout<1024, 256, 8>;    // 1 408 B per block (host simulation of a short queue; not launched)
-static_assert(LayoutBig::BLK_LDS == 2496 && LayoutBig::FLUSH_AT == 712 && LayoutSmall::BLK_LDS == 1408, "LDS per block");
+static_assert(LayoutSmall::BLK_LDS == 1408, "LDS per block");
 // the default layout's constants at namespace level (host simulation, tools)
 constexpr uint32_t QD = LayoutBig::QD, OUT_H = LayoutBig::OUT_H, OUT_CAP = LayoutBig::OUT_CAP, FLUSH_AT = LayoutBig::FLUSH_AT;
 constexpr uint32_t Q_OFF = LayoutBig::Q_OFF, CTL_OFF = LayoutBig::CTL_OFF, TAIL_OFF = LayoutBig::TAIL_OFF, SINK_OFF = LayoutBig::SINK_OFF, RING_OFF = LayoutBig::RING_OFF;
@@ -129,7 +136,9 @@ struct ParserT {
     // registers: sliding it and selecting 24 bytes at a per-lane offset cost ~85 of a step's 172 instructions; two aligned
     // LDS reads at computed addresses cost 10.
     uint32_t vhi;
-    uint32_t rare_below;     // matches with a smaller offset are marked R_RARE (the copier moves this many bytes per lane)
+    uint32_t rare_below;     // matches with a smaller offset are marked R_RARE (the copier's periodic path)
+    uint32_t lit_slack;      // >= 3: a copier lane reads up to this many bytes behind the end of a plain record's literals (its
+                             // word width - 1); literals closer to the block's end go through the exact path (R_CAREFUL)
     uint32_t climit;         // start of the last chunk that lies entirely inside the block (loads are clamped to it)
     u32x4 N;
 #ifdef LZ4FLEX_SPLIT_DEBUG
@@ -312,24 +321,30 @@ struct ParserT {
             b = tailmode ? q.blk + TAIL_OFF + (r2 & ~3u) : b;
             shb = tailmode ? (r2 & 3u) : shb;
         }
-        const uint32_t t = rd4(b, shb);
-        const uint32_t offset = t & 0xFFFFu;
-        const uint32_t ee = mlc == 15u ? (t >> 16) & 0xFFu : 0u;          // 255 = the extension continues (exact path)
-        const uint32_t ml = 4u + mlc + ee;
+        // the second sequence's token sits behind the first one's offset (and one length byte if its match nibble is 15):
+        // its address is known before the offset is, both reads share one LDS round trip
         const uint32_t lit_src = ip + 1u + lc15;
         const uint32_t lit_end = lit_src + lit;
         const uint32_t seq_end = lit_end + 2u + (mlc == 15u ? 1u : 0u);
+        const uint32_t xa = seq_end + A;
+        const uint32_t t = rd4(b, shb);
+        uint32_t V0 = 0u;
+        if (!TAIL) V0 = rd4(LZ4_ALIGNED_PLUS(ring(), xa & (RING - 4u)), xa & 3u);
+        const uint32_t offset = t & 0xFFFFu;
+        const uint32_t ee = mlc == 15u ? (t >> 16) & 0xFFu : 0u;          // 255 = the extension continues (exact path)
+        const uint32_t ml = 4u + mlc + ee;
         const uint32_t mstart = op + lit;
         // ---- classify.  Every condition is a signed slack (>= 0 holds), folded with min: sizes are below 2 GiB, larger
         // values only send a sequence to the exact path.  decompress.rs:334-408 in one go for the plain sequence:
         const int32_t common = imin3((int32_t)(0u - done), (TAIL && tailmode) ? 0 : (int32_t)(ahead_ - 24u),   // live, the ring holds 24 bytes from ip on
                                      (int32_t)(QD - 3u - (qtail - qhead)));                              // queue has room
-        const int32_t short_s = imin3(imin3((int32_t)(ilen - 1u - seq_end),                              // a byte follows the sequence
+        const uint32_t tail_need = lit_slack - 2u;                                                       // >= 1; seq_end >= lit_end + 2
+        const int32_t short_s = imin3(imin3((int32_t)(ilen - tail_need - seq_end),                       // a byte follows the sequence (lit_slack bytes its literals)
                                             (int32_t)(mstart - offset), (int32_t)(offset - 1u)),         // 1 <= offset <= output so far
                                       imin3((int32_t)(cap - mstart - ml), (int32_t)(17u - pos_off),      // fits; offset inside the window
                                             (int32_t)(254u - ee)), common);
         // a literal run too long for the window: push it alone, parse the offset next time
-        const int32_t long_s = imin3(imin3((int32_t)(pos_off - 18u), (int32_t)(269u - lit), (int32_t)(ilen - 3u - lit_end)),
+        const int32_t long_s = imin3(imin3((int32_t)(pos_off - 18u), (int32_t)(269u - lit), (int32_t)(ilen - lit_slack - lit_end)),
                                      imin3((int32_t)(cap - mstart), (int32_t)(0u - tok_over), common), 0);
         const bool is_short = short_s >= 0;
         const bool is_long = long_s >= 0;
@@ -350,23 +365,21 @@ struct ParserT {
         uint32_t lit_src2 = 0u, lit2 = 0u, ml2 = 0u, offset2 = 0u, seq_end2 = 0u, op_end2 = 0u;
         if (!TAIL) {
             const uint32_t ip1 = seq_end, op1 = mstart + ml;
-            const uint32_t xa = ip1 + A;
-            const uint32_t V0 = rd4(LZ4_ALIGNED_PLUS(ring(), xa & (RING - 4u)), xa & 3u);
             const uint32_t lcb = (V0 >> 4) & 15u, mlcb = V0 & 15u;
             const uint32_t l15 = lcb == 15u ? 1u : 0u;
             lit2 = lcb + (l15 ? (V0 >> 8) & 0xFFu : 0u);
             const uint32_t pob = 1u + l15 + lit2;
             const uint32_t xb = xa + (pob < 20u ? pob : 20u);
+            lit_src2 = ip1 + 1u + l15;
+            const uint32_t lit_end2 = lit_src2 + lit2;
+            seq_end2 = lit_end2 + 2u + (mlcb == 15u ? 1u : 0u);
             const uint32_t t2 = rd4(LZ4_ALIGNED_PLUS(ring(), xb & (RING - 4u)), xb & 3u);
             offset2 = t2 & 0xFFFFu;
             const uint32_t ee2 = mlcb == 15u ? (t2 >> 16) & 0xFFu : 0u;
             ml2 = 4u + mlcb + ee2;
-            lit_src2 = ip1 + 1u + l15;
-            const uint32_t lit_end2 = lit_src2 + lit2;
-            seq_end2 = lit_end2 + 2u + (mlcb == 15u ? 1u : 0u);
             const uint32_t mstart2 = op1 + lit2;
             op_end2 = mstart2 + ml2;
-            const int32_t s2 = imin3(imin3((int32_t)(ilen - 1u - seq_end2), (int32_t)(mstart2 - offset2), (int32_t)(offset2 - 1u)),
+            const int32_t s2 = imin3(imin3((int32_t)(ilen - tail_need - seq_end2), (int32_t)(mstart2 - offset2), (int32_t)(offset2 - 1u)),
                                      imin3((int32_t)(cap - mstart2 - ml2), (int32_t)(17u - pob), (int32_t)(254u - ee2)),
                                      imin3(short_s, imin3((int32_t)(ahead_ - 44u), (int32_t)(QD - 4u - (qtail - qhead)), (int32_t)(ilen - 48u - ip1)), 0));
             two = s2 >= 0;

@@ -31,9 +31,11 @@ static int sim_run(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t ca
     p.q.set_tail(0);
     p.init_window(gin, in_len);
     p.rare_below = (misalign & 4u) ? 8u : 4u;
+    p.lit_slack = (misalign & 4u) ? 15u : 3u;
     p.cap = cap;
     for (uint32_t i = 0; i < TAIL_BUF; ++i) lds[TAIL_OFF + i] = (p.tstart + i < in_len) ? gin[p.tstart + i] : 0;
     p.ip = 0; p.op = 0; p.tok_over = 0; p.qtail = 0; p.status = 0; p.expected = 0; p.done = 0;
+    lz4_sim_chaos_state = (misalign & 16u) ? 0x9E3779B9u ^ in_len ^ (cap << 7) : 0u;
     p.prime();
     if (in_len == 0) p.fail(LZ4FLEX_DEV_E_EXPECTED_ANOTHER_BYTE);
     uint32_t head = 0, op = 0, recs = 0, steps = 0;
@@ -48,7 +50,7 @@ static int sim_run(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t ca
             const uint32_t lsrc = e.x, ln = e.y, ml = e.z, off = e.w & 0xFFFFu;
             if (ln) {
                 if ((uint64_t)lsrc + ln > in_len || (uint64_t)op + ln > cap) return -1000;   // protocol violation
-                if ((e.w >> 16) < R_CAREFUL && (uint64_t)lsrc + ln + 3 > in_len) return -1001;   // wild reads must stay inside
+                if ((e.w >> 16) < R_CAREFUL && (uint64_t)lsrc + ln + p.lit_slack > in_len) return -1001;   // wild reads must stay inside
                 memcpy(out + op, gin + lsrc, ln);
                 op += ln;
             }
@@ -77,7 +79,7 @@ static int sim_run(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t ca
     return p.status;
 }
 
-// misalign: bits 0-1 source misalignment, bit 2 the copier moves 8 bytes per lane, bit 3 the small LDS layout (8-record queue)
+// misalign: bits 0-1 source misalignment, bit 2 a wide copier (offsets < 8 are rare, 16-byte words: 15 bytes of literal slack), bit 3 the small LDS layout (8-record queue), bit 4 the wave-level "any lane" tests fire at random (other lanes of the wavefront)
 extern "C" int split_parser_sim(const uint8_t* in, uint32_t in_len, uint8_t* out, uint32_t cap, uint32_t* out_len,
                                 uint64_t* detail, uint32_t misalign, uint32_t* n_records, uint32_t* n_steps) {
     return (misalign & 8u) ? sim_run<LayoutSmall>(in, in_len, out, cap, out_len, detail, misalign, n_records, n_steps)

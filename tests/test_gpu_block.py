@@ -32,10 +32,10 @@ def _gpu_decode(blk, data, cap, dict_data=None):
 
 
 # every decoder kernel behind lz4flex_decompress_batch: lanes > 0 = lz4_decompress.hip (variant 1) group widths,
-# -30 / -31 = pipelined decoder with 8 lanes x 4 B / 4 lanes x 8 B per block,
-# -408 / -464 = parser / copier split decoder with 8 / 64 blocks per workgroup, -5 = one block per wavefront (wave decoder),
-# -6 = the wave decoder with a parser and an executor wavefront per block
-DECODERS = [8, 16, 32, 64, -30, -31, -408, -464, -5, -6]
+# -408 / -432 / -464 = parser / copier split decoder with 8 / 32 / 64 blocks per workgroup (8 copier lanes x 4 bytes per block;
+# 64: 4 lanes x 16 bytes), -5 = one block per wavefront (wave decoder), -6 = the wave decoder with a parser and an executor
+# wavefront per block
+DECODERS = [8, 16, 32, 64, -408, -432, -464, -5, -6]
 
 
 def _select_decoder(lib, ctx, lanes):
@@ -45,9 +45,6 @@ def _select_decoder(lib, ctx, lanes):
     elif lanes <= -400:
         assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 4) == 0
         assert lib.lz4flex_set_tuning(ctx, b"decompress_blocks_per_wg", -lanes - 400) == 0
-    elif lanes <= -30:
-        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 3) == 0
-        assert lib.lz4flex_set_tuning(ctx, b"decompress_geometry", -lanes - 30) == 0
     elif lanes in (-5, -6):
         assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", -lanes) == 0
     else:

@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Time and check several builds of the library's split decoder in ONE process (GPU minutes are scarce): every path given is a
+variant library built by `python -m lz4_flex_amd.build --variant NAME -D...` (linked -Bsymbolic, so each library calls its own
+kernels).  For each: (1) an adversarial batch -- every prefix of a small block, single-byte corruptions, short sinks, runs,
+short-period data, random data -- decoded with the split decoder (64 blocks per workgroup) must equal the oracle's result
+block by block (bytes, length, status, OutputTooSmall detail); (2) the configs[1] workload (16 384 x 64 KiB JSON tiles,
+compressed once by the default library) is decoded --reps times, timed with events on the launch stream, and compared with
+the source.  Not the reported bench (bench.py)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def bind(path):
+    from lz4_flex_amd import _lib as L
+    lib = C.CDLL(path)
+    for name in ("lz4flex_ctx_create", "lz4flex_ctx_destroy", "lz4flex_set_tuning", "lz4flex_decompress_batch", "lz4flex_build_id",
+                 "lz4flex_last_error"):
+        res, args = L.SIGNATURES[name]
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def adversarial():
+    """[(compressed bytes, sink capacity)]"""
+    import random
+    import oracle_api as O
+    rnd = random.Random(5)
+    cases = []
+    small = O.fixture_plain("compression_1k")
+    blk = O.compress(small)
+    for k in range(len(blk) + 1):
+        cases.append((blk[:k], len(small)))
+    mid = O.fixture_plain("compression_34k")
+    cm = O.compress(mid)
+    for k in range(0, len(cm), 11):
+        bad = bytearray(cm)
+        bad[k] ^= 0x5A
+        cases.append((bytes(bad), len(mid)))
+    for cap in (0, 1, 100, len(mid) - 1, len(mid) + 1000):
+        cases.append((cm, cap))
+    gen = [bytes(30000), b"ab" * 9000, b"abc" * 7000, bytes(range(5)) * 3000, bytes(range(7)) * 2000, bytes(range(13)) * 3000,
+           bytes(range(17)) * 2000, bytes(range(33)) * 900, bytes(rnd.getrandbits(8) for _ in range(20000)),
+           bytes(rnd.choice(b"ab") for _ in range(40000)), O.fixture_plain("compression_65k")[:65536],
+           O.fixture_plain("compression_66k_JSON")[:65536], b"x" * 300 + bytes(rnd.getrandbits(8) for _ in range(300)) + b"y" * 70000]
+    for d in gen:
+        for enc in (O.compress, O.c_compress):
+            c = enc(d)
+            cases.append((c, len(d)))
+            cases.append((c[:-1], len(d)))
+            cases.append((c, len(d) - 7))
+    for n in range(0, 40):
+        d = bytes(rnd.getrandbits(2) for _ in range(n))
+        cases.append((O.compress(d), n))
+    return cases
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("libs", nargs="+")
+    ap.add_argument("--blocks", type=int, default=16384)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--data", default="json")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import oracle_api as O
+    from lz4_flex_amd import _lib as L, workloads
+    base = L.load()
+    dev = torch.device("cuda", 0)
+    n, B = args.blocks, 65536
+    src = workloads.json_tiles(O.fixture_plain("compression_66k_JSON" if args.data == "json" else "compression_65k"), n * B, device=dev)
+    stride = (20 + B * 110 // 100 + 63) // 64 * 64
+    comp = torch.empty(n * stride, dtype=torch.uint8, device=dev)
+    ar = torch.arange(n, dtype=torch.int64, device=dev)
+    in_off, comp_off = ar * B, ar * stride
+    in_len = torch.full((n,), B, dtype=torch.int32, device=dev)
+    cap = torch.full((n,), stride, dtype=torch.int32, device=dev)
+    clen = torch.zeros(n, dtype=torch.int32, device=dev)
+    st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ctx0 = C.c_void_p()
+    assert base.lz4flex_ctx_create(C.byref(ctx0), 0) == 0
+    assert base.lz4flex_compress_batch(ctx0, p(src), p(in_off), p(in_len), None, n, p(comp), p(comp_off), p(cap), p(clen), p(st),
+                                       L.MEM_DEVICE, stream) == 0, L.last_error()
+    torch.cuda.synchronize()
+    assert int((st != 0).sum().item()) == 0
+
+    # the adversarial batch and the oracle's verdicts
+    cases = adversarial()
+    want = [O.decompress(c, k) for c, k in cases]
+    a_in = np.frombuffer(b"".join(c for c, _ in cases) + bytes(64), dtype=np.uint8)
+    a_ioff = np.cumsum([0] + [len(c) for c, _ in cases[:-1]]).astype(np.uint64)
+    a_ilen = np.array([len(c) for c, _ in cases], dtype=np.uint32)
+    a_cap = np.array([k for _, k in cases], dtype=np.uint32)
+    a_ooff = np.cumsum([0] + [k + 64 for _, k in cases[:-1]]).astype(np.uint64)
+    out_bytes = int(a_ooff[-1]) + int(a_cap[-1]) + 64
+    t_in, t_ioff, t_ilen = torch.from_numpy(a_in.copy()).to(dev), torch.from_numpy(a_ioff.astype(np.int64)).to(dev), torch.from_numpy(a_ilen.astype(np.int32)).to(dev)
+    t_ooff, t_cap = torch.from_numpy(a_ooff.astype(np.int64)).to(dev), torch.from_numpy(a_cap.astype(np.int32)).to(dev)
+    na = len(cases)
+
+    for path in args.libs:
+        lib = bind(path)
+        ctx = C.c_void_p()
+        assert lib.lz4flex_ctx_create(C.byref(ctx), 0) == 0
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 4) == 0
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_blocks_per_wg", 64) == 0
+        tag = "%s [%s]" % (os.path.basename(os.path.dirname(path)), lib.lz4flex_build_id().decode())
+        # (1) adversarial batch
+        t_out = torch.full((out_bytes,), 0xA5, dtype=torch.uint8, device=dev)
+        t_ol = torch.zeros(na, dtype=torch.int32, device=dev)
+        t_st = torch.full((na,), -1, dtype=torch.int32, device=dev)
+        t_det = torch.zeros(2 * na, dtype=torch.int64, device=dev)
+        rc = lib.lz4flex_decompress_batch(ctx, p(t_in), p(t_ioff), p(t_ilen), na, p(t_out), p(t_ooff), p(t_cap), p(t_ol), p(t_st), p(t_det),
+                                          L.MEM_DEVICE, stream)
+        torch.cuda.synchronize()
+        bad = []
+        if rc != 0:
+            bad.append("rc=%d %s" % (rc, lib.lz4flex_last_error().decode(errors="replace")))
+        else:
+            h_out, h_ol, h_st, h_det = t_out.cpu().numpy(), t_ol.cpu().numpy(), t_st.cpu().numpy(), t_det.cpu().numpy()
+            for i, ((c, k), w) in enumerate(zip(cases, want)):
+                o = int(a_ooff[i])
+                if w[0] == "ok":
+                    if h_st[i] != 0 or h_ol[i] != len(w[1]) or h_out[o:o + len(w[1])].tobytes() != w[1]:
+                        bad.append("case %d (in %d cap %d): want ok/%d got st %d len %d" % (i, len(c), k, len(w[1]), h_st[i], h_ol[i]))
+                else:
+                    name = O.ERR_NAMES.get(int(h_st[i]), str(h_st[i]))
+                    if name != w[0] or (w[0] == "OutputTooSmall" and (int(h_det[2 * i]), int(h_det[2 * i + 1])) != tuple(w[1])):
+                        bad.append("case %d (in %d cap %d): want %s %s got %s (%d, %d)" % (i, len(c), k, w[0], w[1], name, h_det[2 * i], h_det[2 * i + 1]))
+                if h_out[o + k:o + k + 64].tobytes() != b"\xA5" * 64:
+                    bad.append("case %d: wrote behind its sink" % i)
+        # (2) the bench workload
+        back = torch.empty(n * B, dtype=torch.uint8, device=dev)
+        blen = torch.zeros(n, dtype=torch.int32, device=dev)
+        bst = torch.full((n,), -1, dtype=torch.int32, device=dev)
+
+        def dec_once():
+            assert lib.lz4flex_decompress_batch(ctx, p(comp), p(comp_off), p(clen), n, p(back), p(in_off), p(in_len), p(blen), p(bst), None,
+                                                L.MEM_DEVICE, stream) == 0, lib.lz4flex_last_error()
+        dec_once(); dec_once(); torch.cuda.synchronize()
+        ok = int((bst != 0).sum().item()) == 0 and torch.equal(back, src)
+        if hasattr(lib, "lz4flex_debug_phase_split"):
+            lib.lz4flex_debug_phase_split.argtypes = [C.c_void_p, C.c_int]
+            v = (C.c_ulonglong * 16)()
+            lib.lz4flex_debug_phase_split(None, 1)
+            dec_once(); torch.cuda.synchronize()
+            lib.lz4flex_debug_phase_split(v, 0)
+            v = list(v)
+            pw = max(n // 64, 1)
+            cw = max(v[9], 1)
+            print("  phases: parser wave cycles %.0f, steps %.0f (%.0f cycles per step); lane steps live %d, queue full %.1f%%, ring not ready %.1f%%, "
+                  "exact %.2f%%, records %d; copier: sum of wave cycles per workgroup %.0f, iterations per workgroup %.0f, write-back visits %.0f, cycles in them %.0f; "
+                  "group-steps piece %d idle %d blocked %d" %
+                  (v[0] / pw, v[1] / pw, v[0] / max(v[1], 1), v[2], 100.0 * v[3] / max(v[2], 1), 100.0 * v[4] / max(v[2], 1), 100.0 * v[5] / max(v[2], 1), v[6],
+                   v[8] / pw, v[9] / pw, v[10] / pw, v[14] / pw, v[11], v[12], v[13]), flush=True)
+        ts = []
+        for _ in range(args.reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); dec_once(); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        print("%-34s adversarial %s (%d cases)  bench round trip %s  ms %s" %
+              (tag, "OK" if not bad else "FAIL %d" % len(bad), na, ok, " ".join("%.3f" % t for t in ts)), flush=True)
+        for b in bad[:6]:
+            print("    " + b, flush=True)
+        lib.lz4flex_ctx_destroy(ctx)
+
+
+if __name__ == "__main__":
+    main()
