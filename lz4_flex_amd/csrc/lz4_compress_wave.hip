@@ -488,8 +488,8 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
     uint32_t cursor = s0, carry = 0u, dlast = 0u;
     // sequences chosen but not encoded yet: lane k < npend holds the k-th
     uint32_t psq = 0u, psp = 0u, npend = 0u;
-#ifdef LZ4W_PROF_STEPS      // tools: cycles per part of a superstep -> prof[8..13] (heads, compaction + lengths, scan, walk, merge + encode, supersteps)
-    uint64_t pt[5] = {0, 0, 0, 0, 0}, pn = 0, pt0 = __builtin_readcyclecounter();
+#ifdef LZ4W_PROF_STEPS      // tools: cycles per part of a superstep -> prof[8..15] (heads, compaction + lengths, scan, walk, merge, supersteps, loop + cand[] wait, encode_seqs)
+    uint64_t pt[7] = {0, 0, 0, 0, 0, 0, 0}, pn = 0, pt0 = __builtin_readcyclecounter();
 #define LZ4W_TICK(i) { const uint64_t t_ = __builtin_readcyclecounter(); pt[i] += t_ - pt0; pt0 = t_; }
 #elif defined(LZ4W_MARK)   // tools: phase boundaries visible in a -S listing
 #define LZ4W_TICK(i) asm volatile("; LZ4W_PHASE_END " #i);
@@ -512,7 +512,9 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
     // was changed, the caller halves.
     auto superstep = [&](auto nsc, const uint32_t b, const uint32_t t0, const uint32_t t1, const uint32_t t2, const uint32_t t3) -> bool {
         constexpr uint32_t NS = decltype(nsc)::value;
-        LZ4W_TICK(4)
+#ifdef LZ4W_PROF_STEPS
+        LZ4W_TICK(5)
+#endif
 #ifdef LZ4W_EXP_PAD_VALU     // tools: what does one more vector / scalar instruction per superstep cost?
         { uint32_t pad_ = lane; _Pragma("unroll") for (int i_ = 0; i_ < LZ4W_EXP_PAD_VALU; ++i_) asm volatile("v_add_u32 %0, 1, %0" : "+v"(pad_)); asm volatile("" :: "v"(pad_)); }
 #endif
@@ -736,7 +738,7 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
         const uint32_t n0 = (uint32_t)__builtin_popcountll(S0), n1 = (uint32_t)__builtin_popcountll(S1),
                        n2 = (uint32_t)__builtin_popcountll(S2), n3 = (uint32_t)__builtin_popcountll(S3);
         const uint32_t nsel = n0 + n1 + n2 + n3;
-        if (nsel == 0u) return true;
+        if (nsel == 0u) { LZ4W_TICK(4) return true; }
 #ifdef LZ4W_EXP_NOENC
         asm volatile("" :: "s"(S0), "s"(S1), "s"(S2), "s"(S3));
         return true;
@@ -758,17 +760,22 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
             scatter(0u);
             uint32_t nq = 0u, np = 0u;
             if (lane < nsel) { nq = cmp[lane]; np = tmp[lane]; }
+            LZ4W_TICK(4)
             st = encode_seqs(psq, psp, npend, w, body_, lane, 0u, st);
             psq = nq; psp = np; npend = nsel;
+#ifdef LZ4W_PROF_STEPS
+            LZ4W_TICK(6)
+#endif
             return true;
         }
         scatter(npend);
         if ((lane >= npend) & (lane < npend + nsel)) { psq = cmp[lane]; psp = tmp[lane]; }
         npend += nsel;
+        LZ4W_TICK(4)
         return true;
     };
 
-    // cand[]: 8 bytes per lane and 256-block (see index_window), fetched one block ahead.  The load is unconditional (the
+    // cand[]: 8 bytes per lane and 256-block (see index_window), fetched one block ahead (two blocks ahead: same time).  The load is unconditional (the
     // block behind the last one is still inside the workspace): a conditional load made hipcc wait for the data right
     // where it was requested.
     u32x2 dn = *reinterpret_cast<const g_u32x2*>(cand_t + ((s0 >> 8) * 512u + lane * 8u));
@@ -795,6 +802,8 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
     if (prof_ && lane == 0u) {
         for (int i = 0; i < 5; ++i) atomicAdd(prof_ + 8 + i, (unsigned long long)pt[i]);
         atomicAdd(prof_ + 13, (unsigned long long)pn);
+        atomicAdd(prof_ + 14, (unsigned long long)pt[5]);
+        atomicAdd(prof_ + 15, (unsigned long long)pt[6]);
     }
 #endif
     if (lane == 0u) {

@@ -32,7 +32,7 @@ for only in ("compress", "decompress"):
             k = r.get("Kernel_Name", "")
             if "lz4" not in k and "CompareEq" not in k:
                 continue
-            agg[re.sub(r"\(.*", "", k)[-70:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[re.sub(r"\(.*", "", k)[-110:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         print("== %s pass, kernel %s" % (only, k))
         for c, vals in sorted(v.items()):

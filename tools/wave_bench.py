@@ -76,9 +76,9 @@ def main():
         names = ["idx_busy", "idx_barrier", "match(sum 8 waves)", "wait_after_match", "place", "load_window", "wait_after_load"]
         print("per window cycles: " + ", ".join("%s=%.0f" % (nm, x / nw) for nm, x in zip(names, v)) + " windows=%d" % v[7], flush=True)
         if v[13]:
-            sn = ["heads", "compact+lengths", "scan", "walk", "encode+rest"]
+            sn = ["heads", "compact+lengths", "scan", "walk", "merge"]
             print("per superstep cycles (LZ4W_PROF_STEPS build): " + ", ".join("%s=%.0f" % (nm, x / v[13]) for nm, x in zip(sn, v[8:13])) +
-                  " supersteps/window=%.1f" % (v[13] / nw), flush=True)
+                  " loop+cand-wait=%.0f encode_seqs=%.0f supersteps/window=%.1f" % (v[14] / v[13], v[15] / v[13], v[13] / nw), flush=True)
     ok = int((st != 0).sum().item()) == 0 and int((bst != 0).sum().item()) == 0 and torch.equal(back, src)
     if hasattr(lib, "lz4flex_debug_wdec_prof"):          # -DLZ4D_PROF variant build
         lib.lz4flex_debug_wdec_prof.argtypes = [C.c_void_p, C.c_int]
