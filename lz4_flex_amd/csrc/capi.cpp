@@ -418,7 +418,8 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
         hipLaunchKernelGGL(lz4flex_pack_results_kernel, dim3(n), dim3(256), 0, s, d + a_out,
                            (const uint64_t*)(dd + at_out_off), (const uint32_t*)(dd + at_out_len),
                            (const int32_t*)(dd + at_status), d_dense, d + a_in, n);
-        if (hipGetLastError() != hipSuccess) return hip_fail(hipGetLastError(), "pack kernel launch");
+        const hipError_t pe = hipGetLastError();              // (reading it clears it: read once)
+        if (pe != hipSuccess) return hip_fail(pe, "pack kernel launch");
         HIP_TRY(hipMemcpyAsync(c->h_pay, d + a_in, (size_t)produced, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         at = 0;
@@ -556,6 +557,8 @@ int lz4flex_compress_chains(lz4flex_ctx* ctx, const void* in_base, const lz4flex
         return le == hipSuccess ? 0 : hip_fail(le, "chain kernel launch");
     }
     if (mem_kind != LZ4FLEX_MEM_HOST) return -LZ4FLEX_E_INVALID_ARG;
+    for (uint32_t k = 0; k < n_chains; k++)                     // host arrays can be checked: a chain stays inside `blocks`
+        if (chain_first[k] > n_blocks || chain_count[k] > n_blocks - chain_first[k]) return -LZ4FLEX_E_INVALID_ARG;
     lz4flex_ctx* c = ctx;
     int prev = 0;
     (void)hipGetDevice(&prev);
@@ -651,6 +654,7 @@ int64_t lz4flex_compress_into_with_dict(const uint8_t* in, size_t in_len, uint8_
 
 int64_t lz4flex_compress_prepend_size(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap) {
     // compress.rs:624-634: 4-byte LE length, then the block
+    if (in_len > 0xFFFFFFFFull) return -LZ4FLEX_E_INVALID_ARG;   // (nothing is written before the arguments are known to be fine)
     if (out_cap < 4 || out_cap - 4 < lz4flex_get_maximum_output_size(in_len)) return -LZ4FLEX_E_OUTPUT_TOO_SMALL;
     const uint32_t n = (uint32_t)in_len;
     out[0] = (uint8_t)n; out[1] = (uint8_t)(n >> 8); out[2] = (uint8_t)(n >> 16); out[3] = (uint8_t)(n >> 24);
@@ -777,6 +781,7 @@ int64_t lz4flex_compress_into_with_table(const uint8_t* in, size_t in_len, uint8
 // compress_prepend_size_with_dict, src/block/compress.rs:692-694: LE u32 length, then compress_into_with_dict's block
 int64_t lz4flex_compress_prepend_size_with_dict(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, const uint8_t* dict,
                                                 size_t dict_len) {
+    if (in_len > 0x7FFFFFFFull) return -LZ4FLEX_E_INVALID_ARG;
     if (out_cap < 4 || out_cap - 4 < lz4flex_get_maximum_output_size(in_len)) return -LZ4FLEX_E_OUTPUT_TOO_SMALL;
     const uint32_t n = (uint32_t)in_len;
     out[0] = (uint8_t)n; out[1] = (uint8_t)(n >> 8); out[2] = (uint8_t)(n >> 16); out[3] = (uint8_t)(n >> 24);

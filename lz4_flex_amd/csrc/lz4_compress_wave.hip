@@ -465,8 +465,8 @@ template <uint32_t V> struct UConst { static constexpr uint32_t value = V; };
 // compacted into the 64 lanes (rank = popcount of the head ballots below the lane, a 256-byte LDS buffer), counted,
 // prefix-maximised and gathered back to the positions; a scalar greedy walk over the eligibility masks marks the chosen
 // positions, which join the pending sequences in lanes (encode_seqs takes them a wavefront at a time).
-// A superstep holds at most 64 heads by construction: 256 positions if that many fit, else 128, else 64 (the scalar
-// model walks the same supersteps).
+// A superstep holds at most 128 heads: 256 positions if that many fit, else 128 (the scalar model walks the same
+// supersteps); more than 64 heads pass through the wavefront in two chunks of 64.
 //
 // What is counted here is instructions, not latencies: 18 wavefronts share a CU whose ONE scalar unit retires about an
 // instruction per cycle, and a vector instruction occupies its SIMD for 4 cycles whatever the number of active lanes;
@@ -508,7 +508,7 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
         return umin3(umin3(f0, f1 | 32u, f2 | 64u), f3 | 96u, 128u);        // f < 32 or all ones: "or" is "add" or keeps "none"
     };
 
-    // One superstep of NS steps at b (a multiple of 64 NS); t_u = distances of step u.  false: more than 64 heads, nothing
+    // One superstep of NS steps at b (a multiple of 64 NS); t_u = distances of step u.  false: more than 128 heads, nothing
     // was changed, the caller halves.
     auto superstep = [&](auto nsc, const uint32_t b, const uint32_t t0, const uint32_t t1, const uint32_t t2, const uint32_t t3) -> bool {
         constexpr uint32_t NS = decltype(nsc)::value;
@@ -565,96 +565,132 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
         const uint32_t c0 = (uint32_t)__builtin_popcountll(M0), c1 = (uint32_t)__builtin_popcountll(M1),
                        c2 = (uint32_t)__builtin_popcountll(M2), c3 = (uint32_t)__builtin_popcountll(M3);
         const uint32_t H = c0 + c1 + c2 + c3;
-        if (NS > 1u && H > 64u) return false;
+        if (NS > 2u && H > 128u) return false;                   // (128 positions hold at most 128 heads)
         dlast = rdlane(tl, 63u);
         LZ4W_TICK(0)
         if (H == 0u && cursor >= e1) return true;                // no head, nothing to select: the running best is unchanged
-        // compaction: head of rank r -> lane r, as (position << 16 | distance); v_mbcnt adds the heads of the earlier steps
+        // compaction: head of rank r -> lane r, as (position << 16 | distance); v_mbcnt adds the heads of the earlier steps.
+        // A superstep holds up to 128 heads: more than 64 are counted in two chunks of 64 (ranks 0..63, then 64..) -- the
+        // positions' part of a superstep (heads, scan, walk, merge) is paid once for them; round 2 first halved such a
+        // superstep and paid everything twice (JSON tiles: 44 of a window's 256 blocks, text: 184).
         const uint32_t r0 = mbcnt(M0, 0u), r1 = mbcnt(M1, c0), r2 = mbcnt(M2, c0 + c1), r3 = mbcnt(M3, c0 + c1 + c2);   // heads before this position
         const bool hh0 = __builtin_amdgcn_inverse_ballot_w64(M0), hh1 = __builtin_amdgcn_inverse_ballot_w64(M1),
                    hh2 = __builtin_amdgcn_inverse_ballot_w64(M2), hh3 = __builtin_amdgcn_inverse_ballot_w64(M3);
-        if (hh0) cmp[r0] = (p0 << 16) | t0;
-        if (NS > 1u) if (hh1) cmp[r1] = (p1 << 16) | t1;
-        if (NS > 2u) { if (hh2) cmp[r2] = (p2 << 16) | t2; if (hh3) cmp[r3] = (p3 << 16) | t3; }
-        const bool isH = lane < H;
-        uint32_t hv = 0u;
-        if (isH) hv = cmp[lane];
-        const uint32_t p = hv >> 16, d = hv & 0xFFFFu;
-        // true match lengths of the heads (their first 4 bytes are known to match)
-        uint32_t lim = __builtin_elementwise_sub_sat(mend, p);
-        lim = lim < CAP ? lim : CAP;
-        uint32_t k = 4u;
-        bool act = isH & (lim > 4u);
+        // the match of one chunk's heads that reaches furthest: bestv[r] = best among heads 0..r of the chunk and everything
+        // before it (cin); returns the best behind the chunk's last head
+        auto chunk_best = [&](const uint32_t hv, const bool isH, const uint32_t cin, uint32_t& bestv) -> uint32_t {
+            const uint32_t p = hv >> 16, d = hv & 0xFFFFu;
+            // true match lengths of the heads (their first 4 bytes are known to match)
+            uint32_t lim = __builtin_elementwise_sub_sat(mend, p);
+            lim = lim < CAP ? lim : CAP;
+            uint32_t k = 4u;
+            bool act = isH & (lim > 4u);
 #ifdef LZ4W_EXP_NOLEN
-        act = false;
+            act = false;
 #endif
-        if (__builtin_amdgcn_ballot_w64(act) != 0ull) {
-            if (act) {                                          // 16 bytes, branch-free: most candidates end here
-                const lds_u8* ap = win + p + 4u;
-                u32x4 va, vc;
-                __builtin_memcpy(&va, (const void*)ap, 16);
-                __builtin_memcpy(&vc, (const void*)(ap - d), 16);
-                const uint32_t bits = first_diff(va, vc);
-                k = 4u + (bits >> 3);
-                act = (bits == 128u) & (k < lim);
-            }
-            for (uint32_t rounds = 0u; __builtin_amdgcn_ballot_w64(act) != 0ull; ++rounds) {
-                if (rounds == 2u) {
-                    // Heads still matching after LONGK bytes.  In a run (zeros, a repeated record) EVERY position is one, and 64
-                    // lanes reading unaligned to the cap keep the LDS pipe busy for 16 ms per GiB: a head followed within NEARP
-                    // positions by another such head stays at LONGK bytes (it starts just before a match that is at least as
-                    // long as it is known to be); the last one of such a group goes on.
-                    static_assert(LONGK == 4u + 16u + 2u * 32u, "the check sits behind the third compare round");
-                    const uint64_t am = __builtin_amdgcn_ballot_w64(act);
-                    if ((uint32_t)__builtin_popcountll(am) >= LONGN) {       // (a handful of long matches is ordinary data: no check)
-                    const uint64_t above = (am >> lane) >> 1;                                      // active lanes behind this one, bit 0 = lane + 1
-                    const uint32_t next = lane + 1u + ctz64(above | (1ull << 63));                 // the next active lane (anything if none)
-                    const uint32_t pn = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((next & 63u) << 2), (int)p);
-                    act = act & ((above == 0ull) | (pn - p > NEARP));
-                    if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
+            if (__builtin_amdgcn_ballot_w64(act) != 0ull) {
+                if (act) {                                          // 16 bytes, branch-free: most candidates end here
+                    const lds_u8* ap = win + p + 4u;
+                    u32x4 va, vc;
+                    __builtin_memcpy(&va, (const void*)ap, 16);
+                    __builtin_memcpy(&vc, (const void*)(ap - d), 16);
+                    const uint32_t bits = first_diff(va, vc);
+                    k = 4u + (bits >> 3);
+                    act = (bits == 128u) & (k < lim);
+                }
+                for (uint32_t rounds = 0u; __builtin_amdgcn_ballot_w64(act) != 0ull; ++rounds) {
+                    if (rounds == 2u) {
+                        // Heads still matching after LONGK bytes.  In a run (zeros, a repeated record) EVERY position is one, and 64
+                        // lanes reading unaligned to the cap keep the LDS pipe busy for 16 ms per GiB: a head followed within NEARP
+                        // positions by another such head stays at LONGK bytes (it starts just before a match that is at least as
+                        // long as it is known to be); the last one of such a group goes on.
+                        static_assert(LONGK == 4u + 16u + 2u * 32u, "the check sits behind the third compare round");
+                        const uint64_t am = __builtin_amdgcn_ballot_w64(act);
+                        if ((uint32_t)__builtin_popcountll(am) >= LONGN) {       // (a handful of long matches is ordinary data: no check)
+                        const uint64_t above = (am >> lane) >> 1;                                      // active lanes behind this one, bit 0 = lane + 1
+                        const uint32_t next = lane + 1u + ctz64(above | (1ull << 63));                 // the next active lane (anything if none)
+                        const uint32_t pn = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((next & 63u) << 2), (int)p);
+                        act = act & ((above == 0ull) | (pn - p > NEARP));
+                        if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
+                        }
+                    }
+                    if (act) {                                      // 32 bytes per further round
+                        const lds_u8* ap = win + p + k;
+                        u32x4 va0, vc0, va1, vc1;
+                        __builtin_memcpy(&va0, (const void*)ap, 16);
+                        __builtin_memcpy(&vc0, (const void*)(ap - d), 16);
+                        __builtin_memcpy(&va1, (const void*)(ap + 16), 16);
+                        __builtin_memcpy(&vc1, (const void*)(ap - d + 16), 16);
+                        const uint32_t d0 = first_diff(va0, vc0), d1 = first_diff(va1, vc1);
+                        const uint32_t bits = d0 < 128u ? d0 : 128u + d1;
+                        k += bits >> 3;
+                        act = (bits == 256u) & (k < lim);
                     }
                 }
-                if (act) {                                      // 32 bytes per further round
-                    const lds_u8* ap = win + p + k;
-                    u32x4 va0, vc0, va1, vc1;
-                    __builtin_memcpy(&va0, (const void*)ap, 16);
-                    __builtin_memcpy(&vc0, (const void*)(ap - d), 16);
-                    __builtin_memcpy(&va1, (const void*)(ap + 16), 16);
-                    __builtin_memcpy(&vc1, (const void*)(ap - d + 16), 16);
-                    const uint32_t d0 = first_diff(va0, vc0), d1 = first_diff(va1, vc1);
-                    const uint32_t bits = d0 < 128u ? d0 : 128u + d1;
-                    k += bits >> 3;
-                    act = (bits == 256u) & (k < lim);
-                }
             }
-        }
-        k = k < lim ? k : lim;
-        LZ4W_TICK(1)
-        const uint32_t own_e = (isH & (k >= 4u)) ? hv + (k << 16) : 0u;      // (p + k) << 16 | d
-        // bestv[r]: the match that reaches furthest among heads 0..r and everything before the superstep;
-        // bestsh[r]: the same before head r, i.e. with r heads passed
-        uint32_t bestv = wave_incl_max(own_e);
-        bestv = bestv > carry ? bestv : carry;
-        const uint32_t bestsh = dpp_wave_shr1(bestv, carry);
-        carry = rdlane(bestv, 63u);
+            k = k < lim ? k : lim;
+            const uint32_t own_e = (isH & (k >= 4u)) ? hv + (k << 16) : 0u;      // (p + k) << 16 | d
+            bestv = wave_incl_max(own_e);
+            bestv = bestv > cin ? bestv : cin;
+            return rdlane(bestv, 63u);
+        };
         // back to positions: every position takes the best of the heads at or before it (a gather by rank), then the
         // eligibility mask of each step: a match of >= 4 that does not yield to the next position (one-step lazy
         // evaluation: the successor reaches further by more than a byte; the last position of a superstep has none)
         auto incl_rank = [](uint32_t rbefore, uint64_t m) -> uint32_t {      // rbefore + (lane's bit of m): one v_addc with m as the carry-in
             uint32_t ri; uint64_t co;
             asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(ri), "=s"(co) : "v"(rbefore), "s"(m));
-            return ri;                                            // <= 64; 64 (only with 64 heads) is patched below
+            return ri;                                            // <= H; H == all heads passed: the new running best
         };
-        auto best_at = [&](uint32_t ri) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ri << 2), (int)bestsh); };
         const uint32_t ri0 = incl_rank(r0, M0), ri1 = incl_rank(r1, M1), ri2 = incl_rank(r2, M2), ri3 = incl_rank(r3, M3);
-        uint32_t q0 = best_at(ri0), q1 = 0u, q2 = 0u, q3 = 0u;
-        if (NS > 1u) q1 = best_at(ri1);
-        if (NS > 2u) { q2 = best_at(ri2); q3 = best_at(ri3); }
-        if (H == 64u) {                                          // rank 64 = all heads passed: the new running best
-            q0 = ri0 >= 64u ? carry : q0;
-            q1 = ri1 >= 64u ? carry : q1;
-            q2 = ri2 >= 64u ? carry : q2;
-            q3 = ri3 >= 64u ? carry : q3;
+        uint32_t q0, q1 = 0u, q2 = 0u, q3 = 0u;
+        if (NS == 1u || H <= 64u) {
+            if (hh0) cmp[r0] = (p0 << 16) | t0;
+            if (NS > 1u) if (hh1) cmp[r1] = (p1 << 16) | t1;
+            if (NS > 2u) { if (hh2) cmp[r2] = (p2 << 16) | t2; if (hh3) cmp[r3] = (p3 << 16) | t3; }
+            const bool isH = lane < H;
+            uint32_t hv = 0u;
+            if (isH) hv = cmp[lane];
+            uint32_t bestv;
+            const uint32_t cin = carry;
+            carry = chunk_best(hv, isH, cin, bestv);
+            const uint32_t bestsh = dpp_wave_shr1(bestv, cin);      // the same before head r, i.e. with r heads passed
+            LZ4W_TICK(1)
+            auto best_at = [&](uint32_t ri) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ri << 2), (int)bestsh); };
+            q0 = best_at(ri0);
+            if (NS > 1u) q1 = best_at(ri1);
+            if (NS > 2u) { q2 = best_at(ri2); q3 = best_at(ri3); }
+            if (H == 64u) {                                      // rank 64 = all heads passed: the new running best
+                q0 = ri0 >= 64u ? carry : q0;
+                q1 = ri1 >= 64u ? carry : q1;
+                q2 = ri2 >= 64u ? carry : q2;
+                q3 = ri3 >= 64u ? carry : q3;
+            }
+        } else {
+            // 65..128 heads: ranks 0..63 through the wavefront, then ranks 64.. ; the results go to a 129-entry array in LDS --
+            // best[r] = the best with r heads passed: best[0] the running best before the superstep, best[1 + r] = bestv of
+            // rank r -- which starts one word below tmp | cmp (contiguous; LDS operations of a wavefront execute in order: a
+            // chunk's heads are read before its results overwrite them); the positions gather from it
+            lds_u32* const best = tmp - 1;
+            static_assert(192u + 256u == STG_BYTES && FLUSH_AT <= 188u, "tmp and cmp are contiguous, the word below them is free");
+            best[0] = carry;
+            if (hh0 && r0 < 64u) cmp[r0] = (p0 << 16) | t0;
+            if (hh1 && r1 < 64u) cmp[r1] = (p1 << 16) | t1;
+            if (NS > 2u) { if (hh2 && r2 < 64u) cmp[r2] = (p2 << 16) | t2; if (hh3 && r3 < 64u) cmp[r3] = (p3 << 16) | t3; }
+            uint32_t hv = cmp[lane], bestv;
+            const uint32_t cmid = chunk_best(hv, true, carry, bestv);
+            best[1u + lane] = bestv;
+            if (hh0 && r0 >= 64u) cmp[r0 - 64u] = (p0 << 16) | t0;
+            if (hh1 && r1 >= 64u) cmp[r1 - 64u] = (p1 << 16) | t1;
+            if (NS > 2u) { if (hh2 && r2 >= 64u) cmp[r2 - 64u] = (p2 << 16) | t2; if (hh3 && r3 >= 64u) cmp[r3 - 64u] = (p3 << 16) | t3; }
+            const bool isH1 = lane < H - 64u;
+            hv = 0u;
+            if (isH1) hv = cmp[lane];
+            carry = chunk_best(hv, isH1, cmid, bestv);
+            best[65u + lane] = bestv;
+            LZ4W_TICK(1)
+            q0 = best[ri0]; q1 = best[ri1];
+            if (NS > 2u) { q2 = best[ri2]; q3 = best[ri3]; }
         }
         const uint32_t e0 = q0 >> 16, ee1 = q1 >> 16, ee2 = q2 >> 16, ee3 = q3 >> 16;
         auto elig = [&](uint32_t pp, uint32_t e, uint32_t enext) -> uint64_t {
@@ -780,7 +816,7 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
     // where it was requested.
     u32x2 dn = *reinterpret_cast<const g_u32x2*>(cand_t + ((s0 >> 8) * 512u + lane * 8u));
     for (uint32_t B0 = s0; B0 < s1; B0 += 256u) {
-        // the four steps of this 256-block: as one superstep if it holds at most 64 heads, else in halves, else in quarters
+        // the four steps of this 256-block: as one superstep if it holds at most 128 heads, else in halves
         const uint32_t dq0 = dn.x & 0xFFFFu, dq1 = dn.x >> 16, dq2 = dn.y & 0xFFFFu, dq3 = dn.y >> 16;
         dn = *reinterpret_cast<const g_u32x2*>(cand_t + (((B0 >> 8) + 1u) * 512u + lane * 8u));
         if (superstep(UConst<4u>{}, B0, dq0, dq1, dq2, dq3)) continue;
@@ -789,12 +825,7 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
             const uint32_t bh = B0 + 128u * hf;
             if (bh >= s1) break;
             const uint32_t ta = hf ? dq2 : dq0, tb = hf ? dq3 : dq1;
-            if (superstep(UConst<2u>{}, bh, ta, tb, 0u, 0u)) continue;
-#pragma unroll 1
-            for (uint32_t qt = 0u; qt < 2u; ++qt) {
-                if (bh + 64u * qt >= s1) break;
-                superstep(UConst<1u>{}, bh + 64u * qt, qt ? tb : ta, 0u, 0u, 0u);
-            }
+            superstep(UConst<2u>{}, bh, ta, tb, 0u, 0u);          // (128 positions: never more than 128 heads)
         }
     }
     st = encode_seqs(psq, psp, npend, w, body_, lane, 1u, st);

@@ -214,7 +214,8 @@ struct Copier {
         const bool far = !isl && msrc < L0;
 #endif
         // one load per step and lane: literal bytes, far match bytes (already written back: msrc + PIECE <= L0 + PIECE - 1 < F),
-        // or nothing useful (position 0).  Literal positions are clamped so that no lane reads behind the block.
+        // or nothing useful (position 0; a load only where a piece needs one: 1.94 instead of 1.65 ms, hipcc waits for a
+        // conditional load where it is issued).  Literal positions are clamped so that no lane reads behind the block.
         const uint32_t lpos = lit_src + WB * g;
         const uint32_t off = isl ? (lpos < ilen_w ? lpos : ilen_w) : (far ? msrc + WB * g : 0u);
 #ifdef LZ4S_EXP_NOGLOB   // ... no global load at all in a step

@@ -32,6 +32,7 @@
 #define LONGK 84u
 #define NEARP 20u
 #define LONGN 8u
+#define MAXHEADS 128u   /* heads per superstep: the kernel counts them in chunks of 64 (one wavefront) */
 
 typedef struct {
     uint32_t nseg;   /* segments per 64 KiB window (the kernel's worker wavefronts); boundaries are multiples of 512 */
@@ -84,8 +85,8 @@ static int is_head(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_
 }
 
 /* parse of one block; returns the number of sequences (the last one has mlen == 0: final literals).
- * A segment is walked in "supersteps": 256 positions at a time when they hold at most 64 heads (the kernel
- * compacts the heads of a superstep into the 64 lanes of its wavefront), else 128, else 64. */
+ * A segment is walked in "supersteps": 256 positions at a time when they hold at most 128 heads (the kernel
+ * compacts the heads of a superstep into the 64 lanes of its wavefront, 64 heads at a time), else 128. */
 size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_params *P, lz4w_seq *seqs) {
     size_t ns = 0;
     uint32_t anchor = 0;
@@ -104,24 +105,26 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
         uint32_t cursor = s0;
         uint32_t b = s0;
         while (b < s1) {
-            /* superstep size: the largest aligned power of two <= 256 whose positions hold <= 64 heads (64: always) */
+            /* superstep size: the largest aligned power of two <= 256 whose positions hold <= MAXHEADS heads (128: always) */
             uint32_t size = 256, e1 = 0;
             for (;; size >>= 1) {
                 if ((b & (size - 1)) == 0) {
                     e1 = (b + size < s1) ? b + size : s1;
                     uint32_t h = 0;
                     for (uint32_t p = b; p < e1; p++) h += (uint32_t)is_head(in, n, d, P, wbase, s0, s1, carry, p);
-                    if (h <= 64 || size == 64) break;
+                    if (h <= MAXHEADS || size == 64) break;
                 }
             }
             const uint32_t cnt = e1 - b;
             /* heads and their own lengths */
             uint32_t klen[256];
-            uint8_t is_long[256];
+            uint8_t is_long[256], chunk[256];
+            uint32_t rank = 0;
             for (uint32_t i = 0; i < cnt; i++) {
                 const uint32_t p = b + i;
-                own[i] = 0; klen[i] = 0; is_long[i] = 0;
+                own[i] = 0; klen[i] = 0; is_long[i] = 0; chunk[i] = 0xFF;
                 if (!is_head(in, n, d, P, wbase, s0, s1, carry, p)) continue;
+                chunk[i] = (uint8_t)(rank++ / WAVE);                  /* heads are counted 64 at a time, in position order */
                 const uint32_t dp = d[p];
                 uint32_t lim = (mend > p) ? mend - p : 0;
                 if (lim > P->cap) lim = P->cap;
@@ -130,14 +133,16 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
                 klen[i] = k;
                 is_long[i] = (k >= LONGK && lim > LONGK);            /* still matching at the check behind the third compare round */
             }
-            /* a head that still matches after LONGK bytes and is followed within NEARP positions by another such head of the
-             * superstep stops counting there (runs: every position would count to the cap); the last one of a group goes on */
-            uint32_t next_long = 0xFFFFFFFFu, n_long = 0;
-            for (uint32_t i = 0; i < cnt; i++) n_long += is_long[i];
-            for (uint32_t i = cnt; n_long >= LONGN && i-- > 0;) {     /* (a handful of long matches is ordinary data: left alone) */
-                if (!is_long[i]) continue;
-                if (next_long != 0xFFFFFFFFu && next_long - i <= NEARP) klen[i] = LONGK;
-                next_long = i;
+            /* a head that still matches after LONGK bytes and is followed within NEARP positions by another such head of its
+             * chunk stops counting there (runs: every position would count to the cap); the last one of a group goes on */
+            for (uint32_t c = 0; c * WAVE < rank; c++) {
+                uint32_t next_long = 0xFFFFFFFFu, n_long = 0;
+                for (uint32_t i = 0; i < cnt; i++) n_long += (chunk[i] == c) & is_long[i];
+                for (uint32_t i = cnt; n_long >= LONGN && i-- > 0;) {     /* (a handful of long matches is ordinary data: left alone) */
+                    if (!is_long[i] || chunk[i] != c) continue;
+                    if (next_long != 0xFFFFFFFFu && next_long - i <= NEARP) klen[i] = LONGK;
+                    next_long = i;
+                }
             }
             for (uint32_t i = 0; i < cnt; i++)
                 if (klen[i] >= 4) own[i] = ((b + i - wbase + klen[i]) << 16) | d[b + i];
