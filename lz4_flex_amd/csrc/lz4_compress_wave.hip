@@ -25,7 +25,7 @@
 //     after a barrier every worker places its segment's bytes: the literals left over at a segment's end are
 //     carried into the first sequence of the next segment (its token is written at that point).
 // HBM traffic: the input once, the output once; cand[] and the segment bodies stay in L2 / Infinity Cache
-// (329 728 B of workspace per workgroup, 512 workgroups).
+// (335 872 B of workspace per workgroup, 512 workgroups).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -51,9 +51,23 @@ constexpr uint32_t WINDOW = 65536u;
 #endif
 constexpr uint32_t WORKERS = LZ4W_WORKERS;   // worker wavefronts = segments per window
 constexpr uint32_t GROUPS = WINDOW / 512u;   // segment boundaries are multiples of 512 (one cand[] group)
-// segment w of a full window = [seg_lo(w), seg_lo(w + 1)); a shorter window clips them
-__host__ __device__ constexpr uint32_t seg_lo(uint32_t w) { return 512u * ((GROUPS * w) / WORKERS); }
-constexpr uint32_t SEG = seg_lo(1u) > WINDOW / WORKERS ? seg_lo(1u) : 512u * ((GROUPS + WORKERS - 1u) / WORKERS);   // longest segment
+// segment w of a full window = [seg_lo(w), seg_lo(w + 1)); a shorter window clips them.  Eight workers do not get equal
+// shares: a later segment sees more of the window, finds more candidates and costs more per position (JSON tiles, cycles per
+// window with 16 groups each: 241 226 224 232 253 252 252 263 k -- the window waits for the slowest), so the segments are
+// 16 17 17 17 15 16 15 15 groups long (the scalar model has the same table)
+__host__ __device__ constexpr uint32_t seg_lo(uint32_t w) {
+    if (WORKERS == 8u) {
+        constexpr uint32_t lo[9] = {0u, 16u, 33u, 50u, 67u, 82u, 98u, 113u, 128u};
+        return 512u * lo[w < 8u ? w : 8u];
+    }
+    return 512u * ((GROUPS * w) / WORKERS);
+}
+__host__ __device__ constexpr uint32_t seg_longest() {
+    uint32_t m = 0u;
+    for (uint32_t w = 0u; w < WORKERS; ++w) m = seg_lo(w + 1u) - seg_lo(w) > m ? seg_lo(w + 1u) - seg_lo(w) : m;
+    return m;
+}
+constexpr uint32_t SEG = seg_longest();   // longest segment
 constexpr uint32_t CAP = 1024u;           // longest match a head counts
 constexpr uint32_t SKIPD = 64u;           // a position buried this deep in a running match is not evaluated
 constexpr uint32_t CARRY_SLOTS = 16u;        // per block: a ring of {out_pos, pend, window} records, one cache line each
@@ -1198,6 +1212,12 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
             if (prof && lane == 0u)
                 for (uint32_t i = 0; i < 7u; ++i)
                     if (t_acc[i] != 0ull) atomicAdd(prof + i, (unsigned long long)t_acc[i]);
+#ifdef LZ4W_PROF_WORKERS    // tools: matching cycles per worker -> prof[8 + w], SIMD of the wavefront (HW_ID bits 5:4) -> prof[8 + w] high digits
+            if (prof && lane == 0u && w < 8u) {
+                const uint32_t simd = (__builtin_amdgcn_s_getreg((4 << 0) | (4 << 6) | (1 << 11))) & 3u;   // hwreg(HW_REG_HW_ID, 4, 2)
+                atomicAdd(prof + 8u + w, (unsigned long long)t_acc[2] + ((unsigned long long)simd << 56));
+            }
+#endif
             break;
         }
         if (w != WORKERS) do_load(it);

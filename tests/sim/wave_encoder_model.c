@@ -95,7 +95,11 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
     for (uint32_t sj = 0; sj < nwin * P->nseg; sj++) {
         const uint32_t wbase = (sj / P->nseg) * WINDOW;            /* candidates must lie in the segment's 64 KiB window */
         const uint32_t wj = sj % P->nseg;
-        uint32_t s0 = wbase + 512u * ((128u * wj) / P->nseg), s1 = wbase + 512u * ((128u * (wj + 1)) / P->nseg);
+        /* eight segments are 16 17 17 17 15 16 15 15 groups of 512 long (later segments cost more per position: the kernel's
+         * workers finish together), any other count tiles the window evenly */
+        static const uint32_t lo8[9] = {0, 16, 33, 50, 67, 82, 98, 113, 128};
+        uint32_t s0 = wbase + 512u * (P->nseg == 8 ? lo8[wj] : (128u * wj) / P->nseg);
+        uint32_t s1 = wbase + 512u * (P->nseg == 8 ? lo8[wj + 1] : (128u * (wj + 1)) / P->nseg);
         if (s0 > n) s0 = n;
         if (s1 > n) s1 = n;
         if (s0 == s1) continue;
