@@ -117,3 +117,40 @@ def lcg_bytes(n, seed, alphabet=256, run=1):
                 out[i] = b
                 i += 1
     return bytes(out)
+
+
+def adversarial_blocks():
+    """[(compressed bytes, sink capacity)]: every prefix of a small block, single-byte corruptions of a 34 KB one, short and
+    long sinks, runs, short-period data (offsets 2..33: the copiers' single-lane pieces and periodic path), random data (long
+    literal runs), blocks from both encoders, truncated and with a sink 7 bytes short, tiny inputs.  Shared by
+    tests/test_gpu_block.py (every decoder kernel against the oracle) and tools/dec_variants.py (variant builds)."""
+    import random
+    import oracle_api as O
+    rnd = random.Random(5)
+    cases = []
+    small = O.fixture_plain("compression_1k")
+    blk = O.compress(small)
+    for k in range(len(blk) + 1):
+        cases.append((blk[:k], len(small)))
+    mid = O.fixture_plain("compression_34k")
+    cm = O.compress(mid)
+    for k in range(0, len(cm), 11):
+        bad = bytearray(cm)
+        bad[k] ^= 0x5A
+        cases.append((bytes(bad), len(mid)))
+    for cap in (0, 1, 100, len(mid) - 1, len(mid) + 1000):
+        cases.append((cm, cap))
+    gen = [bytes(30000), b"ab" * 9000, b"abc" * 7000, bytes(range(5)) * 3000, bytes(range(7)) * 2000, bytes(range(13)) * 3000,
+           bytes(range(17)) * 2000, bytes(range(33)) * 900, bytes(rnd.getrandbits(8) for _ in range(20000)),
+           bytes(rnd.choice(b"ab") for _ in range(40000)), O.fixture_plain("compression_65k")[:65536],
+           O.fixture_plain("compression_66k_JSON")[:65536], b"x" * 300 + bytes(rnd.getrandbits(8) for _ in range(300)) + b"y" * 70000]
+    for d in gen:
+        for enc in (O.compress, O.c_compress):
+            c = enc(d)
+            cases.append((c, len(d)))
+            cases.append((c[:-1], len(d)))
+            cases.append((c, len(d) - 7))
+    for n in range(0, 40):
+        d = bytes(rnd.getrandbits(2) for _ in range(n))
+        cases.append((O.compress(d), n))
+    return cases

@@ -28,37 +28,9 @@ def bind(path):
 
 
 def adversarial():
-    """[(compressed bytes, sink capacity)]"""
-    import random
-    import oracle_api as O
-    rnd = random.Random(5)
-    cases = []
-    small = O.fixture_plain("compression_1k")
-    blk = O.compress(small)
-    for k in range(len(blk) + 1):
-        cases.append((blk[:k], len(small)))
-    mid = O.fixture_plain("compression_34k")
-    cm = O.compress(mid)
-    for k in range(0, len(cm), 11):
-        bad = bytearray(cm)
-        bad[k] ^= 0x5A
-        cases.append((bytes(bad), len(mid)))
-    for cap in (0, 1, 100, len(mid) - 1, len(mid) + 1000):
-        cases.append((cm, cap))
-    gen = [bytes(30000), b"ab" * 9000, b"abc" * 7000, bytes(range(5)) * 3000, bytes(range(7)) * 2000, bytes(range(13)) * 3000,
-           bytes(range(17)) * 2000, bytes(range(33)) * 900, bytes(rnd.getrandbits(8) for _ in range(20000)),
-           bytes(rnd.choice(b"ab") for _ in range(40000)), O.fixture_plain("compression_65k")[:65536],
-           O.fixture_plain("compression_66k_JSON")[:65536], b"x" * 300 + bytes(rnd.getrandbits(8) for _ in range(300)) + b"y" * 70000]
-    for d in gen:
-        for enc in (O.compress, O.c_compress):
-            c = enc(d)
-            cases.append((c, len(d)))
-            cases.append((c[:-1], len(d)))
-            cases.append((c, len(d) - 7))
-    for n in range(0, 40):
-        d = bytes(rnd.getrandbits(2) for _ in range(n))
-        cases.append((O.compress(d), n))
-    return cases
+    """[(compressed bytes, sink capacity)] -- tests/corpus.py::adversarial_blocks, the batch of tests/test_gpu_block.py"""
+    import corpus
+    return corpus.adversarial_blocks()
 
 
 def main():
