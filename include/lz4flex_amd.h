@@ -194,7 +194,10 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  * "compress_mode": 0 = throughput encoder (default; lz4_compress_wave.hip: a valid LZ4 block with this library's own
  *   parse -- any LZ4 decoder returns the input; ratio within a percent of the reference's, usually better), 1 = the
  *   reference's exact bytes (src/block/compress.rs:318-489 restated; about 3x slower).  Blocks with a dictionary / prefix
- *   and Linked frames always use the exact encoder.  Environment: LZ4FLEX_COMPRESS_MODE=exact|fast.
+ *   always use the exact encoder.  A Linked frame (src/frame/compress.rs:261-371) written in mode 0 holds independently
+ *   parsed blocks -- a valid Linked frame that any decoder returns to the input, with the Independent frame's ratio and one
+ *   launch per batch of blocks; in mode 1 it holds the reference's bytes (one dependency chain, milliseconds per block).
+ *   Environment: LZ4FLEX_COMPRESS_MODE=exact|fast.
  * Kernel selection, for measurements only (every choice produces the same bytes / lengths / error variants):
  * "decompress_variant": 0 = by batch size (default), 5 = one block per wavefront (lz4_decompress_wave.hip), 6 = the same with a
  *   parser and an executor wavefront per block (few, large blocks), 4 = parser /
@@ -203,6 +206,8 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  *   (8/16/32/64, variant 1); exact encoder: "compress_lanes" (8/16 lanes of a wavefront per block), "compress_variant"
  *   (1 = group encoder + emitter wavefront, 3 = group encoder alone). */
 int lz4flex_set_tuning(lz4flex_ctx *ctx, const char *key, int value);
+/* the current value of a setting (>= 0), or -LZ4FLEX_E_INVALID_ARG for an unknown key */
+int lz4flex_get_tuning(lz4flex_ctx *ctx, const char *key);
 
 /* ---- frame (src/frame/) ------------------------------------------------------------------ */
 typedef struct lz4flex_frame_info {   /* frame::FrameInfo, src/frame/header.rs:130-149 */

@@ -69,6 +69,7 @@ SIGNATURES = {
     "lz4flex_decompress_batch_ex": (_I32, [_VP, _VP, _VP, _VP, _U32, _VP, _VP, _VP, _VP, _VP, _VP,
                                             C.POINTER(DecompressExt), _I32, _VP]),
     "lz4flex_set_tuning": (_I32, [_VP, C.c_char_p, _I32]),
+    "lz4flex_get_tuning": (_I32, [_VP, C.c_char_p]),
     "lz4flex_frame_encoder_new": (_VP, [C.POINTER(FrameInfoC), WRITE_FN, _VP]),
     "lz4flex_frame_encoder_write": (_I64, [_VP, _VP, _SZ]),
     "lz4flex_frame_encoder_flush": (_I32, [_VP]),

@@ -256,6 +256,18 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
     return -LZ4FLEX_E_INVALID_ARG;
 }
 
+int lz4flex_get_tuning(lz4flex_ctx* c, const char* key) {
+    if (!key) return -LZ4FLEX_E_INVALID_ARG;
+    if (!c) { const int rc = default_ctx(&c); if (rc) return rc; }
+    if (!strcmp(key, "compress_mode")) return c->comp_mode;
+    if (!strcmp(key, "compress_variant")) return c->comp_variant;
+    if (!strcmp(key, "compress_lanes")) return c->comp_lanes;
+    if (!strcmp(key, "decompress_variant")) return c->dec_variant;
+    if (!strcmp(key, "decompress_blocks_per_wg")) return c->dec_blocks_per_wg;
+    if (!strcmp(key, "decompress_lanes")) return c->dec_lanes;
+    return -LZ4FLEX_E_INVALID_ARG;
+}
+
 size_t lz4flex_get_maximum_output_size(size_t input_len) {
     return 16 + 4 + (size_t)((uint64_t)input_len * 110 / 100);
 }

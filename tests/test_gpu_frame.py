@@ -123,6 +123,34 @@ def test_linked_encode_multi_block_bit_exact(fr):
     assert len(whole) < len(_enc(fr, data, block_size=fr.BlockSize.Max64KB))
 
 
+def test_linked_frame_throughput_mode(fr):
+    """compress_mode fast: a Linked frame holds independently parsed blocks (one launch per batch instead of one dependency
+    chain).  Its contract is the throughput encoder's: every LZ4 frame decoder -- the oracle's restatement of lz4_flex's,
+    C liblz4's, this library's -- returns the input; header and framing stay the reference's."""
+    from lz4_flex_amd import block
+    data = O.fixture_plain("compression_66k_JSON") * 7 + corpus.lcg_bytes(200000, 3, 8, 5) + O.fixture_plain("compression_65k") * 3
+    block.set_compress_mode("fast")
+    try:
+        for bs in (fr.BlockSize.Max64KB, fr.BlockSize.Max256KB):
+            for kw in ({}, {"block_checksums": True, "content_checksum": True}):
+                f = _enc(fr, data, block_mode=fr.BlockMode.Linked, block_size=bs, **kw)
+                assert f[:6] == fr.FrameInfo(block_mode=fr.BlockMode.Linked, block_size=bs, **kw).write()[:6]     # a Linked frame's header
+                r = O.frame_decompress(f, len(data))
+                assert r[0] == 0 and r[1] == data
+                assert O.c_frame_decompress(f, len(data)) == data
+                assert _dec(fr, f) == data
+                assert len(f) < 0.5 * len(data)
+        whole = _enc(fr, data, block_mode=fr.BlockMode.Linked, block_size=fr.BlockSize.Max64KB)
+        assert _enc(fr, data, chunks=[1, 7, 65535, 1, 65536, 100000, 13], block_mode=fr.BlockMode.Linked,
+                    block_size=fr.BlockSize.Max64KB) == whole
+        # two frames through one encoder, empty input, a short tail
+        for d in (b"", b"x", data[:70000]):
+            f = _enc(fr, d, block_mode=fr.BlockMode.Linked, block_size=fr.BlockSize.Max64KB)
+            assert _dec(fr, f) == d and O.c_frame_decompress(f, len(d)) == d
+    finally:
+        block.set_compress_mode("exact")       # the module's fixture state
+
+
 def test_linked_multi_block_decode(fr):
     data = O.fixture_plain("compression_66k_JSON") * 9 + corpus.lcg_bytes(300000, 3, 8, 5)
     for bs in (4, 5):
