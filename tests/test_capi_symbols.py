@@ -68,6 +68,8 @@ def test_host_logic_without_gpu(lib_path):
             block.compress(b"no gpu, no codec")
         with pytest.raises(block.DeviceError):
             block.decompress(bytes([0x10, 0x61]), 1)
+        assert lib.lz4flex_get_tuning(None, b"compress_mode") == -_lib.E_NO_DEVICE      # the default context needs a device too
+        assert lib.lz4flex_set_tuning(None, b"compress_mode", 1) == -_lib.E_NO_DEVICE
 
 
 def test_stale_library_is_detected(lib_path):

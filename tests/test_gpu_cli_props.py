@@ -92,3 +92,23 @@ def test_property_corrupt_blocks_match_oracle(mods):   # fuzz_decomp_corrupt_blo
         if exp[0] in ("ok", "OutputTooSmall"):
             assert got[1] == exp[1]
     prop()
+
+
+def test_tuning_reads_back():
+    """lz4flex_get_tuning returns what lz4flex_set_tuning stored; unknown keys and values are refused"""
+    import ctypes as C
+    from lz4_flex_amd import _lib
+    lib = _lib.load()
+    ctx = C.c_void_p()
+    assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
+    try:
+        for key, vals in ((b"compress_mode", (1, 0)), (b"decompress_variant", (4, 5, 6, 1, 0)), (b"decompress_blocks_per_wg", (32, 64, 0)),
+                          (b"decompress_lanes", (8, 64, 16)), (b"compress_lanes", (16, 8)), (b"compress_variant", (3, 1))):
+            for v in vals:
+                assert lib.lz4flex_set_tuning(ctx, key, v) == 0, (key, v)
+                assert lib.lz4flex_get_tuning(ctx, key) == v, (key, v)
+        assert lib.lz4flex_get_tuning(ctx, b"no_such_key") == -_lib.E_INVALID_ARG
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 3) == -_lib.E_INVALID_ARG     # round 1's pipelined decoder is gone
+        assert lib.lz4flex_get_tuning(ctx, b"decompress_variant") == 0
+    finally:
+        lib.lz4flex_ctx_destroy(ctx)
