@@ -1212,11 +1212,8 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
             if (prof && lane == 0u)
                 for (uint32_t i = 0; i < 7u; ++i)
                     if (t_acc[i] != 0ull) atomicAdd(prof + i, (unsigned long long)t_acc[i]);
-#ifdef LZ4W_PROF_WORKERS    // tools: matching cycles per worker -> prof[8 + w], SIMD of the wavefront (HW_ID bits 5:4) -> prof[8 + w] high digits
-            if (prof && lane == 0u && w < 8u) {
-                const uint32_t simd = (__builtin_amdgcn_s_getreg((4 << 0) | (4 << 6) | (1 << 11))) & 3u;   // hwreg(HW_REG_HW_ID, 4, 2)
-                atomicAdd(prof + 8u + w, (unsigned long long)t_acc[2] + ((unsigned long long)simd << 56));
-            }
+#ifdef LZ4W_PROF_WORKERS    // tools: matching cycles per worker -> prof[8 + w] (the segment table above comes from these)
+            if (prof && lane == 0u && w < 8u) atomicAdd(prof + 8u + w, (unsigned long long)t_acc[2]);
 #endif
             break;
         }

@@ -76,8 +76,7 @@ def main():
         names = ["idx_busy", "idx_barrier", "match(sum 8 waves)", "wait_after_match", "place", "load_window", "wait_after_load"]
         print("per window cycles: " + ", ".join("%s=%.0f" % (nm, x / nw) for nm, x in zip(names, v)) + " windows=%d" % v[7], flush=True)
         if os.environ.get("LZ4W_PROF_WORKERS"):                  # -DLZ4W_PROF_WORKERS variant build
-            wgs = 512
-            print("matching cycles per window by worker: " + ", ".join("w%d=%.0f (simd sum %d)" % (i, (x & ((1 << 56) - 1)) / nw, x >> 56) for i, x in enumerate(v[8:16])), flush=True)
+            print("matching cycles per window by worker: " + ", ".join("w%d=%.0f" % (i, x / nw) for i, x in enumerate(v[8:16])), flush=True)
         elif v[13]:
             sn = ["heads", "compact+lengths", "scan", "walk", "merge"]
             print("per superstep cycles (LZ4W_PROF_STEPS build): " + ", ".join("%s=%.0f" % (nm, x / v[13]) for nm, x in zip(sn, v[8:13])) +
