@@ -125,3 +125,62 @@ long pcm_parallel(const uint8_t *c, uint32_t n, const uint32_t *starts, uint32_t
     free(owner); free(next); free(seq_at);
     return k;
 }
+
+/* ---- the whole decoder on top of the recovered chain: output positions by a prefix sum over the sequences, all literals
+ * at once, then the matches of every group of G consecutive sequences in ROUNDS -- a round executes every match whose
+ * source bytes exist (written by literals, by matches of earlier rounds or groups; a match that overlaps its own output is
+ * one lane's periodic copy) -- which is how a wavefront would execute them.  Returns the decoded length; -1: irregular
+ * chain, -2: an offset reaches before the output, -3: the sink is too small (a decoder built on this hands all three to the
+ * reference-order path, which names the exact error).  *rounds = rounds summed over the groups (the depth statistics of
+ * tools/spec_parse_study.py). */
+long pcm_decode(const uint8_t *c, uint32_t n, const uint32_t *starts, uint32_t K, uint32_t G, uint8_t *out, uint64_t cap,
+                uint64_t *rounds) {
+    pcm_seq *sq = (pcm_seq *)malloc(sizeof(pcm_seq) * ((size_t)n + 2));
+    uint64_t total = 0;
+    const long ns = pcm_parallel(c, n, starts, K, sq, &total, NULL);
+    if (ns < 0) { free(sq); return -1; }
+    if (total > cap) { free(sq); return -3; }
+    uint64_t *mpos = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)ns);      /* where each sequence's match starts */
+    uint8_t *have = (uint8_t *)calloc((size_t)total + 1, 1);                   /* output bytes that exist */
+    uint64_t op = 0;
+    for (long i = 0; i < ns; i++) {                                             /* prefix sum + literals (independent of each other) */
+        const uint32_t hdr = 1u + (sq[i].lit >= 15u ? (sq[i].lit - 15u) / 255u + 1u : 0u);
+        memcpy(out + op, c + sq[i].ip + hdr, sq[i].lit);
+        memset(have + op, 1, sq[i].lit);
+        op += sq[i].lit;
+        mpos[i] = op;
+        if (sq[i].ml != 0 && sq[i].off > op) { free(sq); free(mpos); free(have); return -2; }
+        op += sq[i].ml;
+    }
+    uint64_t nr = 0;
+    uint8_t *done = (uint8_t *)calloc((size_t)ns, 1), *ready = (uint8_t *)malloc((size_t)(G ? G : 1));
+    for (long g0 = 0; g0 < ns; g0 += G) {
+        const long g1 = g0 + (long)G < ns ? g0 + (long)G : ns;
+        for (;;) {
+            long left = 0, nready = 0;
+            for (long i = g0; i < g1; i++) {                                    /* decisions from the state at the round's start */
+                ready[i - g0] = 0;
+                if (done[i] || sq[i].ml == 0) continue;
+                left++;
+                const uint64_t s0 = mpos[i] - sq[i].off;
+                const uint64_t s1 = s0 + sq[i].ml < mpos[i] ? s0 + sq[i].ml : mpos[i];   /* the part of the source outside its own output */
+                int ok = 1;
+                for (uint64_t p = s0; p < s1 && ok; p++) ok = have[p];
+                ready[i - g0] = (uint8_t)ok;
+                nready += ok;
+            }
+            if (left == 0) break;
+            if (nready == 0) { free(sq); free(mpos); free(have); free(done); free(ready); return -1; }   /* cannot happen: the first open match's source is complete */
+            for (long i = g0; i < g1; i++) {
+                if (!ready[i - g0]) continue;
+                for (uint32_t k = 0; k < sq[i].ml; k++) out[mpos[i] + k] = out[mpos[i] + k - sq[i].off];
+                memset(have + mpos[i], 1, sq[i].ml);
+                done[i] = 1;
+            }
+            nr++;
+        }
+    }
+    if (rounds) *rounds = nr;
+    free(sq); free(mpos); free(have); free(done); free(ready);
+    return (long)total;
+}

@@ -31,7 +31,18 @@ def pcm():
     m.pcm_parallel.restype = C.c_long
     m.pcm_parallel.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(Seq), C.POINTER(C.c_uint64),
                                C.POINTER(C.c_uint32)]
+    m.pcm_decode.restype = C.c_long
+    m.pcm_decode.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64,
+                             C.POINTER(C.c_uint64)]
     return m
+
+
+def _decode(m, c, starts, group, cap):
+    out = C.create_string_buffer(max(cap, 1))
+    st = (C.c_uint32 * len(starts))(*starts)
+    rounds = C.c_uint64(0)
+    r = m.pcm_decode(c, len(c), st, len(starts), group, out, cap, C.byref(rounds))
+    return r, out.raw[:max(r, 0)], rounds.value
 
 
 def _serial(m, c):
@@ -111,3 +122,37 @@ def test_big_block_overlap_is_small(pcm):
     assert (k, seqs, out_len) == _serial(pcm, c) and out_len == len(p)
     part = len(c) / 64
     assert max(walked) < part + 600 and sum(walked) < 1.1 * len(c)
+
+
+def test_whole_decoder_equals_the_oracle(pcm):
+    """parallel chain + prefix-summed positions + literals at once + matches in rounds == the oracle's bytes; whatever the oracle
+    rejects is handed back (negative): the reference-order path names the error"""
+    rnd = random.Random(6)
+    n_ok = n_rej = 0
+    for c, cap in corpus.adversarial_blocks():
+        if len(c) == 0:
+            continue
+        want = O.decompress(c, cap)
+        for k, group in ((1, 64), (64, 64), (7, 16)):
+            starts = _cuts(len(c), k, rnd)[1] if len(c) > 1 else [0]
+            r, got, _ = _decode(pcm, c, starts, group, cap)
+            if want[0] == "ok":
+                assert r == len(want[1]) and got == want[1], (len(c), cap, k, r)
+                n_ok += 1
+            else:
+                assert r < 0, (len(c), cap, k, want[0], r)
+                n_rej += 1
+    assert n_ok > 1000 and n_rej > 1000
+
+
+def test_rounds_per_group(pcm):
+    """the copies' dependency depth on the benchmark's data (tools/spec_parse_study.py): a group of 64 sequences of JSON needs 11
+    rounds when the reference's encoder wrote the block, 7.4 when the throughput encoder's model did"""
+    import wave_model
+    p = (O.fixture_plain("compression_66k_JSON") * 5)[:1 << 18]
+    for enc, lo, hi in ((O.compress, 9.0, 13.0), (wave_model.compress, 6.0, 9.0)):
+        c = enc(p)
+        r, got, rounds = _decode(pcm, c, [0], 64, len(p))
+        assert r == len(p) and got == p
+        nseq = _serial(pcm, c)[0]
+        assert lo < rounds / (nseq / 64.0) < hi, rounds / (nseq / 64.0)
