@@ -35,7 +35,27 @@ sys.path.insert(0, ROOT)
 
 BLOCK = 65536
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
-ROUND = 2               # stamped into the traffic figure's provenance
+ROUND = 3               # stamped into the traffic figure's provenance
+
+
+def median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+def relaunch_ranks(gpus):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks here (one process per GPU over
+    torch.distributed / RCCL, rendezvous on 127.0.0.1) and become the launcher.  Under torch.distributed.run (WORLD_SIZE is
+    set) this is never reached."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
 
 
 def load_fixture(block_mod, stem):
@@ -71,7 +91,8 @@ def attach_traffic(kernels, n, mode):
         for k in kernels:
             key = k + ("_" + mode if k == "compress" else "")
             e = tr.get(key) or tr.get(k)
-            if e and kernels[k]["roofline"] and e.get("blocks") == n and e.get("kernel") == kernels[k]["kernel"]:
+            # kernel_key = the kernel's plain name (the "kernel" field may carry template arguments and a description)
+            if e and kernels[k]["roofline"] and e.get("blocks") == n and e.get("kernel_key", e.get("kernel")) == kernels[k]["kernel"]:
                 kernels[k]["roofline"]["traffic"] = e["hbm_bytes_per_launch"]
                 kernels[k]["roofline"]["traffic_source"] = "profiles/traffic.json (round %s, %s)" % (e.get("round", "?"), e.get("source", "?"))
     except Exception:
@@ -92,6 +113,8 @@ def main():
     ap.add_argument("--only", choices=["both", "compress", "decompress"], default="both",
                     help="profiling aid: run only one kernel in the timed steps (value then covers that kernel only)")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        relaunch_ranks(args.gpus)                  # does not return
 
     import torch
     import torch.distributed as dist
@@ -100,6 +123,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "--gpus %d but the launcher started %d rank(s): n_gpus must be what was asked for" % (args.gpus, world)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -233,8 +257,9 @@ def run_blocks(args, env):
         assert torch.equal(back, src), "round trip mismatch"
     comp_bytes = int(comp_len.to(torch.int64).sum().item())
     ratio = comp_bytes / total
-    t_c = sum(ev[s][0].elapsed_time(ev[s][1]) for s in range(args.steps)) / args.steps * 1e-3   # s per launch
-    t_d = sum(ev[s][1].elapsed_time(ev[s][2]) for s in range(args.steps)) / args.steps * 1e-3
+    # per-kernel durations: MEDIAN over the timed steps, events on the stream the kernels are launched on
+    t_c = median([ev[s][0].elapsed_time(ev[s][1]) for s in range(args.steps)]) * 1e-3   # s per launch
+    t_d = median([ev[s][1].elapsed_time(ev[s][2]) for s in range(args.steps)]) * 1e-3
     alg_bytes = total + comp_bytes    # compress moves u (read) + c (write); decompress c (read) + u (write)
     kernels = {}
     if args.only in ("both", "compress"):
@@ -267,7 +292,9 @@ def run_blocks(args, env):
                    "blocks_per_gpu": n, "block_bytes": BLOCK, "compress_mode": args.compress_mode,
                    "compress_contract": ("valid LZ4 blocks that the reference decoder returns to the input (own parse)" if args.compress_mode == "fast"
                                          else "bytes identical to the oracle restatement of lz4_flex's encoder"),
-                   "parallelism": "blocks sharded across ranks, no data-path collective", "only": args.only},
+                   "parallelism": "blocks sharded across ranks, no data-path collective", "only": args.only,
+                   "oversubscribed": ("%d ranks on %d device(s): functional run of the multi-process path, not a scaling figure" % (world, torch.cuda.device_count()))
+                                     if env["oversub"] else None},
         "ratio": round(ratio, 5),
         "compress_MiB_per_s_per_gpu": kernels.get("compress", {}).get("MiB_per_s"),
         "decompress_MiB_per_s_per_gpu": kernels.get("decompress", {}).get("MiB_per_s"),
@@ -316,6 +343,18 @@ def run_sharded_frame(args, env):
         exp = workloads.log_stream(lo * bs, (hi - lo) * bs, device=dev)
         assert torch.equal(state["out"], exp), "sharded frame round trip mismatch"
     total = per_rank * world
+    oracle_checked = None
+    if rank == 0 and not args.no_verify and total <= (2 << 30):
+        # the gathered frame through the REFERENCE's frame decoder (oracle restatement), once, after the timed loop
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_api as O
+        h_frame = state["frame"].cpu().numpy().tobytes()
+        rc, back, _used = O.frame_decompress(h_frame, total)
+        assert rc == 0, "the reference's FrameDecoder (oracle) rejects the gathered frame: %r" % (rc,)
+        want = b"".join(workloads.log_stream(r * per_rank, per_rank, device="cpu").numpy().tobytes() for r in range(world))
+        assert back == want, "the reference's FrameDecoder (oracle) does not return the stream"
+        oracle_checked = "gathered frame (%d bytes) decoded by the oracle's FrameDecoder == the stream" % len(h_frame)
+        del h_frame, back, want
     frame_bytes = int(state["frame"].numel()) if rank == 0 else 0
     alg = total + frame_bytes
     out = {
@@ -330,7 +369,8 @@ def run_sharded_frame(args, env):
         "ratio": round(frame_bytes / total, 5) if frame_bytes else None,
         "parts_ms": {k: round(v / args.steps * 1e3, 3) for k, v in t_parts.items()},
         "roofline": dict(roof(alg, elapsed / args.steps), kernel="whole step (lz4_compress_wave_kernel + frame assembly + decoder)"),
-        "verified": "NOT VERIFIED" if args.no_verify else "every rank's decoded block range equals the stream bytes it owns",
+        "verified": "NOT VERIFIED" if args.no_verify else "every rank's decoded block range equals the stream bytes it owns" +
+                    ("; " + oracle_checked if oracle_checked else ""),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -393,11 +433,36 @@ def _oracle_fresh():
     return O
 
 
+def host_topology():
+    """(hardware threads this process may run on, physical cores among them): the thread counts the CPU baseline is timed at"""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    cores = set()
+    try:
+        cur = {}
+        with open("/proc/cpuinfo") as f:
+            for line in f.read().split("\n") + [""]:
+                if ":" in line:
+                    k, v = line.split(":", 1)
+                    cur[k.strip()] = v.strip()
+                elif cur:
+                    if int(cur.get("processor", -1)) in cpus:
+                        cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                    cur = {}
+    except OSError:
+        pass
+    return len(cpus), (len(cores) or len(cpus))
+
+
 def _time_codecs(O, h_src, ns, bs, stride):
-    """oracle port and system liblz4 1.9.3 over ns blocks of bs bytes: all host threads and one thread, best of 3"""
+    """oracle port and system liblz4 1.9.3 over ns blocks of bs bytes.  A persistent thread pool per measurement (threads are
+    created outside the timed passes), passes of >= 0.3 s (the sweep is repeated inside a pass), best of 3; at three thread
+    counts: every hardware thread, one thread per physical core, one thread (over an eighth of the sample)."""
     import numpy as np
     o = O.lib()
-    cores = os.cpu_count() or 1
+    hw, phys = host_topology()
     h_in_off = (np.arange(ns, dtype=np.uint64) * bs)
     h_in_len = np.full(ns, bs, dtype=np.uint32)
     h_out = np.zeros(ns * stride, dtype=np.uint8)
@@ -418,60 +483,80 @@ def _time_codecs(O, h_src, ns, bs, stride):
         fns = {}
     fns["oracle_port"] = (None, None)
     mib = ns * bs / 1048576
+    counts = [hw] + ([phys] if phys != hw else []) + [1]
     for name, (fc, fd) in fns.items():
-        for threads in (cores, 1):
+        for threads in counts:
             sub = ns if threads > 1 else max(ns // 8, 1)                 # one thread: an eighth of the sample
-            tc = o.lz4o_bench_batch_fn(0, fc, vp(h_src), vp(h_in_off), vp(h_in_len), vp(h_out), vp(h_out_off), vp(h_out_cap),
-                                       vp(h_out_len), sub, threads, 3)
-            td = o.lz4o_bench_batch_fn(1, fd, vp(h_out), vp(h_out_off), vp(h_out_len), vp(h_back), vp(h_in_off), vp(h_in_len),
-                                       vp(h_back_len), sub, threads, 3)
+            used = C.c_int(0)
+            tc = o.lz4o_bench_pool(0, fc, vp(h_src), vp(h_in_off), vp(h_in_len), vp(h_out), vp(h_out_off), vp(h_out_cap),
+                                   vp(h_out_len), sub, threads, 3, 0.3, C.byref(used))
+            td = o.lz4o_bench_pool(1, fd, vp(h_out), vp(h_out_off), vp(h_out_len), vp(h_back), vp(h_in_off), vp(h_in_len),
+                                   vp(h_back_len), sub, threads, 3, 0.3, C.byref(used))
+            assert tc > 0 and td > 0, "thread pool could not be created"
             assert (h_back[:sub * bs] == h_src[:sub * bs]).all(), name
             m = mib * sub / ns
-            res[(name, threads)] = (m / tc, m / td, m / (tc + td), float(h_out_len[:sub].sum()) / (sub * bs))
-    return res, cores, h_out, h_out_len
+            res[(name, threads)] = (m / tc, m / td, m / (tc + td), float(h_out_len[:sub].sum()) / (sub * bs), used.value)
+    return res, (hw, phys), h_out, h_out_len
 
 
-def _baseline_dict(res, cores, sample):
-    port = res[("oracle_port", cores)]
-    out = {"value": round(port[2], 1), "unit": "MiB/s", "cores": cores, "kind": "port", "sample": sample,
+def _baseline_dict(res, topo, sample):
+    hw, phys = topo
+    best_t = max((t for (nm, t) in res if nm == "oracle_port" and t > 1), key=lambda t: res[("oracle_port", t)][2], default=1)
+    port = res[("oracle_port", best_t)]
+
+    def leg(r):
+        return {"compress_MiB_per_s": round(r[0], 1), "decompress_MiB_per_s": round(r[1], 1), "round_trip_MiB_per_s": round(r[2], 1),
+                "threads_run": r[4]}
+
+    out = {"value": round(port[2], 1), "unit": "MiB/s", "cores": best_t, "kind": "port", "sample": sample,
            "compress_MiB_per_s": round(port[0], 1), "decompress_MiB_per_s": round(port[1], 1),
-           "single_thread": {"compress_MiB_per_s": round(res[("oracle_port", 1)][0], 1),
-                             "decompress_MiB_per_s": round(res[("oracle_port", 1)][1], 1),
-                             "round_trip_MiB_per_s": round(res[("oracle_port", 1)][2], 1)}}
-    if ("liblz4_1.9.3", cores) in res:
-        a, s1 = res[("liblz4_1.9.3", cores)], res[("liblz4_1.9.3", 1)]
+           "host": {"hardware_threads": hw, "physical_cores": phys},
+           "by_threads": {str(t): leg(res[("oracle_port", t)]) for (nm, t) in sorted(res) if nm == "oracle_port"},
+           "single_thread": leg(res[("oracle_port", 1)])}
+    if ("liblz4_1.9.3", hw) in res:
+        a = res[("liblz4_1.9.3", max((t for (nm, t) in res if nm == "liblz4_1.9.3" and t > 1), key=lambda t: res[("liblz4_1.9.3", t)][2], default=1))]
         out["liblz4_1.9.3"] = {"note": "system C liblz4 (LZ4_compress_default / LZ4_decompress_safe), the library the reference's tests "
-                                       "cross-check against; same sample, same thread counts",
+                                       "cross-check against; same sample, same thread counts, same pool",
                                "round_trip_MiB_per_s": round(a[2], 1), "compress_MiB_per_s": round(a[0], 1),
                                "decompress_MiB_per_s": round(a[1], 1), "ratio": round(a[3], 5),
-                               "single_thread": {"compress_MiB_per_s": round(s1[0], 1), "decompress_MiB_per_s": round(s1[1], 1),
-                                                 "round_trip_MiB_per_s": round(s1[2], 1)}}
+                               "by_threads": {str(t): leg(res[("liblz4_1.9.3", t)]) for (nm, t) in sorted(res) if nm == "liblz4_1.9.3"},
+                               "single_thread": leg(res[("liblz4_1.9.3", 1)])}
     return out
 
 
 def cpu_baseline(src, comp, comp_off, comp_len, n, mode):
-    """Times oracle/ (kind 'port': lz4_flex is Rust, no toolchain here) and the system liblz4 on the same bytes: a bounded
-    sample of the workload, all host cores and one core, best of 3 passes per direction."""
+    """Times oracle/ (kind 'port': lz4_flex is Rust, no toolchain here) and the system liblz4 on the same bytes as the GPU: the
+    whole batch on all host threads / all physical cores, an eighth of it on one thread; then the ORACLE's decoder (= lz4_flex's,
+    restated) decodes EVERY block the GPU encoder wrote and must return the input."""
     import numpy as np
     O = _oracle_fresh()
-    ns = min(n, 4096)                              # 256 MiB sample
+    ns = n
     h_src = src[:ns * BLOCK].cpu().numpy()
     stride = int(comp_off[1].item()) if n > 1 else 72128
-    res, cores, h_out, h_out_len = _time_codecs(O, h_src, ns, BLOCK, stride)
+    res, topo, h_out, h_out_len = _time_codecs(O, h_src, ns, BLOCK, stride)
     g_len = comp_len[:ns].cpu().numpy().astype(np.uint32)
     g = comp[:ns * stride].cpu().numpy()
     if mode == "exact":                            # the reference-exact encoder: same sizes and bytes as the oracle
         assert (h_out_len == g_len).all(), "GPU encoder output size differs from the oracle"
-        for i in (0, 1, ns // 2, ns - 1):
-            assert (g[i * stride:i * stride + int(g_len[i])] == h_out[i * stride:i * stride + int(g_len[i])]).all()
-    else:                                          # the throughput encoder: the ORACLE's decoder must return the input
-        for i in (0, 1, ns // 2, ns - 1):
-            st, back = O.decompress(bytes(g[i * stride:i * stride + int(g_len[i])]), BLOCK)
-            assert st == "ok" and back == bytes(h_src[i * BLOCK:(i + 1) * BLOCK]), "reference decoder rejects a GPU block"
-    d = _baseline_dict(res, cores, "first %d of the %d blocks (%d MiB), compress+decompress round trip, best of 3, %d threads (one thread: "
-                       "an eighth of it); oracle = C restatement of lz4_flex's block codec, rebuilt on this node with gcc -O3 -march=native"
-                       % (ns, n, ns * BLOCK >> 20, cores))
-    d["oracle_ratio"] = round(res[("oracle_port", cores)][3], 5)
+        for i in range(ns):
+            assert (g[i * stride:i * stride + int(g_len[i])] == h_out[i * stride:i * stride + int(g_len[i])]).all(), i
+    # either encoder: the reference's decoder (oracle) over every GPU-written block, in one batch call
+    g_off = (np.arange(ns, dtype=np.uint64) * stride)
+    b_off = (np.arange(ns, dtype=np.uint64) * BLOCK)
+    b_cap = np.full(ns, BLOCK, dtype=np.uint32)
+    b_len = np.zeros(ns, dtype=np.uint32)
+    back = np.zeros(ns * BLOCK, dtype=np.uint8)
+
+    def vp(a):
+        return C.c_void_p(a.ctypes.data)
+    O.lib().lz4o_bench_pool(1, None, vp(g), vp(g_off), vp(g_len), vp(back), vp(b_off), vp(b_cap), vp(b_len), ns, topo[1], 1, 0.0, None)
+    assert (b_len == BLOCK).all(), "the reference decoder (oracle) rejects %d GPU-encoded block(s)" % int((b_len != BLOCK).sum())
+    assert (back == h_src).all(), "the reference decoder (oracle) does not return the input for a GPU-encoded block"
+    d = _baseline_dict(res, topo, "all %d blocks of the workload (%d MiB), compress + decompress round trip; thread pool created outside the "
+                       "timed passes, passes of >= 0.3 s, best of 3; one thread: an eighth of the blocks; oracle = C restatement of "
+                       "lz4_flex's block codec, rebuilt on this node with gcc -O3 -march=native" % (ns, ns * BLOCK >> 20))
+    d["oracle_ratio"] = round(res[("oracle_port", topo[0])][3], 5)
+    d["gpu_blocks_decoded_by_oracle"] = int(ns)
     return d
 
 
@@ -480,9 +565,10 @@ def cpu_baseline_buffer(buf, bs):
     h = buf.cpu().numpy()
     ns = h.size // bs
     stride = int(O.max_out(bs)) + 64
-    res, cores, _o, _l = _time_codecs(O, h, ns, bs, stride)
-    d = _baseline_dict(res, cores, "first %d blocks of %d bytes of rank 0's stream, block codec only (no frame bytes), best of 3" % (ns, bs))
-    d["oracle_ratio"] = round(res[("oracle_port", cores)][3], 5)
+    res, topo, _o, _l = _time_codecs(O, h, ns, bs, stride)
+    d = _baseline_dict(res, topo, "first %d blocks of %d bytes of rank 0's stream, block codec only (no frame bytes); thread pool created "
+                       "outside the timed passes, passes of >= 0.3 s, best of 3" % (ns, bs))
+    d["oracle_ratio"] = round(res[("oracle_port", topo[0])][3], 5)
     return d
 
 

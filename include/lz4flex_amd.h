@@ -61,10 +61,12 @@ typedef struct lz4flex_err_detail {
 } lz4flex_err_detail;
 
 /* ---- context ------------------------------------------------------------------------------ */
-/* Owns the device workspace (staging arena, per-block descriptor arrays) and a HIP stream.
- * One context per thread; distinct contexts are independent (reference: no global state,
- * all fns reentrant).  The scalar calls below use a lazily created per-thread default context
- * on the current HIP device. */
+/* Owns the device workspace (the throughput encoder's 164 MiB of candidate slots and segment bodies, allocated HERE so
+ * that no compress call allocates; the staging arena and descriptor arrays of MEM_HOST calls) and a HIP stream.
+ * One context per thread; distinct contexts are independent (reference: no global state, all fns reentrant).  MEM_DEVICE
+ * compress batches of ONE context share its encoder workspace: the library orders them on the device (a batch enqueued on
+ * another stream than the previous one waits for it), so they never overlap -- use one context per stream for concurrency.
+ * The scalar calls below use a lazily created per-thread default context on the current HIP device. */
 typedef struct lz4flex_ctx lz4flex_ctx;
 int lz4flex_ctx_create(lz4flex_ctx **ctx, int device /* -1 = current */);
 void lz4flex_ctx_destroy(lz4flex_ctx *ctx);
@@ -80,7 +82,13 @@ const char *lz4flex_last_error(void);
 /* block::get_maximum_output_size, src/block/compress.rs:588-590 */
 size_t lz4flex_get_maximum_output_size(size_t input_len);
 /* block::compress_into, src/block/compress.rs:599-601.  Err(OutputTooSmall) up front iff
- * out_cap < get_maximum_output_size(in_len) (:338-340). Output bytes identical to lz4_flex's. */
+ * out_cap < get_maximum_output_size(in_len) (:338-340).
+ * CONTRACT OF THE OUTPUT BYTES (this entry point, compress_prepend_size, compress_into_with_table, lz4flex_compress_batch and
+ * the frame encoder): in the DEFAULT compress_mode (0, "fast") the block is a valid LZ4 block with this library's own parse --
+ * lz4_flex's decoder (and any other LZ4 decoder) returns the input, the ratio is within a percent of lz4_flex's (usually
+ * better) -- but the bytes are NOT lz4_flex's.  Callers that hash, deduplicate or golden-file compressed output must select
+ * compress_mode 1 ("exact": lz4flex_set_tuning / LZ4FLEX_COMPRESS_MODE=exact), which reproduces the reference encoder byte
+ * for byte as restated by oracle/ (no Rust toolchain exists here: "oracle-exact, reference byte-unpinned"). */
 int64_t lz4flex_compress_into(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap);
 /* block::compress_into_with_dict, src/block/compress.rs:610-616 */
 int64_t lz4flex_compress_into_with_dict(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
@@ -125,7 +133,9 @@ int64_t lz4flex_decompress_size_prepended_with_dict(const uint8_t *in, size_t in
  * HOST batches detect it themselves) */
 #define LZ4FLEX_MEM_BIG_BLOCKS 0x100
 
-/* per-block compress flags */
+/* per-block compress flags.  They select among the REFERENCE's hash tables and therefore only have a meaning in compress_mode
+ * exact; the throughput encoder (compress_mode fast, the default) has one table layout of its own and ignores them, as it
+ * ignores the Small / Large state of a lz4flex_compress_table. */
 #define LZ4FLEX_BLOCK_DEFAULT 0u            /* block::compress_into: table/hash picked by length (compress.rs:559-566) */
 /* bit 1: the FrameEncoder's table (HashTable4K + 5-byte hash whatever the length,
  * src/frame/compress.rs:76,141) with a freshly zeroed table: block 0 of a frame */

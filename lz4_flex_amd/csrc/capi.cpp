@@ -47,9 +47,15 @@ struct lz4flex_ctx {
     int comp_lanes = 8;           // lanes per block, encode
     int comp_mode = 0;            // 0 = throughput ("wave") encoder, own parse (default); 1 = reference-exact encoder (lz4_flex's bytes)
     int comp_variant = 1;         // reference-exact encoder: 1 = group encoder + emitter wave (default), 3 = group encoder alone
-    void* wave_ws = nullptr;      // wave encoder workspace: wave_wgs persistent workgroups
+    void* wave_ws = nullptr;      // wave encoder workspace: wave_wgs persistent workgroups; allocated by lz4flex_ctx_create
     unsigned long long* wave_prof = nullptr;   // tools: per-role cycle counters of the wave encoder (lz4flex_debug_wave_prof)
     int wave_wgs = 0;
+    // The workspace is ONE per context, and MEM_DEVICE batches are enqueued on the caller's stream: two batches on different
+    // streams could overlap on the GPU and race on it.  Every wave launch records wave_done; a launch on another stream than
+    // the previous one first makes its stream wait for it (same stream: already ordered).
+    hipEvent_t wave_done = nullptr;
+    hipStream_t wave_last = nullptr;
+    bool wave_used = false;
     int dec_blocks_per_wg = 0;    // split decoder: blocks per workgroup (8/16/32/64), 0 = by batch size
     int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 4 = parser / copier split (lz4_decompress_split.hip), 5 / 6 = a wavefront / a pair of wavefronts per block (lz4_decompress_wave.hip)
 };
@@ -89,14 +95,14 @@ __global__ void lz4flex_flag_long_blocks_kernel(const uint32_t* in_len, uint32_t
 static int launch_compress_any(lz4flex_ctx* c, const CompressArgs& a, bool big, hipStream_t s) {
     hipError_t le;
     if (c->comp_mode == 0) {
-        if (!c->wave_ws) {
-            hipDeviceProp_t prop;
-            HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-            const int wgs = 2 * prop.multiProcessorCount;      // two 80 KiB workgroups per CU
-            HIP_TRY(hipMalloc(&c->wave_ws, compress_wave_workspace_bytes(wgs)));
-            c->wave_wgs = wgs;
-        }
+        if (!c->wave_ws || !c->wave_done) { g_last_error = "context without encoder workspace"; return -LZ4FLEX_E_INVALID_ARG; }
+        if (c->wave_used && s != c->wave_last) HIP_TRY(hipStreamWaitEvent(s, c->wave_done, 0));
         le = launch_compress_wave(a, c->wave_ws, c->wave_wgs, s, c->wave_prof);
+        if (le == hipSuccess) {
+            HIP_TRY(hipEventRecord(c->wave_done, s));
+            c->wave_last = s;
+            c->wave_used = true;
+        }
     } else {
         le = launch_compress(a, c->comp_lanes | (big ? 0x100 : 0) | comp_mode_bits(c->comp_variant), s);
         if (le == hipSuccess && !big && a.n) {
@@ -151,7 +157,7 @@ static int default_ctx(lz4flex_ctx** out);
 
 extern "C" {
 
-const char* lz4flex_version(void) { return "lz4flex-amd 0.2.0 (gfx950)"; }
+const char* lz4flex_version(void) { return "lz4flex-amd 0.3.0 (gfx950)"; }
 #ifndef LZ4FLEX_BUILD_ID
 #define LZ4FLEX_BUILD_ID "unstamped"
 #endif
@@ -179,14 +185,32 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
     if (!c) return -LZ4FLEX_E_NOMEM;
     c->device = device;
     if (const char* e = getenv("LZ4FLEX_COMPRESS_MODE")) c->comp_mode = (!strcmp(e, "exact") || !strcmp(e, "1")) ? 1 : 0;
+#ifdef LZ4FLEX_ALL_VARIANTS
     if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v == 1 || v == 3) c->comp_variant = v; }
+#endif
     if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v == 0 || v == 1 || (v >= 4 && v <= 6)) c->dec_variant = v; }
     int prev = 0;
     (void)hipGetDevice(&prev);
     e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // the throughput encoder's workspace (two 80 KiB workgroups per CU, 164 MiB on an MI355X) and its ordering event: here, not
+    // inside the first compress call -- a hipMalloc in an "asynchronous" entry point is a device synchronisation and breaks
+    // stream capture
+    if (e == hipSuccess) {
+        int cus = 0;
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        if (e == hipSuccess) {
+            c->wave_wgs = 2 * cus;
+            e = hipMalloc(&c->wave_ws, compress_wave_workspace_bytes(c->wave_wgs));
+        }
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->wave_done, hipEventDisableTiming);
     (void)hipSetDevice(prev);
-    if (e != hipSuccess) { delete c; return hip_fail(e, "ctx_create"); }
+    if (e != hipSuccess) {
+        const int rc = hip_fail(e, "ctx_create");
+        lz4flex_ctx_destroy(c);
+        return e == hipErrorOutOfMemory ? -LZ4FLEX_E_NOMEM : rc;
+    }
     *out = c;
     return 0;
 }
@@ -195,6 +219,7 @@ void lz4flex_ctx_destroy(lz4flex_ctx* c) {
     if (!c) return;
     if (c->d_arena) (void)hipFree(c->d_arena);
     if (c->wave_ws) (void)hipFree(c->wave_ws);
+    if (c->wave_done) (void)hipEventDestroy(c->wave_done);
     if (c->wave_prof) (void)hipFree(c->wave_prof);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_pay) (void)hipHostFree(c->h_pay);
@@ -202,8 +227,9 @@ void lz4flex_ctx_destroy(lz4flex_ctx* c) {
     delete c;
 }
 
-// tools only (not in the public header): enable != 0 starts / resets the wave encoder's per-role cycle counters of
-// this context, vals (nullable) receives the 16 sums accumulated so far
+#ifdef LZ4FLEX_TOOLS
+// variant builds for tools/ only (-DLZ4FLEX_TOOLS; not in the public header, not in the product library): enable != 0 starts /
+// resets the wave encoder's per-role cycle counters of this context, vals (nullable) receives the 16 sums accumulated so far
 int lz4flex_debug_wave_prof(lz4flex_ctx* c, int enable, unsigned long long* vals) {
     if (!c) return -LZ4FLEX_E_INVALID_ARG;
     if (vals && c->wave_prof) {
@@ -219,12 +245,17 @@ int lz4flex_debug_wave_prof(lz4flex_ctx* c, int enable, unsigned long long* vals
     }
     return 0;
 }
+#endif
 
 int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
     if (!key) return -LZ4FLEX_E_INVALID_ARG;
     if (!c) { const int rc = default_ctx(&c); if (rc) return rc; }   // NULL: this thread's default context (the scalar calls)
     if (!strcmp(key, "decompress_lanes")) {
+#ifdef LZ4FLEX_ALL_VARIANTS
         if (value != 8 && value != 16 && value != 32 && value != 64) return -LZ4FLEX_E_INVALID_ARG;
+#else
+        if (value != 16) return -LZ4FLEX_E_INVALID_ARG;          // the other widths exist in variant builds only (-DLZ4FLEX_ALL_VARIANTS)
+#endif
         c->dec_lanes = value;
         return 0;
     }
@@ -244,7 +275,11 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "compress_variant")) {
+#ifdef LZ4FLEX_ALL_VARIANTS
         if (value != 1 && value != 3) return -LZ4FLEX_E_INVALID_ARG;
+#else
+        if (value != 1) return -LZ4FLEX_E_INVALID_ARG;           // 3 (no emitter wavefront) exists in variant builds only
+#endif
         c->comp_variant = value;
         return 0;
     }

@@ -935,7 +935,11 @@ static hipError_t launch_m(const CompressArgs& a, int mode, hipStream_t s) {
     // MODE 2 (prefetch-only second wavefront) and MODE 4 (LDS input ring) were round-1 experiments that measured slower than
     // MODE 3; they are no longer instantiated
     if (mode == 3) return launch_c<G, TblT, 3, BPW>(a, s);
+#ifdef LZ4FLEX_ALL_VARIANTS   // MODE 0 (the group encoder without an emitter wavefront) is a cross-check: variant builds only
     return launch_c<G, TblT, 0, BPW>(a, s);
+#else
+    return hipErrorInvalidValue;
+#endif
 }
 
 // variant: bits 0..7 = lanes per block (8 or 16), bit 8 = blocks may exceed 64 KiB (u32 table),

@@ -471,7 +471,7 @@ __device__ __attribute__((noinline)) EncState encode_seqs(uint32_t psq, uint32_t
 
 template <uint32_t V> struct UConst { static constexpr uint32_t value = V; };
 
-// One segment [s0, s1) of the window in LDS.  mfl_end: positions p < mfl_end may start a match (p <= n - 12);
+// One segment [s0, s1) of the window in LDS (s0 < s1).  mfl_end: positions p < mfl_end may start a match (p <= n - 12);
 // mend: matches end here at the latest (segment end, block end - 5, 65535).
 //
 // The segment is walked in SUPERSTEPS of up to 256 positions (4 steps of 64: lane i looks at positions b + 64 u + i).
@@ -556,6 +556,14 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
         if (NS > 2u) {
             K2 = bal(t2 != 0u) & bal(t2 != dpp_wave_shr1(t2, rdlane(t1, 63u)));
             K3 = bal(t3 != 0u) & bal(t3 != dpp_wave_shr1(t3, rdlane(t2, 63u)));
+        }
+        if (b < s0) {
+            // the segment starts inside this superstep (only the anchored last window of a block, see win_base): positions before
+            // s0 are history and no heads; s0 itself has no predecessor (a head whenever it has a candidate), as at an aligned start
+            const uint64_t N0 = bal(t0 != 0u), N1 = bal(t1 != 0u), N2 = bal(t2 != 0u), N3 = bal(t3 != 0u);
+            K0 = (K0 | (N0 & bal(p0 == s0))) & bal(p0 >= s0);
+            if (NS > 1u) K1 = (K1 | (N1 & bal(p1 == s0))) & bal(p1 >= s0);
+            if (NS > 2u) { K2 = (K2 | (N2 & bal(p2 == s0))) & bal(p2 >= s0); K3 = (K3 | (N3 & bal(p3 == s0))) & bal(p3 >= s0); }
         }
         if (cend >= b + SKIPD) {                                 // positions buried >= SKIPD deep in the running best match
             const uint32_t T = cend - SKIPD;                      // p <= T: buried
@@ -829,7 +837,7 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
     // block behind the last one is still inside the workspace): a conditional load made hipcc wait for the data right
     // where it was requested.
     u32x2 dn = *reinterpret_cast<const g_u32x2*>(cand_t + ((s0 >> 8) * 512u + lane * 8u));
-    for (uint32_t B0 = s0; B0 < s1; B0 += 256u) {
+    for (uint32_t B0 = s0 & ~255u; B0 < s1; B0 += 256u) {       // (s0 is a multiple of 512 except in an anchored last window)
         // the four steps of this 256-block: as one superstep if it holds at most 128 heads, else in halves
         const uint32_t dq0 = dn.x & 0xFFFFu, dq1 = dn.x >> 16, dq2 = dn.y & 0xFFFFu, dq3 = dn.y >> 16;
         dn = *reinterpret_cast<const g_u32x2*>(cand_t + (((B0 >> 8) + 1u) * 512u + lane * 8u));
@@ -899,7 +907,7 @@ __device__ __forceinline__ void put_len_header(g_u8* dst, uint32_t lit, uint32_t
 
 // Place segment w of the current window (after the barrier: every worker's SegMeta is final).
 __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8_t* __restrict__ gin_, uint32_t blk_len_, uint32_t win_idx_, bool last_win_,
-                              uint32_t wl_, const uint8_t* body_, uint8_t* gout_, uint32_t carry_slot_, uint32_t w_, uint32_t lane,
+                              uint32_t wl_, uint32_t wbase_, uint32_t wskip_, const uint8_t* body_, uint8_t* gout_, uint32_t carry_slot_, uint32_t w_, uint32_t lane,
                               uint32_t* out_len_, int32_t* status_, uint32_t* gcarry_, uint32_t iter_) {
     const g_u8* __restrict__ gin = uni_gptr<const g_u8>(gin_);
     const g_u8* body = uni_gptr<const g_u8>(body_);
@@ -907,6 +915,7 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
     g_u32* out_len = uni_gptr<g_u32>(out_len_);
     g_i32* status = uni_gptr<g_i32>(status_);
     const uint32_t blk_len = uni(blk_len_), win_idx = uni(win_idx_), wl = uni(wl_), carry_slot = uni(carry_slot_), w = uni(w_);
+    const uint32_t wbase = uni(wbase_), wskip = uni(wskip_);       // the window's first byte in the block; its first wskip positions are history
     const bool last_win = uni((uint32_t)last_win_) != 0u;
     const lds_u32* mp = (const lds_u32*)(lds + L_META);
     lds_u32* cp = (lds_u32*)(lds + L_META) + 5u * WORKERS;          // BlkCarry[2]
@@ -948,10 +957,11 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
             out_pos = cp[2u * (carry_slot ^ 1u)]; pend = cp[2u * (carry_slot ^ 1u) + 1u];
         }
     }
-    auto seg_len = [&](uint32_t j) -> uint32_t {
-        const uint32_t lo = seg_lo(j) < wl ? seg_lo(j) : wl, hi = seg_lo(j + 1u) < wl ? seg_lo(j + 1u) : wl;
-        return hi - lo;
+    auto seg_at = [&](uint32_t j) -> uint32_t {                     // start of segment j, clipped to the parsed part of the window
+        const uint32_t v = seg_lo(j) > wskip ? seg_lo(j) : wskip;
+        return v < wl ? v : wl;
     };
+    auto seg_len = [&](uint32_t j) -> uint32_t { return seg_at(j + 1u) - seg_at(j); };
     for (uint32_t j = 0; j < w; ++j) {
         const uint32_t sl = seg_len(j);
         if (mp[5u * j] != 0u) {
@@ -963,7 +973,7 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
         }
     }
     const uint32_t sl = seg_len(w);
-    const uint32_t abs0 = win_idx * WINDOW + seg_lo(w);            // block-relative start of this segment
+    const uint32_t abs0 = wbase + seg_at(w);                       // block-relative start of this segment
     if (gcarry != nullptr && w == WORKERS - 1u && !last_win && lane == 0u) {
         // the next window's carry depends on sizes only: hand it on BEFORE the bytes are copied (the windows of a block form a
         // chain through global memory; with the copies inside it a block advanced one window per 4 microseconds)
@@ -1123,20 +1133,28 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
     if (it.blk >= a.n) return;
     uint32_t k = 0u;
 
-    auto win_len = [](const Item& t) -> uint32_t {
-        const uint32_t base = t.win * WINDOW;
+    // Window t.win of a block starts at t.win * 64 KiB -- except the LAST window of a block that is longer than 64 KiB: it is
+    // anchored at the block's end (base = len - 64 KiB) and overlaps the window before it.  Its first win_skip positions are
+    // history only (indexed and loaded, not parsed), so the block's tail can match backwards like the reference's
+    // (src/block/compress.rs:403-405: the window is the previous 64 KiB; a 66 675-byte block is 65 536 + 1 139 bytes).
+    auto win_base = [](const Item& t) -> uint32_t {
+        return (t.win + 1u == t.nwin && t.len > WINDOW) ? t.len - WINDOW : t.win * WINDOW;
+    };
+    auto win_skip = [&](const Item& t) -> uint32_t { return t.win * WINDOW - win_base(t); };
+    auto win_len = [&](const Item& t) -> uint32_t {
+        const uint32_t base = win_base(t);
         return t.len > base ? (t.len - base < WINDOW ? t.len - base : WINDOW) : 0u;
     };
     auto do_index = [&](const Item& t, uint32_t slot) {
         if (t.skip) return;
-        const uint32_t base = t.win * WINDOW, wl = win_len(t);
+        const uint32_t base = win_base(t), wl = win_len(t);
         const uint32_t act_abs = t.len >= 12u ? t.len - 11u : 0u;            // positions p < act_abs start 4 readable bytes and may match
         const uint32_t act_n = act_abs > base ? (act_abs - base < wl ? act_abs - base : wl) : 0u;
         index_window(a.in_base + t.in_off + base, wl, act_n, t.len - base, slots + (size_t)slot * SLOT_BYTES, lds, lane);
     };
     auto do_load = [&](const Item& t) {
         if (t.skip) return;
-        load_window(a.in_base + t.in_off + (size_t)t.win * WINDOW, win_len(t), lds, threadIdx.x);
+        load_window(a.in_base + t.in_off + (size_t)win_base(t), win_len(t), lds, threadIdx.x);
     };
 
     // (sums are kept in registers and added to prof[] once, when the workgroup is done: an atomic per tick made the
@@ -1176,16 +1194,23 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
         if (w == WORKERS) {
             if (ix.blk < a.n) do_index(ix, (k + 1u) & 1u);
         } else if (!it.skip) {
-            const uint32_t base = it.win * WINDOW;
-            const uint32_t s0 = seg_lo(w) < wl ? seg_lo(w) : wl;
-            const uint32_t s1 = seg_lo(w + 1u) < wl ? seg_lo(w + 1u) : wl;
+            const uint32_t base = win_base(it), skip = win_skip(it);
+            uint32_t s0 = seg_lo(w) > skip ? seg_lo(w) : skip;
+            uint32_t s1 = seg_lo(w + 1u) > skip ? seg_lo(w + 1u) : skip;
+            s0 = s0 < wl ? s0 : wl;
+            s1 = s1 < wl ? s1 : wl;
             const uint32_t act_abs = it.len >= 12u ? it.len - 11u : 0u;
             const uint32_t mfl_end = act_abs > base ? act_abs - base : 0u;      // window-relative, may exceed wl
             uint32_t mend = it.len >= 5u ? it.len - 5u : 0u;                    // block-relative
             mend = mend > base ? mend - base : 0u;
             mend = mend < s1 ? mend : s1;
             mend = mend < 65535u ? mend : 65535u;
-            match_segment(slots + (size_t)(k & 1u) * SLOT_BYTES, bodies + (size_t)w * BODY_STRIDE, w, lane, s0, s1, mfl_end, mend, prof);
+            if (s0 < s1) {
+                match_segment(slots + (size_t)(k & 1u) * SLOT_BYTES, bodies + (size_t)w * BODY_STRIDE, w, lane, s0, s1, mfl_end, mend, prof);
+            } else if (lane == 0u) {                              // an empty segment (history only, or behind the block's end)
+                lds_u32* mp = (lds_u32*)(lds + L_META) + 5u * w;
+                mp[0] = 0u; mp[1] = 0u; mp[2] = 0u; mp[3] = 0u; mp[4] = 0u;
+            }
         }
         tick(w == WORKERS ? 0u : 2u);
         __syncthreads();
@@ -1199,7 +1224,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
             if (it.skip) {
                 if (threadIdx.x == 0u) { a.out_len[it.blk] = 0u; a.status[it.blk] = LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL; }
             } else {
-                place_segment(lds, a.in_base + it.in_off, it.len, it.win, last_win, wl, bodies + (size_t)w * BODY_STRIDE,
+                place_segment(lds, a.in_base + it.in_off, it.len, it.win, last_win, wl, win_base(it), win_skip(it), bodies + (size_t)w * BODY_STRIDE,
                               a.out_base + a.out_off[it.blk], k & 1u, w, lane, a.out_len + it.blk, a.status + it.blk,
                               wmode ? carry + CARRY_DWORDS * (size_t)it.blk : nullptr, k + 1u);
             }

@@ -115,12 +115,15 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t* __restrict__ in, 
         // ---- literals (decompress.rs:334-362) ----------------------------------------------
         if (lit != 0u) {
             if (lit == 15u) {
+                uint64_t acc = lit;   // usize in the reference: > 16 MiB of 0xFF length bytes must not wrap a 32-bit sum
                 for (;;) {   // read_integer_ptr, decompress.rs:126-157
                     if (ip >= ilen) return LZ4FLEX_DEV_E_EXPECTED_ANOTHER_BYTE;
                     const uint32_t e = in[ip++];
-                    lit += e;
+                    acc += e;
                     if (e != 0xFFu) break;
                 }
+                if (acc > (uint64_t)(ilen - ip)) return LZ4FLEX_DEV_E_LITERAL_OUT_OF_BOUNDS;
+                lit = (uint32_t)acc;
             }
             if (lit > ilen - ip) return LZ4FLEX_DEV_E_LITERAL_OUT_OF_BOUNDS;
             if (lit > cap - op) {
@@ -148,12 +151,19 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t* __restrict__ in, 
         if (offset == 0u) return LZ4FLEX_DEV_E_OFFSET_ZERO;
         uint32_t ml = 4u + (token & 15u);
         if (ml == 19u) {
+            uint64_t acc = ml;
             for (;;) {
                 if (ip >= ilen) return LZ4FLEX_DEV_E_EXPECTED_ANOTHER_BYTE;
                 const uint32_t e = in[ip++];
-                ml += e;
+                acc += e;
                 if (e != 0xFFu) break;
             }
+            if (acc > 0xFFFFFFFFull) {   // (same order as below: the offset check comes first)
+                if (offset > op + dict_len) return LZ4FLEX_DEV_E_OFFSET_OUT_OF_BOUNDS;
+                *det_expected = (uint64_t)op + acc;
+                return LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL;
+            }
+            ml = (uint32_t)acc;
         }
         // ---- bounds (decompress.rs:398-408; unsafe-flavour order) --------------------------
         if (offset > op + dict_len) return LZ4FLEX_DEV_E_OFFSET_OUT_OF_BOUNDS;
@@ -232,10 +242,12 @@ hipError_t launch_decompress(const DecompressArgs& a, int lanes_per_block, hipSt
     if (a.n == 0u) return hipSuccess;
     const bool d = a.dict_base != nullptr;
     switch (lanes_per_block) {
-        case 8: return d ? launch_g<8, true>(a, s) : launch_g<8, false>(a, s);
         case 16: return d ? launch_g<16, true>(a, s) : launch_g<16, false>(a, s);
+#ifdef LZ4FLEX_ALL_VARIANTS   // the other group widths measured slower at every batch size (round 1); variant builds only
+        case 8: return d ? launch_g<8, true>(a, s) : launch_g<8, false>(a, s);
         case 32: return d ? launch_g<32, true>(a, s) : launch_g<32, false>(a, s);
         case 64: return d ? launch_g<64, true>(a, s) : launch_g<64, false>(a, s);
+#endif
         default: return hipErrorInvalidValue;
     }
 }

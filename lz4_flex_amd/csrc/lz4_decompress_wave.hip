@@ -167,6 +167,7 @@ __device__ bool exact_token(Dec& D, uint32_t& ip, bool& done) {
             const uint32_t b = in[ip];
             ip += 1u;
             lit += b;
+            if (lit > 0x7FFFFFFFu) return false;      // (a 32-bit sum must not wrap: the reference counts in usize)
             if (b != 255u) break;
         }
     }
@@ -190,6 +191,7 @@ __device__ bool exact_token(Dec& D, uint32_t& ip, bool& done) {
             const uint32_t b = in[ip];
             ip += 1u;
             ml += b;
+            if (ml > 0x7FFFFFFFu) return false;
             if (b != 255u) break;
         }
     }

@@ -214,13 +214,16 @@ struct ParserT {
             uint32_t lit = tok >> 4;
             mlc = tok & 15u;
             if (lit == 15u) {
+                uint64_t acc = lit;   // usize in the reference: > 16 MiB of 0xFF length bytes must not wrap a 32-bit sum
                 for (;;) {   // read_integer_ptr :126-157
                     if (ip >= ilen) return fail(LZ4FLEX_DEV_E_EXPECTED_ANOTHER_BYTE);
                     const uint32_t e = rd8(ip);
                     ip += 1u;
-                    lit += e;
+                    acc += e;
                     if (e != 0xFFu) break;
                 }
+                if (acc > (uint64_t)(ilen - ip)) return fail(LZ4FLEX_DEV_E_LITERAL_OUT_OF_BOUNDS);
+                lit = (uint32_t)acc;
             }
             if (lit > ilen - ip) return fail(LZ4FLEX_DEV_E_LITERAL_OUT_OF_BOUNDS);
             if (lit > cap - op) { expected = (uint64_t)op + lit; return fail(LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL); }
@@ -244,13 +247,20 @@ struct ParserT {
         if (offset == 0u) return fail(LZ4FLEX_DEV_E_OFFSET_ZERO);
         uint32_t ml = 4u + mlc;
         if (ml == 19u) {
+            uint64_t acc = ml;
             for (;;) {
                 if (ip >= ilen) return fail(LZ4FLEX_DEV_E_EXPECTED_ANOTHER_BYTE);
                 const uint32_t e = rd8(ip);
                 ip += 1u;
-                ml += e;
+                acc += e;
                 if (e != 0xFFu) break;
             }
+            if (acc > 0xFFFFFFFFull) {
+                if (offset > op) return fail(LZ4FLEX_DEV_E_OFFSET_OUT_OF_BOUNDS);
+                expected = (uint64_t)op + acc;
+                return fail(LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL);
+            }
+            ml = (uint32_t)acc;
         }
         if (offset > op) return fail(LZ4FLEX_DEV_E_OFFSET_OUT_OF_BOUNDS);       // :398-408, unsafe-flavour order
         if (ml > cap - op) { expected = (uint64_t)op + ml; return fail(LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL); }

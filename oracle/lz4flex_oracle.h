@@ -142,6 +142,13 @@ double lz4o_bench_batch_fn(int dir, void *fn, const uint8_t *in_base, const uint
                            uint8_t *out_base, const uint64_t *out_off, const uint32_t *out_cap,
                            uint32_t *out_len, uint32_t n_blocks, int threads, int reps);
 
+/* The measurement proper: a pool of `threads` workers created once, `reps` timed passes of >= min_pass_s seconds each (a
+ * pass repeats the sweep over the batch as often as that takes), returns the best time of ONE sweep.  *used (nullable) =
+ * worker threads that really ran. */
+double lz4o_bench_pool(int dir, void *fn, const uint8_t *in_base, const uint64_t *in_off, const uint32_t *in_len,
+                       uint8_t *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
+                       uint32_t n_blocks, int threads, int reps, double min_pass_s, int *used);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,9 @@ def lib():
         o.lz4o_bench_batch_fn.restype = C.c_double
         o.lz4o_bench_batch_fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_uint32, C.c_int, C.c_int]
+        o.lz4o_bench_pool.restype = C.c_double
+        o.lz4o_bench_pool.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int)]
         _o = o
     return _o
 

@@ -42,24 +42,36 @@ typedef struct {
 
 static inline uint32_t ld32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 
-/* index pass: d[p] for every p (0 = no candidate).  The table is cleared at every 64 KiB window start, so a
- * candidate never lies before its position's window. */
+/* A block longer than 64 KiB is a sequence of windows.  Window wi covers [wi * 64 KiB, ...) -- except the LAST window of a block
+ * whose length is not a multiple of 64 KiB: it is anchored at the block's END (base = n - 64 KiB), so it overlaps the window
+ * before it.  Only the positions behind that window's end ("newfrom") are parsed; the overlap is history (it is indexed
+ * again, and matches may start in it).  Without this a 66 675-byte block would be 65 536 + 1 139 bytes with no history for
+ * the tail, and the reference's ratio pin for its JSON fixture (tests/tests.rs:168-170) fails. */
+static uint32_t win_count(uint32_t n) { return (n + WINDOW - 1) / WINDOW; }
+static uint32_t win_base(uint32_t n, uint32_t wi) { return (wi + 1 == win_count(n) && n > WINDOW) ? n - WINDOW : wi * WINDOW; }
+
+/* index pass: d[p] for every p (0 = no candidate).  The table is cleared at every window start, so a candidate never lies
+ * before its position's window; steps of 64 positions are counted from the window's base. */
 void lz4w_index(const uint8_t *in, uint32_t n, uint16_t *d) {
     uint16_t *tab = (uint16_t *)calloc(1u << HBITS, 2);
-    for (uint32_t b = 0; b < n; b += WAVE) {
-        uint32_t idx[WAVE];
-        int act[WAVE];
-        if ((b & (WINDOW - 1)) == 0) memset(tab, 0, 2u << HBITS);
-        for (int i = 0; i < WAVE; i++) {
-            const uint32_t p = b + i;
-            act[i] = (n >= 12 && p <= n - 12);
-            if (p < n) d[p] = 0;
-            if (!act[i]) continue;
-            idx[i] = (ld32(in + p) * 2654435761u) >> (32 - HBITS);
-            d[p] = (uint16_t)((p & (WINDOW - 1)) - tab[idx[i]]);
+    for (uint32_t p = 0; p < n; p++) d[p] = 0;
+    for (uint32_t wi = 0; wi < win_count(n); wi++) {
+        const uint32_t base = win_base(n, wi), newfrom = wi * WINDOW;
+        const uint32_t wend = (n - base < WINDOW) ? n : base + WINDOW;
+        memset(tab, 0, 2u << HBITS);
+        for (uint32_t b = base; b < wend; b += WAVE) {
+            uint32_t idx[WAVE];
+            int act[WAVE];
+            for (int i = 0; i < WAVE; i++) {
+                const uint32_t p = b + i;
+                act[i] = (p < wend && n >= 12 && p <= n - 12);
+                if (!act[i]) continue;
+                idx[i] = (ld32(in + p) * 2654435761u) >> (32 - HBITS);
+                if (p >= newfrom) d[p] = (uint16_t)((p - base) - tab[idx[i]]);
+            }
+            for (int i = 0; i < WAVE; i++)
+                if (act[i]) tab[idx[i]] = (uint16_t)(b + i - base);
         }
-        for (int i = 0; i < WAVE; i++)
-            if (act[i]) tab[idx[i]] = (uint16_t)((b + i) & (WINDOW - 1));
     }
     free(tab);
 }
@@ -75,7 +87,7 @@ typedef struct { uint32_t lit_start, lit_len, off, mlen; } lz4w_seq;
 /* is p a head of segment [s0, s1) given the running best match `carry` (window-relative end << 16 | distance)? */
 static int is_head(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_params *P, uint32_t wbase, uint32_t s0, uint32_t s1,
                    uint32_t carry, uint32_t p) {
-    if (p >= s1 || n < 12 || p > n - 12) return 0;
+    if (p < s0 || p >= s1 || n < 12 || p > n - 12) return 0;
     const uint32_t dp = d[p], dprev = (p > s0) ? d[p - 1] : 0;
     if (dp == 0 || dp == dprev) return 0;
     if (p - wbase < dp) return 0;                                 /* candidate before the window */
@@ -91,15 +103,18 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
     size_t ns = 0;
     uint32_t anchor = 0;
     uint32_t best[256], own[256];
-    const uint32_t nwin = (n + WINDOW - 1) / WINDOW;
+    const uint32_t nwin = win_count(n);
     for (uint32_t sj = 0; sj < nwin * P->nseg; sj++) {
-        const uint32_t wbase = (sj / P->nseg) * WINDOW;            /* candidates must lie in the segment's 64 KiB window */
+        const uint32_t wbase = win_base(n, sj / P->nseg);          /* candidates must lie in the segment's 64 KiB window */
+        const uint32_t newfrom = (sj / P->nseg) * WINDOW;          /* an anchored last window: the positions before this are history */
         const uint32_t wj = sj % P->nseg;
         /* eight segments are 16 17 17 17 15 16 15 15 groups of 512 long (later segments cost more per position: the kernel's
          * workers finish together), any other count tiles the window evenly */
         static const uint32_t lo8[9] = {0, 16, 33, 50, 67, 82, 98, 113, 128};
         uint32_t s0 = wbase + 512u * (P->nseg == 8 ? lo8[wj] : (128u * wj) / P->nseg);
         uint32_t s1 = wbase + 512u * (P->nseg == 8 ? lo8[wj + 1] : (128u * (wj + 1)) / P->nseg);
+        if (s0 < newfrom) s0 = newfrom;
+        if (s1 < newfrom) s1 = newfrom;
         if (s0 > n) s0 = n;
         if (s1 > n) s1 = n;
         if (s0 == s1) continue;
@@ -107,12 +122,12 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
         if (mend > wbase + 65535u) mend = wbase + 65535u;                    /* ends are 16-bit window-relative numbers */
         uint32_t carry = 0;    /* the match that reaches furthest so far in this segment: window-relative end << 16 | distance */
         uint32_t cursor = s0;
-        uint32_t b = s0;
+        uint32_t b = wbase + ((s0 - wbase) & ~255u);              /* supersteps are aligned in the window; positions before s0 are no heads */
         while (b < s1) {
             /* superstep size: the largest aligned power of two <= 256 whose positions hold <= MAXHEADS heads (128: always) */
             uint32_t size = 256, e1 = 0;
             for (;; size >>= 1) {
-                if ((b & (size - 1)) == 0) {
+                if (((b - wbase) & (size - 1)) == 0) {
                     e1 = (b + size < s1) ? b + size : s1;
                     uint32_t h = 0;
                     for (uint32_t p = b; p < e1; p++) h += (uint32_t)is_head(in, n, d, P, wbase, s0, s1, carry, p);

@@ -31,11 +31,12 @@ def _gpu_decode(blk, data, cap, dict_data=None):
     return "ok", bytes(out[:n])
 
 
-# every decoder kernel behind lz4flex_decompress_batch: lanes > 0 = lz4_decompress.hip (variant 1) group widths,
+# every decoder kernel behind lz4flex_decompress_batch: lanes > 0 = lz4_decompress.hip (variant 1; the default build keeps the
+# 16-lane group width, 8 / 32 / 64 exist with -DLZ4FLEX_ALL_VARIANTS only),
 # -408 / -432 / -464 = parser / copier split decoder with 8 / 32 / 64 blocks per workgroup (8 copier lanes x 4 bytes per block;
 # 64: 4 lanes x 16 bytes), -5 = one block per wavefront (wave decoder), -6 = the wave decoder with a parser and an executor
 # wavefront per block
-DECODERS = [8, 16, 32, 64, -408, -432, -464, -5, -6]
+DECODERS = [16, -408, -432, -464, -5, -6]
 
 
 def _select_decoder(lib, ctx, lanes):
@@ -285,9 +286,10 @@ def _tile(src, total, block):
     return buf
 
 
-@pytest.mark.parametrize("lanes,variant", [(8, 1), (16, 1), (8, 3), (16, 3)])
+@pytest.mark.parametrize("lanes,variant", [(8, 1), (16, 1)])
 def test_compress_batch_bit_exact_vs_oracle(blk, lanes, variant):
-    """the reference-exact encoder (compress_mode 1): both variants and both group widths produce the reference's bytes"""
+    """the reference-exact encoder (compress_mode 1): both group widths produce the reference's bytes (variant 3, the encoder
+    without its emitter wavefront, exists with -DLZ4FLEX_ALL_VARIANTS only)"""
     from lz4_flex_amd import _lib
     import ctypes as C
     lib = _lib.load()
