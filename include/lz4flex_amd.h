@@ -209,12 +209,15 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  *   launch per batch of blocks; in mode 1 it holds the reference's bytes (one dependency chain, milliseconds per block).
  *   Environment: LZ4FLEX_COMPRESS_MODE=exact|fast.
  * Kernel selection, for measurements only (every choice produces the same bytes / lengths / error variants):
- * "decompress_variant": 0 = by batch size (default), 5 = one block per wavefront (lz4_decompress_wave.hip), 6 = the same with a
- *   parser and an executor wavefront per block (few, large blocks), 4 = parser /
- *   copier split decoder, 1 = decoder whose window lives in HBM/L2 (always used for dictionary /
+ * "decompress_variant": 0 = by batch size (default), 7 = one block per WORKGROUP, token chain and copies parallel inside the
+ *   block (lz4_decompress_pcd.hip: few, large blocks; 8 = the same with its small test geometry), 5 = one block per wavefront
+ *   (lz4_decompress_wave.hip), 6 = the same with a parser and an executor wavefront per block, 4 = parser /
+ *   copier split decoder (large batches), 1 = decoder whose window lives in HBM/L2 (always used for dictionary /
  *   prefix blocks); "decompress_blocks_per_wg" (variant 4: 0 = by batch size, 8/16/32/64); "decompress_lanes"
- *   (8/16/32/64, variant 1); exact encoder: "compress_lanes" (8/16 lanes of a wavefront per block), "compress_variant"
- *   (1 = group encoder + emitter wavefront, 3 = group encoder alone). */
+ *   (16; 8/32/64 in -DLZ4FLEX_ALL_VARIANTS builds, variant 1); exact encoder: "compress_lanes" (8/16 lanes of a wavefront per
+ *   block), "compress_variant" (1 = group encoder + emitter wavefront; 3 = group encoder alone, -DLZ4FLEX_ALL_VARIANTS builds);
+ *   "decompress_second_pass" (tests: 0 leaves the blocks that variants 5..8 hand to the reference-order kernel marked with
+ *   status 0x7F000001 instead of decoding them again). */
 int lz4flex_set_tuning(lz4flex_ctx *ctx, const char *key, int value);
 /* the current value of a setting (>= 0), or -LZ4FLEX_E_INVALID_ARG for an unknown key */
 int lz4flex_get_tuning(lz4flex_ctx *ctx, const char *key);

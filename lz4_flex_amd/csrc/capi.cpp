@@ -57,8 +57,14 @@ struct lz4flex_ctx {
     hipStream_t wave_last = nullptr;
     bool wave_used = false;
     int dec_blocks_per_wg = 0;    // split decoder: blocks per workgroup (8/16/32/64), 0 = by batch size
-    int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 4 = parser / copier split (lz4_decompress_split.hip), 5 / 6 = a wavefront / a pair of wavefronts per block (lz4_decompress_wave.hip)
+    int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 4 = parser / copier split (lz4_decompress_split.hip), 5 / 6 = a wavefront / a pair of wavefronts per block (lz4_decompress_wave.hip), 7 = a workgroup per block (lz4_decompress_pcd.hip; 8: its test geometry)
+    int dec_second_pass = 1;      // tests: 0 leaves the blocks a first-pass decoder marked (status 0x7F000001) instead of decoding them again
 };
+
+#ifndef LZ4FLEX_PCD_MAX_BLOCKS
+#define LZ4FLEX_PCD_MAX_BLOCKS 1024
+#endif
+static constexpr uint32_t PCD_MAX_BLOCKS = LZ4FLEX_PCD_MAX_BLOCKS;
 
 // the decoders for blocks without dictionary / prefix
 static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressArgs& a, hipStream_t s) {
@@ -69,13 +75,16 @@ static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressA
     // 1.31 / 1.31 / 1.52 / 1.55 / 1.79 / 3.86 (round 1's pipelined decoder 2.43 / 2.54 / 2.62 / 2.59 / 2.9 / 4.15: deleted).
     // up to 2 304 blocks (nine pairs of wavefronts per CU) the wave decoder runs with a parser and an executor wavefront per
     // block: 256 / 1 024 / 2 048 blocks 0.45 / 0.52 / 0.65 ms against 0.73 / 0.75 / 0.82 with one wavefront
-    const int v = c->dec_variant != 0 ? c->dec_variant : (a.n <= 2304u ? 6 : (a.n <= 5120u ? 5 : 4));
-    if (v == 5 || v == 6) {
-        // one block per wavefront (6: per pair of wavefronts); blocks it marks (errors, sinks too small) are decoded again in
-        // the reference's order
+    // up to PCD_MAX_BLOCKS blocks: a whole workgroup per block, token chain and copies parallel INSIDE the block (lz4_decompress_pcd.hip):
+    // the only decoder here whose time for a block does not grow with the block's chain alone
+    const int v = c->dec_variant != 0 ? c->dec_variant : (a.n <= PCD_MAX_BLOCKS ? 7 : (a.n <= 2304u ? 6 : (a.n <= 5120u ? 5 : 4)));
+    if (v >= 5 && v <= 8) {
+        // one block per wavefront (6: per pair of wavefronts; 7 / 8: per workgroup); blocks it marks (errors, sinks too small) are
+        // decoded again in the reference's order
         constexpr int32_t REDO = 0x7F000001;
-        hipError_t e = v == 6 ? launch_decompress_wave_pair(a, REDO, s) : launch_decompress_wave(a, REDO, s);
+        hipError_t e = v >= 7 ? launch_decompress_pcd(a, REDO, s, v == 8) : (v == 6 ? launch_decompress_wave_pair(a, REDO, s) : launch_decompress_wave(a, REDO, s));
         if (e != hipSuccess) return e;
+        if (!c->dec_second_pass) return hipSuccess;
         DecompressArgs r = a;
         r.only_status = REDO;
         return launch_decompress(r, c->dec_lanes, s);
@@ -188,7 +197,7 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
 #ifdef LZ4FLEX_ALL_VARIANTS
     if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v == 1 || v == 3) c->comp_variant = v; }
 #endif
-    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v == 0 || v == 1 || (v >= 4 && v <= 6)) c->dec_variant = v; }
+    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v == 0 || v == 1 || (v >= 4 && v <= 8)) c->dec_variant = v; }
     int prev = 0;
     (void)hipGetDevice(&prev);
     e = hipSetDevice(device);
@@ -270,8 +279,13 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "decompress_variant")) {
-        if (value != 0 && value != 1 && (value < 4 || value > 6)) return -LZ4FLEX_E_INVALID_ARG;
+        if (value != 0 && value != 1 && (value < 4 || value > 8)) return -LZ4FLEX_E_INVALID_ARG;
         c->dec_variant = value;
+        return 0;
+    }
+    if (!strcmp(key, "decompress_second_pass")) {
+        if (value != 0 && value != 1) return -LZ4FLEX_E_INVALID_ARG;
+        c->dec_second_pass = value;
         return 0;
     }
     if (!strcmp(key, "compress_variant")) {
@@ -298,6 +312,7 @@ int lz4flex_get_tuning(lz4flex_ctx* c, const char* key) {
     if (!strcmp(key, "compress_variant")) return c->comp_variant;
     if (!strcmp(key, "compress_lanes")) return c->comp_lanes;
     if (!strcmp(key, "decompress_variant")) return c->dec_variant;
+    if (!strcmp(key, "decompress_second_pass")) return c->dec_second_pass;
     if (!strcmp(key, "decompress_blocks_per_wg")) return c->dec_blocks_per_wg;
     if (!strcmp(key, "decompress_lanes")) return c->dec_lanes;
     return -LZ4FLEX_E_INVALID_ARG;

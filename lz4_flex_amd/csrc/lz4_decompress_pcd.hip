@@ -1,0 +1,570 @@
+// lz4_decompress_pcd.hip -- PARALLEL-CHAIN LZ4 block decoder for gfx950: FEW, LARGE blocks (and small batches).
+//
+// What it replaces: lz4_flex::block::decompress_into / decompress_internal (src/block/decompress.rs:201-449) for the batch
+// shapes that leave most of the chip idle when a block is one serial token chain: BASELINE configs[3] (256 x 4 MiB blocks per
+// GPU), configs[2] (160 blocks), a scalar decompress_into of one large block.  Every other decoder here walks a block's token
+// chain with ONE lane (or one wavefront's scalar hop): 80-140 MB/s per block whatever its size.  Here ONE WORKGROUP of 1 024
+// lanes decodes a block, and both halves of the reference's loop are parallel inside the block:
+//
+//   PARSE (the token chain, decompress.rs:244-332).  The compressed stream is consumed in tiles of 32 KiB staged in LDS; a tile
+//   is cut into 128 parts of 256 bytes and lane k walks part k from an ASSUMED entry (the part's first byte), marking the
+//   token positions it visits in an LDS bitmap and noting where its chain leaves the part.  A chain started at a wrong byte
+//   falls into step with the true chain after a few sequences, and two chains that share a position are identical from
+//   there on.  One wavefront then follows the exits from part 0 (whose entry is true) by pointer jumping: the exit of a live
+//   part is the true entry of the part it lands in.  Parts whose entry changed are walked again; this repeats until nothing
+//   changes (1.8 walks per part on the benchmark data; NP + 1 rounds at worst).  The set bits of the live parts are the
+//   tile's sequences, in order.  No lane needs the output position.
+//
+//   COPY (decompress.rs:334-437).  Sequences are executed 1 024 at a time, one lane each: token re-parsed from the LDS tile, a
+//   block-wide prefix sum of literal + match lengths places all of them at once in an LDS WINDOW of the output (16 KiB of
+//   history + up to 32 KiB new bytes); all literals are copied at once; a match waits until the sequences that produce its
+//   source bytes (a range of the batch found by binary search over the start positions) have set their DONE bits, then copies
+//   16 bytes at a time and sets its own.  Wavefronts poll independently: a dependency costs an LDS round trip, not a barrier.
+//   Long / overlapping / window-straddling matches and long literal runs are copied by a whole wavefront (non-overlapping
+//   steps of doubling size for periodic matches); a sequence longer than the window is executed alone by the whole workgroup
+//   on the output itself.  The window is written back 16 bytes per lane after every batch.
+//
+// It diagnoses nothing: any irregularity (every DecompressError of src/block/mod.rs:82-98, a sink too small, an offset behind
+// the output, a tile that does not settle) marks the block, and lz4_decompress_blocks_kernel decodes it again in the
+// reference's check order and names the error (as behind lz4_decompress_wave.hip).  The host model of this algorithm is
+// tests/sim/pcd_model.cpp (same walker: lz4_pcd_common.h; tests/test_pcd_model.py).  Every wait in here is bounded.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lz4_device.h"
+#include "lz4_pcd_common.h"
+
+namespace lz4flex_dev {
+namespace pcd {
+
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1u) / a * a; }
+constexpr uint32_t ceil_log2(uint32_t v) { uint32_t r = 0u; while ((1u << r) < v) ++r; return r; }
+
+// CT compressed bytes per tile (+ CM staged behind it), parts of P bytes, T threads = sequences per batch, window = HIST + WNEW
+template <uint32_t CT_, uint32_t CM_, uint32_t P_, uint32_t T_, uint32_t HIST_, uint32_t WNEW_>
+struct Geo {
+    static constexpr uint32_t CT = CT_, CM = CM_, P = P_, NP = CT_ / P_, T = T_, HIST = HIST_, WNEW = WNEW_, WIN = HIST_ + WNEW_;
+    static constexpr uint32_t MW = CT / 32u;                      // mark words
+    static constexpr uint32_t PW = P / 32u;                       // mark words per part
+    static constexpr uint32_t NW = T / 64u;                       // wavefronts
+    static constexpr uint32_t MAXSEQ = CT / 3u + 2u;              // a sequence with a match is >= 3 bytes
+    static constexpr uint32_t PPL = (NP + 63u) / 64u;             // parts per lane of the resolving wavefront
+    static constexpr uint32_t MAX_ITERS = NP + 2u;
+    static constexpr uint32_t KP = (HIST + 16u * T - 1u) / (16u * T);   // 16-byte pieces per thread when the history slides
+    // LDS layout
+    static constexpr uint32_t L_CT = 0u;
+    static constexpr uint32_t L_MARK = align_up(L_CT + CT + CM + 16u, 16u);
+    static constexpr uint32_t L_ENT = L_MARK + 4u * MW;
+    static constexpr uint32_t L_EXT = L_ENT + 4u * NP;
+    static constexpr uint32_t L_NXT = L_EXT + 4u * NP;
+    static constexpr uint32_t L_RCH = L_NXT + 4u * (NP + 4u);
+    static constexpr uint32_t L_TOK = align_up(L_RCH + 4u * (NP + 4u), 16u);
+    static constexpr uint32_t L_BST = align_up(L_TOK + 2u * MAXSEQ, 16u);
+    static constexpr uint32_t L_DONE = align_up(L_BST + 4u * (T + 1u), 16u);
+    static constexpr uint32_t L_WSUM = L_DONE + 4u * align_up(T / 32u, 4u);
+    static constexpr uint32_t L_CTL = L_WSUM + 4u * align_up(NW, 4u);
+    static constexpr uint32_t L_WIN = align_up(L_CTL + 4u * 32u, 16u);
+    static constexpr uint32_t LDS_BYTES = L_WIN + WIN + 64u;
+    static_assert(CT % P == 0 && P % 32 == 0 && T % 64 == 0 && MW <= T && NP <= T && NP <= 64u * PPL && HIST % 16 == 0, "geometry");
+    static_assert(LDS_BYTES <= 160u * 1024u, "LDS");
+};
+using GeoProd = Geo<CT, CM, P, BATCH, HIST, WNEW>;              // lz4_pcd_common.h: 32 KiB tiles, 256-byte parts, 1 024 lanes, 16 + 32 KiB window
+using GeoTest = Geo<2048u, 256u, 64u, 128u, 512u, 1024u>;       // tests: boundaries of every kind inside small inputs
+
+enum : uint32_t { C_EXIT = 0, C_CUT = 1, C_TOTAL = 2, C_BAD = 3, C_G_SRC = 4, C_G_LIT = 5, C_G_ML = 6, C_G_OFF = 7, C_TIMEOUT = 8 };
+
+#define PCD_DPP(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xf, false))
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
+    v += PCD_DPP(v, 0x111, 0xf);     // row_shr:1
+    v += PCD_DPP(v, 0x112, 0xf);     // row_shr:2
+    v += PCD_DPP(v, 0x114, 0xf);     // row_shr:4
+    v += PCD_DPP(v, 0x118, 0xf);     // row_shr:8
+    v += PCD_DPP(v, 0x142, 0xa);     // row_bcast:15 -> rows 1, 3
+    v += PCD_DPP(v, 0x143, 0xc);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t l) { return (uint32_t)__shfl((int)v, (int)l, 64); }
+__device__ __forceinline__ u32x4 ld16l(const lds_u8* p) { u32x4 v; __builtin_memcpy(&v, (const void*)p, 16); return v; }
+__device__ __forceinline__ void st16l(lds_u8* p, const u32x4& v) { __builtin_memcpy((void*)p, &v, 16); }
+__device__ __forceinline__ u32x4 ld16g(const uint8_t* p) { u32x4 v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ void st16g(uint8_t* p, const u32x4& v) { __builtin_memcpy(p, &v, 16); }
+__device__ __forceinline__ uint32_t byte_of(const u32x4& v, uint32_t j) {     // byte j of 16 (j uniform or not: selects)
+    const uint32_t w = j < 8u ? (j < 4u ? v.x : v.y) : (j < 12u ? v.z : v.w);
+    return (w >> (8u * (j & 3u))) & 0xFFu;
+}
+
+// n in 1..16 bytes of v, exactly, at any LDS address: 16, or 8 / 4 / 2 / 1-byte pieces
+__device__ __forceinline__ void st_exact(lds_u8* d, const u32x4& v, uint32_t n) {
+    if (n >= 16u) { st16l(d, v); return; }
+    const bool n8 = (n & 8u) != 0u, n4 = (n & 4u) != 0u, n2 = (n & 2u) != 0u;
+    const uint32_t w4 = n8 ? v.z : v.x;                               // the dword at byte offset (n & 8)
+    const uint32_t wq = n8 ? (n4 ? v.w : v.z) : (n4 ? v.y : v.x);     // the dword at byte offset (n & 12)
+    if (n8) { const uint64_t t = (uint64_t)v.x | ((uint64_t)v.y << 32); __builtin_memcpy((void*)d, &t, 8); }
+    if (n4) __builtin_memcpy((void*)(d + (n & 8u)), &w4, 4);
+    if (n2) { const uint16_t t = (uint16_t)wq; __builtin_memcpy((void*)(d + (n & 12u)), &t, 2); }
+    if (n & 1u) d[n & 14u] = (uint8_t)(wq >> (n2 ? 16 : 0));
+}
+
+// the compressed stream: the tile's bytes from LDS, anything behind them (a long sequence's tail) from memory
+template <class G>
+struct Rd {
+    const lds_u8* ct;
+    const uint8_t* gin;
+    uint32_t cbase;
+    __device__ __forceinline__ uint32_t operator()(uint32_t pos) const {
+        const uint32_t r = pos - cbase;
+        return r < G::CT + G::CM ? (uint32_t)ct[r] : (uint32_t)gin[pos];
+    }
+};
+
+template <class G>
+struct Ctx {
+    lds_u8* lds;
+    const uint8_t* gin;
+    uint8_t* gout;
+    uint32_t ilen, cap;
+    uint32_t tid, lane, wv;
+    __device__ __forceinline__ lds_u8* ct() const { return lds + G::L_CT; }
+    __device__ __forceinline__ lds_u32* marks() const { return (lds_u32*)(lds + G::L_MARK); }
+    __device__ __forceinline__ lds_u32* ent() const { return (lds_u32*)(lds + G::L_ENT); }
+    __device__ __forceinline__ lds_u32* ext() const { return (lds_u32*)(lds + G::L_EXT); }
+    __device__ __forceinline__ lds_u32* nxt() const { return (lds_u32*)(lds + G::L_NXT); }
+    __device__ __forceinline__ lds_u32* rch() const { return (lds_u32*)(lds + G::L_RCH); }
+    __device__ __forceinline__ lds_u16* tok() const { return (lds_u16*)(lds + G::L_TOK); }
+    __device__ __forceinline__ lds_u32* bst() const { return (lds_u32*)(lds + G::L_BST); }
+    __device__ __forceinline__ lds_u32* done() const { return (lds_u32*)(lds + G::L_DONE); }
+    __device__ __forceinline__ lds_u32* wsum() const { return (lds_u32*)(lds + G::L_WSUM); }
+    __device__ __forceinline__ volatile lds_u32* ctl() const { return (volatile lds_u32*)(lds + G::L_CTL); }
+    __device__ __forceinline__ lds_u8* win() const { return lds + G::L_WIN; }
+
+    // exclusive prefix sum of v over the workgroup (thread order); *total = the sum.  Two barriers.
+    __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* total) const {
+        const uint32_t incl = wave_incl_add(v);
+        lds_u32* ws = wsum();
+        if (lane == 63u) ws[wv] = incl;
+        __syncthreads();
+        uint32_t base = 0u, tot = 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < G::NW; ++i) {
+            const uint32_t s = ws[i];
+            base += i < wv ? s : 0u;
+            tot += s;
+        }
+        __syncthreads();
+        *total = tot;
+        return base + incl - v;
+    }
+
+    // ---- the tile [cbase, cbase + CT + CM) of the compressed stream into LDS (never a byte behind the block)
+    __device__ __forceinline__ void load_tile(uint32_t cbase) const {
+        const uint32_t avail = ilen - cbase;
+        const uint32_t n = avail < G::CT + G::CM ? avail : G::CT + G::CM;
+        const uint8_t* src = gin + cbase;
+        const uint32_t n16 = n & ~15u;
+        for (uint32_t o = 16u * tid; o < n16; o += 16u * G::T) st16l(ct() + o, ld16g(src + o));
+        if (tid < n - n16) ct()[n16 + tid] = src[n16 + tid];
+    }
+
+    // ---- wavefront 0: follow the exits from part 0 by pointer jumping; live parts get their true entries
+    __device__ __forceinline__ void resolve(uint32_t cbase, uint32_t parts) const {
+        lds_u32 *nx = nxt(), *rc = rch(), *ex = ext(), *en = ent();
+        uint32_t k[G::PPL], a[G::PPL], b2[G::PPL], r[G::PPL];
+#pragma unroll
+        for (uint32_t j = 0; j < G::PPL; ++j) {
+            k[j] = lane + 64u * j;
+            if (k[j] < parts) {
+                const uint32_t x = ex[k[j]];
+                const uint32_t q = (x - cbase) / G::P;
+                nx[k[j]] = (x < X_ERR && q < parts) ? q : G::NP;      // NP: the chain leaves the tile here (or ends, or dies)
+                rc[k[j]] = k[j] == 0u ? 1u : 0u;
+            }
+        }
+        if (lane == 0u) { nx[G::NP] = G::NP; rc[G::NP] = 0u; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (uint32_t round = 0; round < ceil_log2(G::NP) + 1u; ++round) {
+            // every read of the round precedes every write of the round (LDS operations of a wavefront execute in order)
+#pragma unroll
+            for (uint32_t j = 0; j < G::PPL; ++j) {
+                a[j] = G::NP; r[j] = 0u;
+                if (k[j] < parts) { a[j] = nx[k[j]]; r[j] = rc[k[j]]; }
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < G::PPL; ++j) b2[j] = nx[a[j]];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (uint32_t j = 0; j < G::PPL; ++j) {
+                if (k[j] < parts) {
+                    if (r[j]) rc[a[j]] = 1u;
+                    nx[k[j]] = b2[j];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < G::PPL; ++j) {
+            if (k[j] < parts && rc[k[j]] != 0u) {
+                const uint32_t x = ex[k[j]];
+                const uint32_t q = (x - cbase) / G::P;
+                if (x < X_ERR && q < parts) en[q] = x;                 // one live predecessor per live part: no conflict
+                else ctl()[C_EXIT] = x;                                // the one live part whose chain leaves the tile
+            }
+        }
+    }
+
+    // ---- n bytes, any alignment, by ONE WAVEFRONT into the window: literals from the compressed stream
+    __device__ __forceinline__ void wave_literals(uint32_t dstw, uint32_t src, uint32_t n) const {
+        for (uint32_t o = 16u * lane; o < n; o += 1024u) {
+            const uint32_t m = n - o < 16u ? n - o : 16u;
+            const uint32_t p = src + o;
+            if (p + 16u <= ilen) {
+                st_exact(win() + dstw + o, ld16g(gin + p), m);
+            } else {
+                for (uint32_t j = 0; j < m; ++j) win()[dstw + o + j] = gin[p + j];
+            }
+        }
+    }
+    // n bytes from output position src to output position dst (src + n <= dst: no overlap) by ONE WAVEFRONT; the destination
+    // lies in the window (base Lo), source bytes before Lo come from the written-back output
+    __device__ __forceinline__ void wave_copy(uint32_t dst, uint32_t src, uint32_t n, uint32_t Lo) const {
+        for (uint32_t o = 16u * lane; o < n; o += 1024u) {
+            const uint32_t m = n - o < 16u ? n - o : 16u;
+            const uint32_t p = src + o;
+            lds_u8* d = win() + (dst + o - Lo);
+            if (p >= Lo) {
+                st_exact(d, ld16l(win() + (p - Lo)), m);               // (may read up to 15 bytes behind the source: unused, inside the window's slack)
+            } else if (p + 16u <= Lo) {
+                st_exact(d, ld16g(gout + p), m);
+            } else {
+                for (uint32_t j = 0; j < m; ++j) d[j] = p + j < Lo ? gout[p + j] : win()[p + j - Lo];
+            }
+        }
+    }
+    // a match of any offset and length at output position ms by ONE WAVEFRONT: non-overlapping steps of growing size -- after
+    // `done` bytes (a multiple of the offset) the `done + off` bytes from ms - off on are final and periodic
+    __device__ __forceinline__ void wave_match(uint32_t ms, uint32_t off, uint32_t ml, uint32_t Lo) const {
+        uint32_t donem = 0u;
+        while (donem < ml) {
+            const uint32_t room = donem + off;
+            const uint32_t n = ml - donem < room ? ml - donem : room;
+            wave_copy(ms + donem, ms - off, n, Lo);
+            donem += n;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the next step reads what other lanes wrote in this one
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- the whole WORKGROUP, output memory to output memory / compressed stream to output memory (a sequence longer than the window)
+    __device__ __forceinline__ void block_copy(uint8_t* dst, const uint8_t* src, uint32_t n) const {
+        const uint32_t n16 = n & ~15u;
+        for (uint32_t o = 16u * tid; o < n16; o += 16u * G::T) st16g(dst + o, ld16g(src + o));
+        if (tid < n - n16) dst[n16 + tid] = src[n16 + tid];
+    }
+};
+
+template <class G>
+__global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs a, int32_t redo_code) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t pcd_lds[];
+    const uint32_t b = blockIdx.x;
+    if (b >= a.n) return;
+    Ctx<G> X;
+    X.lds = (lds_u8*)pcd_lds;
+    X.gin = a.in_base + a.in_off[b];
+    X.gout = a.out_base + a.out_off[b];
+    X.ilen = a.in_len[b];
+    X.cap = a.out_cap[b];
+    X.tid = threadIdx.x;
+    X.lane = threadIdx.x & 63u;
+    X.wv = threadIdx.x >> 6;
+    const uint32_t tid = X.tid, lane = X.lane;
+    volatile lds_u32* ctl = X.ctl();
+    if (X.ilen == 0u) {                                           // decompress.rs:207-209: the reference-order kernel reports it
+        if (tid == 0u) { a.status[b] = redo_code; a.out_len[b] = 0u; }
+        return;
+    }
+    if (tid < 32u) ctl[tid] = 0u;
+    uint32_t cbase = 0u;       // the tile's first byte: a true token position
+    uint32_t OP = 0u;          // output position: everything before it is written back
+    uint32_t hist = 0u;        // window bytes [0, hist) hold output [OP - hist, OP)
+    bool ended = false, bad = false;
+    __syncthreads();
+
+    while (!ended) {
+        // ================================================================ PARSE one tile
+        X.load_tile(cbase);
+        const uint32_t span = X.ilen - cbase;
+        const uint32_t parts = span >= G::CT ? G::NP : (span + G::P - 1u) / G::P;
+        for (uint32_t w = tid; w < G::MW; w += G::T) X.marks()[w] = 0u;
+        uint32_t my_e = cbase + tid * G::P;
+        if (tid < parts) { X.ent()[tid] = my_e; X.ext()[tid] = X_ERR; }
+        bool dirty = tid < parts;
+        if (tid == 0u) ctl[C_EXIT] = X_ERR;
+        __syncthreads();
+        const Rd<G> rd{X.ct(), X.gin, cbase};
+        bool settled = false;
+        for (uint32_t it = 0u; it < G::MAX_ITERS; ++it) {
+            if (dirty) {                                          // lane k walks part k from its entry
+                lds_u32* mk = X.marks() + tid * G::PW;
+#pragma unroll
+                for (uint32_t w = 0; w < G::PW; ++w) mk[w] = 0u;
+                const uint32_t pend = cbase + (tid + 1u) * G::P;
+                uint32_t p = my_e, x;
+                for (;;) {
+                    if (p >= pend) { x = p; break; }
+                    const uint32_t r = p - cbase;
+                    X.marks()[r >> 5] |= 1u << (r & 31u);               // (the part's mark words belong to this lane alone)
+                    Seq s;
+                    const uint32_t nx = parse_seq(rd, X.ilen, p, s);
+                    if (nx >= X_ERR) { x = nx; break; }
+                    p = nx;
+                }
+                X.ext()[tid] = x;
+            }
+            __syncthreads();
+            if (X.wv == 0u) X.resolve(cbase, parts);
+            __syncthreads();
+            dirty = false;
+            if (tid < parts) {
+                const uint32_t e = X.ent()[tid];
+                if (e != my_e) { my_e = e; dirty = true; }
+            }
+            if (!__syncthreads_or(dirty ? 1 : 0)) { settled = true; break; }
+        }
+        const uint32_t tile_exit = ctl[C_EXIT];
+        if (!settled || tile_exit == X_ERR) { bad = true; break; }     // (uniform)
+        ended = tile_exit == X_END;
+
+        // ---- the tile's sequences: set bits of the live parts, in order
+        uint32_t ntok;
+        {
+            uint32_t word = 0u;
+            if (tid < G::MW) {
+                const uint32_t part = tid / G::PW;
+                if (part < parts && X.rch()[part] != 0u) word = X.marks()[tid];
+            }
+            uint32_t at = X.block_excl_scan((uint32_t)__builtin_popcount(word), &ntok);
+            while (word != 0u) {
+                const uint32_t bit = (uint32_t)__builtin_ctz(word);
+                word &= word - 1u;
+                X.tok()[at++] = (uint16_t)(tid * 32u + bit);
+            }
+        }
+        __syncthreads();
+
+        // ================================================================ COPY: batches of consecutive sequences
+        uint32_t idx = 0u;
+        while (idx < ntok) {
+            const uint32_t m = ntok - idx < G::T ? ntok - idx : G::T;
+            Seq s;
+            s.lit_src = 0u; s.lit = 0u; s.ml = 0u; s.off = 0u;
+            uint32_t len = 0u;
+            bool perr = false;
+            if (tid < m) {
+                const uint32_t nx = parse_seq(rd, X.ilen, cbase + X.tok()[idx + tid], s);
+                perr = nx == X_ERR || (nx == X_END && !(ended && idx + tid + 1u == ntok));
+                len = s.lit + s.ml;                                // (both < 2^31)
+            }
+            if (tid == 0u) ctl[C_CUT] = m;
+            const uint32_t lenc = len <= G::WNEW ? len : G::WNEW + 1u;
+            uint32_t sum_all;
+            const uint32_t ex = X.block_excl_scan(lenc, &sum_all);     // (its barriers publish C_CUT)
+            const bool fits = ex + lenc <= G::WNEW;
+            if (tid < m && !fits) __hip_atomic_fetch_min((lds_u32*)(X.lds + G::L_CTL) + C_CUT, tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (perr) ctl[C_BAD] = 1u;
+            __syncthreads();
+            const uint32_t cnt = ctl[C_CUT];
+            if (ctl[C_BAD] != 0u) { bad = true; break; }
+            if (cnt == 0u) {
+                // ---- a sequence longer than the window: alone, by the whole workgroup, on the output itself
+                if (tid == 0u) { ctl[C_G_SRC] = s.lit_src; ctl[C_G_LIT] = s.lit; ctl[C_G_ML] = s.ml; ctl[C_G_OFF] = s.off; }
+                __syncthreads();
+                const uint32_t g_src = ctl[C_G_SRC], g_lit = ctl[C_G_LIT], g_ml = ctl[C_G_ML], g_off = ctl[C_G_OFF];
+                if (g_lit > X.cap - OP) { bad = true; break; }                      // OutputTooSmall
+                X.block_copy(X.gout + OP, X.gin + g_src, g_lit);
+                OP += g_lit;
+                __syncthreads();                                                    // (workgroup-scope release / acquire: the bytes are visible)
+                if (g_ml != 0u) {
+                    if (g_off > OP || g_ml > X.cap - OP) { bad = true; break; }     // OffsetOutOfBounds / OutputTooSmall
+                    uint32_t donem = 0u;
+                    while (donem < g_ml) {
+                        const uint32_t room = donem + g_off;
+                        const uint32_t n = g_ml - donem < room ? g_ml - donem : room;
+                        X.block_copy(X.gout + OP + donem, X.gout + OP - g_off, n);
+                        donem += n;
+                        __syncthreads();
+                    }
+                    OP += g_ml;
+                }
+                hist = 0u;
+                idx += 1u;
+                continue;
+            }
+            // ---- a batch of cnt sequences: [OP, OP + total) in the window behind the history
+            if (tid + 1u == cnt) ctl[C_TOTAL] = ex + len;
+            if (tid < cnt) X.bst()[tid] = OP + ex;
+            const uint32_t Lo = OP - hist;
+            const uint32_t ms = OP + ex + s.lit;                   // where my match starts
+            const bool has_m = tid < cnt && s.ml != 0u;
+            if (has_m && s.off > ms) ctl[C_BAD] = 1u;              // OffsetOutOfBounds (decompress.rs:398-400)
+            {   // DONE bits: set for lanes without a match
+                const uint64_t nm = __ballot(!has_m);
+                if (lane == 0u) { X.done()[2u * X.wv] = (uint32_t)nm; X.done()[2u * X.wv + 1u] = (uint32_t)(nm >> 32); }
+            }
+            // literals: short runs by their lane, long ones by the wavefront
+            {
+                const uint32_t dstw = hist + ex;
+                const bool mine = tid < cnt && s.lit != 0u;
+                const bool shortl = mine && s.lit <= 32u && s.lit_src + 32u <= X.ilen;
+                if (shortl) {
+                    st_exact(X.win() + dstw, ld16g(X.gin + s.lit_src), s.lit < 16u ? s.lit : 16u);
+                    if (s.lit > 16u) st_exact(X.win() + dstw + 16u, ld16g(X.gin + s.lit_src + 16u), s.lit - 16u);
+                }
+                uint64_t lm = __ballot(mine && !shortl);
+                while (lm != 0ull) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(lm);
+                    lm &= lm - 1ull;
+                    X.wave_literals(bcast(dstw, l), bcast(s.lit_src, l), bcast(s.lit, l));
+                }
+            }
+            __syncthreads();                                       // literals placed, bst[] / DONE / C_TOTAL / C_BAD published
+            const uint32_t total = ctl[C_TOTAL];
+            if (ctl[C_BAD] != 0u || total > X.cap - OP) { bad = true; break; }     // ... / OutputTooSmall somewhere in the batch
+            // ---- matches
+            {
+                const uint32_t s0 = ms - s.off;                                    // source start (has_m: off <= ms)
+                const uint32_t s1 = s0 + s.ml < ms ? s0 + s.ml : ms;               // source end outside its own output
+                // producers: the batch's sequences whose output holds [max(s0, OP), s1) -- lo..hi, all before mine
+                uint32_t lo = 1u, hi = 0u;
+                if (has_m && s1 > OP) {
+                    const uint32_t a0 = s0 > OP ? s0 : OP, a1 = s1 - 1u;
+                    uint32_t jl = 0u, jh = 0u;
+#pragma unroll 1
+                    for (uint32_t step = G::T / 2u; step != 0u; step >>= 1) {      // largest j < cnt with bst[j] <= a
+                        const uint32_t cl = jl + step, ch = jh + step;
+                        if (cl < cnt && X.bst()[cl] <= a0) jl = cl;
+                        if (ch < cnt && X.bst()[ch] <= a1) jh = ch;
+                    }
+                    if (jl < tid) { lo = jl; hi = jh < tid ? jh : tid - 1u; }      // (a source inside my own literals has no producer)
+                }
+                // one lane, 16 bytes at a time: offset >= 16, up to 64 bytes, source entirely in the window or entirely written back
+                const bool near = s0 >= Lo;
+                const bool farok = s0 + ((s.ml + 15u) & ~15u) <= Lo;
+                const bool inl = s.off >= 16u && s.ml <= 64u && (near || farok);
+                bool pending = has_m;
+                uint32_t spins = 0u;
+                while (__any(pending)) {
+                    bool ready = pending;
+                    if (ready && lo <= hi) {
+                        for (uint32_t w = lo >> 5; w <= (hi >> 5); ++w) {
+                            const uint32_t first = w == (lo >> 5) ? (lo & 31u) : 0u, last = w == (hi >> 5) ? (hi & 31u) : 31u;
+                            const uint32_t mask = (0xFFFFFFFFu >> (31u - last)) & (0xFFFFFFFFu << first);
+                            const uint32_t d = __hip_atomic_load(X.done() + w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if ((d & mask) != mask) { ready = false; break; }
+                        }
+                    }
+                    if (ready && inl) {
+                        lds_u8* d = X.win() + (ms - Lo);
+#pragma unroll
+                        for (uint32_t o = 0u; o < 64u; o += 16u) {
+                            if (o < s.ml) {
+                                const u32x4 v = near ? ld16l(X.win() + (s0 - Lo) + o) : ld16g(X.gout + s0 + o);
+                                st_exact(d + o, v, s.ml - o < 16u ? s.ml - o : 16u);
+                            }
+                        }
+                    }
+                    uint64_t cm = __ballot(ready && !inl);
+                    const bool progress = __any(ready);
+                    while (cm != 0ull) {
+                        const uint32_t l = (uint32_t)__builtin_ctzll(cm);
+                        cm &= cm - 1ull;
+                        X.wave_match(bcast(ms, l), bcast(s.off, l), bcast(s.ml, l), Lo);
+                    }
+                    if (ready) {
+                        __hip_atomic_fetch_or(X.done() + (tid >> 5), 1u << (tid & 31u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        pending = false;
+                    }
+                    if (!progress) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 22)) { ctl[C_TIMEOUT] = 1u; break; }   // (cannot happen: the lowest open match is always ready)
+                    }
+                }
+            }
+            __syncthreads();
+            if (ctl[C_TIMEOUT] != 0u) { bad = true; break; }
+            // ---- write the batch back, slide the history
+            for (uint32_t o = 16u * tid; o < total; o += 16u * G::T) {
+                const u32x4 v = ld16l(X.win() + hist + o);
+                const uint32_t mrem = total - o;
+                if (mrem >= 16u) st16g(X.gout + OP + o, v);
+                else for (uint32_t j = 0; j < mrem; ++j) X.gout[OP + o + j] = (uint8_t)byte_of(v, j);
+            }
+            const uint32_t have = hist + total;
+            const uint32_t keep = have < G::HIST ? have : G::HIST;
+            const uint32_t from = have - keep;
+            if (from != 0u) {
+                u32x4 v[G::KP];
+#pragma unroll
+                for (uint32_t j = 0; j < G::KP; ++j) {
+                    const uint32_t o = 16u * (tid + G::T * j);
+                    if (o < keep) v[j] = ld16l(X.win() + from + o);
+                }
+                __syncthreads();
+#pragma unroll
+                for (uint32_t j = 0; j < G::KP; ++j) {
+                    const uint32_t o = 16u * (tid + G::T * j);
+                    if (o < keep) st16l(X.win() + o, v[j]);
+                }
+            }
+            OP += total;
+            hist = keep;
+            idx += cnt;
+            __syncthreads();                                       // window and written-back output are consistent for the next batch
+        }
+        if (bad) break;
+        cbase = tile_exit;
+        __syncthreads();                                           // the tile's LDS is free
+    }
+    if (tid == 0u) {
+        if (bad) { a.status[b] = redo_code; a.out_len[b] = 0u; }
+        else { a.status[b] = 0; a.out_len[b] = OP; }
+    }
+}
+
+template <class G>
+static hipError_t launch_geo(const DecompressArgs& a, int32_t redo_code, hipStream_t s) {
+    auto kern = lz4_decompress_pcd_kernel<G>;
+    if (G::LDS_BYTES > 65536u) {   // the attribute is per device: remember which devices have it (per instantiation)
+        static unsigned long long have = 0ull;   // benign race: setting it twice is harmless
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(have & bit)) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            have |= bit;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n), dim3(G::T), G::LDS_BYTES, s, a, redo_code);
+    return hipGetLastError();
+}
+
+}  // namespace pcd
+
+// one workgroup per block; blocks it marks (status redo_code) are decoded again by launch_decompress (only_status = redo_code).
+// test_geometry: the small geometry (2 KiB tiles, 64-byte parts, 128 lanes, 0.5 + 1 KiB window) that puts every kind of boundary
+// inside small inputs -- tests only.
+hipError_t launch_decompress_pcd(const DecompressArgs& a, int32_t redo_code, hipStream_t s, bool test_geometry) {
+    if (a.n == 0u) return hipSuccess;
+    if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;   // dictionary / prefix: lz4_decompress.hip
+    return test_geometry ? pcd::launch_geo<pcd::GeoTest>(a, redo_code, s) : pcd::launch_geo<pcd::GeoProd>(a, redo_code, s);
+}
+
+}  // namespace lz4flex_dev

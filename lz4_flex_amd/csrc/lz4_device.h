@@ -50,6 +50,9 @@ hipError_t launch_decompress(const DecompressArgs& a, int lanes_per_block, hipSt
 hipError_t launch_decompress_wave(const DecompressArgs& a, int32_t redo_code, hipStream_t s);
 hipError_t launch_decompress_wave_pair(const DecompressArgs& a, int32_t redo_code, hipStream_t s);
 hipError_t launch_decompress_split(const DecompressArgs& a, hipStream_t s, int blocks_per_wg = 0);   // parser / copier wavefronts, no dict/prefix
+// one WORKGROUP per block, token chain and copies parallel inside the block (lz4_decompress_pcd.hip: few, large blocks); irregular
+// blocks are left with status redo_code like behind launch_decompress_wave.  test_geometry: tiny tiles / batches (tests only)
+hipError_t launch_decompress_pcd(const DecompressArgs& a, int32_t redo_code, hipStream_t s, bool test_geometry = false);
 hipError_t launch_compress(const CompressArgs& a, int variant, hipStream_t s);
 // throughput ("wave") encoder, lz4_compress_wave.hip: persistent workgroups, `workspace` holds
 // compress_wave_workspace_bytes(n_workgroups) bytes (cand[] slots + segment bodies, L2 / Infinity Cache resident)

@@ -180,6 +180,43 @@ def _world(group):
     return 0, 1
 
 
+# Collectives on device tensors go straight to RCCL (backend "nccl").  Under gloo -- the CPU tests, and bench.py's
+# oversubscribed functional run with several ranks on one GPU, which RCCL refuses -- device tensors are staged through the host.
+def _staged(t, group):
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _bcast(t, src, group):
+    if _staged(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+
+
+def _send(t, dst, group):
+    dist.send(t.cpu() if _staged(t, group) else t, dst=dst, group=group)
+
+
+def _isend(t, dst, group):
+    return dist.isend(t.cpu() if _staged(t, group) else t, dst=dst, group=group)
+
+
+def _recv_into(view, src, group):
+    """returns a completion callable"""
+    if _staged(view, group):
+        h = torch.empty(view.shape, dtype=view.dtype)
+        q = dist.irecv(h, src=src, group=group)
+
+        def done():
+            q.wait()
+            view.copy_(h)
+        return done
+    q = dist.irecv(view, src=src, group=group)
+    return q.wait
+
+
 def compress_frame_sharded(local, first_block, frame_info, group=None, root=0, compress_blocks=compress_blocks_device,
                            xxh32_blocks=None):
     """Every rank passes the bytes of its contiguous block range (`local`, uint8 tensor) and the global index
@@ -205,8 +242,9 @@ def compress_frame_sharded(local, first_block, frame_info, group=None, root=0, c
     # 1) all-gather of the segment sizes, 2) exclusive prefix sum
     my = torch.tensor([seg.numel()], dtype=torch.int64, device=dev)
     if world > 1:
-        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(sizes, my, group=group)
+        gdev = torch.device("cpu") if _staged(my, group) else dev
+        sizes = [torch.zeros(1, dtype=torch.int64, device=gdev) for _ in range(world)]
+        dist.all_gather(sizes, my.to(gdev), group=group)
         sizes = [int(s.item()) for s in sizes]
     else:
         sizes = [int(my.item())]
@@ -226,12 +264,12 @@ def compress_frame_sharded(local, first_block, frame_info, group=None, root=0, c
             if r == rank:
                 view.copy_(seg)
             elif sizes[r]:
-                reqs.append(dist.irecv(view, src=r, group=group))
-        for q in reqs:
-            q.wait()
+                reqs.append(_recv_into(view, r, group))
+        for done in reqs:
+            done()
         return frame
     if seg.numel():
-        dist.send(seg, dst=root, group=group)
+        _send(seg, root, group)
     return None
 
 
@@ -258,9 +296,10 @@ def walk_blocks(frame_host, header_len, block_checksums=False, block_size=None):
         p += ln + (4 if block_checksums else 0)
 
 
-def walk_blocks_device(frame, header_len, block_checksums, block_size):
+def walk_blocks_device_tensors(frame, header_len, block_checksums, block_size):
     """walk_blocks for a frame in device memory: the chain of block headers is followed by a kernel
-    (lz4flex_frame_walk_device); only 12 bytes per block come back to the host, not the frame."""
+    (lz4flex_frame_walk_device).  Returns DEVICE tensors (payload_off[i64], len_word[i64]: bit 31 = stored raw) -- one scalar
+    pair (block count, status) comes back to the host, not the frame and not the per-block results."""
     from . import _lib as L
     from .frame import BlockTooBig
     lib = L.load()
@@ -284,120 +323,145 @@ def walk_blocks_device(frame, header_len, block_checksums, block_size):
         raise BlockTooBig()
     if st != 0:
         raise ValueError("truncated frame")
-    offs = off[:n].cpu().tolist()
-    words = (ln[:n].to(torch.int64) & 0xFFFFFFFF).cpu().tolist()
-    return [(int(o), int(w) & ~UNCOMPRESSED_BIT, bool(int(w) & UNCOMPRESSED_BIT)) for o, w in zip(offs, words)]
+    return off[:n], ln[:n].to(torch.int64) & 0xFFFFFFFF
+
+
+def walk_blocks_device(frame, header_len, block_checksums, block_size):
+    """the same as a host list [(payload_off, len, raw)] (tests; the sharded decoder keeps the tensors on the device)"""
+    off, words = walk_blocks_device_tensors(frame, header_len, block_checksums, block_size)
+    offs, ws = off.cpu().tolist(), words.cpu().tolist()
+    return [(int(o), int(w) & ~UNCOMPRESSED_BIT, bool(int(w) & UNCOMPRESSED_BIT)) for o, w in zip(offs, ws)]
 
 
 def decompress_frame_sharded(frame, group=None, root=0, decompress_blocks=decompress_blocks_device, device=None,
                              xxh32_blocks=None):
     """`frame` (uint8 tensor) is needed on the root only.  The root walks the block headers, every rank
-    receives and decodes a contiguous block range.  Returns (local_out tensor, (lo, hi) block range, FrameInfo)."""
+    receives and decodes a contiguous block range.  Returns (local_out tensor, (lo, hi) block range, FrameInfo).
+    Only tensors move between the ranks: a 3-word description of the frame, the per-block offset / length words (two
+    broadcasts) and every rank's contiguous byte range (point-to-point); no Python objects, no per-block host lists."""
     rank, world = _world(group)
     dev = frame.device if frame is not None else torch.device(device or "cpu")
-    meta = [None]
+    meta = torch.zeros(3, dtype=torch.int64, device=dev)          # block count, BlockSize code, block checksums
+    off = words = None
     if rank == root:
         fi = FrameInfo.read(bytes(frame[:19].cpu().numpy()))      # validates magic, version, flags, header checksum (header.rs:277-373)
         hdr_len = len(fi.write())
         if fi.legacy_frame or fi.block_mode != BlockMode.Independent or fi.content_checksum:
             raise ValueError("only Independent frames without a content checksum shard")
         if frame.is_cuda:
-            blocks = walk_blocks_device(frame, hdr_len, fi.block_checksums, fi.block_size.get_size())
+            off, words = walk_blocks_device_tensors(frame, hdr_len, fi.block_checksums, fi.block_size.get_size())
         else:
             blocks, _end = walk_blocks(frame.numpy(), hdr_len, fi.block_checksums, fi.block_size.get_size())
-        meta = [(blocks, int(fi.block_size), bool(fi.block_checksums))]
+            off = torch.tensor([b[0] for b in blocks], dtype=torch.int64)
+            words = torch.tensor([b[1] | (UNCOMPRESSED_BIT if b[2] else 0) for b in blocks], dtype=torch.int64)
+        meta = torch.tensor([off.numel(), int(fi.block_size), int(bool(fi.block_checksums))], dtype=torch.int64, device=dev)
     if world > 1:
-        dist.broadcast_object_list(meta, src=root, group=group)
-    blocks, bs_code, has_bc = meta[0]
+        _bcast(meta, root, group)
+    nb, bs_code, has_bc = (int(x) for x in meta.cpu().tolist())
+    if world > 1:
+        table = torch.empty(2 * nb, dtype=torch.int64, device=dev)
+        if rank == root:
+            table[:nb] = off
+            table[nb:] = words
+        if nb:
+            _bcast(table, root, group)
+        off, words = table[:nb], table[nb:]
     bs = BlockSize(bs_code).get_size()
     tail = 4 if has_bc else 0
-    lo, hi = partition(len(blocks), world)[rank]
-    mine = blocks[lo:hi]
-    # the bytes of my range are contiguous in the frame: one transfer per rank
-    if mine:
-        a = mine[0][0]
-        b = mine[-1][0] + mine[-1][1] + tail
+    ranges = partition(nb, world)
+    lo, hi = ranges[rank]
+    n = hi - lo
+    length = words & ~UNCOMPRESSED_BIT
+    israw = (words & UNCOMPRESSED_BIT) != 0
+    # the bytes of a rank's range are contiguous in the frame: one transfer per rank.  The range ends come to the host in one
+    # copy of 2 * world numbers.
+    los = torch.tensor([r[0] for r in ranges], dtype=torch.int64, device=dev)
+    his = torch.tensor([r[1] for r in ranges], dtype=torch.int64, device=dev)
+    if nb:
+        last = (his - 1).clamp(min=0)
+        ra_all = off[los.clamp(max=nb - 1)]
+        rb_all = off[last] + length[last] + tail
+        ends = torch.stack([ra_all, rb_all]).cpu().tolist()
     else:
-        a = b = 0
+        ends = [[0] * world, [0] * world]
+    a, b = (ends[0][rank], ends[1][rank]) if n else (0, 0)
     if rank == root:
-        ranges = partition(len(blocks), world)
         reqs = []
         for r, (l2, h2) in enumerate(ranges):
             if r == rank or l2 == h2:
                 continue
-            ra, rb = blocks[l2][0], blocks[h2 - 1][0] + blocks[h2 - 1][1] + tail
-            reqs.append(dist.isend(frame[ra:rb].contiguous(), dst=r, group=group))
+            reqs.append(_isend(frame[ends[0][r]:ends[1][r]].contiguous(), r, group))
         local = frame[a:b]
         for q in reqs:
             q.wait()
     else:
         local = torch.empty(b - a, dtype=torch.uint8, device=dev)
         if b > a:
-            dist.recv(local, src=root, group=group)
-    n = len(mine)
+            _recv_into(local, root, group)()
+    poff = (off[lo:hi] - a).contiguous()                          # my blocks: payload offset in `local`, length, stored-raw bit
+    plen = length[lo:hi].contiguous()
+    praw = israw[lo:hi]
     if has_bc and n:   # verify the block checksums (frame/decompress.rs:255-261,275-278) before decoding
-        poff = torch.tensor([m[0] - a for m in mine], dtype=torch.int64, device=dev)
-        plen = torch.tensor([m[1] for m in mine], dtype=torch.int64, device=dev)
         got = (xxh32_blocks or xxh32_blocks_device)(local, poff, plen)
         idx = (poff + plen).unsqueeze(1) + torch.arange(4, device=dev).unsqueeze(0)
         stored = (local[idx].to(torch.int64) << torch.tensor([0, 8, 16, 24], device=dev)).sum(dim=1)
         if not torch.equal(got.cpu(), stored.cpu()):
             raise RuntimeError("BlockChecksumError")
     out = torch.empty(n * bs, dtype=torch.uint8, device=dev)
-    produced = [0] * n
-    comp_idx = [i for i, m in enumerate(mine) if not m[2]]
-    raw_idx = [i for i, m in enumerate(mine) if m[2]]
+    produced = torch.zeros(n, dtype=torch.int64, device=dev)
+    comp_idx = torch.nonzero(~praw).flatten()
+    raw_idx = torch.nonzero(praw).flatten()
+    nc, nr = int(comp_idx.numel()), int(raw_idx.numel())
     if dev.type == "cuda" and decompress_blocks is decompress_blocks_device:
         # every block goes straight to its place: compressed ones through the batched decoder (out_off = i * bs), stored ones
         # through one batched copy (csrc/frame_kernels.hip); no per-block Python work on the data path
         lib = L.load()
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        if comp_idx:
-            coff = torch.tensor([mine[i][0] - a for i in comp_idx], dtype=torch.int64, device=dev)
-            clen = torch.tensor([mine[i][1] for i in comp_idx], dtype=torch.int32, device=dev)
-            ooff = torch.tensor(comp_idx, dtype=torch.int64, device=dev) * bs
-            ocap = torch.full((len(comp_idx),), bs, dtype=torch.int32, device=dev)
-            dlen = torch.zeros(len(comp_idx), dtype=torch.int32, device=dev)
-            st = torch.zeros(len(comp_idx), dtype=torch.int32, device=dev)
+        if nc:
+            coff = poff[comp_idx].contiguous()
+            clen = plen[comp_idx].to(torch.int32).contiguous()
+            ooff = (comp_idx * bs).contiguous()
+            ocap = torch.full((nc,), bs, dtype=torch.int32, device=dev)
+            dlen = torch.zeros(nc, dtype=torch.int32, device=dev)
+            st = torch.zeros(nc, dtype=torch.int32, device=dev)
             with torch.cuda.device(dev):
-                rc = lib.lz4flex_decompress_batch(None, _p(local), _p(coff), _p(clen), len(comp_idx), _p(out), _p(ooff), _p(ocap),
+                rc = lib.lz4flex_decompress_batch(None, _p(local), _p(coff), _p(clen), nc, _p(out), _p(ooff), _p(ocap),
                                                   _p(dlen), _p(st), None, L.MEM_DEVICE, stream)
             if rc:
                 raise RuntimeError("lz4flex_decompress_batch: %d %s" % (rc, L.last_error()))
             if int((st != 0).sum().item()):
                 raise RuntimeError("DecompressionError in a sharded block")
-            for k, i in zip(dlen.tolist(), comp_idx):
-                produced[i] = k
-        if raw_idx:
-            roff = torch.tensor([mine[i][0] - a for i in raw_idx], dtype=torch.int64, device=dev)
-            rlen = torch.tensor([mine[i][1] for i in raw_idx], dtype=torch.int32, device=dev)
-            doff = torch.tensor(raw_idx, dtype=torch.int64, device=dev) * bs
+            produced[comp_idx] = dlen.to(torch.int64)
+        if nr:
+            roff = poff[raw_idx].contiguous()
+            rlen = plen[raw_idx].to(torch.int32).contiguous()
+            doff = (raw_idx * bs).contiguous()
             with torch.cuda.device(dev):
-                rc = lib.lz4flex_copy_batch_device(_p(local), _p(roff), _p(rlen), _p(out), _p(doff), len(raw_idx), stream)
+                rc = lib.lz4flex_copy_batch_device(_p(local), _p(roff), _p(rlen), _p(out), _p(doff), nr, stream)
             if rc:
                 raise RuntimeError("lz4flex_copy_batch_device: %d %s" % (rc, L.last_error()))
-            for i in raw_idx:
-                produced[i] = mine[i][1]
+            produced[raw_idx] = plen[raw_idx]
     else:
-        if comp_idx:
-            coff = torch.tensor([mine[i][0] - a for i in comp_idx], dtype=torch.int64, device=dev)
-            clen = torch.tensor([mine[i][1] for i in comp_idx], dtype=torch.int32, device=dev)
+        # CPU tensors (the gloo tests; the codec is injected): per-block placement in Python is test plumbing, not the product path
+        if nc:
+            coff = poff[comp_idx].contiguous()
+            clen = plen[comp_idx].to(torch.int32).contiguous()
             dec, dlen, st = decompress_blocks(local, coff, clen, None, bs)
             if int((st != 0).sum().item()):
                 raise RuntimeError("DecompressionError in a sharded block")
             dl = dlen.tolist()
-            for k, i in enumerate(comp_idx):
+            for k, i in enumerate(comp_idx.tolist()):
                 out[i * bs:i * bs + dl[k]] = dec[k * bs:k * bs + dl[k]]
                 produced[i] = dl[k]
-        for i in raw_idx:
-            m = mine[i]
-            out[i * bs:i * bs + m[1]] = local[m[0] - a:m[0] - a + m[1]]
-            produced[i] = m[1]
+        h_off, h_len = poff.tolist(), plen.tolist()
+        for i in raw_idx.tolist():
+            out[i * bs:i * bs + h_len[i]] = local[h_off[i]:h_off[i] + h_len[i]]
+            produced[i] = h_len[i]
     # blocks are full except possibly the frame's last one: compact view
-    total = sum(produced)
-    if n and any(p != bs for p in produced[:-1]):
-        pieces = [out[i * bs:i * bs + produced[i]] for i in range(n)]
-        out = torch.cat(pieces) if pieces else out[:0]
+    total = int(produced.sum().item())
+    if n > 1 and bool((produced[:-1] != bs).any().item()):
+        pr = produced.tolist()
+        out = torch.cat([out[i * bs:i * bs + pr[i]] for i in range(n)])
     else:
         out = out[:total]
     return out, (lo, hi), FrameInfo(block_size=BlockSize(bs_code))

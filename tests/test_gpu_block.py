@@ -35,8 +35,9 @@ def _gpu_decode(blk, data, cap, dict_data=None):
 # 16-lane group width, 8 / 32 / 64 exist with -DLZ4FLEX_ALL_VARIANTS only),
 # -408 / -432 / -464 = parser / copier split decoder with 8 / 32 / 64 blocks per workgroup (8 copier lanes x 4 bytes per block;
 # 64: 4 lanes x 16 bytes), -5 = one block per wavefront (wave decoder), -6 = the wave decoder with a parser and an executor
-# wavefront per block
-DECODERS = [16, -408, -432, -464, -5, -6]
+# wavefront per block, -7 = one block per workgroup (parallel-chain decoder, lz4_decompress_pcd.hip), -8 = the same kernel with
+# its small test geometry (2 KiB tiles, 64-byte parts, 128 sequences per batch, 0.5 + 1 KiB window: boundaries everywhere)
+DECODERS = [16, -408, -432, -464, -5, -6, -7, -8]
 
 
 def _select_decoder(lib, ctx, lanes):
@@ -46,7 +47,7 @@ def _select_decoder(lib, ctx, lanes):
     elif lanes <= -400:
         assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 4) == 0
         assert lib.lz4flex_set_tuning(ctx, b"decompress_blocks_per_wg", -lanes - 400) == 0
-    elif lanes in (-5, -6):
+    elif lanes in (-5, -6, -7, -8):
         assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", -lanes) == 0
     else:
         raise AssertionError(lanes)

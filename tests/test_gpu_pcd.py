@@ -1,0 +1,170 @@
+"""GPU (-m gpu): the parallel-chain decoder (lz4_flex_amd/csrc/lz4_decompress_pcd.hip: one workgroup per block, token chain and
+copies parallel INSIDE the block) on the shapes it exists for -- few, large blocks -- and against its host model.
+
+Checker: the oracle (lz4_flex's decoder restated).  Both geometries of the kernel run everything: the production one (32 KiB
+tiles, 1 024 sequences per batch, 16 + 32 KiB window) and the test one (2 KiB tiles, 128 sequences, 0.5 + 1 KiB window), which
+puts tile / part / batch / window boundaries and the giant-sequence path inside ordinary inputs.  The generic decoder matrix
+of test_gpu_block.py (KATs, the 2 490-block adversarial batch, mixed batches) runs both geometries too (DECODERS -7, -8)."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+import corpus
+import oracle_api as O
+import pcd_model as M
+import wave_model as W
+
+pytestmark = pytest.mark.gpu
+REDO = 0x7F000001
+
+
+@pytest.fixture(scope="module")
+def env():
+    from lz4_flex_amd import _lib, block
+    lib = _lib.load()
+    assert lib.lz4flex_device_count() >= 1
+    return lib, block
+
+
+def _ctx(lib, variant, second_pass=1):
+    ctx = C.c_void_p()
+    assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
+    assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", variant) == 0
+    assert lib.lz4flex_set_tuning(ctx, b"decompress_second_pass", second_pass) == 0
+    return ctx
+
+
+def _batch(block, ctx, comps, caps, slack=64):
+    inb = np.frombuffer(b"".join(comps) + bytes(64), dtype=np.uint8)
+    in_len = [len(c) for c in comps]
+    in_off = np.concatenate([[0], np.cumsum(in_len[:-1], dtype=np.uint64)]).astype(np.uint64)
+    out_off = np.concatenate([[0], np.cumsum([k + slack for k in caps[:-1]], dtype=np.uint64)]).astype(np.uint64)
+    out = np.full(int(out_off[-1]) + caps[-1] + slack, 0xA5, dtype=np.uint8)
+    ol, st, det = block.decompress_batch(inb, in_off, in_len, out, out_off, caps, ctx=ctx)
+    return out, out_off, ol, st, det
+
+
+def big_inputs():
+    from lz4_flex_amd import workloads
+    rnd = random.Random(21)
+    j = O.fixture_plain("compression_66k_JSON")
+    t = O.fixture_plain("compression_65k")
+    log = bytes(workloads.log_stream(0, 4 << 20, device="cpu").numpy())
+    return [
+        ("log 4 MiB", log),
+        ("json 1 MiB", (j * 17)[:1 << 20]),
+        ("text 300 KB", (t * 5)[:300000]),
+        ("zeros 1 MiB (one match longer than the window)", bytes(1 << 20)),
+        ("random 300 KB (one literal run longer than the window)", bytes(rnd.getrandbits(8) for _ in range(300000))),
+        ("period 3 / 7 / 20 / 300 runs", b"abc" * 40000 + bytes(range(7)) * 20000 + bytes(rnd.getrandbits(8) for _ in range(20)) * 9000
+         + bytes(rnd.getrandbits(8) for _ in range(300)) * 700),
+        ("mixed: random, zeros, text, random", bytes(rnd.getrandbits(8) for _ in range(50000)) + bytes(200000) + t + bytes(rnd.getrandbits(8) for _ in range(70000)) + j),
+        ("two-letter alphabet (chains rarely meet: many rounds per tile)", bytes(rnd.choice(b"ab") for _ in range(120000))),
+        ("tiny", b"q"), ("empty", b""), ("13 zeros", bytes(13)),
+    ]
+
+
+@pytest.mark.parametrize("variant", [7, 8])
+def test_large_blocks_every_encoder(env, variant):
+    """blocks of up to 4 MiB from the reference encoder (oracle), C liblz4 and this library's throughput encoder (model): bytes ==
+    oracle, nothing behind the sink, also with a sink larger than needed"""
+    lib, block = env
+    comps, caps, plains = [], [], []
+    for name, d in big_inputs():
+        for enc in (O.compress, W.compress) + ((O.c_compress,) if d else ()):
+            c = enc(d)
+            comps += [c, c]
+            caps += [len(d), len(d) + 777]
+            plains += [d, d]
+    ctx = _ctx(lib, variant)
+    try:
+        out, out_off, ol, st, det = _batch(block, ctx, comps, caps)
+    finally:
+        lib.lz4flex_ctx_destroy(ctx)
+    for i, d in enumerate(plains):
+        o = int(out_off[i])
+        assert st[i] == 0 and ol[i] == len(d), (i, int(st[i]), int(ol[i]), len(d))
+        assert out[o:o + len(d)].tobytes() == d, "block %d differs" % i
+        assert out[o + caps[i]:o + caps[i] + 64].tobytes() == b"\xA5" * 64, "block %d wrote behind its sink" % i
+        if caps[i] > len(d):
+            assert out[o + len(d):o + caps[i]].tobytes() == b"\xA5" * (caps[i] - len(d)), "block %d wrote behind its end" % i
+
+
+@pytest.mark.parametrize("variant", [7, 8])
+def test_first_pass_marks_exactly_what_the_model_calls_irregular(env, variant):
+    """kernel == model: without the second pass, the blocks the kernel leaves marked are exactly the ones tests/sim/pcd_model.cpp
+    (same geometry) calls irregular, every other block is decoded (== oracle); with the second pass every result equals the
+    oracle's, error variants and OutputTooSmall{expected, actual} included"""
+    lib, block = env
+    cases = corpus.adversarial_blocks()
+    rnd = random.Random(3)
+    big = O.compress(bytes(rnd.choice(b"ab") for _ in range(60000)))
+    cases += [(big, 60000), (big, 59990), (big[:-5], 60000)]
+    prm = M.defaults() if variant == 7 else M.Params(ct=2048, p=64, batch=128, hist=512, wnew=1024, max_iters=34)
+    model = [M.decode(c, k, prm, seed=i)[0] for i, (c, k) in enumerate(cases)]
+    want = [O.decompress(c, k) for c, k in cases]
+    comps, caps = [c for c, _ in cases], [k for _, k in cases]
+    ctx = _ctx(lib, variant, second_pass=0)
+    try:
+        out, out_off, ol, st, det = _batch(block, ctx, comps, caps)
+    finally:
+        lib.lz4flex_ctx_destroy(ctx)
+    n_marked = 0
+    for i, (c, k) in enumerate(cases):
+        o = int(out_off[i])
+        if len(c) == 0 or model[i] is None:
+            assert int(st[i]) == REDO, (i, int(st[i]))
+            n_marked += 1
+        else:
+            assert st[i] == 0 and ol[i] == len(model[i]) and out[o:o + ol[i]].tobytes() == model[i], (i, int(st[i]))
+        assert out[o + k:o + k + 64].tobytes() == b"\xA5" * 64, "block %d wrote behind its sink" % i
+    assert n_marked > 100
+    ctx = _ctx(lib, variant)
+    try:
+        out, out_off, ol, st, det = _batch(block, ctx, comps, caps)
+    finally:
+        lib.lz4flex_ctx_destroy(ctx)
+    for i, w in enumerate(want):
+        o = int(out_off[i])
+        if w[0] == "ok":
+            assert st[i] == 0 and out[o:o + ol[i]].tobytes() == w[1], i
+        else:
+            assert O.ERR_NAMES.get(int(st[i])) == w[0], (i, int(st[i]), w[0])
+            if w[0] == "OutputTooSmall":
+                assert (int(det[i][0]), int(det[i][1])) == tuple(w[1])
+
+
+def test_scalar_decompress_into_of_large_blocks_uses_the_workgroup_decoder(env):
+    """block::decompress_into of ONE large block (a 1-block batch picks the parallel-chain decoder): 16 MiB of log lines and of
+    JSON, from both encoders; the GPU encoder's own output round-trips"""
+    lib, block = env
+    from lz4_flex_amd import workloads
+    assert lib.lz4flex_set_tuning(None, b"decompress_variant", 0) == 0
+    log = bytes(workloads.log_stream(128 * 999, 16 << 20, device="cpu").numpy())
+    j = (O.fixture_plain("compression_66k_JSON") * 40)[:2 << 20]
+    for d in (log, j):
+        for c in (O.compress(d), block.compress(d)):
+            assert block.decompress(c, len(d)) == d
+            with pytest.raises(block.OutputTooSmall) as ei:
+                block.decompress(c, len(d) - 1)
+            exp = O.decompress(c, len(d) - 1)
+            assert exp[0] == "OutputTooSmall" and (ei.value.expected, ei.value.actual) == tuple(exp[1])
+
+
+def test_device_batch_of_4mib_blocks_round_trip(env):
+    """configs[3]'s decode shape: 4 MiB log blocks, device resident, through compress_batch / decompress_batch"""
+    import torch
+    from lz4_flex_amd import sharded, workloads
+    lib, block = env
+    bs = 4 << 20
+    src = workloads.log_stream(0, 24 * bs + 12345, device="cuda")
+    comp, comp_off, comp_len, in_len = sharded.compress_blocks_device(src, bs, np.zeros(25, dtype=np.uint32))
+    out, out_len, st = sharded.decompress_blocks_device(comp, comp_off, comp_len, None, bs)
+    torch.cuda.synchronize()
+    assert int((st != 0).sum().item()) == 0 and torch.equal(out_len.to(torch.int32), in_len.to(torch.int32))
+    assert torch.equal(out[:src.numel()], src)
+    h = src[:bs].cpu().numpy().tobytes()
+    first = comp[:int(comp_len[0].item())].cpu().numpy().tobytes()
+    assert O.decompress(first, bs) == ("ok", h)
