@@ -76,7 +76,10 @@ struct Geo {
 using GeoProd = Geo<CT, CM, P, BATCH, HIST, WNEW>;              // lz4_pcd_common.h: 32 KiB tiles, 256-byte parts, 1 024 lanes, 16 + 32 KiB window
 using GeoTest = Geo<2048u, 256u, 64u, 128u, 512u, 1024u>;       // tests: boundaries of every kind inside small inputs
 
-enum : uint32_t { C_EXIT = 0, C_CUT = 1, C_TOTAL = 2, C_BAD = 3, C_G_SRC = 4, C_G_LIT = 5, C_G_ML = 6, C_G_OFF = 7, C_TIMEOUT = 8 };
+// control words in LDS.  A word is written on one side of a barrier and read on the other: C_BAD (a sequence that does not parse) is
+// written before the batch's first barrier and read behind it, C_BAD2 (an offset behind the output) before the second one --
+// with one word for both, a fast thread's second write could reach a slow thread's first read and split the workgroup
+enum : uint32_t { C_EXIT = 0, C_CUT = 1, C_TOTAL = 2, C_BAD = 3, C_G_SRC = 4, C_G_LIT = 5, C_G_ML = 6, C_G_OFF = 7, C_TIMEOUT = 8, C_BAD2 = 9 };
 
 #define PCD_DPP(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xf, false))
 __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
@@ -413,7 +416,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
             const uint32_t Lo = OP - hist;
             const uint32_t ms = OP + ex + s.lit;                   // where my match starts
             const bool has_m = tid < cnt && s.ml != 0u;
-            if (has_m && s.off > ms) ctl[C_BAD] = 1u;              // OffsetOutOfBounds (decompress.rs:398-400)
+            if (has_m && s.off > ms) ctl[C_BAD2] = 1u;             // OffsetOutOfBounds (decompress.rs:398-400)
             {   // DONE bits: set for lanes without a match
                 const uint64_t nm = __ballot(!has_m);
                 if (lane == 0u) { X.done()[2u * X.wv] = (uint32_t)nm; X.done()[2u * X.wv + 1u] = (uint32_t)(nm >> 32); }
@@ -436,7 +439,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
             }
             __syncthreads();                                       // literals placed, bst[] / DONE / C_TOTAL / C_BAD published
             const uint32_t total = ctl[C_TOTAL];
-            if (ctl[C_BAD] != 0u || total > X.cap - OP) { bad = true; break; }     // ... / OutputTooSmall somewhere in the batch
+            if (ctl[C_BAD2] != 0u || total > X.cap - OP) { bad = true; break; }    // ... / OutputTooSmall somewhere in the batch
             // ---- matches
             {
                 const uint32_t s0 = ms - s.off;                                    // source start (has_m: off <= ms)
