@@ -65,7 +65,8 @@ struct Geo {
     static constexpr uint32_t L_RCH = L_NXT + 4u * (NP + 4u);
     static constexpr uint32_t L_TOK = align_up(L_RCH + 4u * (NP + 4u), 16u);
     static constexpr uint32_t L_BST = align_up(L_TOK + 2u * MAXSEQ, 16u);
-    static constexpr uint32_t L_DONE = align_up(L_BST + 4u * (T + 1u), 16u);
+    static constexpr uint32_t L_MST = align_up(L_BST + 4u * (T + 1u), 16u);
+    static constexpr uint32_t L_DONE = align_up(L_MST + 4u * T, 16u);
     static constexpr uint32_t L_WSUM = L_DONE + 4u * align_up(T / 32u, 4u);
     static constexpr uint32_t L_CTL = L_WSUM + 4u * align_up(NW, 4u);
     static constexpr uint32_t L_WIN = align_up(L_CTL + 4u * 32u, 16u);
@@ -79,6 +80,25 @@ using GeoTest = Geo<2048u, 256u, 64u, 128u, 512u, 1024u>;       // tests: bounda
 // control words in LDS.  A word is written on one side of a barrier and read on the other: C_BAD (a sequence that does not parse) is
 // written before the batch's first barrier and read behind it, C_BAD2 (an offset behind the output) before the second one --
 // with one word for both, a fast thread's second write could reach a slow thread's first read and split the workgroup
+#ifndef LZ4P_SLEEP
+#define LZ4P_SLEEP 1     // x 64 cycles: a wavefront whose open matches all wait for their producers yields its issue slots
+#endif
+#ifdef LZ4P_PROF     // tools (variant build): cycles of thread 0 per phase, summed over the workgroups -> g_pcd_prof
+__device__ unsigned long long g_pcd_prof[32];
+#define PCD_PROF_DECL unsigned long long pr_acc[24] = {0}; unsigned long long pr_t0 = __builtin_readcyclecounter();
+#define PCD_TICK(i) { const unsigned long long t_ = __builtin_readcyclecounter(); pr_acc[i] += t_ - pr_t0; pr_t0 = t_; }
+#define PCD_COUNT(i, v) { pr_acc[i] += (v); }
+#define PCD_PROF_FLUSH if (tid == 0u) { for (int i_ = 0; i_ < 24; ++i_) if (pr_acc[i_]) atomicAdd(&g_pcd_prof[i_], pr_acc[i_]); }
+#else
+#define PCD_PROF_DECL
+#define PCD_TICK(i)
+#define PCD_COUNT(i, v)
+#define PCD_PROF_FLUSH
+#endif
+// phases: 0 load tile, 1 walks, 2 resolve + dirty check, 3 token list, 4 batch parse + scan + cut, 5 literals, 6 dependency search,
+// 7 matches (polling), 8 write-back + slide, 9 giant sequences; counts: 16 tiles, 17 rounds, 18 batches, 19 sequences, 20 giants,
+// 21 / 22 turns of thread 0's polling loop with / without a ready match, 23 matches copied by thread 0's whole wavefront
+
 enum : uint32_t { C_EXIT = 0, C_CUT = 1, C_TOTAL = 2, C_BAD = 3, C_G_SRC = 4, C_G_LIT = 5, C_G_ML = 6, C_G_OFF = 7, C_TIMEOUT = 8, C_BAD2 = 9 };
 
 #define PCD_DPP(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xf, false))
@@ -123,7 +143,64 @@ struct Rd {
         const uint32_t r = pos - cbase;
         return r < G::CT + G::CM ? (uint32_t)ct[r] : (uint32_t)gin[pos];
     }
+    __device__ __forceinline__ uint32_t u32(uint32_t pos) const {      // pos + 4 <= ilen
+        const uint32_t r = pos - cbase;
+        uint32_t v;
+        if (r + 4u <= G::CT + G::CM) __builtin_memcpy(&v, (const void*)(ct + r), 4);
+        else __builtin_memcpy(&v, gin + pos, 4);
+        return v;
+    }
 };
+
+// The sequence whose token is at p, like parse_seq -- but the usual sequence (at most one length byte per length, not at the
+// block's end, inside the staged tile) is decoded from aligned dwords of the LDS tile: ONE LDS round trip for up to 4 literals
+// (token, offset and length byte lie in the 8 bytes at p), two otherwise, instead of a byte read per field.  A lane's walk is a
+// chain of these -- its latency is the parse's critical path -- and a wavefront pays for the byte-wise path whenever ONE of its
+// lanes takes it, so that path must be rare per lane (255-chains, the block's end).
+template <class G>
+__device__ __attribute__((noinline)) uint32_t seq_slow(const Rd<G>& rd, uint32_t ilen, uint32_t p, Seq& s) {
+    return parse_seq(rd, ilen, p, s);
+}
+// mark_addr: LDS byte address of a word that is fetched in the same round trip (the walk's "was this position marked before"),
+// or 0; its value comes back in *mark_word.
+template <class G>
+__device__ __forceinline__ uint32_t seq_at(const Rd<G>& rd, uint32_t ilen, uint32_t staged, uint32_t p, Seq& s,
+                                           uint32_t mark_addr = 0u, uint32_t* mark_word = nullptr) {
+    // Straight-line code: every lane reads the 12 aligned bytes around its token and then the 8 around its offset, whether it
+    // needs them or not -- both addresses lie inside the LDS tile for every token position below CT (a length byte adds at most
+    // 270 bytes, the tile is staged with CM = 1 024 behind it).  Written with plain loads, hipcc moved each read into the
+    // branch that uses it: four dependent round trips and ~170 instructions per sequence.
+    const uint32_t r = p - rd.cbase;
+    const uint32_t base = (uint32_t)(uintptr_t)rd.ct;
+    uint64_t d01;
+    uint32_t d2, mk = 0u;
+    if (mark_word != nullptr) asm volatile("ds_read_b32 %0, %1" : "=v"(mk) : "v"(mark_addr) : "memory");
+    asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8" : "=v"(d01), "=v"(d2) : "v"(base + (r & ~3u)) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d01), "+v"(d2), "+v"(mk) :: "memory");
+    if (mark_word != nullptr) *mark_word = mk;
+    const uint32_t d0 = (uint32_t)d01, d1 = (uint32_t)(d01 >> 32);
+    const uint32_t sh = r & 3u;
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    const uint32_t t = w0 & 0xFFu, lc = t >> 4, mlc = t & 15u;
+    const uint32_t l15 = lc == 15u ? 1u : 0u, e1 = (w0 >> 8) & 0xFFu;
+    const uint32_t lit = lc + (l15 ? e1 : 0u);                           // (one length byte: up to 269 literals)
+    const uint32_t hdr = 1u + l15;
+    const uint32_t rq = r + hdr + lit;
+    const uint32_t q = p + hdr + lit;                                    // the offset's position
+    uint64_t e01;
+    asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(e01) : "v"(base + (rq & ~3u)) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e01) :: "memory");
+    const uint32_t x3 = __builtin_amdgcn_alignbyte((uint32_t)(e01 >> 32), (uint32_t)e01, rq & 3u);   // the 3 bytes at q
+    const uint32_t off = x3 & 0xFFFFu, e = (x3 >> 16) & 0xFFu;
+    // the usual sequence: at most one length byte per length; offset, a length byte and one more byte exist (no end-of-block
+    // case) and are staged
+    const bool usual = r + 12u <= staged && !(l15 && e1 == 255u) && q + 3u < ilen && rq + 8u <= staged && !(mlc == 15u && e == 255u);
+    if (usual) {
+        s.lit_src = p + hdr; s.lit = lit; s.off = off; s.ml = 4u + mlc + (mlc == 15u ? e : 0u);
+        return off != 0u ? q + 2u + (mlc == 15u ? 1u : 0u) : X_ERR;      // (offset 0: what parse_seq returns, decompress.rs:168-173)
+    }
+    return seq_slow(rd, ilen, p, s);
+}
 
 template <class G>
 struct Ctx {
@@ -140,6 +217,7 @@ struct Ctx {
     __device__ __forceinline__ lds_u32* rch() const { return (lds_u32*)(lds + G::L_RCH); }
     __device__ __forceinline__ lds_u16* tok() const { return (lds_u16*)(lds + G::L_TOK); }
     __device__ __forceinline__ lds_u32* bst() const { return (lds_u32*)(lds + G::L_BST); }
+    __device__ __forceinline__ lds_u32* mst() const { return (lds_u32*)(lds + G::L_MST); }
     __device__ __forceinline__ lds_u32* done() const { return (lds_u32*)(lds + G::L_DONE); }
     __device__ __forceinline__ lds_u32* wsum() const { return (lds_u32*)(lds + G::L_WSUM); }
     __device__ __forceinline__ volatile lds_u32* ctl() const { return (volatile lds_u32*)(lds + G::L_CTL); }
@@ -299,6 +377,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
     uint32_t hist = 0u;        // window bytes [0, hist) hold output [OP - hist, OP)
     bool ended = false, bad = false;
     __syncthreads();
+    PCD_PROF_DECL
 
     while (!ended) {
         // ================================================================ PARSE one tile
@@ -306,6 +385,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
         const uint32_t span = X.ilen - cbase;
         const uint32_t parts = span >= G::CT ? G::NP : (span + G::P - 1u) / G::P;
         for (uint32_t w = tid; w < G::MW; w += G::T) X.marks()[w] = 0u;
+        const uint32_t staged = span < G::CT + G::CM ? span : G::CT + G::CM;      // bytes of the block in the LDS tile
         uint32_t my_e = cbase + tid * G::P;
         if (tid < parts) { X.ent()[tid] = my_e; X.ext()[tid] = X_ERR; }
         bool dirty = tid < parts;
@@ -313,25 +393,48 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
         __syncthreads();
         const Rd<G> rd{X.ct(), X.gin, cbase};
         bool settled = false;
+        PCD_TICK(0) PCD_COUNT(16, 1)
         for (uint32_t it = 0u; it < G::MAX_ITERS; ++it) {
-            if (dirty) {                                          // lane k walks part k from its entry
+            if (dirty) {
+                // Lane k walks part k from its entry.  A walk that lands on a position the part's PREVIOUS walk marked is
+                // identical to it from there on: it stops, keeps those marks and the exit (the first walk of a tile, from an
+                // assumed entry, meets no marks: the tile's are cleared).  So a part is walked once in full and then only as far
+                // as its chains differ -- a few sequences.
                 lds_u32* mk = X.marks() + tid * G::PW;
-#pragma unroll
-                for (uint32_t w = 0; w < G::PW; ++w) mk[w] = 0u;
                 const uint32_t pend = cbase + (tid + 1u) * G::P;
-                uint32_t p = my_e, x;
+                uint32_t nm[G::PW];
+#pragma unroll
+                for (uint32_t w = 0; w < G::PW; ++w) nm[w] = 0u;
+                uint32_t p = my_e, x = 0u, mw = G::PW, mbit = 0u;
+                bool merged = false;
                 for (;;) {
                     if (p >= pend) { x = p; break; }
                     const uint32_t r = p - cbase;
-                    X.marks()[r >> 5] |= 1u << (r & 31u);               // (the part's mark words belong to this lane alone)
+                    const uint32_t wi = (r >> 5) - tid * G::PW, bit = 1u << (r & 31u);
+                    uint32_t oldw;                                     // (fetched together with the token's dwords)
                     Seq s;
-                    const uint32_t nx = parse_seq(rd, X.ilen, p, s);
+                    const uint32_t nx = seq_at(rd, X.ilen, staged, p, s, (uint32_t)(uintptr_t)(X.marks() + (r >> 5)), &oldw);
+                    PCD_COUNT(24, 1)
+                    if ((oldw & bit) != 0u) { merged = true; mw = wi; mbit = r & 31u; break; }
+#pragma unroll
+                    for (uint32_t w = 0; w < G::PW; ++w) nm[w] |= w == wi ? bit : 0u;
                     if (nx >= X_ERR) { x = nx; break; }
                     p = nx;
                 }
-                X.ext()[tid] = x;
+                if (merged) {
+#pragma unroll
+                    for (uint32_t w = 0; w < G::PW; ++w) {
+                        const uint32_t old = mk[w];
+                        mk[w] = w < mw ? nm[w] : (w == mw ? (nm[w] | (old & (0xFFFFFFFFu << mbit))) : old);
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t w = 0; w < G::PW; ++w) mk[w] = nm[w];
+                    X.ext()[tid] = x;
+                }
             }
             __syncthreads();
+            PCD_TICK(1) PCD_COUNT(17, 1)
             if (X.wv == 0u) X.resolve(cbase, parts);
             __syncthreads();
             dirty = false;
@@ -339,7 +442,9 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 const uint32_t e = X.ent()[tid];
                 if (e != my_e) { my_e = e; dirty = true; }
             }
-            if (!__syncthreads_or(dirty ? 1 : 0)) { settled = true; break; }
+            const int any_dirty = __syncthreads_or(dirty ? 1 : 0);
+            PCD_TICK(2)
+            if (!any_dirty) { settled = true; break; }
         }
         const uint32_t tile_exit = ctl[C_EXIT];
         if (!settled || tile_exit == X_ERR) { bad = true; break; }     // (uniform)
@@ -361,6 +466,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
             }
         }
         __syncthreads();
+        PCD_TICK(3)
 
         // ================================================================ COPY: batches of consecutive sequences
         uint32_t idx = 0u;
@@ -371,7 +477,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
             uint32_t len = 0u;
             bool perr = false;
             if (tid < m) {
-                const uint32_t nx = parse_seq(rd, X.ilen, cbase + X.tok()[idx + tid], s);
+                const uint32_t nx = seq_at(rd, X.ilen, staged, cbase + X.tok()[idx + tid], s);
                 perr = nx == X_ERR || (nx == X_END && !(ended && idx + tid + 1u == ntok));
                 len = s.lit + s.ml;                                // (both < 2^31)
             }
@@ -384,6 +490,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
             if (perr) ctl[C_BAD] = 1u;
             __syncthreads();
             const uint32_t cnt = ctl[C_CUT];
+            PCD_TICK(4)
             if (ctl[C_BAD] != 0u) { bad = true; break; }
             if (cnt == 0u) {
                 // ---- a sequence longer than the window: alone, by the whole workgroup, on the output itself
@@ -408,13 +515,14 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 }
                 hist = 0u;
                 idx += 1u;
+                PCD_TICK(9) PCD_COUNT(20, 1)
                 continue;
             }
             // ---- a batch of cnt sequences: [OP, OP + total) in the window behind the history
             if (tid + 1u == cnt) ctl[C_TOTAL] = ex + len;
-            if (tid < cnt) X.bst()[tid] = OP + ex;
             const uint32_t Lo = OP - hist;
             const uint32_t ms = OP + ex + s.lit;                   // where my match starts
+            if (tid < cnt) { X.bst()[tid] = OP + ex; X.mst()[tid] = ms; }
             const bool has_m = tid < cnt && s.ml != 0u;
             if (has_m && s.off > ms) ctl[C_BAD2] = 1u;             // OffsetOutOfBounds (decompress.rs:398-400)
             {   // DONE bits: set for lanes without a match
@@ -438,6 +546,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 }
             }
             __syncthreads();                                       // literals placed, bst[] / DONE / C_TOTAL / C_BAD published
+            PCD_TICK(5) PCD_COUNT(18, 1) PCD_COUNT(19, cnt)
             const uint32_t total = ctl[C_TOTAL];
             if (ctl[C_BAD2] != 0u || total > X.cap - OP) { bad = true; break; }    // ... / OutputTooSmall somewhere in the batch
             // ---- matches
@@ -455,52 +564,100 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                         if (cl < cnt && X.bst()[cl] <= a0) jl = cl;
                         if (ch < cnt && X.bst()[ch] <= a1) jh = ch;
                     }
-                    if (jl < tid) { lo = jl; hi = jh < tid ? jh : tid - 1u; }      // (a source inside my own literals has no producer)
+                    if (jl < tid) {                                                // (a source inside my own literals has no producer)
+                        lo = jl;
+                        hi = jh < tid ? jh : tid - 1u;
+                        // the last one only counts if the source reaches into its MATCH (its literals are placed already)
+                        if (hi == jh && s1 <= X.mst()[hi]) { if (hi == lo) { lo = 1u; hi = 0u; } else hi -= 1u; }
+                    }
                 }
-                // one lane, 16 bytes at a time: offset >= 16, up to 64 bytes, source entirely in the window or entirely written back
+                PCD_TICK(6)
+                // one lane, 16 bytes at a time: offset >= 16, up to 256 bytes, source entirely in the window or entirely written back;
+                // everything else (periodic, long, straddling the window's start) is copied by the whole wavefront
+                const bool dep = lo <= hi;
                 const bool near = s0 >= Lo;
                 const bool farok = s0 + ((s.ml + 15u) & ~15u) <= Lo;
-                const bool inl = s.off >= 16u && s.ml <= 64u && (near || farok);
-                bool pending = has_m;
-                uint32_t spins = 0u;
-                while (__any(pending)) {
-                    bool ready = pending;
-                    if (ready && lo <= hi) {
-                        for (uint32_t w = lo >> 5; w <= (hi >> 5); ++w) {
-                            const uint32_t first = w == (lo >> 5) ? (lo & 31u) : 0u, last = w == (hi >> 5) ? (hi & 31u) : 31u;
-                            const uint32_t mask = (0xFFFFFFFFu >> (31u - last)) & (0xFFFFFFFFu << first);
-                            const uint32_t d = __hip_atomic_load(X.done() + w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if ((d & mask) != mask) { ready = false; break; }
-                        }
-                    }
-                    if (ready && inl) {
-                        lds_u8* d = X.win() + (ms - Lo);
+                const bool inl = s.off >= 16u && (near ? s.ml <= 256u : (farok && s.ml <= 64u));   // (far: four loads in flight, no more)
+                lds_u8* const dstp = X.win() + (ms - Lo);
+                auto copy_inline = [&]() {
+                    if (near) {
+                        const lds_u8* sp = X.win() + (s0 - Lo);
+                        if (s.off >= s.ml) {          // no byte of the source is my own output: 64 bytes of loads before their stores
+                            for (uint32_t o = 0u; o < s.ml; o += 64u) {
+                                u32x4 v[4];
 #pragma unroll
-                        for (uint32_t o = 0u; o < 64u; o += 16u) {
-                            if (o < s.ml) {
-                                const u32x4 v = near ? ld16l(X.win() + (s0 - Lo) + o) : ld16g(X.gout + s0 + o);
-                                st_exact(d + o, v, s.ml - o < 16u ? s.ml - o : 16u);
+                                for (uint32_t k = 0u; k < 4u; ++k) if (o + 16u * k < s.ml) v[k] = ld16l(sp + o + 16u * k);
+#pragma unroll
+                                for (uint32_t k = 0u; k < 4u; ++k) {
+                                    const uint32_t at = o + 16u * k;
+                                    if (at < s.ml) st_exact(dstp + at, v[k], s.ml - at < 16u ? s.ml - at : 16u);
+                                }
                             }
+                        } else {
+                            for (uint32_t o = 0u; o < s.ml; o += 16u) st_exact(dstp + o, ld16l(sp + o), s.ml - o < 16u ? s.ml - o : 16u);
                         }
+                    } else {                                  // written-back output: every load is issued before the first store waits
+                        const uint8_t* sp = X.gout + s0;
+                        u32x4 v[4];
+#pragma unroll
+                        for (uint32_t k = 0u; k < 4u; ++k) if (16u * k < s.ml) v[k] = ld16g(sp + 16u * k);
+#pragma unroll
+                        for (uint32_t k = 0u; k < 4u; ++k) if (16u * k < s.ml) st_exact(dstp + 16u * k, v[k], s.ml - 16u * k < 16u ? s.ml - 16u * k : 16u);
                     }
-                    uint64_t cm = __ballot(ready && !inl);
-                    const bool progress = __any(ready);
+                };
+                auto copy_coop = [&](bool want) {
+                    uint64_t cm = __ballot(want);
                     while (cm != 0ull) {
                         const uint32_t l = (uint32_t)__builtin_ctzll(cm);
                         cm &= cm - 1ull;
                         X.wave_match(bcast(ms, l), bcast(s.off, l), bcast(s.ml, l), Lo);
+                        PCD_COUNT(23, 1)
                     }
-                    if (ready) {
-                        __hip_atomic_fetch_or(X.done() + (tid >> 5), 1u << (tid & 31u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        pending = false;
+                };
+                auto publish = [&]() {     // my match's bytes are in the window: the DONE bit follows them (release)
+                    __hip_atomic_fetch_or(X.done() + (tid >> 5), 1u << (tid & 31u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                };
+                // matches without a producer in this batch (history, written-back output, own literals): all at once
+                bool pending = has_m;
+                {
+                    const bool go = has_m && !dep;
+                    if (go && inl) copy_inline();
+                    copy_coop(go && !inl);
+                    if (go) { publish(); pending = false; }
+                }
+                // the others poll their producers' DONE bits: [lo, hi] = bits lo & 31 .. of word wl up to bit hi & 31 of word wh.
+                // A wavefront without open matches leaves (and waits at the barrier, off the issue slots); one with open
+                // matches none of which is ready sleeps a little.  What a dependency costs is one turn of this loop.
+                const uint32_t wl = lo >> 5, wh = hi >> 5;
+                const uint32_t mlo = 0xFFFFFFFFu << (lo & 31u), mhi = 0xFFFFFFFFu >> (31u - (hi & 31u));
+                const volatile lds_u32* dn = (const volatile lds_u32*)X.done();
+                uint32_t spins = 0u;
+                while (__any(pending)) {
+                    bool ready = false;
+                    if (pending) {
+                        if (wl == wh) {
+                            const uint32_t mk = mlo & mhi;
+                            ready = (dn[wl] & mk) == mk;
+                        } else {
+                            ready = (dn[wl] & mlo) == mlo && (dn[wh] & mhi) == mhi;
+                            for (uint32_t w = wl + 1u; ready && w < wh; ++w) ready = dn[w] == 0xFFFFFFFFu;
+                        }
                     }
-                    if (!progress) {
-                        __builtin_amdgcn_s_sleep(1);
+                    if (__any(ready)) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // the producers' bytes behind their DONE bits
+                        if (ready && inl) copy_inline();
+                        copy_coop(ready && !inl);
+                        if (ready) { publish(); pending = false; }
+                        PCD_COUNT(21, 1)
+                    } else {
+                        __builtin_amdgcn_s_sleep(LZ4P_SLEEP);
+                        PCD_COUNT(22, 1)
                         if (++spins > (1u << 22)) { ctl[C_TIMEOUT] = 1u; break; }   // (cannot happen: the lowest open match is always ready)
                     }
                 }
             }
             __syncthreads();
+            PCD_TICK(7)
             if (ctl[C_TIMEOUT] != 0u) { bad = true; break; }
             // ---- write the batch back, slide the history
             for (uint32_t o = 16u * tid; o < total; o += 16u * G::T) {
@@ -530,11 +687,13 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
             hist = keep;
             idx += cnt;
             __syncthreads();                                       // window and written-back output are consistent for the next batch
+            PCD_TICK(8)
         }
         if (bad) break;
         cbase = tile_exit;
         __syncthreads();                                           // the tile's LDS is free
     }
+    PCD_PROF_FLUSH
     if (tid == 0u) {
         if (bad) { a.status[b] = redo_code; a.out_len[b] = 0u; }
         else { a.status[b] = 0; a.out_len[b] = OP; }
@@ -571,3 +730,16 @@ hipError_t launch_decompress_pcd(const DecompressArgs& a, int32_t redo_code, hip
 }
 
 }  // namespace lz4flex_dev
+
+#ifdef LZ4P_PROF
+extern "C" int lz4flex_debug_pcd_prof(unsigned long long* vals, int reset) {
+    if (reset) {
+        unsigned long long z[32] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(lz4flex_dev::pcd::g_pcd_prof), z, sizeof z);
+        return 0;
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(vals, HIP_SYMBOL(lz4flex_dev::pcd::g_pcd_prof), 256);
+    return 0;
+}
+#endif

@@ -29,8 +29,8 @@ namespace pcd {
 // Then the set bits of the live parts ARE the tile's sequences, in order.
 constexpr uint32_t CT = 32768u;           // compressed bytes per tile
 constexpr uint32_t CM = 1024u;            // bytes behind the tile that are staged with it (a walk's last sequence reads past the tile)
-constexpr uint32_t P = 256u;              // bytes per part
-constexpr uint32_t NP = CT / P;           // 128 parts
+constexpr uint32_t P = 128u;              // bytes per part
+constexpr uint32_t NP = CT / P;           // 256 parts
 // every round of walks + exit following makes at least one more live part final (the first one whose entry was wrong), so NP + 1
 // rounds always settle a tile; real data needs two or three (a chain in step with the true one after a few sequences), data
 // on which chains rarely meet (random bytes over a two-letter alphabet: every byte is a plausible token) degrades to one part
@@ -41,7 +41,7 @@ constexpr uint32_t MAXSEQ = CT / 3u + 2u; // a sequence with a match is at least
 // The tile's sequences are executed in BATCHES of up to BATCH consecutive sequences, one lane each, on an LDS WINDOW of the
 // output: HIST bytes of history before the batch + at most WNEW bytes the batch produces.
 constexpr uint32_t BATCH = 1024u;
-constexpr uint32_t HIST = 16384u;
+constexpr uint32_t HIST = 49152u;
 constexpr uint32_t WNEW = 32768u;
 constexpr uint32_t WIN = HIST + WNEW;
 constexpr uint32_t X_END = 0xFFFFFFFFu;   // exit: the block's last sequence ended exactly at the block's end
@@ -55,7 +55,7 @@ struct Seq {
 };
 
 // One sequence whose token is at p (p < ilen); rd(pos) returns the compressed byte at pos < ilen.  Returns the position of
-// the next token, X_END, or X_ERR.  Checks: everything src/block/decompress.rs:244-443 checks WITHOUT knowing the output
+// (rd.u32(pos): the four bytes at pos, pos + 4 <= ilen) the next token, X_END, or X_ERR.  Checks: everything src/block/decompress.rs:244-443 checks WITHOUT knowing the output
 // position (the copy side checks offset <= position and the sink's capacity).
 template <class R>
 PCD_FN uint32_t parse_seq(const R& rd, uint32_t ilen, uint32_t p, Seq& s) {
@@ -63,6 +63,11 @@ PCD_FN uint32_t parse_seq(const R& rd, uint32_t ilen, uint32_t p, Seq& s) {
     uint32_t q = p + 1u;
     uint32_t lit = t >> 4;
     if (lit == 15u) {                                   // read_integer_ptr :126-157
+        while (ilen - q >= 4u && rd.u32(q) == 0xFFFFFFFFu) {   // (four length bytes at a time: a 4 MiB literal run has 16 K of them)
+            lit += 1020u;
+            q += 4u;
+            if (lit > 0x7FFFFFFFu) return X_ERR;
+        }
         for (;;) {
             if (q >= ilen) return X_ERR;
             const uint32_t b = rd(q);
@@ -85,6 +90,11 @@ PCD_FN uint32_t parse_seq(const R& rd, uint32_t ilen, uint32_t p, Seq& s) {
     if (off == 0u) return X_ERR;                        // :168-173
     uint32_t ml = 4u + (t & 15u);
     if (ml == 19u) {
+        while (ilen - q >= 4u && rd.u32(q) == 0xFFFFFFFFu) {
+            ml += 1020u;
+            q += 4u;
+            if (ml > 0x7FFFFFFFu) return X_ERR;
+        }
         for (;;) {
             if (q >= ilen) return X_ERR;
             const uint32_t b = rd(q);

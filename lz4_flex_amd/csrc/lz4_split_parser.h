@@ -176,9 +176,16 @@ struct ParserT {
         }
         vhi += 16u;
     }
-    // fill the ring with the block's first 64 bytes, request the chunk behind them
+    // fill the ring with the block's first 64 bytes, request the chunk behind them.  Only lanes that own a block: with fewer
+    // than 64 blocks per workgroup the spare lanes point at block 0's LDS area, and their (zero) chunks landed in ITS ring --
+    // which dword of which lane survives such a write is the hardware's business; a sequence in block 0's first 64 bytes
+    // whose length byte was zeroed that way decoded 3 bytes short with status 0 (round 3: block 2 096 of the JSON batch with
+    // 8 / 16 blocks per workgroup).
     LZ4_FN void prime() {
-        for (uint32_t c = 0u; c < RING; c += 16u) ring_put(*reinterpret_cast<const u32x4*>(chunk_addr(c)));
+        for (uint32_t c = 0u; c < RING; c += 16u) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(chunk_addr(c));
+            if (done == 0u) ring_put(v); else vhi += 16u;
+        }
         N = *reinterpret_cast<const u32x4*>(chunk_addr(vhi));
     }
     LZ4_FN const uint8_t* chunk_addr(uint32_t c) const { return gal + (c < climit ? c : climit); }
@@ -290,7 +297,7 @@ struct ParserT {
         const uint32_t ipa4 = ipa & ~3u;
         const bool rebase = (int32_t)(ipa - vhi) >= 16;      // a long literal run led behind the chunk in flight: restart at the target (the steps until the ring is full again do not parse)
         const bool slide = !rebase && (int32_t)(ipa4 - (vhi - 48u)) >= 0;   // slot [vhi - 64, vhi - 48) is behind the dwords at ip
-        if (slide) ring_put(N);
+        if (slide && done == 0u) ring_put(N);            // (a lane without a block, or past its block's end, owns no ring)
         vhi = rebase ? (ipa & ~15u) : vhi;
         N = *reinterpret_cast<const u32x4*>(chunk_addr(vhi));
         ahead_ = vhi - ipa;                                  // valid bytes from ip on (signed)

@@ -37,6 +37,7 @@ namespace {
 struct Rd {
     const uint8_t* c;
     uint32_t operator()(uint32_t pos) const { return c[pos]; }
+    uint32_t u32(uint32_t pos) const { uint32_t v; memcpy(&v, c + pos, 4); return v; }
 };
 
 struct Rng {
@@ -189,6 +190,10 @@ extern "C" long pcd_model_decode(const uint8_t* c, uint32_t n, uint8_t* out, uin
                 uint32_t h = (uint32_t)(std::upper_bound(start.begin(), start.begin() + cnt, s1 - 1) - start.begin()) - 1;
                 if (l >= i) { level[i] = 1; continue; }      // the source lies in its own literals only (placed already)
                 if (h >= i) h = i - 1;
+                else if (s1 <= start[h] + sq[h].lit) {       // the source ends inside sequence h's literals: its match is no producer
+                    if (h == l) { level[i] = 1; continue; }
+                    h -= 1;
+                }
                 lo[i] = l; hi[i] = h;
                 uint32_t lv = 0;
                 for (uint32_t j = l; j <= h; j++) lv = std::max(lv, level[j]);

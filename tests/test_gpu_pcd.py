@@ -159,7 +159,7 @@ def test_device_batch_of_4mib_blocks_round_trip(env):
     from lz4_flex_amd import sharded, workloads
     lib, block = env
     bs = 4 << 20
-    src = workloads.log_stream(0, 24 * bs + 12345, device="cuda")
+    src = workloads.log_stream(0, 24 * bs + 128 * 97, device="cuda")
     comp, comp_off, comp_len, in_len = sharded.compress_blocks_device(src, bs, np.zeros(25, dtype=np.uint32))
     out, out_len, st = sharded.decompress_blocks_device(comp, comp_off, comp_len, None, bs)
     torch.cuda.synchronize()
@@ -168,3 +168,44 @@ def test_device_batch_of_4mib_blocks_round_trip(env):
     h = src[:bs].cpu().numpy().tobytes()
     first = comp[:int(comp_len[0].item())].cpu().numpy().tobytes()
     assert O.decompress(first, bs) == ("ok", h)
+
+
+@pytest.mark.parametrize("variant,bpw", [(4, 8), (4, 16), (4, 32), (4, 64), (5, 0), (6, 0), (7, 0)])
+def test_every_decoder_geometry_on_2304_benchmark_blocks(env, variant, bpw):
+    """2 304 JSON tiles (configs[1]'s data) written by the throughput encoder, decoded on the device by every kernel and every
+    blocks-per-workgroup geometry of the split decoder.  Regression: with 8 / 16 blocks per workgroup the split parser's spare
+    lanes wrote their empty chunks into block 0's ring; block 2 096 of this batch then decoded 3 bytes short with status 0."""
+    import torch
+    from lz4_flex_amd import _lib as L, workloads
+    lib, block = env
+    n, B, stride = 2304, 65536, 72128
+    dev = torch.device("cuda", 0)
+    src = workloads.json_tiles(O.fixture_plain("compression_66k_JSON"), n * B, device=dev)
+    comp = torch.empty(n * stride, dtype=torch.uint8, device=dev)
+    back = torch.zeros(n * B, dtype=torch.uint8, device=dev)
+    ar = torch.arange(n, dtype=torch.int64, device=dev)
+    in_off, comp_off = ar * B, ar * stride
+    in_len = torch.full((n,), B, dtype=torch.int32, device=dev)
+    cap = torch.full((n,), stride, dtype=torch.int32, device=dev)
+    clen = torch.zeros(n, dtype=torch.int32, device=dev)
+    st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    blen = torch.zeros(n, dtype=torch.int32, device=dev)
+    bst = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    ctx = _ctx(lib, variant)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    try:
+        assert lib.lz4flex_set_tuning(ctx, b"compress_mode", 0) == 0
+        if bpw:
+            assert lib.lz4flex_set_tuning(ctx, b"decompress_blocks_per_wg", bpw) == 0
+        assert lib.lz4flex_compress_batch(ctx, p(src), p(in_off), p(in_len), None, n, p(comp), p(comp_off), p(cap), p(clen), p(st),
+                                          L.MEM_DEVICE, stream) == 0
+        assert lib.lz4flex_decompress_batch(ctx, p(comp), p(comp_off), p(clen), n, p(back), p(in_off), p(in_len), p(blen), p(bst),
+                                            None, L.MEM_DEVICE, stream) == 0
+        torch.cuda.synchronize()
+    finally:
+        lib.lz4flex_ctx_destroy(ctx)
+    assert int((st != 0).sum().item()) == 0 and int((bst != 0).sum().item()) == 0
+    assert int((blen != B).sum().item()) == 0
+    bad = torch.nonzero((back.view(n, B) != src.view(n, B)).any(dim=1)).flatten().tolist()
+    assert not bad, "blocks that differ from the input: %r" % bad[:10]

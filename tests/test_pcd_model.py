@@ -17,7 +17,7 @@ def geometries():
     d = M.defaults()
     tiny = M.Params(ct=128, p=32, batch=4, hist=16, wnew=48, max_iters=200)
     small = M.Params(ct=1024, p=64, batch=16, hist=64, wnew=256, max_iters=200)
-    mid = M.Params(ct=4096, p=256, batch=64, hist=1024, wnew=4096, max_iters=200)
+    mid = M.Params(ct=4096, p=128, batch=64, hist=1024, wnew=4096, max_iters=200)
     return [("default", d), ("tiny", tiny), ("small", small), ("mid", mid)]
 
 
@@ -76,5 +76,5 @@ def test_model_statistics_on_the_benchmark_data():
             got, st = M.decode(c, len(d))
             assert got == d
             assert st.iters <= 8 * st.tiles, (name, st.iters, st.tiles)              # measured: 2.1 - 4.6 rounds per tile ...
-            assert st.part_walks <= 2.2 * (len(c) / 256 + st.tiles)                 # ... but only 1.8 walks per part: later rounds re-walk a few parts
+            assert st.part_walks <= 2.2 * (len(c) / 128 + st.tiles)                 # ... but only 1.8 walks per part: later rounds re-walk a few parts
             assert st.giants <= 1

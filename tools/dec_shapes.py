@@ -82,6 +82,26 @@ def main():
                     ok = int((bst != 0).sum().item()) == 0 and torch.equal(back, src)
             ts.sort()
             row.append("v%d %s%.3f ms (%.1f GB/s)" % (v, "" if ok else "WRONG ", ts[len(ts) // 2], n * B / ts[len(ts) // 2] / 1e6))
+            if v in (7, 8) and hasattr(lib, "lz4flex_debug_pcd_prof"):           # -DLZ4P_PROF variant build
+                lib.lz4flex_debug_pcd_prof.argtypes = [C.c_void_p, C.c_int]
+                pv = (C.c_ulonglong * 32)()
+                lib.lz4flex_debug_pcd_prof(None, 1)
+                assert lib.lz4flex_decompress_batch(ctx, p(comp), p(comp_off), p(clen), n, p(back), p(in_off), p(in_len), p(blen), p(bst),
+                                                    None, L.MEM_DEVICE, stream) == 0
+                torch.cuda.synchronize()
+                lib.lz4flex_debug_pcd_prof(pv, 0)
+                pv = list(pv)
+                names = ["load", "walk", "resolve", "toklist", "parse+scan", "literals", "search", "matches", "writeback", "giant"]
+                tot = max(sum(pv[:10]), 1)
+                print("   pcd cycles per block: %.0f k; %s | tiles %.1f rounds/tile %.2f batches %.1f seq/batch %.0f giants %.1f" % (
+                    tot / n / 1e3, ", ".join("%s %.1f%%" % (nm, 100.0 * x / tot) for nm, x in zip(names, pv)), pv[16] / n, pv[17] / max(pv[16], 1),
+                    pv[18] / n, pv[19] / max(pv[18], 1), pv[20] / n), flush=True)
+                print("      wavefront 0 per batch: polling turns with a ready match %.1f, without %.1f, wavefront copies %.1f" % (
+                    pv[21] / max(pv[18], 1), pv[22] / max(pv[18], 1), pv[23] / max(pv[18], 1)), flush=True)
+                print("      thread 0: hops per walk round %.1f, cycles per hop %.0f" % (pv[24] / max(pv[17], 1), pv[1] / max(pv[24], 1)), flush=True)
+                for nm, x, cnt in (("walk round", pv[1], pv[17]), ("resolve round", pv[2], pv[17]), ("batch (4..8)", sum(pv[4:9]), pv[18]), ("matches phase", pv[7], pv[18]), ("giant", pv[9], pv[20])):
+                    if cnt:
+                        print("      cycles per %s: %.0f" % (nm, x / cnt), flush=True)
         print("%-7s block %8d x %5d  ratio %.3f | %s" % (data, B, n, ratio, " | ".join(row)), flush=True)
         del src, comp, back
 
