@@ -129,8 +129,10 @@ int64_t lz4flex_decompress_size_prepended_with_dict(const uint8_t *in, size_t in
  *      src/frame/compress.rs:282-298 and src/frame/decompress.rs:288-305, batched) ------------ */
 #define LZ4FLEX_MEM_HOST 0   /* every pointer is host memory; the call stages through the ctx arena and is synchronous */
 #define LZ4FLEX_MEM_DEVICE 1 /* every pointer (data AND descriptor/result arrays) is device memory; asynchronous on `stream` */
-/* OR into mem_kind for DEVICE compress batches that may hold blocks > 64 KiB (selects the u32 hash table;
- * HOST batches detect it themselves) */
+/* OR into mem_kind for DEVICE batches that may hold blocks > 64 KiB: the lengths live in device memory where the host cannot see
+ * them (HOST batches detect it themselves).  compress, reference-exact mode: selects the u32 hash table; decompress: a hint
+ * that the blocks are large, so any number of them goes to the one-workgroup-per-block decoder (lz4_decompress_pcd.hip), which
+ * otherwise serves batches of up to 512 blocks.  Results do not depend on the hint. */
 #define LZ4FLEX_MEM_BIG_BLOCKS 0x100
 
 /* per-block compress flags.  They select among the REFERENCE's hash tables and therefore only have a meaning in compress_mode

@@ -62,12 +62,12 @@ struct lz4flex_ctx {
 };
 
 #ifndef LZ4FLEX_PCD_MAX_BLOCKS
-#define LZ4FLEX_PCD_MAX_BLOCKS 1024
+#define LZ4FLEX_PCD_MAX_BLOCKS 512
 #endif
 static constexpr uint32_t PCD_MAX_BLOCKS = LZ4FLEX_PCD_MAX_BLOCKS;
 
 // the decoders for blocks without dictionary / prefix
-static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressArgs& a, hipStream_t s) {
+static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressArgs& a, hipStream_t s, bool big_blocks = false) {
     // 0: by batch shape.  Up to ~5 000 blocks the wave decoder (a wavefront per block: a block is done in half the time the
     // split decoder's serial chain needs, and blocks larger than 64 KiB stay tolerable); larger batches have enough blocks
     // to fill the chip with one chain per lane, which costs half the instructions per byte.  tools/wave_bench.py --dec, JSON
@@ -75,9 +75,12 @@ static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressA
     // 1.31 / 1.31 / 1.52 / 1.55 / 1.79 / 3.86 (round 1's pipelined decoder 2.43 / 2.54 / 2.62 / 2.59 / 2.9 / 4.15: deleted).
     // up to 2 304 blocks (nine pairs of wavefronts per CU) the wave decoder runs with a parser and an executor wavefront per
     // block: 256 / 1 024 / 2 048 blocks 0.45 / 0.52 / 0.65 ms against 0.73 / 0.75 / 0.82 with one wavefront
-    // up to PCD_MAX_BLOCKS blocks: a whole workgroup per block, token chain and copies parallel INSIDE the block (lz4_decompress_pcd.hip):
-    // the only decoder here whose time for a block does not grow with the block's chain alone
-    const int v = c->dec_variant != 0 ? c->dec_variant : (a.n <= PCD_MAX_BLOCKS ? 7 : (a.n <= 2304u ? 6 : (a.n <= 5120u ? 5 : 4)));
+    // up to PCD_MAX_BLOCKS blocks, or blocks known to be large: a whole workgroup per block, token chain and copies parallel INSIDE
+    // the block (lz4_decompress_pcd.hip) -- the only decoder here whose time for a block is not the length of the block's chain.
+    // tools/dec_shapes.py, JSON tiles, 256 / 512 / 1 024 blocks: 0.25 / 0.44 / 0.86 ms against 0.45 / 0.50 / 0.52 (pair of
+    // wavefronts per block); 256 x 4 MiB log blocks: 7.1 ms against 28.8; one 16 MiB block: 27.7 ms against 113.
+    const int v = c->dec_variant != 0 ? c->dec_variant
+                                      : ((a.n <= PCD_MAX_BLOCKS || big_blocks) ? 7 : (a.n <= 2304u ? 6 : (a.n <= 5120u ? 5 : 4)));
     if (v >= 5 && v <= 8) {
         // one block per wavefront (6: per pair of wavefronts; 7 / 8: per workgroup); blocks it marks (errors, sinks too small) are
         // decoded again in the reference's order
@@ -438,7 +441,9 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
         a.dict_len = has_dict ? (const uint32_t*)(dd + at_dict_len) : nullptr;
         a.out_len = (uint32_t*)(dd + at_out_len); a.status = (int32_t*)(dd + at_status);
         a.detail = (uint64_t*)(dd + at_detail); a.n = n;
-        le = (c->dec_variant != 1 && !has_dict && !has_pos) ? launch_decompress_fast(c, a, s) : launch_decompress(a, c->dec_lanes, s);
+        bool big = false;                                    // host arrays are visible: blocks beyond 128 KiB compressed are "large"
+        for (uint32_t i = 0; i < n; i++) big |= in_len[i] > 131072u;
+        le = (c->dec_variant != 1 && !has_dict && !has_pos) ? launch_decompress_fast(c, a, s, big) : launch_decompress(a, c->dec_lanes, s);
     }
     if (le != hipSuccess) return hip_fail(le, "kernel launch");
     HIP_TRY(hipMemcpyAsync(hp + at_out_len, dd + at_out_len, desc_bytes - at_out_len, hipMemcpyDeviceToHost, s));
@@ -525,7 +530,7 @@ static int run_device_batch(lz4flex_ctx* c, bool compress, const void* in_base, 
         a.dict_off = ext ? ext->dict_off : nullptr;
         a.dict_len = ext ? ext->dict_len : nullptr;
         a.out_len = out_len; a.status = status; a.detail = detail; a.n = n;
-        le = (c->dec_variant != 1 && !a.dict_base && !a.out_pos) ? launch_decompress_fast(c, a, s) : launch_decompress(a, c->dec_lanes, s);
+        le = (c->dec_variant != 1 && !a.dict_base && !a.out_pos) ? launch_decompress_fast(c, a, s, big_hint != 0) : launch_decompress(a, c->dec_lanes, s);
     }
     if (le != hipSuccess) return hip_fail(le, "kernel launch");
     return 0;
@@ -573,7 +578,7 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx* ctx, const void* in_base, const uin
                               out_cap, out_len, status, detail, ext ? &e : nullptr);
     if ((mem_kind & 0xFF) == LZ4FLEX_MEM_DEVICE)
         return run_device_batch(ctx, false, in_base, in_off, in_len, nullptr, n, out_base, out_off, out_cap, out_len,
-                                status, detail, ext ? &e : nullptr, hip_stream, 0);
+                                status, detail, ext ? &e : nullptr, hip_stream, (mem_kind & LZ4FLEX_MEM_BIG_BLOCKS) != 0);
     return -LZ4FLEX_E_INVALID_ARG;
 }
 

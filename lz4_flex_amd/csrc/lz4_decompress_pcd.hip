@@ -85,11 +85,15 @@ using GeoTest = Geo<2048u, 256u, 64u, 128u, 512u, 1024u>;       // tests: bounda
 #endif
 #ifdef LZ4P_PROF     // tools (variant build): cycles of thread 0 per phase, summed over the workgroups -> g_pcd_prof
 __device__ unsigned long long g_pcd_prof[32];
-#define PCD_PROF_DECL unsigned long long pr_acc[24] = {0}; unsigned long long pr_t0 = __builtin_readcyclecounter();
+#define PCD_PROF_DECL unsigned long long pr_acc[32] = {0}; unsigned long long pr_t0 = __builtin_readcyclecounter();
+#define PCD_WAVE_ADD(i, v) { if (lane == 0u) atomicAdd(&g_pcd_prof[i], (unsigned long long)(v)); }
+#define PCD_NOW() __builtin_readcyclecounter()
 #define PCD_TICK(i) { const unsigned long long t_ = __builtin_readcyclecounter(); pr_acc[i] += t_ - pr_t0; pr_t0 = t_; }
 #define PCD_COUNT(i, v) { pr_acc[i] += (v); }
-#define PCD_PROF_FLUSH if (tid == 0u) { for (int i_ = 0; i_ < 24; ++i_) if (pr_acc[i_]) atomicAdd(&g_pcd_prof[i_], pr_acc[i_]); }
+#define PCD_PROF_FLUSH if (tid == 0u) { for (int i_ = 0; i_ < 26; ++i_) if (pr_acc[i_]) atomicAdd(&g_pcd_prof[i_], pr_acc[i_]); }
 #else
+#define PCD_WAVE_ADD(i, v)
+#define PCD_NOW() 0ull
 #define PCD_PROF_DECL
 #define PCD_TICK(i)
 #define PCD_COUNT(i, v)
@@ -268,8 +272,21 @@ struct Ctx {
         if (lane == 0u) { nx[G::NP] = G::NP; rc[G::NP] = 0u; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // the usual tile: every part's chain lands in the next part (sequences are short against a part), the last one leaves the
+        // tile -- every part is live and nothing has to be followed
+        bool adjacent = true;
+#pragma unroll
+        for (uint32_t j = 0; j < G::PPL; ++j)
+            if (k[j] < parts) adjacent = adjacent && nx[k[j]] == (k[j] + 1u < parts ? k[j] + 1u : G::NP);
+        const bool chain = __all(adjacent);
+        if (chain) {
+#pragma unroll
+            for (uint32_t j = 0; j < G::PPL; ++j) if (k[j] < parts) rc[k[j]] = 1u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll 1
-        for (uint32_t round = 0; round < ceil_log2(G::NP) + 1u; ++round) {
+        for (uint32_t round = 0; !chain && round < ceil_log2(G::NP) + 1u; ++round) {
             // every read of the round precedes every write of the round (LDS operations of a wavefront execute in order)
 #pragma unroll
             for (uint32_t j = 0; j < G::PPL; ++j) {
@@ -582,19 +599,18 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 auto copy_inline = [&]() {
                     if (near) {
                         const lds_u8* sp = X.win() + (s0 - Lo);
-                        if (s.off >= s.ml) {          // no byte of the source is my own output: 64 bytes of loads before their stores
-                            for (uint32_t o = 0u; o < s.ml; o += 64u) {
-                                u32x4 v[4];
+                        // 64 bytes of loads before their stores where no byte of those 64 is the match's own output, else 16 (one loop
+                        // for both: two loops would be executed one after the other by a wavefront that holds both kinds)
+                        const uint32_t grp = (s.off >= 64u || s.off >= s.ml) ? 64u : 16u;
+                        for (uint32_t o = 0u; o < s.ml; o += grp) {
+                            u32x4 v[4];
 #pragma unroll
-                                for (uint32_t k = 0u; k < 4u; ++k) if (o + 16u * k < s.ml) v[k] = ld16l(sp + o + 16u * k);
+                            for (uint32_t k = 0u; k < 4u; ++k) if (16u * k < grp && o + 16u * k < s.ml) v[k] = ld16l(sp + o + 16u * k);
 #pragma unroll
-                                for (uint32_t k = 0u; k < 4u; ++k) {
-                                    const uint32_t at = o + 16u * k;
-                                    if (at < s.ml) st_exact(dstp + at, v[k], s.ml - at < 16u ? s.ml - at : 16u);
-                                }
+                            for (uint32_t k = 0u; k < 4u; ++k) {
+                                const uint32_t at = o + 16u * k;
+                                if (16u * k < grp && at < s.ml) st_exact(dstp + at, v[k], s.ml - at < 16u ? s.ml - at : 16u);
                             }
-                        } else {
-                            for (uint32_t o = 0u; o < s.ml; o += 16u) st_exact(dstp + o, ld16l(sp + o), s.ml - o < 16u ? s.ml - o : 16u);
                         }
                     } else {                                  // written-back output: every load is issued before the first store waits
                         const uint8_t* sp = X.gout + s0;
@@ -619,6 +635,8 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 };
                 // matches without a producer in this batch (history, written-back output, own literals): all at once
                 bool pending = has_m;
+                const unsigned long long tw0 = PCD_NOW();
+                uint32_t turns_ready = 0u, turns_idle = 0u;
                 {
                     const bool go = has_m && !dep;
                     if (go && inl) copy_inline();
@@ -628,33 +646,45 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 // the others poll their producers' DONE bits: [lo, hi] = bits lo & 31 .. of word wl up to bit hi & 31 of word wh.
                 // A wavefront without open matches leaves (and waits at the barrier, off the issue slots); one with open
                 // matches none of which is ready sleeps a little.  What a dependency costs is one turn of this loop.
-                const uint32_t wl = lo >> 5, wh = hi >> 5;
-                const uint32_t mlo = 0xFFFFFFFFu << (lo & 31u), mhi = 0xFFFFFFFFu >> (31u - (hi & 31u));
+                const unsigned long long tw1 = PCD_NOW();
+                // This loop is what the batch waits for -- a chain of d dependent matches costs d turns -- so a turn is as little
+                // code as possible: both DONE words in one round trip, one copy loop (a match with producers reads the window, from
+                // OP on: never the written-back output), 16 bytes per step in order (it may read its own output).
+                const uint32_t wl = lo >> 5, wh = dep ? hi >> 5 : wl;
+                const uint32_t m1 = (0xFFFFFFFFu << (lo & 31u)) & (wl == wh ? 0xFFFFFFFFu >> (31u - (hi & 31u)) : 0xFFFFFFFFu);
+                const uint32_t m2 = wl == wh ? m1 : 0xFFFFFFFFu >> (31u - (hi & 31u));
+                const bool wide = dep && wh - wl > 1u;                   // (whole words between the two: a source of > 32 sequences)
                 const volatile lds_u32* dn = (const volatile lds_u32*)X.done();
+                const lds_u8* const srcp = X.win() + (s0 - Lo);          // (only used where the source lies in the window)
+                const uint32_t nfull = s.ml >> 4, rem = s.ml & 15u;
+                const bool inl2 = s.off >= 16u && s.ml <= 256u && near;
                 uint32_t spins = 0u;
                 while (__any(pending)) {
                     bool ready = false;
                     if (pending) {
-                        if (wl == wh) {
-                            const uint32_t mk = mlo & mhi;
-                            ready = (dn[wl] & mk) == mk;
-                        } else {
-                            ready = (dn[wl] & mlo) == mlo && (dn[wh] & mhi) == mhi;
-                            for (uint32_t w = wl + 1u; ready && w < wh; ++w) ready = dn[w] == 0xFFFFFFFFu;
-                        }
+                        const uint32_t d1 = dn[wl], d2 = dn[wh];
+                        ready = (d1 & m1) == m1 && (d2 & m2) == m2;
+                        if (wide) for (uint32_t w = wl + 1u; ready && w < wh; ++w) ready = dn[w] == 0xFFFFFFFFu;
                     }
                     if (__any(ready)) {
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // the producers' bytes behind their DONE bits
-                        if (ready && inl) copy_inline();
-                        copy_coop(ready && !inl);
+                        if (ready && inl2) {
+                            for (uint32_t k = 0u; k < nfull; ++k) st16l(dstp + 16u * k, ld16l(srcp + 16u * k));
+                            if (rem != 0u) st_exact(dstp + 16u * nfull, ld16l(srcp + 16u * nfull), rem);
+                        }
+                        copy_coop(ready && !inl2);
                         if (ready) { publish(); pending = false; }
                         PCD_COUNT(21, 1)
+                        turns_ready++;
                     } else {
                         __builtin_amdgcn_s_sleep(LZ4P_SLEEP);
                         PCD_COUNT(22, 1)
+                        turns_idle++;
                         if (++spins > (1u << 22)) { ctl[C_TIMEOUT] = 1u; break; }   // (cannot happen: the lowest open match is always ready)
                     }
                 }
+                PCD_WAVE_ADD(26, tw1 - tw0) PCD_WAVE_ADD(27, PCD_NOW() - tw1) PCD_WAVE_ADD(28, turns_ready) PCD_WAVE_ADD(29, turns_idle)
+                PCD_WAVE_ADD(30, __builtin_popcountll(__ballot(has_m && !inl))) PCD_WAVE_ADD(31, __builtin_popcountll(__ballot(has_m && dep)))
             }
             __syncthreads();
             PCD_TICK(7)

@@ -29,7 +29,10 @@ namespace pcd {
 // Then the set bits of the live parts ARE the tile's sequences, in order.
 constexpr uint32_t CT = 32768u;           // compressed bytes per tile
 constexpr uint32_t CM = 1024u;            // bytes behind the tile that are staged with it (a walk's last sequence reads past the tile)
-constexpr uint32_t P = 128u;              // bytes per part
+#ifndef LZ4P_PART
+#define LZ4P_PART 128
+#endif
+constexpr uint32_t P = LZ4P_PART;         // bytes per part
 constexpr uint32_t NP = CT / P;           // 256 parts
 // every round of walks + exit following makes at least one more live part final (the first one whose entry was wrong), so NP + 1
 // rounds always settle a tile; real data needs two or three (a chain in step with the true one after a few sequences), data

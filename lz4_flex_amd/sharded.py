@@ -98,7 +98,7 @@ def decompress_blocks_device(comp, comp_off, comp_len, out_len_expected, block_s
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     with torch.cuda.device(dev):
         rc = lib.lz4flex_decompress_batch(None, _p(comp), _p(comp_off), _p(comp_len), n, _p(out), _p(out_off), _p(out_cap),
-                                          _p(out_len), _p(status), None, L.MEM_DEVICE, stream)
+                                          _p(out_len), _p(status), None, L.MEM_DEVICE | (L.MEM_BIG_BLOCKS if block_size > 65536 else 0), stream)
     if rc:
         raise RuntimeError("lz4flex_decompress_batch: %d %s" % (rc, L.last_error()))
     return out, out_len, status
@@ -426,7 +426,7 @@ def decompress_frame_sharded(frame, group=None, root=0, decompress_blocks=decomp
             st = torch.zeros(nc, dtype=torch.int32, device=dev)
             with torch.cuda.device(dev):
                 rc = lib.lz4flex_decompress_batch(None, _p(local), _p(coff), _p(clen), nc, _p(out), _p(ooff), _p(ocap),
-                                                  _p(dlen), _p(st), None, L.MEM_DEVICE, stream)
+                                                  _p(dlen), _p(st), None, L.MEM_DEVICE | (L.MEM_BIG_BLOCKS if bs > 65536 else 0), stream)
             if rc:
                 raise RuntimeError("lz4flex_decompress_batch: %d %s" % (rc, L.last_error()))
             if int((st != 0).sum().item()):

@@ -99,6 +99,10 @@ def main():
                 print("      wavefront 0 per batch: polling turns with a ready match %.1f, without %.1f, wavefront copies %.1f" % (
                     pv[21] / max(pv[18], 1), pv[22] / max(pv[18], 1), pv[23] / max(pv[18], 1)), flush=True)
                 print("      thread 0: hops per walk round %.1f, cycles per hop %.0f" % (pv[24] / max(pv[17], 1), pv[1] / max(pv[24], 1)), flush=True)
+                nwb = max(pv[18], 1) * 16
+                print("      per wavefront and batch: %.0f cycles in the matches without producers, %.0f polling (%.1f turns with a ready match, %.1f without); "
+                      "per batch: %.0f matches with producers, %.0f copied by a whole wavefront" % (pv[26] / nwb, pv[27] / nwb, pv[28] / nwb, pv[29] / nwb,
+                                                                                                 pv[31] / max(pv[18], 1), pv[30] / max(pv[18], 1)), flush=True)
                 for nm, x, cnt in (("walk round", pv[1], pv[17]), ("resolve round", pv[2], pv[17]), ("batch (4..8)", sum(pv[4:9]), pv[18]), ("matches phase", pv[7], pv[18]), ("giant", pv[9], pv[20])):
                     if cnt:
                         print("      cycles per %s: %.0f" % (nm, x / cnt), flush=True)
