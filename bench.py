@@ -385,7 +385,7 @@ def run_linked_frame(args, env):
     torch, dev, world, rank, block = (env[k] for k in ("torch", "dev", "world", "rank", "block"))
     from lz4_flex_amd import frame as F, workloads
     # fast (default): the Linked frame holds independently parsed blocks, one compress launch per batch; exact: the
-    # reference's bytes, one dependency chain on the device.  Decoding a Linked frame is one block after the other either way.
+    # reference's bytes, one dependency chain on the device.  Decoding: one chained launch per batch of blocks either way.
     block.set_compress_mode(args.compress_mode)
     exact = args.compress_mode == "exact"
     n = args.blocks or 64
@@ -410,14 +410,15 @@ def run_linked_frame(args, env):
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8",
         "data": "synthetic: JSON tiles, %d x 64 KiB blocks in ONE Linked frame per GPU" % n,
-        "config": {"workload": "BASELINE configs[4]: frame format, BlockLinked 64 KiB blocks -- sequential-dependency stress: the prefix decoder "
-                               "runs one block after the other (a block may need the previous 64 KiB)" +
+        "config": {"workload": "BASELINE configs[4]: frame format, BlockLinked 64 KiB blocks -- sequential-dependency stress: the blocks of a frame are "
+                               "decoded by ONE chained launch (lz4_decompress_pcd_kernel: every block's token chain at once; a block waits for its "
+                               "predecessors only where a match reaches behind its start)" +
                                ("; compress_mode exact: the chain encoder does too (the reference's bytes)" if exact else
                                 "; compress_mode fast: the encoder parses every block on its own (one launch, a valid Linked frame, the Independent frame's ratio)") +
                                "; host buffers (PCIe included)",
                    "blocks": n, "compress_mode": args.compress_mode},
         "ratio": round(len(state["frame"]) / len(data), 5),
-        "roofline": dict(roof(alg, elapsed / args.steps), kernel=("lz4_compress_chain_kernel" if exact else "lz4_compress_wave_kernel") + " + lz4_decompress_blocks_kernel (one block per launch)"),
+        "roofline": dict(roof(alg, elapsed / args.steps), kernel=("lz4_compress_chain_kernel" if exact else "lz4_compress_wave_kernel") + " + lz4_decompress_pcd_kernel (chained batch)"),
         "verified": "NOT VERIFIED" if args.no_verify else "frame round trip bit-exact",
         "cpu_baseline": {"note": "not timed for this stress configuration (see --config 2)"},
     }

@@ -135,6 +135,14 @@ int64_t lz4flex_decompress_size_prepended_with_dict(const uint8_t *in, size_t in
  * otherwise serves batches of up to 512 blocks.  Results do not depend on the hint. */
 #define LZ4FLEX_MEM_BIG_BLOCKS 0x100
 
+/* OR into mem_kind for lz4flex_decompress_batch_ex with ext->out_pos: the batch is a CHAIN -- every block has the same out_off,
+ * and block i's prefix [out_off, out_off + out_pos[i]) is what blocks 0 .. i-1 of this batch produce (plus whatever lay before
+ * out_pos[0] when the call was made).  This is how a Linked frame's blocks are decoded in one launch
+ * (src/frame/decompress.rs:195-222,280-306: the reference decodes them one after the other into one window): the token chains
+ * of all blocks are parsed at once, a block waits for its predecessors only where a match really reaches behind its start.
+ * At most 65 536 blocks per call; no external dictionaries. */
+#define LZ4FLEX_MEM_CHAINED 0x200
+
 /* per-block compress flags.  They select among the REFERENCE's hash tables and therefore only have a meaning in compress_mode
  * exact; the throughput encoder (compress_mode fast, the default) has one table layout of its own and ignores them, as it
  * ignores the Small / Large state of a lz4flex_compress_table. */

@@ -47,6 +47,7 @@ struct lz4flex_ctx {
     int comp_lanes = 8;           // lanes per block, encode
     int comp_mode = 0;            // 0 = throughput ("wave") encoder, own parse (default); 1 = reference-exact encoder (lz4_flex's bytes)
     int comp_variant = 1;         // reference-exact encoder: 1 = group encoder + emitter wave (default), 3 = group encoder alone
+    uint32_t* chain_ws = nullptr; // chained decode batches (Linked frames): one "done" word per block, CHAIN_WS_BLOCKS of them
     void* wave_ws = nullptr;      // wave encoder workspace: wave_wgs persistent workgroups; allocated by lz4flex_ctx_create
     unsigned long long* wave_prof = nullptr;   // tools: per-role cycle counters of the wave encoder (lz4flex_debug_wave_prof)
     int wave_wgs = 0;
@@ -65,6 +66,7 @@ struct lz4flex_ctx {
 #define LZ4FLEX_PCD_MAX_BLOCKS 512
 #endif
 static constexpr uint32_t PCD_MAX_BLOCKS = LZ4FLEX_PCD_MAX_BLOCKS;
+static constexpr uint32_t CHAIN_WS_BLOCKS = 65536u;      // blocks per chained decode batch (LZ4FLEX_MEM_CHAINED)
 
 // the decoders for blocks without dictionary / prefix
 static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressArgs& a, hipStream_t s, bool big_blocks = false) {
@@ -79,8 +81,9 @@ static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressA
     // the block (lz4_decompress_pcd.hip) -- the only decoder here whose time for a block is not the length of the block's chain.
     // tools/dec_shapes.py, JSON tiles, 256 / 512 / 1 024 blocks: 0.25 / 0.44 / 0.86 ms against 0.45 / 0.50 / 0.52 (pair of
     // wavefronts per block); 256 x 4 MiB log blocks: 7.1 ms against 28.8; one 16 MiB block: 27.7 ms against 113.
-    const int v = c->dec_variant != 0 ? c->dec_variant
-                                      : ((a.n <= PCD_MAX_BLOCKS || big_blocks) ? 7 : (a.n <= 2304u ? 6 : (a.n <= 5120u ? 5 : 4)));
+    int v = c->dec_variant != 0 ? c->dec_variant
+                                : ((a.n <= PCD_MAX_BLOCKS || big_blocks) ? 7 : (a.n <= 2304u ? 6 : (a.n <= 5120u ? 5 : 4)));
+    if (a.out_pos != nullptr && v != 8) v = 7;           // prefix mode (Linked frames): only the workgroup decoder knows it
     if (v >= 5 && v <= 8) {
         // one block per wavefront (6: per pair of wavefronts; 7 / 8: per workgroup); blocks it marks (errors, sinks too small) are
         // decoded again in the reference's order
@@ -217,6 +220,7 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
         }
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->wave_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->chain_ws, 4u * CHAIN_WS_BLOCKS);
     (void)hipSetDevice(prev);
     if (e != hipSuccess) {
         const int rc = hip_fail(e, "ctx_create");
@@ -232,6 +236,7 @@ void lz4flex_ctx_destroy(lz4flex_ctx* c) {
     if (c->d_arena) (void)hipFree(c->d_arena);
     if (c->wave_ws) (void)hipFree(c->wave_ws);
     if (c->wave_done) (void)hipEventDestroy(c->wave_done);
+    if (c->chain_ws) (void)hipFree(c->chain_ws);
     if (c->wave_prof) (void)hipFree(c->wave_prof);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_pay) (void)hipHostFree(c->h_pay);
@@ -365,8 +370,9 @@ struct lz4flex_decompress_ext_ {
 static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base, const uint64_t* in_off,
                           const uint32_t* in_len, const uint32_t* flags, uint32_t n, uint8_t* out_base,
                           const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len, int32_t* status,
-                          uint64_t* detail, const lz4flex_decompress_ext_* ext) {
+                          uint64_t* detail, const lz4flex_decompress_ext_* ext, bool chained = false) {
     if (n == 0) return 0;
+    if (chained && (n > CHAIN_WS_BLOCKS || !ext || !ext->out_pos || ext->dict_base)) return -LZ4FLEX_E_INVALID_ARG;
     int prev = 0;
     (void)hipGetDevice(&prev);
     HIP_TRY(hipSetDevice(c->device));
@@ -415,8 +421,10 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
         HIP_TRY(hipMemcpyAsync(d + a_dict, (const uint8_t*)ext->dict_base + hb.dict_span.lo, dict_bytes,
                                hipMemcpyHostToDevice, s));
     if (has_pos && out_bytes) {
-        // prefix mode: the sink already holds bytes [0, out_pos) that matches may reference
-        HIP_TRY(hipMemcpyAsync(d + a_out, out_base + hb.out_span.lo, out_bytes, hipMemcpyHostToDevice, s));
+        // prefix mode: the sink already holds bytes [0, out_pos) that matches may reference; in a chained batch only what lies
+        // before the FIRST block's position exists yet (the rest is what the batch produces)
+        const size_t up = chained ? std::min<size_t>(out_bytes, (size_t)(out_off[0] - hb.out_span.lo) + ext->out_pos[0]) : out_bytes;
+        if (up) HIP_TRY(hipMemcpyAsync(d + a_out, out_base + hb.out_span.lo, up, hipMemcpyHostToDevice, s));
     }
     HIP_TRY(hipMemcpyAsync(d + a_desc, hp, desc_in_bytes, hipMemcpyHostToDevice, s));
     uint8_t* dd = d + a_desc;
@@ -443,7 +451,11 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
         a.detail = (uint64_t*)(dd + at_detail); a.n = n;
         bool big = false;                                    // host arrays are visible: blocks beyond 128 KiB compressed are "large"
         for (uint32_t i = 0; i < n; i++) big |= in_len[i] > 131072u;
-        le = (c->dec_variant != 1 && !has_dict && !has_pos) ? launch_decompress_fast(c, a, s, big) : launch_decompress(a, c->dec_lanes, s);
+        if (chained) {
+            HIP_TRY(hipMemsetAsync(c->chain_ws, 0, 4ull * n, s));
+            a.chain_done = c->chain_ws;
+        }
+        le = ((c->dec_variant != 1 || chained) && !has_dict) ? launch_decompress_fast(c, a, s, big) : launch_decompress(a, c->dec_lanes, s);
     }
     if (le != hipSuccess) return hip_fail(le, "kernel launch");
     HIP_TRY(hipMemcpyAsync(hp + at_out_len, dd + at_out_len, desc_bytes - at_out_len, hipMemcpyDeviceToHost, s));
@@ -497,6 +509,15 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
         }
         return 0;
     }
+    if (chained) {
+        // one region, the blocks back to back behind the first one's position: one transfer up to the end of the last good block
+        uint64_t lo = out_off[0] + ext->out_pos[0], hi = lo;
+        for (uint32_t i = 0; i < n; i++)
+            if (r_st[i] == 0) hi = std::max<uint64_t>(hi, out_off[i] + ext->out_pos[i] + r_len[i]);
+        if (hi > lo) HIP_TRY(hipMemcpyAsync(out_base + lo, d + a_out + (lo - hb.out_span.lo), (size_t)(hi - lo), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return 0;
+    }
     for (uint32_t i = 0; i < n; i++) {
         if (r_st[i] != 0 || r_len[i] == 0) continue;
         const uint32_t pos = has_pos ? ext->out_pos[i] : 0u;
@@ -510,7 +531,8 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
 static int run_device_batch(lz4flex_ctx* c, bool compress, const void* in_base, const uint64_t* in_off,
                             const uint32_t* in_len, const uint32_t* flags, uint32_t n, void* out_base,
                             const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len, int32_t* status,
-                            uint64_t* detail, const lz4flex_decompress_ext_* ext, void* hip_stream, int big_hint) {
+                            uint64_t* detail, const lz4flex_decompress_ext_* ext, void* hip_stream, int big_hint, bool chained = false) {
+    if (chained && (compress || n > CHAIN_WS_BLOCKS || !ext || !ext->out_pos || ext->dict_base)) return -LZ4FLEX_E_INVALID_ARG;
     hipStream_t s = (hipStream_t)hip_stream;   // DEVICE batches run on the caller's stream (NULL = HIP's null stream)
     hipError_t le;
     if (compress) {
@@ -530,7 +552,11 @@ static int run_device_batch(lz4flex_ctx* c, bool compress, const void* in_base, 
         a.dict_off = ext ? ext->dict_off : nullptr;
         a.dict_len = ext ? ext->dict_len : nullptr;
         a.out_len = out_len; a.status = status; a.detail = detail; a.n = n;
-        le = (c->dec_variant != 1 && !a.dict_base && !a.out_pos) ? launch_decompress_fast(c, a, s, big_hint != 0) : launch_decompress(a, c->dec_lanes, s);
+        if (chained && n) {
+            HIP_TRY(hipMemsetAsync(c->chain_ws, 0, 4ull * n, s));
+            a.chain_done = c->chain_ws;
+        }
+        le = ((c->dec_variant != 1 || chained) && !a.dict_base) ? launch_decompress_fast(c, a, s, big_hint != 0) : launch_decompress(a, c->dec_lanes, s);
     }
     if (le != hipSuccess) return hip_fail(le, "kernel launch");
     return 0;
@@ -573,12 +599,13 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx* ctx, const void* in_base, const uin
     if (n && (!in_off || !in_len || !out_off || !out_cap || !out_len || !status)) return -LZ4FLEX_E_INVALID_ARG;
     lz4flex_decompress_ext_ e{};
     if (ext) { e.dict_base = ext->dict_base; e.dict_off = ext->dict_off; e.dict_len = ext->dict_len; e.out_pos = ext->out_pos; }
-    if (mem_kind == LZ4FLEX_MEM_HOST)
+    const bool chained = (mem_kind & LZ4FLEX_MEM_CHAINED) != 0;
+    if ((mem_kind & 0xFF) == LZ4FLEX_MEM_HOST)
         return run_host_batch(ctx, false, (const uint8_t*)in_base, in_off, in_len, nullptr, n, (uint8_t*)out_base, out_off,
-                              out_cap, out_len, status, detail, ext ? &e : nullptr);
+                              out_cap, out_len, status, detail, ext ? &e : nullptr, chained);
     if ((mem_kind & 0xFF) == LZ4FLEX_MEM_DEVICE)
         return run_device_batch(ctx, false, in_base, in_off, in_len, nullptr, n, out_base, out_off, out_cap, out_len,
-                                status, detail, ext ? &e : nullptr, hip_stream, (mem_kind & LZ4FLEX_MEM_BIG_BLOCKS) != 0);
+                                status, detail, ext ? &e : nullptr, hip_stream, (mem_kind & LZ4FLEX_MEM_BIG_BLOCKS) != 0, chained);
     return -LZ4FLEX_E_INVALID_ARG;
 }
 

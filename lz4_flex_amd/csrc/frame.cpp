@@ -425,7 +425,7 @@ struct lz4flex_frame_decoder {
     std::vector<uint64_t> in_off, out_off, detail;
     std::vector<uint32_t> in_len, out_cap, out_len;
     std::vector<int32_t> status;
-    struct Item { size_t off, len; };
+    struct Item { size_t off, len; };     // decoded bytes waiting to be read: offsets into `out` (Independent) or `ldst` (Linked)
     std::vector<Item> ready;   // decoded pieces in stream order (len 0 = a block that decoded to nothing)
     size_t ready_idx = 0, ready_pos = 0;
     int pending_err = 0;       // surfaces after the pieces before it were delivered
@@ -434,6 +434,7 @@ struct lz4flex_frame_decoder {
     // Linked-mode window (frame/decompress.rs:62-72): exact mirror of the reference's dst ring
     std::vector<uint8_t> ldst;
     size_t ext_dict_offset = 0, ext_dict_len = 0, dst_start = 0;
+    size_t lhave = 0;              // Linked: valid bytes in ldst (history + what the last call produced)
 
     bool io_failed = false;    // the read callback itself reported an error (not a short read)
     // read_exact; returns 0 ok, 1 clean EOF before any byte, -code on short read / error
@@ -476,12 +477,11 @@ struct lz4flex_frame_decoder {
         content_hasher.reset(0);
         content_len = 0;
         ext_dict_len = 0; ext_dict_offset = 0; dst_start = 0;
-        if (fi.block_mode == 1) {
-            const size_t mbs = block_size_bytes(fi.block_size);
-            ldst.assign(mbs * 2 + WINDOW_SIZE, 0);
-        }
+        lhave = 0;                                            // Linked: ldst = [history | this launch's blocks], grown on demand, never shrunk
         return 0;
     }
+    bool ready_linked = false;     // the ready items index `ldst` (a Linked frame's blocks stay where they were decoded)
+    const uint8_t* ready_base() const { return (ready_linked ? ldst : out).data(); }
     void fail(int code, const lz4flex_err_detail* d = nullptr) {
         pending_err = code;
         if (d) pending_detail = *d; else memset(&pending_detail, 0, sizeof pending_detail);
@@ -508,6 +508,7 @@ struct lz4flex_frame_decoder {
         const size_t max_blocks = blocks_per_launch(batch_bytes, mbs, batch_auto);
         comp.clear(); in_off.clear(); in_len.clear(); out_off.clear(); out_cap.clear();
         ready.clear(); ready_idx = 0; ready_pos = 0;
+        ready_linked = false;
         struct Slot { bool raw; size_t out_at; size_t idx; size_t raw_len; };
         std::vector<Slot> slots;
         size_t out_need = 0;
@@ -572,64 +573,106 @@ struct lz4flex_frame_decoder {
         if (saw_end && !pending_zero) end_mark();
     }
 
-    // Linked frames: one block per launch, window handling exactly as frame/decompress.rs:195-222,280-306
+    // Linked frames (frame/decompress.rs:195-222,280-306: the reference decodes block after block into one window, a block's
+    // matches may reach up to 64 KiB behind its start).  Here a run of compressed blocks is decoded by ONE launch
+    // (LZ4FLEX_MEM_CHAINED): the staging buffer `ldst` holds [the frame's last <= 64 KiB | block | block | ...], block k is
+    // given the position behind its predecessors as its initial sink position and the kernel makes it wait for them only where
+    // a match really reaches behind its start -- the blocks of a frame written by this library's throughput encoder never do.
+    // A block's decoded size is not in the frame: every block but a frame's last is taken to fill the block size, and the
+    // blocks behind one that did not (a flush() boundary, frame/compress.rs:398-403) are decoded again from their real position.
+    // A block stored raw ends a run (its bytes are placed by the host).
     void read_block_linked() {
         const size_t mbs = block_size_bytes(fi.block_size);
+        const size_t max_blocks = blocks_per_launch(batch_bytes, mbs, batch_auto);
         ready.clear(); ready_idx = 0; ready_pos = 0;
-        if (dst_start + mbs > ldst.size()) {
-            ext_dict_offset = dst_start - WINDOW_SIZE; ext_dict_len = WINDOW_SIZE; dst_start = 0;
-        } else if (dst_start + ext_dict_len > WINDOW_SIZE) {
-            const size_t delta = std::min(ext_dict_len, dst_start + ext_dict_len - WINDOW_SIZE);
-            ext_dict_offset += delta; ext_dict_len -= delta;
+        comp.clear(); in_off.clear(); in_len.clear();
+        ready_linked = true;
+        // ldst = carry (the frame's last <= 64 KiB) followed by this call's output.  The previous call's bytes were handed out
+        // straight from ldst (no copy), so they are moved to the front only now that they have been consumed.
+        if (lhave > WINDOW_SIZE) {
+            memmove(ldst.data(), ldst.data() + (lhave - WINDOW_SIZE), WINDOW_SIZE);
+            lhave = WINDOW_SIZE;
         }
-        uint8_t bi[4];
-        if (read_exact(bi, 4) != 0) { if (io_failed) fail(-LZ4FLEX_FE_IO); else pending_zero = true; return; }
-        const uint32_t size = rd32(bi);
-        if (size == 0) { end_mark(); return; }
-        const bool raw = (size & BLOCK_UNCOMPRESSED_SIZE_BIT) != 0;
-        const size_t len = size & ~BLOCK_UNCOMPRESSED_SIZE_BIT;
-        if (len > mbs) { fail(-LZ4FLEX_FE_BLOCK_TOO_BIG); return; }
-        size_t produced;
-        if (raw) {
-            if (len && read_exact(ldst.data() + dst_start, len) != 0) { fail(-LZ4FLEX_FE_IO); return; }
+        dst_start = lhave;
+        const size_t carry = dst_start;                      // bytes of history at the front of ldst
+        bool saw_end = false, raw_tail = false;
+        size_t raw_at = 0, raw_len = 0;
+        const size_t out_budget = std::max<size_t>(batch_bytes, mbs) * (batch_auto ? 4u : 1u);
+        while (in_off.size() < max_blocks && (in_off.empty() || (in_off.size() + 1) * mbs <= out_budget)) {
+            uint8_t bi[4];
+            const int rc = read_exact(bi, 4);
+            if (rc != 0) {
+                if (io_failed) fail(-LZ4FLEX_FE_IO);
+                else pending_zero = true;                    // UnexpectedEof on the block header => Ok(0), the frame stays open (:231-238)
+                break;
+            }
+            const uint32_t size = rd32(bi);
+            if (size == 0) { saw_end = true; break; }
+            const bool raw = (size & BLOCK_UNCOMPRESSED_SIZE_BIT) != 0;
+            const size_t len = size & ~BLOCK_UNCOMPRESSED_SIZE_BIT;
+            if (len > mbs) { fail(-LZ4FLEX_FE_BLOCK_TOO_BIG); break; }
+            const size_t at = comp.size();
+            comp.resize(at + len);
+            if (len && read_exact(comp.data() + at, len) != 0) { comp.resize(at); fail(-LZ4FLEX_FE_IO); break; }
             if (fi.block_checksums) {
                 uint8_t c[4];
-                if (read_exact(c, 4) != 0) { fail(-LZ4FLEX_FE_IO); return; }
-                if (XxHash32::oneshot(0, ldst.data() + dst_start, len) != rd32(c)) { fail(-LZ4FLEX_FE_BLOCK_CHECKSUM); return; }
+                if (read_exact(c, 4) != 0) { comp.resize(at); fail(-LZ4FLEX_FE_IO); break; }
+                if (XxHash32::oneshot(0, comp.data() + at, len) != rd32(c)) { comp.resize(at); fail(-LZ4FLEX_FE_BLOCK_CHECKSUM); break; }
             }
-            produced = len;
-        } else {
-            comp.resize(len);
-            if (len && read_exact(comp.data(), len) != 0) { fail(-LZ4FLEX_FE_IO); return; }
-            if (fi.block_checksums) {
-                uint8_t c[4];
-                if (read_exact(c, 4) != 0) { fail(-LZ4FLEX_FE_IO); return; }
-                if (XxHash32::oneshot(0, comp.data(), len) != rd32(c)) { fail(-LZ4FLEX_FE_BLOCK_CHECKSUM); return; }
+            if (raw) { raw_tail = true; raw_at = at; raw_len = len; break; }
+            in_off.push_back(at); in_len.push_back((uint32_t)len);
+        }
+        const size_t nb = in_off.size();
+        if (ldst.size() < carry + (nb + 1) * mbs) ldst.resize(carry + (nb + 1) * mbs);
+        size_t produced_total = 0;                           // bytes of this call behind the carry
+        // ---- the run of compressed blocks: launches until every block sits behind its real predecessor
+        out_len.assign(nb, 0); status.assign(nb, 0); detail.assign(2 * nb, 0);
+        std::vector<uint32_t> pos(nb), cap(nb);
+        std::vector<uint64_t> zero_off(nb, 0);
+        size_t first = 0;
+        bool failed = false;
+        while (first < nb) {
+            const size_t m = nb - first;
+            for (size_t k = 0; k < m; k++) {
+                pos[k] = (uint32_t)(carry + produced_total + k * mbs);
+                cap[k] = pos[k] + (uint32_t)mbs;
             }
-            const bool with_dict = ext_dict_len != 0;
-            const uint64_t off0 = 0, doff = ext_dict_offset;
-            const uint32_t ilen = (uint32_t)len, pos = (uint32_t)dst_start, dlen = (uint32_t)ext_dict_len;
-            const uint32_t cap = (uint32_t)(with_dict ? ext_dict_offset : dst_start + mbs);
-            uint32_t olen = 0; int32_t st = 0; uint64_t det[2] = {0, 0};
             lz4flex_decompress_ext ext{};
-            ext.out_pos = &pos;
-            if (with_dict) { ext.dict_base = ldst.data(); ext.dict_off = &doff; ext.dict_len = &dlen; }
-            const int rc = lz4flex_decompress_batch_ex(nullptr, comp.data(), &off0, &ilen, 1, ldst.data(), &off0, &cap, &olen, &st,
-                                                       det, &ext, LZ4FLEX_MEM_HOST, nullptr);
-            if (rc) { fail(rc); return; }
-            if (st) {
-                lz4flex_err_detail d{}; d.expected = det[0]; d.actual = det[1]; d.inner = st;
-                fail(-LZ4FLEX_FE_DECOMPRESSION, &d);
-                return;
+            ext.out_pos = pos.data();
+            const int rc = lz4flex_decompress_batch_ex(nullptr, comp.data(), in_off.data() + first, in_len.data() + first, (uint32_t)m,
+                                                       ldst.data(), zero_off.data(), cap.data(), out_len.data() + first, status.data() + first,
+                                                       detail.data() + 2 * first, &ext, LZ4FLEX_MEM_HOST | LZ4FLEX_MEM_CHAINED, nullptr);
+            if (rc) { fail(rc); pending_zero = false; failed = true; break; }
+            size_t k = 0;
+            for (; k < m; k++) {
+                const size_t i = first + k;
+                if (status[i] != 0) {
+                    lz4flex_err_detail d{}; d.expected = detail[2 * i]; d.actual = detail[2 * i + 1]; d.inner = status[i];
+                    fail(-LZ4FLEX_FE_DECOMPRESSION, &d);
+                    pending_zero = false;
+                    failed = true;
+                    break;
+                }
+                produced_total += out_len[i];
+                if (out_len[i] != mbs) { k++; break; }        // the blocks behind a short one were given a wrong position
             }
-            produced = olen;
+            first += k;
+            if (failed) break;
         }
-        if (out.size() < produced) out.resize(produced);
-        memcpy(out.data(), ldst.data() + dst_start, produced);
-        ready.push_back({0, produced});
-        content_len += produced;
-        if (fi.content_checksum) content_hasher.write(out.data(), produced);
-        dst_start += produced;
+        // ---- a block stored raw behind the run
+        if (!failed && !pending_err && raw_tail) {
+            if (ldst.size() < carry + produced_total + raw_len) ldst.resize(carry + produced_total + raw_len);
+            memcpy(ldst.data() + carry + produced_total, comp.data() + raw_at, raw_len);
+            produced_total += raw_len;
+        }
+        // ---- hand the bytes out where they are (ready items index `ldst` in Linked mode); they stay there as history
+        if (produced_total) ready.push_back({carry, produced_total});
+        else if (!failed && !pending_err && (nb != 0 || raw_tail)) ready.push_back({carry, 0});     // (an empty block: read_more() == 0)
+        content_len += produced_total;
+        if (fi.content_checksum && produced_total) content_hasher.write(ldst.data() + carry, produced_total);
+        lhave = carry + produced_total;
+        if (pending_err) { pending_zero = false; return; }
+        if (saw_end && !pending_zero) end_mark();
     }
 
     // io::Read::read, frame/decompress.rs:353-367
@@ -645,7 +688,7 @@ struct lz4flex_frame_decoder {
                     if (empty_block) { *p = out.data(); return 0; }      // read_more() == 0: an empty slice
                     continue;
                 }
-                *p = out.data() + it.off + ready_pos;
+                *p = ready_base() + it.off + ready_pos;
                 return (int64_t)(it.len - ready_pos);
             }
             if (pending_err) { if (d) *d = pending_detail; return pending_err; }
@@ -676,7 +719,7 @@ struct lz4flex_frame_decoder {
                 if (it.len == 0) { ready_idx++; ready_pos = 0; return 0; }   // read_more() == 0
                 const size_t n = std::min(it.len - ready_pos, len);
                 if (n == 0) return 0;   // zero-length destination
-                memcpy(buf, out.data() + it.off + ready_pos, n);
+                memcpy(buf, ready_base() + it.off + ready_pos, n);
                 ready_pos += n;
                 if (ready_pos == it.len) { ready_idx++; ready_pos = 0; }
                 return (int64_t)n;

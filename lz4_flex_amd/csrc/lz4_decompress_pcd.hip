@@ -103,7 +103,8 @@ __device__ unsigned long long g_pcd_prof[32];
 // 7 matches (polling), 8 write-back + slide, 9 giant sequences; counts: 16 tiles, 17 rounds, 18 batches, 19 sequences, 20 giants,
 // 21 / 22 turns of thread 0's polling loop with / without a ready match, 23 matches copied by thread 0's whole wavefront
 
-enum : uint32_t { C_EXIT = 0, C_CUT = 1, C_TOTAL = 2, C_BAD = 3, C_G_SRC = 4, C_G_LIT = 5, C_G_ML = 6, C_G_OFF = 7, C_TIMEOUT = 8, C_BAD2 = 9 };
+enum : uint32_t { C_EXIT = 0, C_CUT = 1, C_TOTAL = 2, C_BAD = 3, C_G_SRC = 4, C_G_LIT = 5, C_G_ML = 6, C_G_OFF = 7, C_TIMEOUT = 8, C_BAD2 = 9,
+                  C_NEEDPREV = 10, C_PREV = 11 };
 
 #define PCD_DPP(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xf, false))
 __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
@@ -170,21 +171,19 @@ __device__ __attribute__((noinline)) uint32_t seq_slow(const Rd<G>& rd, uint32_t
 template <class G>
 __device__ __forceinline__ uint32_t seq_at(const Rd<G>& rd, uint32_t ilen, uint32_t staged, uint32_t p, Seq& s,
                                            uint32_t mark_addr = 0u, uint32_t* mark_word = nullptr) {
-    // Straight-line code: every lane reads the 12 aligned bytes around its token and then the 8 around its offset, whether it
+    // Straight-line code: every lane reads the 8 aligned bytes around its token and then the 8 around its offset, whether it
     // needs them or not -- both addresses lie inside the LDS tile for every token position below CT (a length byte adds at most
     // 270 bytes, the tile is staged with CM = 1 024 behind it).  Written with plain loads, hipcc moved each read into the
     // branch that uses it: four dependent round trips and ~170 instructions per sequence.
     const uint32_t r = p - rd.cbase;
     const uint32_t base = (uint32_t)(uintptr_t)rd.ct;
     uint64_t d01;
-    uint32_t d2, mk = 0u;
+    uint32_t mk = 0u;
     if (mark_word != nullptr) asm volatile("ds_read_b32 %0, %1" : "=v"(mk) : "v"(mark_addr) : "memory");
-    asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8" : "=v"(d01), "=v"(d2) : "v"(base + (r & ~3u)) : "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d01), "+v"(d2), "+v"(mk) :: "memory");
+    asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(d01) : "v"(base + (r & ~3u)) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d01), "+v"(mk) :: "memory");
     if (mark_word != nullptr) *mark_word = mk;
-    const uint32_t d0 = (uint32_t)d01, d1 = (uint32_t)(d01 >> 32);
-    const uint32_t sh = r & 3u;
-    const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    const uint32_t w0 = __builtin_amdgcn_alignbyte((uint32_t)(d01 >> 32), (uint32_t)d01, r & 3u);     // token and the literal length byte
     const uint32_t t = w0 & 0xFFu, lc = t >> 4, mlc = t & 15u;
     const uint32_t l15 = lc == 15u ? 1u : 0u, e1 = (w0 >> 8) & 0xFFu;
     const uint32_t lit = lc + (l15 ? e1 : 0u);                           // (one length byte: up to 269 literals)
@@ -198,7 +197,7 @@ __device__ __forceinline__ uint32_t seq_at(const Rd<G>& rd, uint32_t ilen, uint3
     const uint32_t off = x3 & 0xFFFFu, e = (x3 >> 16) & 0xFFu;
     // the usual sequence: at most one length byte per length; offset, a length byte and one more byte exist (no end-of-block
     // case) and are staged
-    const bool usual = r + 12u <= staged && !(l15 && e1 == 255u) && q + 3u < ilen && rq + 8u <= staged && !(mlc == 15u && e == 255u);
+    const bool usual = r + 8u <= staged && !(l15 && e1 == 255u) && q + 3u < ilen && rq + 8u <= staged && !(mlc == 15u && e == 255u);
     if (usual) {
         s.lit_src = p + hdr; s.lit = lit; s.off = off; s.ml = 4u + mlc + (mlc == 15u ? e : 0u);
         return off != 0u ? q + 2u + (mlc == 15u ? 1u : 0u) : X_ERR;      // (offset 0: what parse_seq returns, decompress.rs:168-173)
@@ -360,6 +359,32 @@ struct Ctx {
         }
     }
 
+    // ---- chained batches (Linked frames): the bytes before this block's start are written by the batch's earlier blocks, i.e. by
+    // other workgroups.  Called by every thread; returns true once chain_done[b - 1] says "done" (all earlier blocks complete,
+    // their bytes visible to this CU), false if the predecessor gave up or did not finish in time (-> the reference-order
+    // kernel decodes this block after the launch).  Workgroups are dispatched in index order, so a predecessor is running or
+    // done; the wait is bounded all the same (wall clock, 100 MHz).  Protocol: MI355X_MICROARCH.md "valid forms": producer plain
+    // stores -> barrier -> one lane: agent release fence, s_waitcnt, relaxed flag store; consumer: one relaxed poll, one agent
+    // acquire, barrier, plain loads.
+    __device__ __forceinline__ bool wait_predecessor(const uint32_t* flag) const {
+        if (tid == 0u) {
+            const unsigned long long t0 = wall_clock64();
+            uint32_t v = 0u;
+            for (;;) {
+                v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v != 0u) break;
+                if (wall_clock64() - t0 > 1000000000ull) { v = 2u; break; }     // 10 s
+                __builtin_amdgcn_s_sleep(32);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            ctl()[C_PREV] = v;
+        }
+        __syncthreads();
+        const bool ok = ctl()[C_PREV] == 1u;
+        __syncthreads();
+        return ok;
+    }
+
     // ---- the whole WORKGROUP, output memory to output memory / compressed stream to output memory (a sequence longer than the window)
     __device__ __forceinline__ void block_copy(uint8_t* dst, const uint8_t* src, uint32_t n) const {
         const uint32_t n16 = n & ~15u;
@@ -385,12 +410,20 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
     const uint32_t tid = X.tid, lane = X.lane;
     volatile lds_u32* ctl = X.ctl();
     if (X.ilen == 0u) {                                           // decompress.rs:207-209: the reference-order kernel reports it
-        if (tid == 0u) { a.status[b] = redo_code; a.out_len[b] = 0u; }
+        if (tid == 0u) {
+            a.status[b] = redo_code; a.out_len[b] = 0u;
+            if (a.chain_done != nullptr) __hip_atomic_store(a.chain_done + b, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
     if (tid < 32u) ctl[tid] = 0u;
+    // prefix mode (Linked frames): the sink already holds OP0 bytes that matches may refer to; in a chained batch they are being
+    // written by the earlier blocks of the batch
+    const uint32_t OP0 = a.out_pos != nullptr ? a.out_pos[b] : 0u;
+    const uint32_t* const prev_flag = (a.chain_done != nullptr && b != 0u) ? a.chain_done + (b - 1u) : nullptr;
+    bool prev_ok = prev_flag == nullptr;      // the bytes before OP0 are final
     uint32_t cbase = 0u;       // the tile's first byte: a true token position
-    uint32_t OP = 0u;          // output position: everything before it is written back
+    uint32_t OP = OP0;         // output position: everything before it is written back
     uint32_t hist = 0u;        // window bytes [0, hist) hold output [OP - hist, OP)
     bool ended = false, bad = false;
     __syncthreads();
@@ -520,6 +553,10 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 __syncthreads();                                                    // (workgroup-scope release / acquire: the bytes are visible)
                 if (g_ml != 0u) {
                     if (g_off > OP || g_ml > X.cap - OP) { bad = true; break; }     // OffsetOutOfBounds / OutputTooSmall
+                    if (!prev_ok && OP - g_off < OP0) {                             // reads bytes of an earlier block of the chain
+                        if (!X.wait_predecessor(prev_flag)) { bad = true; break; }
+                        prev_ok = true;
+                    }
                     uint32_t donem = 0u;
                     while (donem < g_ml) {
                         const uint32_t room = donem + g_off;
@@ -542,6 +579,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
             if (tid < cnt) { X.bst()[tid] = OP + ex; X.mst()[tid] = ms; }
             const bool has_m = tid < cnt && s.ml != 0u;
             if (has_m && s.off > ms) ctl[C_BAD2] = 1u;             // OffsetOutOfBounds (decompress.rs:398-400)
+            if (!prev_ok && has_m && ms - s.off < OP0) ctl[C_NEEDPREV] = 1u;   // a match reaches into an earlier block of the chain
             {   // DONE bits: set for lanes without a match
                 const uint64_t nm = __ballot(!has_m);
                 if (lane == 0u) { X.done()[2u * X.wv] = (uint32_t)nm; X.done()[2u * X.wv + 1u] = (uint32_t)(nm >> 32); }
@@ -566,6 +604,10 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
             PCD_TICK(5) PCD_COUNT(18, 1) PCD_COUNT(19, cnt)
             const uint32_t total = ctl[C_TOTAL];
             if (ctl[C_BAD2] != 0u || total > X.cap - OP) { bad = true; break; }    // ... / OutputTooSmall somewhere in the batch
+            if (!prev_ok && ctl[C_NEEDPREV] != 0u) {
+                if (!X.wait_predecessor(prev_flag)) { bad = true; break; }
+                prev_ok = true;
+            }
             // ---- matches
             {
                 const uint32_t s0 = ms - s.off;                                    // source start (has_m: off <= ms)
@@ -637,6 +679,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 bool pending = has_m;
                 const unsigned long long tw0 = PCD_NOW();
                 uint32_t turns_ready = 0u, turns_idle = 0u;
+                (void)tw0; (void)turns_ready; (void)turns_idle;
                 {
                     const bool go = has_m && !dep;
                     if (go && inl) copy_inline();
@@ -647,6 +690,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 // A wavefront without open matches leaves (and waits at the barrier, off the issue slots); one with open
                 // matches none of which is ready sleeps a little.  What a dependency costs is one turn of this loop.
                 const unsigned long long tw1 = PCD_NOW();
+                (void)tw1;
                 // This loop is what the batch waits for -- a chain of d dependent matches costs d turns -- so a turn is as little
                 // code as possible: both DONE words in one round trip, one copy loop (a match with producers reads the window, from
                 // OP on: never the written-back output), 16 bytes per step in order (it may read its own output).
@@ -724,9 +768,19 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
         __syncthreads();                                           // the tile's LDS is free
     }
     PCD_PROF_FLUSH
+    if (a.chain_done != nullptr) {
+        // my bytes are complete: say so once every earlier block has (a waiter wants ALL of its prefix), or pass the failure on
+        __syncthreads();                                           // every thread's stores precede the fence below
+        if (!bad && !prev_ok) bad = !X.wait_predecessor(prev_flag);
+        if (tid == 0u) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(a.chain_done + b, bad ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (tid == 0u) {
         if (bad) { a.status[b] = redo_code; a.out_len[b] = 0u; }
-        else { a.status[b] = 0; a.out_len[b] = OP; }
+        else { a.status[b] = 0; a.out_len[b] = OP - OP0; }
     }
 }
 
@@ -755,7 +809,7 @@ static hipError_t launch_geo(const DecompressArgs& a, int32_t redo_code, hipStre
 // inside small inputs -- tests only.
 hipError_t launch_decompress_pcd(const DecompressArgs& a, int32_t redo_code, hipStream_t s, bool test_geometry) {
     if (a.n == 0u) return hipSuccess;
-    if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;   // dictionary / prefix: lz4_decompress.hip
+    if (a.dict_base != nullptr) return hipErrorInvalidValue;   // external dictionary: lz4_decompress.hip
     return test_geometry ? pcd::launch_geo<pcd::GeoTest>(a, redo_code, s) : pcd::launch_geo<pcd::GeoProd>(a, redo_code, s);
 }
 

@@ -29,6 +29,10 @@ struct DecompressArgs {
     uint64_t* detail;          // nullable: 2 per block (expected, actual)
     uint32_t n;
     int32_t only_status;       // lz4_decompress_blocks_kernel: 0 = every block, else only blocks whose status equals it (second pass)
+    // lz4_decompress_pcd_kernel with out_pos: nullable; n words, zero before the launch.  Set => the batch is a CHAIN: the blocks share
+    // one output region and block i's prefix [.., out_pos[i]) is what blocks 0..i-1 of this batch write (Linked frames,
+    // src/frame/decompress.rs:195-222,280-306).  chain_done[i] becomes 1 (done, and every block before it) or 2 (given up).
+    uint32_t* chain_done;
 };
 
 struct CompressArgs {
