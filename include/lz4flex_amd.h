@@ -318,6 +318,29 @@ int lz4flex_copy_batch_device(const void *src_base, const uint64_t *src_off, con
 int lz4flex_frame_walk_device(const void *frame, uint64_t frame_len, uint32_t header_len, int block_checksums, uint32_t block_size,
                               uint32_t max_blocks, uint64_t *payload_off, uint32_t *len_word, uint32_t *info, void *hip_stream);
 
+/* ---- the frame across the GPUs of one node (one process per GPU, an RCCL communicator; BASELINE configs[3]) ----------------
+ * FrameEncoder / FrameDecoder for BlockMode::Independent frames whose blocks are spread over `world` ranks: the per-block
+ * work of src/frame/compress.rs:261-371 / src/frame/decompress.rs:189-342 runs on every rank for its contiguous block
+ * range, ONE exchange step moves the bytes (compress: ncclAllGather of the segment sizes + grouped ncclSend / ncclRecv of the
+ * segments to `root`; decompress: the root walks the block headers on its device, broadcasts the table and sends every rank
+ * its byte range).  nccl_comm: an ncclComm_t (NULL with world == 1: no RCCL call is made and RCCL is not even loaded).  All
+ * data pointers are DEVICE memory; work is enqueued on hip_stream and the calls return after it has completed (they own
+ * temporaries).  Linked frames, content checksums / sizes and BlockSize::Auto do not shard: -LZ4FLEX_E_UNSUPPORTED /
+ * -LZ4FLEX_E_INVALID_ARG.  With more than one rank these entry points have been compiled and linked against RCCL but not run
+ * (no multi-GPU node was available to this build); lz4_flex_amd/sharded.py is the same exchange over torch.distributed. */
+/* bytes a rank's segment can take at most (and the root must be able to receive from it) */
+uint64_t lz4flex_frame_segment_bound(uint64_t local_len, const lz4flex_frame_info *info);
+/* local[0 .. local_len): this rank's blocks (a multiple of the block size except on the last rank); first_block: the global
+ * index of its first block.  On `root`, frame receives header + all segments + EndMark and *frame_len their size (0 elsewhere). */
+int lz4flex_frame_compress_sharded(lz4flex_ctx *ctx, void *nccl_comm, int rank, int world, int root, const void *local,
+                                   uint64_t local_len, uint64_t first_block, const lz4flex_frame_info *info, void *frame,
+                                   uint64_t frame_cap, uint64_t *frame_len, void *hip_stream);
+/* frame / frame_bytes: needed on `root` only.  Every rank decodes blocks [*first_block, *first_block + *n_blocks) into out (block i of
+ * the range at i * block size), *out_len bytes; info_out (nullable) receives the frame's block size and checksum flag. */
+int lz4flex_frame_decompress_sharded(lz4flex_ctx *ctx, void *nccl_comm, int rank, int world, int root, const void *frame,
+                                     uint64_t frame_bytes, void *out, uint64_t out_cap, uint64_t *out_len, uint64_t *first_block,
+                                     uint64_t *n_blocks, lz4flex_frame_info *info_out, lz4flex_err_detail *detail, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

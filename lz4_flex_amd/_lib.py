@@ -13,7 +13,7 @@ FE_WRONG_MAGIC, FE_RESERVED_BITS, FE_INVALID_BLOCK_INFO, FE_BLOCK_TOO_BIG, FE_HE
 FE_BLOCK_CHECKSUM, FE_CONTENT_CHECKSUM, FE_SKIPPABLE_FRAME, FE_DICTIONARY_NOT_SUPPORTED = 26, 27, 28, 29
 FE_CONTENT_LENGTH, FE_OUTPUT_FULL = 30, 31
 E_INVALID_ARG, E_NO_DEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED = 64, 65, 66, 67, 68
-MEM_HOST, MEM_DEVICE, MEM_BIG_BLOCKS = 0, 1, 0x100
+MEM_HOST, MEM_DEVICE, MEM_BIG_BLOCKS, MEM_CHAINED = 0, 1, 0x100, 0x200
 BLOCK_DEFAULT, BLOCK_FRAME_FIRST, BLOCK_FRAME_CONTINUATION = 0, 2, 3
 
 
@@ -93,6 +93,11 @@ SIGNATURES = {
     "lz4flex_frame_assemble_device": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _U32, _I32, _VP, _VP, _VP, _VP]),
     "lz4flex_copy_batch_device": (_I32, [_VP, _VP, _VP, _VP, _VP, _U32, _VP]),
     "lz4flex_frame_walk_device": (_I32, [_VP, _U64, _U32, _I32, _U32, _U32, _VP, _VP, _VP, _VP]),
+    "lz4flex_frame_segment_bound": (_U64, [_U64, C.POINTER(FrameInfoC)]),
+    "lz4flex_frame_compress_sharded": (_I32, [_VP, _VP, _I32, _I32, _I32, _VP, _U64, _U64, C.POINTER(FrameInfoC), _VP, _U64,
+                                               C.POINTER(_U64), _VP]),
+    "lz4flex_frame_decompress_sharded": (_I32, [_VP, _VP, _I32, _I32, _I32, _VP, _U64, _VP, _U64, C.POINTER(_U64), C.POINTER(_U64),
+                                                 C.POINTER(_U64), C.POINTER(FrameInfoC), C.POINTER(ErrDetail), _VP]),
 }
 
 _lib = None

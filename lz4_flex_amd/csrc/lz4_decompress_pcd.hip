@@ -445,6 +445,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
         bool settled = false;
         PCD_TICK(0) PCD_COUNT(16, 1)
         for (uint32_t it = 0u; it < G::MAX_ITERS; ++it) {
+            bool exit_changed = false;
             if (dirty) {
                 // Lane k walks part k from its entry.  A walk that lands on a position the part's PREVIOUS walk marked is
                 // identical to it from there on: it stops, keeps those marks and the exit (the first walk of a tile, from an
@@ -480,11 +481,16 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 } else {
 #pragma unroll
                     for (uint32_t w = 0; w < G::PW; ++w) mk[w] = nm[w];
-                    X.ext()[tid] = x;
+                    exit_changed = X.ext()[tid] != x;              // (a first walk: the slot holds X_ERR ... and an entry that really
+                    X.ext()[tid] = x;                              //  leads to X_ERR again changes nothing: the chain dies there either way)
+                    exit_changed = exit_changed || it == 0u;
                 }
             }
-            __syncthreads();
+            // no exit changed since the exits were last followed: every walk of this round fell into step with its part's old chain,
+            // entries and live parts are what the last round found -- the tile is settled without following them again
+            const int any_exit = __syncthreads_or(exit_changed ? 1 : 0);
             PCD_TICK(1) PCD_COUNT(17, 1)
+            if (!any_exit) { settled = true; break; }
             if (X.wv == 0u) X.resolve(cbase, parts);
             __syncthreads();
             dirty = false;

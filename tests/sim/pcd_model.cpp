@@ -78,23 +78,28 @@ extern "C" long pcd_model_decode(const uint8_t* c, uint32_t n, uint8_t* out, uin
         bool converged = false;
         for (uint32_t it = 0; it < prm->max_iters && !converged; it++) {
             st->iters++;
+            bool exit_changed = it == 0;
             for (uint32_t k = 0; k < parts; k++) {            // every lane with a dirty part: walk it from its entry
                 if (!dirty[k]) continue;
                 dirty[k] = 0;
                 st->part_walks++;
                 const uint32_t pend = cbase + (k + 1) * pp;
                 for (uint32_t i = k * pp; i < (k + 1) * pp; i++) marks[i] = 0;
-                uint32_t p = e[k];
+                uint32_t p = e[k], xn;
                 for (;;) {
-                    if (p >= pend) { x[k] = p; break; }
+                    if (p >= pend) { xn = p; break; }
                     marks[p - cbase] = 1;
                     Seq s;
                     const uint32_t nx = parse_seq(rd, n, p, s);
                     st->hops++;
-                    if (nx >= X_ERR) { x[k] = nx; break; }
+                    if (nx >= X_ERR) { xn = nx; break; }
                     p = nx;
                 }
+                exit_changed |= xn != x[k];
+                x[k] = xn;
             }
+            // (the kernel: no exit changed since the exits were last followed => entries and live parts stand, the tile is settled)
+            if (!exit_changed) { converged = true; break; }
             // follow the exits from part 0 (its entry is the tile's true start)
             std::fill(live.begin(), live.end(), 0);
             uint32_t nd = 0;

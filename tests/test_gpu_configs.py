@@ -156,3 +156,53 @@ def test_device_block_header_walk_equals_host_walk(mods):
             sharded.walk_blocks_device(dev[:len(fr) - 9].contiguous(), hdr, bc, 65536)
         with pytest.raises(frame.BlockTooBig):
             sharded.walk_blocks_device(dev, hdr, bc, 1000)
+
+
+def test_native_sharded_entry_points_world1(mods):
+    """lz4flex_frame_compress_sharded / lz4flex_frame_decompress_sharded (the C ABI's one-shot multi-GPU entry points, here with a
+    world of one rank: no RCCL call is made): the frame == the oracle's FrameEncoder bytes == what lz4_flex_amd/sharded.py
+    builds over torch.distributed, decoding returns the stream; block checksums and stored (incompressible) blocks included."""
+    import ctypes as C
+    from lz4_flex_amd import _lib as L
+    block, frame, sharded, W = mods
+    lib = L.load()
+    rng = np.random.default_rng(5)
+    cases = [(W.log_stream(0, 5 * (4 << 20) + 128 * 777, device="cuda"), 7, False),
+             (torch.cat([W.log_stream(0, 128 * 3000, device="cuda"), torch.from_numpy(rng.integers(0, 256, 200000, dtype=np.uint8)).cuda(),
+                         W.log_stream(128 * 50, 128 * 2000, device="cuda")]), 4, True)]
+    for src, bs_code, bc in cases:
+        fi = frame.FrameInfo(block_size=frame.BlockSize(bs_code), block_checksums=bc)
+        fic = L.FrameInfoC(0, 0, bs_code, 0, 1 if bc else 0, 0, 0)
+        n = int(src.numel())
+        cap = int(lib.lz4flex_frame_segment_bound(n, C.byref(fic))) + 32
+        out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        flen = C.c_uint64(0)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = lib.lz4flex_frame_compress_sharded(None, None, 0, 1, 0, C.c_void_p(src.data_ptr()), n, 0, C.byref(fic), C.c_void_p(out.data_ptr()),
+                                                cap, C.byref(flen), stream)
+        assert rc == 0, (rc, L.last_error())
+        got = out[:flen.value].cpu().numpy().tobytes()
+        host = src.cpu().numpy().tobytes()
+        rc_o, exp = O.frame_compress(host, block_size=bs_code, block_checksums=bc)
+        assert rc_o == 0 and got == exp
+        assert got == sharded.compress_frame_sharded(src, 0, fi).cpu().numpy().tobytes()
+        bs = fi.block_size.get_size()
+        nblk = (n + bs - 1) // bs
+        back = torch.zeros(nblk * bs, dtype=torch.uint8, device="cuda")
+        olen, first, nb = C.c_uint64(0), C.c_uint64(99), C.c_uint64(0)
+        info = L.FrameInfoC()
+        det = L.ErrDetail()
+        rc = lib.lz4flex_frame_decompress_sharded(None, None, 0, 1, 0, C.c_void_p(out.data_ptr()), flen.value, C.c_void_p(back.data_ptr()),
+                                                  nblk * bs, C.byref(olen), C.byref(first), C.byref(nb), C.byref(info), C.byref(det), stream)
+        assert rc == 0, (rc, L.last_error())
+        assert (olen.value, first.value, nb.value, info.block_size) == (n, 0, nblk, bs_code)
+        assert torch.equal(back[:n], src)
+        if bc:                                                  # a corrupted block checksum is reported, not decoded
+            bad = out.clone(); bad[flen.value - 9] ^= 0x55
+            rc = lib.lz4flex_frame_decompress_sharded(None, None, 0, 1, 0, C.c_void_p(bad.data_ptr()), flen.value, C.c_void_p(back.data_ptr()),
+                                                      nblk * bs, C.byref(olen), C.byref(first), C.byref(nb), None, None, stream)
+            assert rc == -L.FE_BLOCK_CHECKSUM
+    # what does not shard is refused
+    fic = L.FrameInfoC(0, 0, 4, 1, 0, 0, 0)                     # Linked
+    assert lib.lz4flex_frame_compress_sharded(None, None, 0, 1, 0, C.c_void_p(src.data_ptr()), 100, 0, C.byref(fic), C.c_void_p(out.data_ptr()),
+                                              cap, C.byref(flen), stream) == -L.E_UNSUPPORTED

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/r03i
+OUT=gpurun_out/r03j
 mkdir -p $OUT
 timeout 1200 python -m pytest tests -m gpu -q --maxfail=30 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; tail -25 $OUT/pytest_gpu.log
 timeout 200 python tools/dec_shapes.py --variants 7,6 --shapes json:65536:256,log:4194304:256,log:16777216:1 > $OUT/pcd_shapes.log 2>&1; cat $OUT/pcd_shapes.log

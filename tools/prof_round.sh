@@ -26,3 +26,5 @@ for c in $CONFIGS; do
   fi
 done
 python tools/prof_summary.py $OUT $1
+# the raw traces are tens of MiB per pass: only the summaries travel back
+rm -rf $OUT/trace_config* $OUT/pmc_config*
