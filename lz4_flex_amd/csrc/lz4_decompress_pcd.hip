@@ -45,10 +45,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1u) / a * a; }
 constexpr uint32_t ceil_log2(uint32_t v) { uint32_t r = 0u; while ((1u << r) < v) ++r; return r; }
 
-// CT compressed bytes per tile (+ CM staged behind it), parts of P bytes, T threads = sequences per batch, window = HIST + WNEW
-template <uint32_t CT_, uint32_t CM_, uint32_t P_, uint32_t T_, uint32_t HIST_, uint32_t WNEW_>
+// CT compressed bytes per tile (+ CM staged behind it), parts of P bytes, T threads, S sequences per thread and batch, window = HIST + WNEW
+template <uint32_t CT_, uint32_t CM_, uint32_t P_, uint32_t T_, uint32_t S_, uint32_t HIST_, uint32_t WNEW_>
 struct Geo {
-    static constexpr uint32_t CT = CT_, CM = CM_, P = P_, NP = CT_ / P_, T = T_, HIST = HIST_, WNEW = WNEW_, WIN = HIST_ + WNEW_;
+    static constexpr uint32_t CT = CT_, CM = CM_, P = P_, NP = CT_ / P_, T = T_, S = S_, HIST = HIST_, WNEW = WNEW_, WIN = HIST_ + WNEW_;
+    static constexpr uint32_t BN = T * S;                         // sequences per batch
     static constexpr uint32_t MW = CT / 32u;                      // mark words
     static constexpr uint32_t PW = P / 32u;                       // mark words per part
     static constexpr uint32_t NW = T / 64u;                       // wavefronts
@@ -65,17 +66,17 @@ struct Geo {
     static constexpr uint32_t L_RCH = L_NXT + 4u * (NP + 4u);
     static constexpr uint32_t L_TOK = align_up(L_RCH + 4u * (NP + 4u), 16u);
     static constexpr uint32_t L_BST = align_up(L_TOK + 2u * MAXSEQ, 16u);
-    static constexpr uint32_t L_MST = align_up(L_BST + 4u * (T + 1u), 16u);
-    static constexpr uint32_t L_DONE = align_up(L_MST + 4u * T, 16u);
-    static constexpr uint32_t L_WSUM = L_DONE + 4u * align_up(T / 32u, 4u);
-    static constexpr uint32_t L_CTL = L_WSUM + 4u * align_up(NW, 4u);
+    static constexpr uint32_t L_MST = align_up(L_BST + 4u * (BN + 1u), 16u);
+    static constexpr uint32_t L_DONE = align_up(L_MST + 4u * BN, 16u);
+    static constexpr uint32_t L_WSUM = L_DONE + 4u * align_up(BN / 32u, 4u);
+    static constexpr uint32_t L_CTL = L_WSUM + 4u * align_up(NW * S, 4u);
     static constexpr uint32_t L_WIN = align_up(L_CTL + 4u * 32u, 16u);
     static constexpr uint32_t LDS_BYTES = L_WIN + WIN + 64u;
     static_assert(CT % P == 0 && P % 32 == 0 && T % 64 == 0 && MW <= T && NP <= T && NP <= 64u * PPL && HIST % 16 == 0, "geometry");
     static_assert(LDS_BYTES <= 160u * 1024u, "LDS");
 };
-using GeoProd = Geo<CT, CM, P, BATCH, HIST, WNEW>;              // lz4_pcd_common.h: 32 KiB tiles, 256-byte parts, 1 024 lanes, 16 + 32 KiB window
-using GeoTest = Geo<2048u, 256u, 64u, 128u, 512u, 1024u>;       // tests: boundaries of every kind inside small inputs
+using GeoProd = Geo<CT, CM, P, THREADS, SEQ_PER_LANE, HIST, WNEW>;   // lz4_pcd_common.h: 32 KiB tiles, 128-byte parts, 1 024 lanes x 2 sequences, 48 + 32 KiB window
+using GeoTest = Geo<2048u, 256u, 64u, 128u, 2u, 512u, 1024u>;        // tests: boundaries of every kind inside small inputs
 
 // control words in LDS.  A word is written on one side of a barrier and read on the other: C_BAD (a sequence that does not parse) is
 // written before the batch's first barrier and read behind it, C_BAD2 (an offset behind the output) before the second one --
@@ -244,6 +245,33 @@ struct Ctx {
         return base + incl - v;
     }
 
+    // the same for S values per thread, laid out slot by slot (all threads' slot 0 in thread order, then slot 1, ...): ex[u] = the
+    // sum of everything before (u, thread).  Two barriers for all slots.
+    __device__ __forceinline__ void block_excl_scan_slots(const uint32_t (&v)[G::S], uint32_t (&ex)[G::S]) const {
+        uint32_t incl[G::S];
+        lds_u32* ws = wsum();
+#pragma unroll
+        for (uint32_t u = 0; u < G::S; ++u) {
+            incl[u] = wave_incl_add(v[u]);
+            if (lane == 63u) ws[u * G::NW + wv] = incl[u];
+        }
+        __syncthreads();
+        uint32_t before = 0u;                                         // the slots before u, whole
+#pragma unroll
+        for (uint32_t u = 0; u < G::S; ++u) {
+            uint32_t base = 0u, tot = 0u;
+#pragma unroll
+            for (uint32_t i = 0; i < G::NW; ++i) {
+                const uint32_t s = ws[u * G::NW + i];
+                base += i < wv ? s : 0u;
+                tot += s;
+            }
+            ex[u] = before + base + incl[u] - v[u];
+            before += tot;
+        }
+        __syncthreads();
+    }
+
     // ---- the tile [cbase, cbase + CT + CM) of the compressed stream into LDS (never a byte behind the block)
     __device__ __forceinline__ void load_tile(uint32_t cbase) const {
         const uint32_t avail = ilen - cbase;
@@ -356,6 +384,121 @@ struct Ctx {
             donem += n;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the next step reads what other lanes wrote in this one
             __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+
+    // ---- the matches of one slot of a batch (sequence i of the batch in this lane: s, at output position OP + exu): find the
+    // producers, copy the ones that have none, poll for the others.  Not inlined: the kernel holds S copies of a batch's state,
+    // and inlined S times this code needed more registers than a 1 024-thread workgroup has (124 spilled).
+    __device__ __attribute__((noinline)) void match_slot(const Seq s, const uint32_t i, const bool hm, const uint32_t exu, uint32_t OP_, uint32_t Lo_,
+                                                         uint32_t cnt_) const {
+        const uint32_t OP = (uint32_t)__builtin_amdgcn_readfirstlane((int)OP_), Lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)Lo_),
+                       cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_);
+        constexpr uint32_t BN = G::BN;
+        const uint32_t ms = OP + exu + s.lit;
+        const uint32_t s0 = ms - s.off;                                    // source start (hm: off <= ms)
+        const uint32_t s1 = s0 + s.ml < ms ? s0 + s.ml : ms;               // source end outside its own output
+        // producers: the batch's sequences whose output holds [max(s0, OP), s1) -- lo..hi, all before mine
+        uint32_t lo = 1u, hi = 0u;
+        if (hm && s1 > OP) {
+            const uint32_t a0 = s0 > OP ? s0 : OP, a1 = s1 - 1u;
+            uint32_t jl = 0u, jh = 0u;
+#pragma unroll 1
+            for (uint32_t step = BN / 2u; step != 0u; step >>= 1) {        // largest j < cnt with bst[j] <= a
+                const uint32_t cl = jl + step, ch = jh + step;
+                if (cl < cnt && bst()[cl] <= a0) jl = cl;
+                if (ch < cnt && bst()[ch] <= a1) jh = ch;
+            }
+            if (jl < i) {                                                  // (a source inside my own literals has no producer)
+                lo = jl;
+                hi = jh < i ? jh : i - 1u;
+                // the last one only counts if the source reaches into its MATCH (its literals are placed already)
+                if (hi == jh && s1 <= mst()[hi]) { if (hi == lo) { lo = 1u; hi = 0u; } else hi -= 1u; }
+            }
+        }
+        // one lane, 16 bytes at a time: offset >= 16, up to 256 bytes, source entirely in the window or (up to 64 bytes)
+        // entirely written back; everything else (periodic, long, straddling the window's start) is copied by the whole wavefront
+        const bool dep = lo <= hi;
+        const bool near = s0 >= Lo;
+        const bool farok = s0 + ((s.ml + 15u) & ~15u) <= Lo;
+        const bool inl = s.off >= 16u && (near ? s.ml <= 256u : (farok && s.ml <= 64u));   // (far: four loads in flight, no more)
+        lds_u8* const dstp = win() + (ms - Lo);
+        const lds_u8* const srcp = win() + (s0 - Lo);          // (only used where the source lies in the window)
+        auto copy_coop = [&](bool want) {
+            uint64_t cm = __ballot(want);
+            while (cm != 0ull) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(cm);
+                cm &= cm - 1ull;
+                wave_match(bcast(ms, l), bcast(s.off, l), bcast(s.ml, l), Lo);
+                                    }
+        };
+        auto publish = [&]() {     // my match's bytes are in the window: the DONE bit follows them (release)
+            __hip_atomic_fetch_or(done() + (i >> 5), 1u << (i & 31u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        // matches without a producer in this batch (history, written-back output, own literals): all at once
+        bool pending = hm;
+        {
+            const bool go = hm && !dep;
+            if (go && inl) {
+                if (near) {
+                    // 64 bytes of loads before their stores where no byte of those 64 is the match's own output, else 16 (one
+                    // loop for both: two loops would be executed one after the other by a wavefront that holds both kinds)
+                    const uint32_t grp = (s.off >= 64u || s.off >= s.ml) ? 64u : 16u;
+                    for (uint32_t o = 0u; o < s.ml; o += grp) {
+                        u32x4 v[4];
+#pragma unroll
+                        for (uint32_t k = 0u; k < 4u; ++k) if (16u * k < grp && o + 16u * k < s.ml) v[k] = ld16l(srcp + o + 16u * k);
+#pragma unroll
+                        for (uint32_t k = 0u; k < 4u; ++k) {
+                            const uint32_t at = o + 16u * k;
+                            if (16u * k < grp && at < s.ml) st_exact(dstp + at, v[k], s.ml - at < 16u ? s.ml - at : 16u);
+                        }
+                    }
+                } else {                                  // written-back output: every load is issued before the first store waits
+                    const uint8_t* sp = gout + s0;
+                    u32x4 v[4];
+#pragma unroll
+                    for (uint32_t k = 0u; k < 4u; ++k) if (16u * k < s.ml) v[k] = ld16g(sp + 16u * k);
+#pragma unroll
+                    for (uint32_t k = 0u; k < 4u; ++k) if (16u * k < s.ml) st_exact(dstp + 16u * k, v[k], s.ml - 16u * k < 16u ? s.ml - 16u * k : 16u);
+                }
+            }
+            copy_coop(go && !inl);
+            if (go) { publish(); pending = false; }
+        }
+        // The others poll their producers' DONE bits: [lo, hi] = bits lo & 31 .. of word wl up to bit hi & 31 of word wh.  This
+        // loop is what the batch waits for -- a chain of d dependent matches costs d turns -- so a turn is as little code as
+        // possible: both DONE words in one round trip, one copy loop (a match with producers reads the window, from OP on:
+        // never the written-back output), 16 bytes per step in order (it may read its own output).  A wavefront without
+        // open matches goes on (to the next slot, then to the barrier: off the issue slots).
+        const uint32_t wl = lo >> 5, wh = dep ? hi >> 5 : wl;
+        const uint32_t m1 = (0xFFFFFFFFu << (lo & 31u)) & (wl == wh ? 0xFFFFFFFFu >> (31u - (hi & 31u)) : 0xFFFFFFFFu);
+        const uint32_t m2 = wl == wh ? m1 : 0xFFFFFFFFu >> (31u - (hi & 31u));
+        const bool wide = dep && wh - wl > 1u;                   // (whole words between the two: a source of > 32 sequences)
+        const volatile lds_u32* dn = (const volatile lds_u32*)done();
+        const uint32_t nfull = s.ml >> 4, rem = s.ml & 15u;
+        const bool inl2 = s.off >= 16u && s.ml <= 256u && near;
+        uint32_t spins = 0u;
+        while (__any(pending)) {
+            bool ready = false;
+            if (pending) {
+                const uint32_t d1 = dn[wl], d2 = dn[wh];
+                ready = (d1 & m1) == m1 && (d2 & m2) == m2;
+                if (wide) for (uint32_t w = wl + 1u; ready && w < wh; ++w) ready = dn[w] == 0xFFFFFFFFu;
+            }
+            if (__any(ready)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // the producers' bytes behind their DONE bits
+                if (ready && inl2) {
+                    for (uint32_t k = 0u; k < nfull; ++k) st16l(dstp + 16u * k, ld16l(srcp + 16u * k));
+                    if (rem != 0u) st_exact(dstp + 16u * nfull, ld16l(srcp + 16u * nfull), rem);
+                }
+                copy_coop(ready && !inl2);
+                if (ready) { publish(); pending = false; }
+            } else {
+                __builtin_amdgcn_s_sleep(LZ4P_SLEEP);
+                if (++spins > (1u << 22)) { ctl()[C_TIMEOUT] = 1u; break; }   // (cannot happen: the lowest open match is always ready)
+            }
         }
     }
 
@@ -525,24 +668,36 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
         PCD_TICK(3)
 
         // ================================================================ COPY: batches of consecutive sequences
+        // A batch is up to S sequences per lane: sequence i of the batch belongs to lane i mod T, slot i / T -- the phases whose cost
+        // is latency and barriers (token decode, prefix sum, cut, literal loads, write-back) are paid once for S x T sequences.
+        constexpr uint32_t S = G::S, BN = G::T * G::S;
         uint32_t idx = 0u;
         while (idx < ntok) {
-            const uint32_t m = ntok - idx < G::T ? ntok - idx : G::T;
-            Seq s;
-            s.lit_src = 0u; s.lit = 0u; s.ml = 0u; s.off = 0u;
-            uint32_t len = 0u;
+            const uint32_t m = ntok - idx < BN ? ntok - idx : BN;
+            Seq sq[S];
+            uint32_t len[S], lenc[S];
             bool perr = false;
-            if (tid < m) {
-                const uint32_t nx = seq_at(rd, X.ilen, staged, cbase + X.tok()[idx + tid], s);
-                perr = nx == X_ERR || (nx == X_END && !(ended && idx + tid + 1u == ntok));
-                len = s.lit + s.ml;                                // (both < 2^31)
+#pragma unroll
+            for (uint32_t u = 0; u < S; ++u) {
+                const uint32_t i = u * G::T + tid;
+                sq[u].lit_src = 0u; sq[u].lit = 0u; sq[u].ml = 0u; sq[u].off = 0u;
+                len[u] = 0u;
+                if (i < m) {
+                    const uint32_t nx = seq_at(rd, X.ilen, staged, cbase + X.tok()[idx + i], sq[u]);
+                    perr = perr || nx == X_ERR || (nx == X_END && !(ended && idx + i + 1u == ntok));
+                    len[u] = sq[u].lit + sq[u].ml;                 // (both < 2^31)
+                }
+                lenc[u] = len[u] <= G::WNEW ? len[u] : G::WNEW + 1u;
             }
             if (tid == 0u) ctl[C_CUT] = m;
-            const uint32_t lenc = len <= G::WNEW ? len : G::WNEW + 1u;
-            uint32_t sum_all;
-            const uint32_t ex = X.block_excl_scan(lenc, &sum_all);     // (its barriers publish C_CUT)
-            const bool fits = ex + lenc <= G::WNEW;
-            if (tid < m && !fits) __hip_atomic_fetch_min((lds_u32*)(X.lds + G::L_CTL) + C_CUT, tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // output position of every sequence: slot by slot, a slot's lanes in order (one pass of barriers for all slots)
+            uint32_t ex[S];
+            X.block_excl_scan_slots(lenc, ex);                       // (its barriers publish C_CUT)
+#pragma unroll
+            for (uint32_t u = 0; u < S; ++u) {
+                const uint32_t i = u * G::T + tid;
+                if (i < m && ex[u] + lenc[u] > G::WNEW) __hip_atomic_fetch_min((lds_u32*)(X.lds + G::L_CTL) + C_CUT, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             if (perr) ctl[C_BAD] = 1u;
             __syncthreads();
             const uint32_t cnt = ctl[C_CUT];
@@ -550,7 +705,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
             if (ctl[C_BAD] != 0u) { bad = true; break; }
             if (cnt == 0u) {
                 // ---- a sequence longer than the window: alone, by the whole workgroup, on the output itself
-                if (tid == 0u) { ctl[C_G_SRC] = s.lit_src; ctl[C_G_LIT] = s.lit; ctl[C_G_ML] = s.ml; ctl[C_G_OFF] = s.off; }
+                if (tid == 0u) { ctl[C_G_SRC] = sq[0].lit_src; ctl[C_G_LIT] = sq[0].lit; ctl[C_G_ML] = sq[0].ml; ctl[C_G_OFF] = sq[0].off; }
                 __syncthreads();
                 const uint32_t g_src = ctl[C_G_SRC], g_lit = ctl[C_G_LIT], g_ml = ctl[C_G_ML], g_off = ctl[C_G_OFF];
                 if (g_lit > X.cap - OP) { bad = true; break; }                      // OutputTooSmall
@@ -579,34 +734,36 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 continue;
             }
             // ---- a batch of cnt sequences: [OP, OP + total) in the window behind the history
-            if (tid + 1u == cnt) ctl[C_TOTAL] = ex + len;
             const uint32_t Lo = OP - hist;
-            const uint32_t ms = OP + ex + s.lit;                   // where my match starts
-            if (tid < cnt) { X.bst()[tid] = OP + ex; X.mst()[tid] = ms; }
-            const bool has_m = tid < cnt && s.ml != 0u;
-            if (has_m && s.off > ms) ctl[C_BAD2] = 1u;             // OffsetOutOfBounds (decompress.rs:398-400)
-            if (!prev_ok && has_m && ms - s.off < OP0) ctl[C_NEEDPREV] = 1u;   // a match reaches into an earlier block of the chain
-            {   // DONE bits: set for lanes without a match
-                const uint64_t nm = __ballot(!has_m);
-                if (lane == 0u) { X.done()[2u * X.wv] = (uint32_t)nm; X.done()[2u * X.wv + 1u] = (uint32_t)(nm >> 32); }
-            }
-            // literals: short runs by their lane, long ones by the wavefront
-            {
-                const uint32_t dstw = hist + ex;
-                const bool mine = tid < cnt && s.lit != 0u;
-                const bool shortl = mine && s.lit <= 32u && s.lit_src + 32u <= X.ilen;
+            bool has_m[S];
+#pragma unroll
+            for (uint32_t u = 0; u < S; ++u) {
+                const uint32_t i = u * G::T + tid;
+                const uint32_t ms = OP + ex[u] + sq[u].lit;        // where the match starts
+                if (i + 1u == cnt) ctl[C_TOTAL] = ex[u] + len[u];
+                if (i < cnt) { X.bst()[i] = OP + ex[u]; X.mst()[i] = ms; }
+                has_m[u] = i < cnt && sq[u].ml != 0u;
+                if (has_m[u] && sq[u].off > ms) ctl[C_BAD2] = 1u;  // OffsetOutOfBounds (decompress.rs:398-400)
+                if (!prev_ok && has_m[u] && ms - sq[u].off < OP0) ctl[C_NEEDPREV] = 1u;   // a match reaches into an earlier block of the chain
+                // DONE bits: set for sequences without a match (and for the slots behind the batch)
+                const uint64_t nm = __ballot(!has_m[u]);
+                if (lane == 0u) { X.done()[u * (G::T / 32u) + 2u * X.wv] = (uint32_t)nm; X.done()[u * (G::T / 32u) + 2u * X.wv + 1u] = (uint32_t)(nm >> 32); }
+                // literals: short runs by their lane, long ones by the wavefront
+                const uint32_t dstw = hist + ex[u];
+                const bool mine = i < cnt && sq[u].lit != 0u;
+                const bool shortl = mine && sq[u].lit <= 32u && sq[u].lit_src + 32u <= X.ilen;
                 if (shortl) {
-                    st_exact(X.win() + dstw, ld16g(X.gin + s.lit_src), s.lit < 16u ? s.lit : 16u);
-                    if (s.lit > 16u) st_exact(X.win() + dstw + 16u, ld16g(X.gin + s.lit_src + 16u), s.lit - 16u);
+                    st_exact(X.win() + dstw, ld16g(X.gin + sq[u].lit_src), sq[u].lit < 16u ? sq[u].lit : 16u);
+                    if (sq[u].lit > 16u) st_exact(X.win() + dstw + 16u, ld16g(X.gin + sq[u].lit_src + 16u), sq[u].lit - 16u);
                 }
                 uint64_t lm = __ballot(mine && !shortl);
                 while (lm != 0ull) {
                     const uint32_t l = (uint32_t)__builtin_ctzll(lm);
                     lm &= lm - 1ull;
-                    X.wave_literals(bcast(dstw, l), bcast(s.lit_src, l), bcast(s.lit, l));
+                    X.wave_literals(bcast(dstw, l), bcast(sq[u].lit_src, l), bcast(sq[u].lit, l));
                 }
             }
-            __syncthreads();                                       // literals placed, bst[] / DONE / C_TOTAL / C_BAD published
+            __syncthreads();                                       // literals placed, bst[] / DONE / C_TOTAL / C_BAD2 published
             PCD_TICK(5) PCD_COUNT(18, 1) PCD_COUNT(19, cnt)
             const uint32_t total = ctl[C_TOTAL];
             if (ctl[C_BAD2] != 0u || total > X.cap - OP) { bad = true; break; }    // ... / OutputTooSmall somewhere in the batch
@@ -614,128 +771,10 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 if (!X.wait_predecessor(prev_flag)) { bad = true; break; }
                 prev_ok = true;
             }
-            // ---- matches
-            {
-                const uint32_t s0 = ms - s.off;                                    // source start (has_m: off <= ms)
-                const uint32_t s1 = s0 + s.ml < ms ? s0 + s.ml : ms;               // source end outside its own output
-                // producers: the batch's sequences whose output holds [max(s0, OP), s1) -- lo..hi, all before mine
-                uint32_t lo = 1u, hi = 0u;
-                if (has_m && s1 > OP) {
-                    const uint32_t a0 = s0 > OP ? s0 : OP, a1 = s1 - 1u;
-                    uint32_t jl = 0u, jh = 0u;
-#pragma unroll 1
-                    for (uint32_t step = G::T / 2u; step != 0u; step >>= 1) {      // largest j < cnt with bst[j] <= a
-                        const uint32_t cl = jl + step, ch = jh + step;
-                        if (cl < cnt && X.bst()[cl] <= a0) jl = cl;
-                        if (ch < cnt && X.bst()[ch] <= a1) jh = ch;
-                    }
-                    if (jl < tid) {                                                // (a source inside my own literals has no producer)
-                        lo = jl;
-                        hi = jh < tid ? jh : tid - 1u;
-                        // the last one only counts if the source reaches into its MATCH (its literals are placed already)
-                        if (hi == jh && s1 <= X.mst()[hi]) { if (hi == lo) { lo = 1u; hi = 0u; } else hi -= 1u; }
-                    }
-                }
-                PCD_TICK(6)
-                // one lane, 16 bytes at a time: offset >= 16, up to 256 bytes, source entirely in the window or entirely written back;
-                // everything else (periodic, long, straddling the window's start) is copied by the whole wavefront
-                const bool dep = lo <= hi;
-                const bool near = s0 >= Lo;
-                const bool farok = s0 + ((s.ml + 15u) & ~15u) <= Lo;
-                const bool inl = s.off >= 16u && (near ? s.ml <= 256u : (farok && s.ml <= 64u));   // (far: four loads in flight, no more)
-                lds_u8* const dstp = X.win() + (ms - Lo);
-                auto copy_inline = [&]() {
-                    if (near) {
-                        const lds_u8* sp = X.win() + (s0 - Lo);
-                        // 64 bytes of loads before their stores where no byte of those 64 is the match's own output, else 16 (one loop
-                        // for both: two loops would be executed one after the other by a wavefront that holds both kinds)
-                        const uint32_t grp = (s.off >= 64u || s.off >= s.ml) ? 64u : 16u;
-                        for (uint32_t o = 0u; o < s.ml; o += grp) {
-                            u32x4 v[4];
+            // ---- matches, slot by slot: a slot's sequences only wait for sequences before them, so a wavefront that is through
+            // with slot u goes on to slot u + 1 while others still poll (no barrier in between)
 #pragma unroll
-                            for (uint32_t k = 0u; k < 4u; ++k) if (16u * k < grp && o + 16u * k < s.ml) v[k] = ld16l(sp + o + 16u * k);
-#pragma unroll
-                            for (uint32_t k = 0u; k < 4u; ++k) {
-                                const uint32_t at = o + 16u * k;
-                                if (16u * k < grp && at < s.ml) st_exact(dstp + at, v[k], s.ml - at < 16u ? s.ml - at : 16u);
-                            }
-                        }
-                    } else {                                  // written-back output: every load is issued before the first store waits
-                        const uint8_t* sp = X.gout + s0;
-                        u32x4 v[4];
-#pragma unroll
-                        for (uint32_t k = 0u; k < 4u; ++k) if (16u * k < s.ml) v[k] = ld16g(sp + 16u * k);
-#pragma unroll
-                        for (uint32_t k = 0u; k < 4u; ++k) if (16u * k < s.ml) st_exact(dstp + 16u * k, v[k], s.ml - 16u * k < 16u ? s.ml - 16u * k : 16u);
-                    }
-                };
-                auto copy_coop = [&](bool want) {
-                    uint64_t cm = __ballot(want);
-                    while (cm != 0ull) {
-                        const uint32_t l = (uint32_t)__builtin_ctzll(cm);
-                        cm &= cm - 1ull;
-                        X.wave_match(bcast(ms, l), bcast(s.off, l), bcast(s.ml, l), Lo);
-                        PCD_COUNT(23, 1)
-                    }
-                };
-                auto publish = [&]() {     // my match's bytes are in the window: the DONE bit follows them (release)
-                    __hip_atomic_fetch_or(X.done() + (tid >> 5), 1u << (tid & 31u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                };
-                // matches without a producer in this batch (history, written-back output, own literals): all at once
-                bool pending = has_m;
-                const unsigned long long tw0 = PCD_NOW();
-                uint32_t turns_ready = 0u, turns_idle = 0u;
-                (void)tw0; (void)turns_ready; (void)turns_idle;
-                {
-                    const bool go = has_m && !dep;
-                    if (go && inl) copy_inline();
-                    copy_coop(go && !inl);
-                    if (go) { publish(); pending = false; }
-                }
-                // the others poll their producers' DONE bits: [lo, hi] = bits lo & 31 .. of word wl up to bit hi & 31 of word wh.
-                // A wavefront without open matches leaves (and waits at the barrier, off the issue slots); one with open
-                // matches none of which is ready sleeps a little.  What a dependency costs is one turn of this loop.
-                const unsigned long long tw1 = PCD_NOW();
-                (void)tw1;
-                // This loop is what the batch waits for -- a chain of d dependent matches costs d turns -- so a turn is as little
-                // code as possible: both DONE words in one round trip, one copy loop (a match with producers reads the window, from
-                // OP on: never the written-back output), 16 bytes per step in order (it may read its own output).
-                const uint32_t wl = lo >> 5, wh = dep ? hi >> 5 : wl;
-                const uint32_t m1 = (0xFFFFFFFFu << (lo & 31u)) & (wl == wh ? 0xFFFFFFFFu >> (31u - (hi & 31u)) : 0xFFFFFFFFu);
-                const uint32_t m2 = wl == wh ? m1 : 0xFFFFFFFFu >> (31u - (hi & 31u));
-                const bool wide = dep && wh - wl > 1u;                   // (whole words between the two: a source of > 32 sequences)
-                const volatile lds_u32* dn = (const volatile lds_u32*)X.done();
-                const lds_u8* const srcp = X.win() + (s0 - Lo);          // (only used where the source lies in the window)
-                const uint32_t nfull = s.ml >> 4, rem = s.ml & 15u;
-                const bool inl2 = s.off >= 16u && s.ml <= 256u && near;
-                uint32_t spins = 0u;
-                while (__any(pending)) {
-                    bool ready = false;
-                    if (pending) {
-                        const uint32_t d1 = dn[wl], d2 = dn[wh];
-                        ready = (d1 & m1) == m1 && (d2 & m2) == m2;
-                        if (wide) for (uint32_t w = wl + 1u; ready && w < wh; ++w) ready = dn[w] == 0xFFFFFFFFu;
-                    }
-                    if (__any(ready)) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // the producers' bytes behind their DONE bits
-                        if (ready && inl2) {
-                            for (uint32_t k = 0u; k < nfull; ++k) st16l(dstp + 16u * k, ld16l(srcp + 16u * k));
-                            if (rem != 0u) st_exact(dstp + 16u * nfull, ld16l(srcp + 16u * nfull), rem);
-                        }
-                        copy_coop(ready && !inl2);
-                        if (ready) { publish(); pending = false; }
-                        PCD_COUNT(21, 1)
-                        turns_ready++;
-                    } else {
-                        __builtin_amdgcn_s_sleep(LZ4P_SLEEP);
-                        PCD_COUNT(22, 1)
-                        turns_idle++;
-                        if (++spins > (1u << 22)) { ctl[C_TIMEOUT] = 1u; break; }   // (cannot happen: the lowest open match is always ready)
-                    }
-                }
-                PCD_WAVE_ADD(26, tw1 - tw0) PCD_WAVE_ADD(27, PCD_NOW() - tw1) PCD_WAVE_ADD(28, turns_ready) PCD_WAVE_ADD(29, turns_idle)
-                PCD_WAVE_ADD(30, __builtin_popcountll(__ballot(has_m && !inl))) PCD_WAVE_ADD(31, __builtin_popcountll(__ballot(has_m && dep)))
-            }
+            for (uint32_t u = 0; u < S; ++u) X.match_slot(sq[u], u * G::T + tid, has_m[u], ex[u], OP, Lo, cnt);
             __syncthreads();
             PCD_TICK(7)
             if (ctl[C_TIMEOUT] != 0u) { bad = true; break; }

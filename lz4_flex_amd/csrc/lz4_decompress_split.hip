@@ -341,22 +341,24 @@ __global__ void __launch_bounds__((64 * split_waves<NB * G / 64, G>())) lz4_deco
     static_assert(NB <= 64 && (NB * G) % 64 == 0, "geometry");
     const uint32_t pw = threadIdx.x / 64u;
     uint32_t wave = pw;                                    // role: < CW copier, == CW parser
+    // (the padding wavefronts only exist to place the others on the SIMDs: they take part in the workgroup's one barrier -- a
+    // wavefront that ends before a barrier the others wait at is outside what HIP defines -- and end right behind it)
     if (G != 8u) {
         if (CW == 4u) {
-            if (pw >= 5u) return;
+            if (pw >= 5u) { __syncthreads(); return; }
             wave = pw == 3u ? CW : (pw < 3u ? pw : 3u);
         } else if (CW == 2u) {
-            if (pw == 2u) return;
+            if (pw == 2u) { __syncthreads(); return; }
             wave = pw == 3u ? CW : pw;
         }
     } else if (split_iso<CW, G>()) {
 #if LZ4S_ISO_WAVES == 12
-        if (pw == 7u || pw >= 10u) return;                 // (finished wavefronts do not count at the barrier)
+        if (pw == 7u || pw >= 10u) { __syncthreads(); return; }
         wave = pw == 3u ? CW : (pw < 3u ? pw : (pw < 7u ? pw - 1u : pw - 2u));
 #elif LZ4S_ISO_WAVES == 9      // experiment: the parser shares SIMD 3 with one copier
         wave = pw == 3u ? CW : (pw < 3u ? pw : pw - 1u);
 #elif LZ4S_ISO_WAVES == 10     // experiment: parser + wavefront 7 idle: SIMDs 0, 1, 2 carry 3, 3, 2 copiers (as 12) 
-        if (pw == 7u) return;
+        if (pw == 7u) { __syncthreads(); return; }
         wave = pw == 3u ? CW : (pw < 3u ? pw : (pw < 7u ? pw - 1u : pw - 2u));
 #endif
     }

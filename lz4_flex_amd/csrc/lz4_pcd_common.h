@@ -41,11 +41,19 @@ constexpr uint32_t NP = CT / P;           // 256 parts
 constexpr uint32_t MAX_ITERS = NP + 2u;
 constexpr uint32_t MAXSEQ = CT / 3u + 2u; // a sequence with a match is at least 3 bytes (token, offset)
 // ---- copy side --------------------------------------------------------------------------------------------------------
-// The tile's sequences are executed in BATCHES of up to BATCH consecutive sequences, one lane each, on an LDS WINDOW of the
-// output: HIST bytes of history before the batch + at most WNEW bytes the batch produces.
-constexpr uint32_t BATCH = 1024u;
-constexpr uint32_t HIST = 49152u;
-constexpr uint32_t WNEW = 32768u;
+// The tile's sequences are executed in BATCHES of up to BATCH consecutive sequences (THREADS lanes, SEQ_PER_LANE each) on an LDS
+// WINDOW of the output: HIST bytes of history before the batch + at most WNEW bytes the batch produces.
+constexpr uint32_t THREADS = 1024u;
+constexpr uint32_t SEQ_PER_LANE = 2u;
+constexpr uint32_t BATCH = THREADS * SEQ_PER_LANE;
+#ifndef LZ4P_HIST
+#define LZ4P_HIST 32768
+#endif
+#ifndef LZ4P_WNEW
+#define LZ4P_WNEW 49152
+#endif
+constexpr uint32_t HIST = LZ4P_HIST;
+constexpr uint32_t WNEW = LZ4P_WNEW;
 constexpr uint32_t WIN = HIST + WNEW;
 constexpr uint32_t X_END = 0xFFFFFFFFu;   // exit: the block's last sequence ended exactly at the block's end
 constexpr uint32_t X_ERR = 0xFFFFFFFEu;   // exit: this chain cannot be a real one (ran past the end, offset 0, ...)

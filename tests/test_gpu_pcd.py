@@ -102,7 +102,7 @@ def test_first_pass_marks_exactly_what_the_model_calls_irregular(env, variant):
     rnd = random.Random(3)
     big = O.compress(bytes(rnd.choice(b"ab") for _ in range(60000)))
     cases += [(big, 60000), (big, 59990), (big[:-5], 60000)]
-    prm = M.defaults() if variant == 7 else M.Params(ct=2048, p=64, batch=128, hist=512, wnew=1024, max_iters=34)
+    prm = M.defaults() if variant == 7 else M.Params(ct=2048, p=64, batch=256, hist=512, wnew=1024, max_iters=34)
     model = [M.decode(c, k, prm, seed=i)[0] for i, (c, k) in enumerate(cases)]
     want = [O.decompress(c, k) for c, k in cases]
     comps, caps = [c for c, _ in cases], [k for _, k in cases]
