@@ -11,10 +11,12 @@
 #include <vector>
 
 #include "../../include/lz4flex_amd.h"
+#include "host_pin.h"
 #include "xxh32.h"
 
 namespace {
 
+using lz4flex::PinBuf;
 using lz4flex::XxHash32;
 
 // src/frame/header.rs:11-34
@@ -128,9 +130,9 @@ struct lz4flex_frame_encoder {
     lz4flex_frame_info fi{};
     lz4flex_write_fn w = nullptr;
     void* user = nullptr;
-    std::vector<uint8_t> src;      // staged uncompressed bytes (whole blocks + a partial tail)
+    PinBuf src;                    // staged uncompressed bytes (whole blocks + a partial tail); page-locked: host_pin.h
     size_t src_len = 0;
-    std::vector<uint8_t> dst;      // compressed blocks at a fixed stride
+    PinBuf dst;                    // compressed blocks at a fixed stride
     std::vector<uint64_t> in_off, out_off;
     std::vector<uint32_t> in_len, out_cap, out_len, flags;
     std::vector<int32_t> status;
@@ -144,7 +146,7 @@ struct lz4flex_frame_encoder {
     int sticky_err = 0;
     // Linked mode (frame/compress.rs:62-93): the reference's src ring (prefix + ext_dict) expressed in
     // stream coordinates; the dependent blocks of a batch run as ONE chain on the GPU.
-    std::vector<uint8_t> lstage;        // stream bytes [lbase, lbase + lstage_len)
+    PinBuf lstage;                      // stream bytes [lbase, lbase + lstage_len)
     size_t lstage_len = 0;
     uint64_t lbase = 0;                 // stream position of lstage[0]
     uint64_t proc_pos = 0;              // stream position of the first byte not yet compressed
@@ -307,7 +309,9 @@ struct lz4flex_frame_encoder {
     }
     int64_t write_linked(const uint8_t* buf, size_t len) {
         const size_t mbs = block_size_bytes(fi.block_size);
-        const size_t per_launch = std::min<size_t>(batch_blocks, 64) * mbs;
+        // (exact mode: the blocks of a launch are ONE dependency chain on the device -- 64 of them keep a launch in the tens of
+        // milliseconds; throughput encoder: independent blocks, a full batch per launch)
+        const size_t per_launch = (linked_fast ? batch_blocks : std::min<size_t>(batch_blocks, 64)) * mbs;
         const size_t total = len;
         while (len) {
             const size_t pending = (size_t)(lbase + lstage_len - proc_pos);
@@ -421,7 +425,7 @@ struct lz4flex_frame_decoder {
     size_t batch_bytes = 64u << 20;
     bool batch_auto = true;
     // staged batch
-    std::vector<uint8_t> comp, out;
+    PinBuf comp, out;          // page-locked staging (host_pin.h)
     std::vector<uint64_t> in_off, out_off, detail;
     std::vector<uint32_t> in_len, out_cap, out_len;
     std::vector<int32_t> status;
@@ -432,7 +436,7 @@ struct lz4flex_frame_decoder {
     lz4flex_err_detail pending_detail{};
     bool pending_zero = false; // EndMark reached: one read() returns 0
     // Linked-mode window (frame/decompress.rs:62-72): exact mirror of the reference's dst ring
-    std::vector<uint8_t> ldst;
+    PinBuf ldst;
     size_t ext_dict_offset = 0, ext_dict_len = 0, dst_start = 0;
     size_t lhave = 0;              // Linked: valid bytes in ldst (history + what the last call produced)
 

@@ -336,31 +336,37 @@ class FrameDecoder:
                 pass
 
 
+_new_bytes = C.pythonapi.PyBytes_FromStringAndSize      # an uninitialised bytes object the library writes into: no zero-fill,
+_new_bytes.restype = C.py_object                         # no copy out (a 4 MiB ctypes array costs 0.35 ms to create and as much to
+_new_bytes.argtypes = [C.c_char_p, C.c_ssize_t]          # turn into bytes -- more than the GPU work on it)
+
+
+def _as_bytes(data):
+    return data if isinstance(data, bytes) else bytes(data)
+
+
 def compress_frame(data, frame_info=None):
     """one-shot: FrameEncoder::with_frame_info + write_all + finish over flat buffers"""
     lib = L.load()
     fi = (frame_info or FrameInfo())._c()
-    b = bytes(data)
+    b = _as_bytes(data)
     cap = int(lib.lz4flex_frame_compress_bound(len(b), C.byref(fi)))
-    out = (C.c_uint8 * cap)()
-    inp = (C.c_uint8 * max(len(b), 1)).from_buffer_copy(b or b"\0")
+    out = _new_bytes(None, cap)
     d = L.ErrDetail()
-    r = lib.lz4flex_frame_compress(C.cast(inp, C.c_void_p), len(b), C.byref(fi), C.cast(out, C.c_void_p), cap, C.byref(d))
+    r = lib.lz4flex_frame_compress(b, len(b), C.byref(fi), out, cap, C.byref(d))
     if r < 0:
         raise _frame_error(int(-r), d)
-    return C.string_at(out, r)
+    return out[:r]
 
 
 def decompress_frame(data, max_size):
     """one-shot: FrameDecoder::new + read_to_end (first frame). Returns (bytes, consumed)."""
     lib = L.load()
-    b = bytes(data)
-    out = (C.c_uint8 * max(max_size, 1))()
-    inp = (C.c_uint8 * max(len(b), 1)).from_buffer_copy(b or b"\0")
+    b = _as_bytes(data)
+    out = _new_bytes(None, max(max_size, 1))
     d = L.ErrDetail()
     consumed = C.c_size_t(0)
-    r = lib.lz4flex_frame_decompress(C.cast(inp, C.c_void_p), len(b), C.cast(out, C.c_void_p), max_size,
-                                     C.byref(consumed), C.byref(d))
+    r = lib.lz4flex_frame_decompress(b, len(b), out, max_size, C.byref(consumed), C.byref(d))
     if r < 0:
         raise _frame_error(int(-r), d)
-    return C.string_at(out, r), int(consumed.value)
+    return out[:r], int(consumed.value)         # (the whole object when the frame filled it: no copy)

@@ -36,20 +36,22 @@ __global__ void k(const uint32_t* addr, uint64_t* out, int iters, int waves, int
 int main() {
     uint32_t* d_addr; uint64_t* d_out; hipMalloc(&d_addr, 512 * 4); hipMalloc(&d_out, 8 * 64 * 8);
     const int iters = 200;
-    struct { const char* name; int mode; } pats[] = {{"random aligned", 0}, {"random unaligned", 1}};
-    for (int waves : {8}) for (int nact : {64, 32, 16, 8, 4, 1}) for (auto& p : pats) for (int bytes : {1, 2, 4, 16}) {
+    struct { const char* name; int mode; } pats[] = {{"random aligned", 0}, {"random unaligned", 1}, {"random, dword aligned only", 5}};
+    for (int waves : {8}) for (int nact : {64, 32, 16, 8, 4, 1}) for (auto& p : pats) for (int bytes : {1, 2, 4, 8, 16}) {
+        if (p.mode == 5 && bytes < 8) continue;
         uint32_t h[512]; srand(7);
         for (int j = 0; j < 512; j++) {
             uint32_t r = rand() % 60000;
             if (p.mode == 0) r &= ~(bytes - 1u);
             if (p.mode == 1) r |= 1u;
+            if (p.mode == 5) r = (r & ~15u) | 4u;
             if (p.mode == 2) r = 1000 * (j / 64) + (j % 64) + 1;
             if (p.mode == 3) r = 2048 * (j / 64) + (j % 64) * 16;
             if (p.mode == 4) r = ((j % 64) % 5 == 0) ? (r | 1u) : 4096u * (j / 64) + 3u;
             h[j] = r;
         }
         hipMemcpy(d_addr, h, sizeof h, hipMemcpyHostToDevice);
-        void (*kern)(const uint32_t*, uint64_t*, int, int, int) = bytes == 16 ? k<16> : bytes == 1 ? k<1> : bytes == 4 ? k<4> : k<2>;
+        void (*kern)(const uint32_t*, uint64_t*, int, int, int) = bytes == 16 ? k<16> : bytes == 8 ? k<8> : bytes == 1 ? k<1> : bytes == 4 ? k<4> : k<2>;
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 64);
         hipLaunchKernelGGL(kern, dim3(1), dim3(64 * waves), 65536 + 64, 0, d_addr, d_out, iters, waves, nact);
         hipDeviceSynchronize();
