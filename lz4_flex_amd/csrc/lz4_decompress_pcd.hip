@@ -167,6 +167,43 @@ template <class G>
 __device__ __attribute__((noinline)) uint32_t seq_slow(const Rd<G>& rd, uint32_t ilen, uint32_t p, Seq& s) {
     return parse_seq(rd, ilen, p, s);
 }
+// the walk's slow path: where the sequence at p ends, offsets not looked at (lz4_pcd_common.h)
+template <class G>
+__device__ __attribute__((noinline)) uint32_t walk_slow(const Rd<G>& rd, uint32_t ilen, uint32_t p) {
+    Seq s;
+    return parse_seq<Rd<G>, false>(rd, ilen, p, s);
+}
+// One hop of a WALK from the token at p (cbase <= p < cbase + CT): the next token position, X_END or X_ERR -- parse_seq<.., false>.
+// A walk only needs where a sequence ENDS: token and literal length byte give that, except for the match length byte of a
+// token whose match nibble is 15, which lies right before the NEXT token -- so every hop reads the four bytes from p - 1 on
+// (ONE LDS round trip; seq_at needs two) and first checks that the previous hop's length byte, if it assumed one, is not 255
+// (redo: the previous sequence is walked again by the byte-wise path).  b15: this hop assumed such a byte at (result - 1).
+template <class G>
+__device__ __forceinline__ uint32_t hop_at(const Rd<G>& rd, uint32_t ilen, uint32_t staged, uint32_t p, bool prev15, bool& redo, bool& b15,
+                                           uint32_t mark_addr, uint32_t& mark_word) {
+    const uint32_t r = p - rd.cbase;
+    const uint32_t base = (uint32_t)(uintptr_t)rd.ct;
+    const uint32_t ra = r != 0u ? r - 1u : 0u;                          // (the tile's first token has nothing before it)
+    uint64_t d01;
+    uint32_t mk;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(mk) : "v"(mark_addr) : "memory");
+    asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(d01) : "v"(base + (ra & ~3u)) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d01), "+v"(mk) :: "memory");
+    mark_word = mk;
+    uint32_t w = __builtin_amdgcn_alignbyte((uint32_t)(d01 >> 32), (uint32_t)d01, ra & 3u);
+    w = r != 0u ? w : w << 8;                                            // byte 0: the byte before the token, 1: token, 2: literal length byte
+    const bool inl = r + 8u <= staged;                                   // those bytes are staged
+    redo = prev15 && (inl ? (w & 0xFFu) == 0xFFu : rd(p - 1u) == 0xFFu);
+    const uint32_t t = (w >> 8) & 0xFFu, lc = t >> 4, e1 = (w >> 16) & 0xFFu;
+    const uint32_t l15 = lc == 15u ? 1u : 0u;
+    const uint32_t q = p + 1u + l15 + lc + (l15 ? e1 : 0u);             // the offset's position
+    b15 = (t & 15u) == 15u;
+    const bool usual = inl && !(l15 && e1 == 255u) && q + 3u < ilen;     // one length byte at most, offset, a length byte and one more byte exist
+    if (usual) return q + 2u + (b15 ? 1u : 0u);
+    b15 = false;
+    return redo ? 0u : walk_slow(rd, ilen, p);
+}
+
 // mark_addr: LDS byte address of a word that is fetched in the same round trip (the walk's "was this position marked before"),
 // or 0; its value comes back in *mark_word.
 template <class G>
@@ -599,20 +636,37 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 uint32_t nm[G::PW];
 #pragma unroll
                 for (uint32_t w = 0; w < G::PW; ++w) nm[w] = 0u;
-                uint32_t p = my_e, x = 0u, mw = G::PW, mbit = 0u;
-                bool merged = false;
+                uint32_t p = my_e, prev_p = my_e, x = 0u, mw = G::PW, mbit = 0u;
+                bool merged = false, p15 = false;                      // p15: the hop from prev_p assumed ONE match length byte, at p - 1
                 for (;;) {
-                    if (p >= pend) { x = p; break; }
+                    if (p >= pend) {
+                        if (p15 && rd(p - 1u) == 0xFFu) {              // (p - 1 < ilen: a hop's "usual" case has a byte behind that one)
+                            p15 = false;
+                            p = walk_slow(rd, X.ilen, prev_p);
+                            if (p >= X_ERR) { x = p; break; }
+                            continue;
+                        }
+                        x = p;
+                        break;
+                    }
                     const uint32_t r = p - cbase;
                     const uint32_t wi = (r >> 5) - tid * G::PW, bit = 1u << (r & 31u);
                     uint32_t oldw;                                     // (fetched together with the token's dwords)
-                    Seq s;
-                    const uint32_t nx = seq_at(rd, X.ilen, staged, p, s, (uint32_t)(uintptr_t)(X.marks() + (r >> 5)), &oldw);
+                    bool redo, b15;
+                    const uint32_t nx = hop_at(rd, X.ilen, staged, p, p15, redo, b15, (uint32_t)(uintptr_t)(X.marks() + (r >> 5)), oldw);
                     PCD_COUNT(24, 1)
+                    if (redo) {                                        // p was not a token: the sequence before it is longer
+                        p15 = false;
+                        p = walk_slow(rd, X.ilen, prev_p);
+                        if (p >= X_ERR) { x = p; break; }
+                        continue;
+                    }
                     if ((oldw & bit) != 0u) { merged = true; mw = wi; mbit = r & 31u; break; }
 #pragma unroll
                     for (uint32_t w = 0; w < G::PW; ++w) nm[w] |= w == wi ? bit : 0u;
                     if (nx >= X_ERR) { x = nx; break; }
+                    prev_p = p;
+                    p15 = b15;
                     p = nx;
                 }
                 if (merged) {

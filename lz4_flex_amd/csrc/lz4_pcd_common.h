@@ -68,7 +68,10 @@ struct Seq {
 // One sequence whose token is at p (p < ilen); rd(pos) returns the compressed byte at pos < ilen.  Returns the position of
 // (rd.u32(pos): the four bytes at pos, pos + 4 <= ilen) the next token, X_END, or X_ERR.  Checks: everything src/block/decompress.rs:244-443 checks WITHOUT knowing the output
 // position (the copy side checks offset <= position and the sink's capacity).
-template <class R>
+// CHECK_OFF = false is the WALK's notion of "next token": the same positions, but an offset of zero does not end the chain --
+// a walk only needs where the sequence ends, and the kernel's walk never reads the offset (one LDS round trip per hop instead
+// of two).  The copy side decodes every sequence of the true chain again with CHECK_OFF = true, so the error is found there.
+template <class R, bool CHECK_OFF = true>
 PCD_FN uint32_t parse_seq(const R& rd, uint32_t ilen, uint32_t p, Seq& s) {
     const uint32_t t = rd(p);
     uint32_t q = p + 1u;
@@ -98,7 +101,7 @@ PCD_FN uint32_t parse_seq(const R& rd, uint32_t ilen, uint32_t p, Seq& s) {
     if (ilen - q < 2u) return X_ERR;                    // :373-375
     const uint32_t off = rd(q) | (rd(q + 1u) << 8);
     q += 2u;
-    if (off == 0u) return X_ERR;                        // :168-173
+    if (CHECK_OFF && off == 0u) return X_ERR;           // :168-173
     uint32_t ml = 4u + (t & 15u);
     if (ml == 19u) {
         while (ilen - q >= 4u && rd.u32(q) == 0xFFFFFFFFu) {

@@ -90,7 +90,7 @@ extern "C" long pcd_model_decode(const uint8_t* c, uint32_t n, uint8_t* out, uin
                     if (p >= pend) { xn = p; break; }
                     marks[p - cbase] = 1;
                     Seq s;
-                    const uint32_t nx = parse_seq(rd, n, p, s);
+                    const uint32_t nx = parse_seq<Rd, false>(rd, n, p, s);      // (the walk does not look at offsets: lz4_pcd_common.h)
                     st->hops++;
                     if (nx >= X_ERR) { xn = nx; break; }
                     p = nx;
@@ -135,7 +135,7 @@ extern "C" long pcd_model_decode(const uint8_t* c, uint32_t n, uint8_t* out, uin
             uint32_t cnt = 0;
             for (uint32_t i = 0; i < m; i++) {
                 const uint32_t nx = parse_seq(rd, n, tok[idx + i], sq[i]);
-                if (nx == X_ERR) return -1;                  // (cannot happen: the walk parsed it)
+                if (nx == X_ERR) return -1;                  // (an offset of zero: the walk went past it)
                 if (nx == X_END && !(ended && idx + i + 1 == tok.size())) return -1;
                 const uint64_t len = (uint64_t)sq[i].lit + sq[i].ml;
                 if (acc + len > prm->wnew) break;
