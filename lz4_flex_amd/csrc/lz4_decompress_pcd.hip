@@ -177,10 +177,11 @@ __device__ __attribute__((noinline)) uint32_t walk_slow(const Rd<G>& rd, uint32_
 // A walk only needs where a sequence ENDS: token and literal length byte give that, except for the match length byte of a
 // token whose match nibble is 15, which lies right before the NEXT token -- so every hop reads the four bytes from p - 1 on
 // (ONE LDS round trip; seq_at needs two) and first checks that the previous hop's length byte, if it assumed one, is not 255
-// (redo: the previous sequence is walked again by the byte-wise path).  b15: this hop assumed such a byte at (result - 1).
+// (prev255: then the previous sequence is walked again by the byte-wise path).  b15: this hop assumes such a byte at nx - 1.
+// Straight-line: the caller decides what applies (usual: nx is the next token).
+struct Hop { uint32_t nx; bool b15, usual, inl, prev255; };
 template <class G>
-__device__ __forceinline__ uint32_t hop_at(const Rd<G>& rd, uint32_t ilen, uint32_t staged, uint32_t p, bool prev15, bool& redo, bool& b15,
-                                           uint32_t mark_addr, uint32_t& mark_word) {
+__device__ __forceinline__ Hop hop_at(const Rd<G>& rd, uint32_t ilen, uint32_t staged, uint32_t p, uint32_t mark_addr, uint32_t& mark_word) {
     const uint32_t r = p - rd.cbase;
     const uint32_t base = (uint32_t)(uintptr_t)rd.ct;
     const uint32_t ra = r != 0u ? r - 1u : 0u;                          // (the tile's first token has nothing before it)
@@ -192,16 +193,16 @@ __device__ __forceinline__ uint32_t hop_at(const Rd<G>& rd, uint32_t ilen, uint3
     mark_word = mk;
     uint32_t w = __builtin_amdgcn_alignbyte((uint32_t)(d01 >> 32), (uint32_t)d01, ra & 3u);
     w = r != 0u ? w : w << 8;                                            // byte 0: the byte before the token, 1: token, 2: literal length byte
-    const bool inl = r + 8u <= staged;                                   // those bytes are staged
-    redo = prev15 && (inl ? (w & 0xFFu) == 0xFFu : rd(p - 1u) == 0xFFu);
+    Hop h;
+    h.inl = r + 8u <= staged;                                            // those bytes are staged
+    h.prev255 = (w & 0xFFu) == 0xFFu;
     const uint32_t t = (w >> 8) & 0xFFu, lc = t >> 4, e1 = (w >> 16) & 0xFFu;
     const uint32_t l15 = lc == 15u ? 1u : 0u;
     const uint32_t q = p + 1u + l15 + lc + (l15 ? e1 : 0u);             // the offset's position
-    b15 = (t & 15u) == 15u;
-    const bool usual = inl && !(l15 && e1 == 255u) && q + 3u < ilen;     // one length byte at most, offset, a length byte and one more byte exist
-    if (usual) return q + 2u + (b15 ? 1u : 0u);
-    b15 = false;
-    return redo ? 0u : walk_slow(rd, ilen, p);
+    h.b15 = (t & 15u) == 15u;
+    h.usual = h.inl && !(l15 && e1 == 255u) && q + 3u < ilen;            // one length byte at most; offset, a length byte and one more byte exist
+    h.nx = q + 2u + (h.b15 ? 1u : 0u);
+    return h;
 }
 
 // mark_addr: LDS byte address of a word that is fetched in the same round trip (the walk's "was this position marked before"),
@@ -636,39 +637,60 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 uint32_t nm[G::PW];
 #pragma unroll
                 for (uint32_t w = 0; w < G::PW; ++w) nm[w] = 0u;
+                // The loop is UNIFORM (every lane of the wavefront turns until the last one is through) and its body straight-line:
+                // written with per-lane breaks it was 250 instructions a hop, half of them exec-mask bookkeeping.  A lane whose
+                // chain has left the part with an unchecked length byte makes one more turn that only checks it.
                 uint32_t p = my_e, prev_p = my_e, x = 0u, mw = G::PW, mbit = 0u;
                 bool merged = false, p15 = false;                      // p15: the hop from prev_p assumed ONE match length byte, at p - 1
-                for (;;) {
-                    if (p >= pend) {
-                        if (p15 && rd(p - 1u) == 0xFFu) {              // (p - 1 < ilen: a hop's "usual" case has a byte behind that one)
-                            p15 = false;
-                            p = walk_slow(rd, X.ilen, prev_p);
-                            if (p >= X_ERR) { x = p; break; }
-                            continue;
-                        }
-                        x = p;
-                        break;
-                    }
-                    const uint32_t r = p - cbase;
+                bool act = true;
+                const unsigned long long pr_w0 = PCD_NOW();
+                uint32_t pr_rare = 0u;
+                while (act) {
+                    const bool over = p >= pend;                       // the chain has left the part: p is the exit once p - 1 is checked
+                    if (over && !p15) { x = p; act = false; }
+                    const uint32_t pp = act ? p : cbase;               // (lanes that are through read something harmless)
+                    const uint32_t r = pp - cbase;
                     const uint32_t wi = (r >> 5) - tid * G::PW, bit = 1u << (r & 31u);
                     uint32_t oldw;                                     // (fetched together with the token's dwords)
-                    bool redo, b15;
-                    const uint32_t nx = hop_at(rd, X.ilen, staged, p, p15, redo, b15, (uint32_t)(uintptr_t)(X.marks() + (r >> 5)), oldw);
+                    const Hop h = hop_at(rd, X.ilen, staged, pp, (uint32_t)(uintptr_t)(X.marks() + (r >> 5)), oldw);
                     PCD_COUNT(24, 1)
-                    if (redo) {                                        // p was not a token: the sequence before it is longer
-                        p15 = false;
-                        p = walk_slow(rd, X.ilen, prev_p);
-                        if (p >= X_ERR) { x = p; break; }
-                        continue;
-                    }
-                    if ((oldw & bit) != 0u) { merged = true; mw = wi; mbit = r & 31u; break; }
+                    const bool rare = act && (!h.inl || (p15 && h.prev255) || (!over && !h.usual));
+                    if (__any(rare)) {
+                        pr_rare += 1u;
+                        if (rare) {
+                            const bool redo = p15 && (h.inl ? h.prev255 : rd(p - 1u) == 0xFFu);
+                            if (redo) {                                // p is not a token: the sequence before it is longer
+                                p = walk_slow(rd, X.ilen, prev_p);
+                                if (p >= X_ERR) { x = p; act = false; }
+                            } else if (over) {
+                                x = p; act = false;
+                            } else if ((oldw & bit) != 0u) {
+                                merged = true; mw = wi; mbit = r & 31u; act = false;
+                            } else {
 #pragma unroll
-                    for (uint32_t w = 0; w < G::PW; ++w) nm[w] |= w == wi ? bit : 0u;
-                    if (nx >= X_ERR) { x = nx; break; }
-                    prev_p = p;
-                    p15 = b15;
-                    p = nx;
+                                for (uint32_t w = 0; w < G::PW; ++w) nm[w] |= w == wi ? bit : 0u;
+                                const uint32_t nx = h.usual ? h.nx : walk_slow(rd, X.ilen, p);
+                                prev_p = p;
+                                if (nx >= X_ERR) { x = nx; act = false; } else p = nx;
+                            }
+                            p15 = act && !redo && !over && h.usual && h.b15;
+                        }
+                    }
+                    if (act && !rare) {
+                        if (over) {                                    // the length byte before the exit is an ordinary one
+                            x = p; act = false;
+                        } else if ((oldw & bit) != 0u) {
+                            merged = true; mw = wi; mbit = r & 31u; act = false;
+                        } else {
+#pragma unroll
+                            for (uint32_t w = 0; w < G::PW; ++w) nm[w] |= w == wi ? bit : 0u;
+                            prev_p = p;
+                            p15 = h.b15;
+                            p = h.nx;                                  // (usual: a real position, below X_ERR)
+                        }
+                    }
                 }
+                PCD_COUNT(25, PCD_NOW() - pr_w0) PCD_COUNT(23, pr_rare) (void)pr_rare;
                 if (merged) {
 #pragma unroll
                     for (uint32_t w = 0; w < G::PW; ++w) {
@@ -686,7 +708,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
             // no exit changed since the exits were last followed: every walk of this round fell into step with its part's old chain,
             // entries and live parts are what the last round found -- the tile is settled without following them again
             const int any_exit = __syncthreads_or(exit_changed ? 1 : 0);
-            PCD_TICK(1) PCD_COUNT(17, 1)
+            PCD_COUNT(it == 0u ? 21 : 22, PCD_NOW() - pr_t0) PCD_TICK(1) PCD_COUNT(17, 1)
             if (!any_exit) { settled = true; break; }
             if (X.wv == 0u) X.resolve(cbase, parts);
             __syncthreads();

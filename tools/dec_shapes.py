@@ -98,7 +98,9 @@ def main():
                     pv[18] / n, pv[19] / max(pv[18], 1), pv[20] / n), flush=True)
                 print("      wavefront 0 per batch: polling turns with a ready match %.1f, without %.1f, wavefront copies %.1f" % (
                     pv[21] / max(pv[18], 1), pv[22] / max(pv[18], 1), pv[23] / max(pv[18], 1)), flush=True)
-                print("      thread 0: hops per walk round %.1f, cycles per hop %.0f" % (pv[24] / max(pv[17], 1), pv[1] / max(pv[24], 1)), flush=True)
+                print("      thread 0: hops per walk round %.1f, cycles per hop %.0f (inside its own loop: %.0f; turns with a rare lane in its wavefront: %.2f of its hops)" %
+                      (pv[24] / max(pv[17], 1), pv[1] / max(pv[24], 1), pv[25] / max(pv[24], 1), pv[23] / max(pv[24], 1)), flush=True)
+                print("      walk rounds: the first %.0f cycles, the later ones %.0f each" % (pv[21] / max(pv[16], 1), pv[22] / max(pv[17] - pv[16], 1)), flush=True)
                 nwb = max(pv[18], 1) * 16
                 print("      per wavefront and batch: %.0f cycles in the matches without producers, %.0f polling (%.1f turns with a ready match, %.1f without); "
                       "per batch: %.0f matches with producers, %.0f copied by a whole wavefront" % (pv[26] / nwb, pv[27] / nwb, pv[28] / nwb, pv[29] / nwb,
