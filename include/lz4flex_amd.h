@@ -227,7 +227,10 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  *   (16; 8/32/64 in -DLZ4FLEX_ALL_VARIANTS builds, variant 1); exact encoder: "compress_lanes" (8/16 lanes of a wavefront per
  *   block), "compress_variant" (1 = group encoder + emitter wavefront; 3 = group encoder alone, -DLZ4FLEX_ALL_VARIANTS builds);
  *   "decompress_second_pass" (tests: 0 leaves the blocks that variants 5..8 hand to the reference-order kernel marked with
- *   status 0x7F000001 instead of decoding them again). */
+ *   status 0x7F000001 instead of decoding them again); "compress_carry_wait" (tests: 0 = a 64 KiB window of the throughput
+ *   encoder that has to wait for the window before it -- few, large blocks: a block's windows run on different workgroups --
+ *   gives up at once instead of after a fraction of a second; such a block is encoded again by the launch that follows, to
+ *   the same bytes: a time-sliced GPU costs time, never an error). */
 int lz4flex_set_tuning(lz4flex_ctx *ctx, const char *key, int value);
 /* the current value of a setting (>= 0), or -LZ4FLEX_E_INVALID_ARG for an unknown key */
 int lz4flex_get_tuning(lz4flex_ctx *ctx, const char *key);

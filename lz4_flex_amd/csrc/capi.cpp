@@ -59,6 +59,7 @@ struct lz4flex_ctx {
     bool wave_used = false;
     int dec_blocks_per_wg = 0;    // split decoder: blocks per workgroup (8/16/32/64), 0 = by batch size
     int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 4 = parser / copier split (lz4_decompress_split.hip), 5 / 6 = a wavefront / a pair of wavefronts per block (lz4_decompress_wave.hip), 7 = a workgroup per block (lz4_decompress_pcd.hip; 8: its test geometry)
+    int comp_carry_wait = 1;      // tests: 0 = a window of the throughput encoder that has to wait for its predecessor's carry gives up at once (the block then takes the second launch)
     int dec_second_pass = 1;      // tests: 0 leaves the blocks a first-pass decoder marked (status 0x7F000001) instead of decoding them again
 };
 
@@ -113,7 +114,7 @@ static int launch_compress_any(lz4flex_ctx* c, const CompressArgs& a, bool big, 
     if (c->comp_mode == 0) {
         if (!c->wave_ws || !c->wave_done) { g_last_error = "context without encoder workspace"; return -LZ4FLEX_E_INVALID_ARG; }
         if (c->wave_used && s != c->wave_last) HIP_TRY(hipStreamWaitEvent(s, c->wave_done, 0));
-        le = launch_compress_wave(a, c->wave_ws, c->wave_wgs, s, c->wave_prof);
+        le = launch_compress_wave(a, c->wave_ws, c->wave_wgs, s, c->wave_prof, c->comp_carry_wait != 0);
         if (le == hipSuccess) {
             HIP_TRY(hipEventRecord(c->wave_done, s));
             c->wave_last = s;
@@ -297,6 +298,11 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         c->dec_second_pass = value;
         return 0;
     }
+    if (!strcmp(key, "compress_carry_wait")) {
+        if (value != 0 && value != 1) return -LZ4FLEX_E_INVALID_ARG;
+        c->comp_carry_wait = value;
+        return 0;
+    }
     if (!strcmp(key, "compress_variant")) {
 #ifdef LZ4FLEX_ALL_VARIANTS
         if (value != 1 && value != 3) return -LZ4FLEX_E_INVALID_ARG;
@@ -319,6 +325,7 @@ int lz4flex_get_tuning(lz4flex_ctx* c, const char* key) {
     if (!c) { const int rc = default_ctx(&c); if (rc) return rc; }
     if (!strcmp(key, "compress_mode")) return c->comp_mode;
     if (!strcmp(key, "compress_variant")) return c->comp_variant;
+    if (!strcmp(key, "compress_carry_wait")) return c->comp_carry_wait;
     if (!strcmp(key, "compress_lanes")) return c->comp_lanes;
     if (!strcmp(key, "decompress_variant")) return c->dec_variant;
     if (!strcmp(key, "decompress_second_pass")) return c->dec_second_pass;

@@ -917,7 +917,7 @@ __device__ __forceinline__ void put_len_header(g_u8* dst, uint32_t lit, uint32_t
 // Place segment w of the current window (after the barrier: every worker's SegMeta is final).
 __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8_t* __restrict__ gin_, uint32_t blk_len_, uint32_t win_idx_, bool last_win_,
                               uint32_t wl_, uint32_t wbase_, uint32_t wskip_, const uint8_t* body_, uint8_t* gout_, uint32_t carry_slot_, uint32_t w_, uint32_t lane,
-                              uint32_t* out_len_, int32_t* status_, uint32_t* gcarry_, uint32_t iter_) {
+                              uint32_t* out_len_, int32_t* status_, uint32_t* gcarry_, uint32_t iter_, uint32_t spins_max_) {
     const g_u8* __restrict__ gin = uni_gptr<const g_u8>(gin_);
     const g_u8* body = uni_gptr<const g_u8>(body_);
     g_u8* gout = uni_gptr<g_u8>(gout_);
@@ -925,13 +925,15 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
     g_i32* status = uni_gptr<g_i32>(status_);
     const uint32_t blk_len = uni(blk_len_), win_idx = uni(win_idx_), wl = uni(wl_), carry_slot = uni(carry_slot_), w = uni(w_);
     const uint32_t wbase = uni(wbase_), wskip = uni(wskip_);       // the window's first byte in the block; its first wskip positions are history
+    const uint32_t spins_max = uni(spins_max_);                    // CARRY_SPINS (tests: 1 -- a window gives up at once)
     const bool last_win = uni((uint32_t)last_win_) != 0u;
     const lds_u32* mp = (const lds_u32*)(lds + L_META);
     lds_u32* cp = (lds_u32*)(lds + L_META) + 5u * WORKERS;          // BlkCarry[2]
     // Where this window's output starts and how many literals the block has pending: from the previous window, which this
     // workgroup placed itself (LDS) or, when the windows of a block are dealt to different workgroups (gcarry: a ring of
     // {out_pos, pend, window} records per block in the workspace), another one did -- that wait is bounded, a window that gives
-    // up poisons the rest of its block (pend bit 31) and the block reports a device failure.
+    // up poisons the rest of its block (pend bit 31): the block is left with status 66 and launch_compress_wave's second launch
+    // encodes it again.
     g_u32* gcarry = uni_gptr<g_u32>(gcarry_);
     uint32_t out_pos = 0u, pend = 0u, poisoned = 0u;
     if (win_idx != 0u) {
@@ -944,10 +946,10 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
             if (w == WORKERS - 1u) {
                 g_u32* sl = gcarry + 16u * (win_idx & (CARRY_SLOTS - 1u));
                 uint32_t spins = 0u;
-                while (__hip_atomic_load(sl + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != win_idx && ++spins < CARRY_SPINS) __builtin_amdgcn_s_sleep(16);
+                while (__hip_atomic_load(sl + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != win_idx && ++spins < spins_max) __builtin_amdgcn_s_sleep(16);
                 out_pos = __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 pend = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (spins >= CARRY_SPINS) pend = 0x80000000u;
+                if (spins >= spins_max) pend = 0x80000000u;
                 if (lane == 0u) { box[0] = out_pos; box[1] = pend; }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0u) box[2] = iter;
@@ -1018,7 +1020,7 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
             out_pos += 1u + len_ext_bytes(pend);
             copy_bytes(gout + out_pos, gin + (blk_len - pend), pend, lane);
             out_pos += pend;
-            if (lane == 0u) { *out_len = poisoned ? 0u : out_pos; *status = poisoned ? 66 /* LZ4FLEX_E_HIP: a window never got its carry */ : 0; }
+            if (lane == 0u) { *out_len = poisoned ? 0u : out_pos; *status = poisoned ? 66 /* a window never got its carry: launch_compress_wave's second launch encodes the block again */ : 0; }
         } else if (lane == 0u) {
             cp[2u * carry_slot] = out_pos;
             cp[2u * carry_slot + 1u] = pend;
@@ -1079,10 +1081,17 @@ __device__ __forceinline__ void item_load(const CompressArgs& a, Item& it) {
 // and draws that block's windows from the block's atomic counter (a team of one draws them in order; a drawn window is
 // always held by a running workgroup, so the wait for the previous window's carry cannot deadlock whatever is resident);
 // when its block has no windows left it moves on to the next block that has.
-__device__ __forceinline__ void item_next_block(const CompressArgs& a, Item& it) {
+// redo != 0 (the second launch behind a window-mode launch): only blocks whose status is `redo` -- a window of theirs gave up
+// waiting for its predecessor's carry (a time-sliced or preempted GPU) -- are encoded, again, in block mode, where nothing waits
+__device__ __forceinline__ void item_seek(const CompressArgs& a, Item& it, int32_t redo) {
+    if (redo != 0)
+        while (it.blk < a.n && a.status[it.blk] != redo) it.blk += gridDim.x;
+    item_load(a, it);
+}
+__device__ __forceinline__ void item_next_block(const CompressArgs& a, Item& it, int32_t redo) {
     if (it.win + 1u < it.nwin) { it.win += 1u; return; }
     it.blk += gridDim.x;
-    item_load(a, it);
+    item_seek(a, it, redo);
 }
 // window mode, one thread: the next window for this workgroup, starting the search at block b0 -> {block, window} (block == n: none)
 __device__ __forceinline__ void item_draw(const CompressArgs& a, uint32_t* wctr, uint32_t b0, uint32_t& ob, uint32_t& ow) {
@@ -1106,7 +1115,7 @@ __device__ __forceinline__ void item_draw(const CompressArgs& a, uint32_t* wctr,
 // [3] workers at the barrier behind matching, [4] placing, [5] loading the next window, [6] at the barrier behind loading,
 // [7] windows
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) lz4_compress_wave_kernel(const CompressArgs a, uint8_t* __restrict__ ws,
-                                                                    uint32_t* __restrict__ carry, unsigned long long* __restrict__ prof) {
+                                                                    uint32_t* __restrict__ carry, unsigned long long* __restrict__ prof, int32_t redo, uint32_t carry_spins) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
     if ((uint32_t)(uintptr_t)lds != 0u) __builtin_trap();        // match_segment addresses LDS from 0 (no static LDS in this kernel)
@@ -1135,9 +1144,9 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
         item_load(a, ix);
     } else {
         it.blk = blockIdx.x;
-        item_load(a, it);
+        item_seek(a, it, redo);
         ix = it;
-        item_next_block(a, ix);
+        item_next_block(a, ix, redo);
     }
     if (it.blk >= a.n) return;
     uint32_t k = 0u;
@@ -1235,7 +1244,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
             } else {
                 place_segment(lds, a.in_base + it.in_off, it.len, it.win, last_win, wl, win_base(it), win_skip(it), bodies + (size_t)w * BODY_STRIDE,
                               a.out_base + a.out_off[it.blk], k & 1u, w, lane, a.out_len + it.blk, a.status + it.blk,
-                              wmode ? carry + CARRY_DWORDS * (size_t)it.blk : nullptr, k + 1u);
+                              wmode ? carry + CARRY_DWORDS * (size_t)it.blk : nullptr, k + 1u, carry_spins);
             }
         }
         tick(w == WORKERS ? 1u : 4u);
@@ -1256,7 +1265,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
         __syncthreads();
         tick(w == WORKERS ? 1u : 6u);
         if (wmode) { ix.blk = giq[2]; item_load(a, ix); ix.win = giq[3]; }
-        else item_next_block(a, ix);
+        else item_next_block(a, ix, redo);
     }
 }
 
@@ -1266,7 +1275,7 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
 // blocks than workgroups
 size_t compress_wave_workspace_bytes(int n_workgroups) { return (size_t)n_workgroups * (wave::WS_BYTES + wave::CARRY_DWORDS * 4u + 4u); }
 
-hipError_t launch_compress_wave(const CompressArgs& a, void* workspace, int n_workgroups, hipStream_t s, unsigned long long* prof) {
+hipError_t launch_compress_wave(const CompressArgs& a, void* workspace, int n_workgroups, hipStream_t s, unsigned long long* prof, bool carry_wait) {
     if (a.n == 0u) return hipSuccess;
     if (!workspace || n_workgroups <= 0) return hipErrorInvalidValue;
     static unsigned long long have = 0ull;
@@ -1288,7 +1297,17 @@ hipError_t launch_compress_wave(const CompressArgs& a, void* workspace, int n_wo
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(wave::lz4_compress_wave_kernel, dim3((uint32_t)n_workgroups), dim3(wave::THREADS), wave::LDS_BYTES, s, a,
-                       (uint8_t*)workspace, carry, prof);
+                       (uint8_t*)workspace, carry, prof, 0, carry_wait ? wave::CARRY_SPINS : 1u);
+#ifndef LZ4W_EXP_NO_REDO     // (tools: shows what the second launch is for)
+    if (carry != nullptr && hipGetLastError() == hipSuccess) {
+        // A window that gave up waiting for its predecessor's carry (every wait is bounded: a GPU shared with another process, a
+        // debugger) left its block with status 66.  Those blocks are encoded again by their own workgroup, window after window,
+        // with the carry in LDS: the same bytes, no waiting, and no valid input turns into an error.  Nothing to do: ~10 us.
+        const uint32_t g = a.n < (uint32_t)n_workgroups ? a.n : (uint32_t)n_workgroups;
+        hipLaunchKernelGGL(wave::lz4_compress_wave_kernel, dim3(g), dim3(wave::THREADS), wave::LDS_BYTES, s, a, (uint8_t*)workspace,
+                           (uint32_t*)nullptr, (unsigned long long*)nullptr, 66, wave::CARRY_SPINS);
+    }
+#endif
     return hipGetLastError();
 }
 

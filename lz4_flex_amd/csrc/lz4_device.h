@@ -62,7 +62,8 @@ hipError_t launch_compress(const CompressArgs& a, int variant, hipStream_t s);
 // compress_wave_workspace_bytes(n_workgroups) bytes (cand[] slots + segment bodies, L2 / Infinity Cache resident)
 size_t compress_wave_workspace_bytes(int n_workgroups);
 hipError_t launch_compress_wave(const CompressArgs& a, void* workspace, int n_workgroups, hipStream_t s,
-                                unsigned long long* prof = nullptr);   // prof: 8 cycle counters (tools), nullable
+                                unsigned long long* prof = nullptr,    // prof: 8 cycle counters (tools), nullable
+                                bool carry_wait = true);               // tests: false = a window that has to wait for its predecessor gives up at once
 
 // chains of dependent blocks (dictionary / Linked frames); `blocks` is an array of the 40-byte ChainBlock
 // records laid out as {u64 in_off, u64 dict_off, u32 in_len, in_pos, dict_len, so, repos, flags}

@@ -132,12 +132,23 @@ def test_wave_encoder_output_too_small(blk):
     assert O.decompress(bytes(outb[2048:2048 + int(ol[1])]), len(data)) == ("ok", data)
 
 
-def test_wave_encoder_few_large_blocks_window_mode(blk):
+@pytest.mark.parametrize("carry_wait", [1, 0])
+def test_wave_encoder_few_large_blocks_window_mode(blk, carry_wait):
     """fewer blocks than persistent workgroups: the windows of a block are dealt to different workgroups and the output position
     travels between them through the workspace.  Ragged sizes (one window ... 90 windows), an empty block, a block whose sink
-    is too small in the middle; every block == model, decodes with the oracle; twice (the carry ring and counters are reset)"""
+    is too small in the middle; every block == model, decodes with the oracle; twice (the carry ring and counters are reset).
+    carry_wait 0: a window that has to wait for its predecessor gives up at once (what a time-sliced GPU does to the bounded
+    wait) -- the blocks it poisons are encoded again by the second launch: same bytes, same statuses, no device error"""
     from lz4_flex_amd import _lib as L
     lib = L.load()
+    assert lib.lz4flex_set_tuning(None, b"compress_carry_wait", carry_wait) == 0
+    try:
+        _window_mode_batch(blk, L)
+    finally:
+        assert lib.lz4flex_set_tuning(None, b"compress_carry_wait", 1) == 0
+
+
+def _window_mode_batch(blk, L):
     rnd = random.Random(17)
     j = O.fixture_plain("compression_66k_JSON")
     t = O.fixture_plain("compression_65k")
