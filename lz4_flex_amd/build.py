@@ -7,6 +7,7 @@ it (`lz4flex_build_id()`), so a test can prove that the loaded binary was built 
 import glob
 import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -65,16 +66,98 @@ def needs_build():
     return not os.path.exists(LIB) or built_hash() != source_hash()
 
 
+# ---- a property of the generated ISA that lz4_compress_wave.hip relies on and the compiler does not guarantee ----------------
+def _vregs(tok):
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def check_async_loads(isa_lines):
+    """The encoder's indexer issues its window loads as inline assembly, several chunks ahead, and waits for them with
+    hand-counted `s_waitcnt vmcnt(N)` (marked "lz4w-load" / "lz4w-wait <registers>").  The compiler does not know these
+    registers are in flight: an instruction that reads, copies or spills one between the load and its wait would move garbage,
+    silently.  Returns (ok, message, loads, waits) for a `hipcc -S` listing of that file."""
+    in_flight = {}          # register -> line number of the load
+    n_loads = n_waits = 0
+    for ln, line in enumerate(isa_lines, 1):
+        code = line.split(";")[0].strip()
+        if "lz4w-load" in line:
+            n_loads += 1
+            dst = re.search(r"global_load_dword(?:x4)?\s+(v\[\d+:\d+\]|v\d+),\s*(v\[\d+:\d+\])", code)
+            if not dst:
+                return False, "line %d: unexpected form of a marked load: %s" % (ln, line.strip()), n_loads, n_waits
+            for r in _vregs(dst.group(1)):      # (the address registers may alias the destination: read at issue)
+                in_flight[r] = ln
+            continue
+        if "lz4w-wait" in line:
+            n_waits += 1
+            named = set()
+            for tok in re.findall(r"v\[\d+:\d+\]|\bv\d+\b", line.split("lz4w-wait")[1]):
+                named |= _vregs(tok)
+            if not named:
+                return False, "line %d: a wait that names no register: %s" % (ln, line.strip()), n_loads, n_waits
+            if re.search(r"vmcnt\(0\)", code):
+                in_flight.clear()                       # everything has landed
+            else:
+                for r in named:
+                    in_flight.pop(r, None)
+            continue
+        if not code or code.endswith(":") or code.startswith("."):
+            continue
+        if code.startswith("s_waitcnt") and "vmcnt(0)" in code:
+            in_flight.clear()
+            continue
+        touched = set()
+        for tok in re.findall(r"v\[\d+:\d+\]|\bv\d+\b", code):
+            touched |= _vregs(tok)
+        bad = touched & set(in_flight)
+        if bad:
+            return False, "line %d touches v%s, requested at line %d and not waited for yet: %s" % (
+                ln, sorted(bad), min(in_flight[r] for r in bad), line.strip()), n_loads, n_waits
+    return True, "", n_loads, n_waits
+
+
+WAVE_SRC = "lz4_compress_wave.hip"
+PLAIN_LOADS = "-DLZ4W_PLAIN_LOADS"     # the indexer's loads as ordinary C++ loads: slower (the compiler sinks them to their use), always right
+
+
+def wave_isa(extra_flags=()):
+    """the `hipcc -S` listing (device code) of the throughput encoder with the build's flags"""
+    out = os.path.join(BDIR, "wave_check.s")
+    os.makedirs(BDIR, exist_ok=True)
+    cmd = [_hipcc()] + [f for f in FLAGS if f != "-fPIC"] + list(extra_flags) + ["-x", "hip", "--cuda-device-only", "-S", os.path.join(CSRC, WAVE_SRC), "-o", out]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc -S failed on %s:\n%s" % (WAVE_SRC, r.stdout.decode(errors="replace")))
+    with open(out) as f:
+        return f.read().splitlines()
+
+
+def wave_extra_flags():
+    """[] when this toolchain leaves the in-flight registers alone (today's does), else [PLAIN_LOADS] -- decided at build time on
+    the ISA that is about to be shipped, so that a compiler update degrades the encoder's speed and not its output"""
+    ok, msg, loads, waits = check_async_loads(wave_isa())
+    if ok and loads >= 16 and waits >= 8:
+        return []
+    print("lz4_flex_amd.build: %s: the hand-scheduled loads of the encoder's indexer are not safe with this compiler (%s); "
+          "building it with %s" % (WAVE_SRC, msg or "markers missing: %d loads, %d waits" % (loads, waits), PLAIN_LOADS), file=sys.stderr)
+    return [PLAIN_LOADS]
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
+    wave_flags = wave_extra_flags()
     hipcc = _hipcc()
     os.makedirs(BDIR, exist_ok=True)
     sh = source_hash()
     objs, procs = [], []
     for src in sources():
         obj = os.path.join(BDIR, src + ".o")
-        cmd = [hipcc] + FLAGS + ['-DLZ4FLEX_BUILD_ID="%s"' % sh, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + (wave_flags if src == WAVE_SRC else []) + ['-DLZ4FLEX_BUILD_ID="%s"' % sh, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -166,15 +166,24 @@ struct ChunkRegs { u32x4 main; uint32_t extra; };
 // most N younger operations outstanding" means the two loads of the chunk have landed.  Between chunk_issue and
 // chunk_wait the destination registers must not be read, copied or spilled: tests/test_isa_checks.py verifies that on
 // the generated ISA (the "; lz4w-wait" marker names the registers).
+// lz4_flex_amd/build.py runs that check on the ISA it is about to ship and compiles this file with -DLZ4W_PLAIN_LOADS if it
+// fails: ordinary loads the compiler waits for itself -- the slow form described above, never a wrong one.
 __device__ __forceinline__ void chunk_issue(ChunkRegs& r, const g_u8* __restrict__ gwin, uint32_t c, uint32_t lane) {
     const g_u8* pm = gwin + c * CHUNK + 16u * lane;
     const g_u8* pe = gwin + c * CHUNK + CHUNK;                     // same address in every lane
+#ifdef LZ4W_PLAIN_LOADS
+    r.main = *reinterpret_cast<const g_u32x4*>(pm);
+    r.extra = *reinterpret_cast<const g_u32*>(pe);
+#else
     asm volatile("global_load_dwordx4 %0, %1, off ; lz4w-load" : "=v"(r.main) : "v"(pm) : "memory");
     asm volatile("global_load_dword %0, %1, off ; lz4w-load" : "=v"(r.extra) : "v"(pe) : "memory");
+#endif
 }
 template <int N>
 __device__ __forceinline__ void chunk_wait(ChunkRegs& r) {
+#ifndef LZ4W_PLAIN_LOADS
     asm volatile("s_waitcnt vmcnt(%2) ; lz4w-wait %0 %1" : "+v"(r.main), "+v"(r.extra) : "n"(N) : "memory");
+#endif
 }
 // 16 steps of one chunk that sits in the LDS slot.  lp = slot + (lane & ~3): every LDS address below is lp + constant.
 // FULL: every position is active (p < act_n), no predication.
@@ -1118,7 +1127,12 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
                                                                     uint32_t* __restrict__ carry, unsigned long long* __restrict__ prof, int32_t redo, uint32_t carry_spins) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
-    if ((uint32_t)(uintptr_t)lds != 0u) __builtin_trap();        // match_segment addresses LDS from 0 (no static LDS in this kernel)
+    if ((uint32_t)(uintptr_t)lds != 0u) {
+        // match_segment addresses LDS from 0 (this kernel has no static LDS, so the dynamic segment starts there -- with today's
+        // toolchain).  If that ever stops being true every block reports a device failure; nothing is encoded from wrong addresses.
+        for (uint32_t b = blockIdx.x * THREADS + threadIdx.x; b < a.n; b += gridDim.x * THREADS) { a.out_len[b] = 0u; a.status[b] = 66; }
+        return;
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = uni(threadIdx.x >> 6);
     uint8_t* my_ws = ws + (size_t)blockIdx.x * WS_BYTES;
