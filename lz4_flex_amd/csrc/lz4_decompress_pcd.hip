@@ -67,7 +67,8 @@ struct Geo {
     static constexpr uint32_t L_TOK = align_up(L_RCH + 4u * (NP + 4u), 16u);
     static constexpr uint32_t L_BST = align_up(L_TOK + 2u * MAXSEQ, 16u);
     static constexpr uint32_t L_MST = align_up(L_BST + 4u * (BN + 1u), 16u);
-    static constexpr uint32_t L_DONE = align_up(L_MST + 4u * BN, 16u);
+    static constexpr uint32_t L_OFF = align_up(L_MST + 4u * BN, 16u);       // the batch's match offsets (u16)
+    static constexpr uint32_t L_DONE = align_up(L_OFF + 2u * BN, 16u);
     static constexpr uint32_t L_WSUM = L_DONE + 4u * align_up(BN / 32u, 4u);
     static constexpr uint32_t L_CTL = L_WSUM + 4u * align_up(NW * S, 4u);
     static constexpr uint32_t L_WIN = align_up(L_CTL + 4u * 32u, 16u);
@@ -260,6 +261,7 @@ struct Ctx {
     __device__ __forceinline__ lds_u16* tok() const { return (lds_u16*)(lds + G::L_TOK); }
     __device__ __forceinline__ lds_u32* bst() const { return (lds_u32*)(lds + G::L_BST); }
     __device__ __forceinline__ lds_u32* mst() const { return (lds_u32*)(lds + G::L_MST); }
+    __device__ __forceinline__ lds_u16* offs() const { return (lds_u16*)(lds + G::L_OFF); }
     __device__ __forceinline__ lds_u32* done() const { return (lds_u32*)(lds + G::L_DONE); }
     __device__ __forceinline__ lds_u32* wsum() const { return (lds_u32*)(lds + G::L_WSUM); }
     __device__ __forceinline__ volatile lds_u32* ctl() const { return (volatile lds_u32*)(lds + G::L_CTL); }
@@ -435,32 +437,59 @@ struct Ctx {
                        cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_);
         constexpr uint32_t BN = G::BN;
         const uint32_t ms = OP + exu + s.lit;
-        const uint32_t s0 = ms - s.off;                                    // source start (hm: off <= ms)
-        const uint32_t s1 = s0 + s.ml < ms ? s0 + s.ml : ms;               // source end outside its own output
+        uint32_t s0 = ms - s.off;                                          // source start (hm: off <= ms)
+        uint32_t s1 = s0 + s.ml < ms ? s0 + s.ml : ms;                     // source end outside its own output
         // producers: the batch's sequences whose output holds [max(s0, OP), s1) -- lo..hi, all before mine
         uint32_t lo = 1u, hi = 0u;
-        if (hm && s1 > OP) {
-            const uint32_t a0 = s0 > OP ? s0 : OP, a1 = s1 - 1u;
-            uint32_t jl = 0u, jh = 0u;
+        auto find = [&](bool want) {
+            lo = 1u; hi = 0u;
+            if (want && s1 > OP) {
+                const uint32_t a0 = s0 > OP ? s0 : OP, a1 = s1 - 1u;
+                uint32_t jl = 0u, jh = 0u;
 #pragma unroll 1
-            for (uint32_t step = BN / 2u; step != 0u; step >>= 1) {        // largest j < cnt with bst[j] <= a
-                const uint32_t cl = jl + step, ch = jh + step;
-                if (cl < cnt && bst()[cl] <= a0) jl = cl;
-                if (ch < cnt && bst()[ch] <= a1) jh = ch;
+                for (uint32_t step = BN / 2u; step != 0u; step >>= 1) {    // largest j < cnt with bst[j] <= a
+                    const uint32_t cl = jl + step, ch = jh + step;
+                    if (cl < cnt && bst()[cl] <= a0) jl = cl;
+                    if (ch < cnt && bst()[ch] <= a1) jh = ch;
+                }
+                if (jl < i) {                                              // (a source inside my own literals has no producer)
+                    lo = jl;
+                    hi = jh < i ? jh : i - 1u;
+                    // the last one only counts if the source reaches into its MATCH (its literals are placed already)
+                    if (hi == jh && s1 <= mst()[hi]) { if (hi == lo) { lo = 1u; hi = 0u; } else hi -= 1u; }
+                }
             }
-            if (jl < i) {                                                  // (a source inside my own literals has no producer)
-                lo = jl;
-                hi = jh < i ? jh : i - 1u;
-                // the last one only counts if the source reaches into its MATCH (its literals are placed already)
-                if (hi == jh && s1 <= mst()[hi]) { if (hi == lo) { lo = 1u; hi = 0u; } else hi -= 1u; }
-            }
+        };
+        find(hm);
+        // RELINKING.  A match whose whole source lies inside the MATCH of one earlier sequence j of the batch copies bytes that j
+        // copies from off_j further back: out[x] = out[x - off_j] for every byte of j's match, overlapping or not (decompress.rs:
+        // 410-437).  So it can read there itself instead of waiting for j -- and its new source may be free (history, literals) or
+        // wait for something earlier.  Chains of copies of copies are what a batch's match phase consists of: one round takes a
+        // third of the levels away (JSON tiles 109 -> 74 per batch, log lines 28 -> 19; two rounds: 56 / 15) and costs one more
+        // search.  Measured, 0 / 1 / 2 / 3 rounds: 256 JSON blocks 0.198 / 0.169 / 0.157 / 0.155 ms, 64 x 1 MiB JSON 2.18 / 1.74 /
+        // 1.61 / 1.63, 256 x 4 MiB log blocks 5.47 / 5.51 / 5.88 / 6.31 (shallow chains: the searches cost more than the levels).
+#ifndef LZ4P_RELINK
+#define LZ4P_RELINK 1
+#endif
+#pragma unroll 1
+        for (uint32_t rr = 0u; rr < LZ4P_RELINK; ++rr) {
+            bool rl = hm && lo == hi && s.off >= s.ml;                     // one producer; I do not read my own output
+            uint32_t mj = 0u, ej = 0u, oj = 0u;
+            if (rl) { mj = mst()[lo]; ej = bst()[lo + 1u]; oj = offs()[lo]; }          // (lo < i: sequence lo + 1 exists)
+            rl = rl && s0 >= mj && s1 <= ej;
+            if (!__any(rl)) break;
+            if (rl) { s0 -= oj; s1 -= oj; }
+            uint32_t lo2 = lo, hi2 = hi;
+            find(rl);
+            if (!rl) { lo = lo2; hi = hi2; }
         }
+        const uint32_t off = ms - s0;                                      // the offset after relinking (>= off)
         // one lane, 16 bytes at a time: offset >= 16, up to 256 bytes, source entirely in the window or (up to 64 bytes)
         // entirely written back; everything else (periodic, long, straddling the window's start) is copied by the whole wavefront
         const bool dep = lo <= hi;
         const bool near = s0 >= Lo;
         const bool farok = s0 + ((s.ml + 15u) & ~15u) <= Lo;
-        const bool inl = s.off >= 16u && (near ? s.ml <= 256u : (farok && s.ml <= 64u));   // (far: four loads in flight, no more)
+        const bool inl = off >= 16u && (near ? s.ml <= 256u : (farok && s.ml <= 64u));   // (far: four loads in flight, no more)
         lds_u8* const dstp = win() + (ms - Lo);
         const lds_u8* const srcp = win() + (s0 - Lo);          // (only used where the source lies in the window)
         auto copy_coop = [&](bool want) {
@@ -468,7 +497,7 @@ struct Ctx {
             while (cm != 0ull) {
                 const uint32_t l = (uint32_t)__builtin_ctzll(cm);
                 cm &= cm - 1ull;
-                wave_match(bcast(ms, l), bcast(s.off, l), bcast(s.ml, l), Lo);
+                wave_match(bcast(ms, l), bcast(off, l), bcast(s.ml, l), Lo);
                                     }
         };
         auto publish = [&]() {     // my match's bytes are in the window: the DONE bit follows them (release)
@@ -482,7 +511,7 @@ struct Ctx {
                 if (near) {
                     // 64 bytes of loads before their stores where no byte of those 64 is the match's own output, else 16 (one
                     // loop for both: two loops would be executed one after the other by a wavefront that holds both kinds)
-                    const uint32_t grp = (s.off >= 64u || s.off >= s.ml) ? 64u : 16u;
+                    const uint32_t grp = (off >= 64u || off >= s.ml) ? 64u : 16u;
                     for (uint32_t o = 0u; o < s.ml; o += grp) {
                         u32x4 v[4];
 #pragma unroll
@@ -516,7 +545,7 @@ struct Ctx {
         const bool wide = dep && wh - wl > 1u;                   // (whole words between the two: a source of > 32 sequences)
         const volatile lds_u32* dn = (const volatile lds_u32*)done();
         const uint32_t nfull = s.ml >> 4, rem = s.ml & 15u;
-        const bool inl2 = s.off >= 16u && s.ml <= 256u && near;
+        const bool inl2 = off >= 16u && s.ml <= 256u && near;
         uint32_t spins = 0u;
         while (__any(pending)) {
             bool ready = false;
@@ -817,7 +846,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 const uint32_t i = u * G::T + tid;
                 const uint32_t ms = OP + ex[u] + sq[u].lit;        // where the match starts
                 if (i + 1u == cnt) ctl[C_TOTAL] = ex[u] + len[u];
-                if (i < cnt) { X.bst()[i] = OP + ex[u]; X.mst()[i] = ms; }
+                if (i < cnt) { X.bst()[i] = OP + ex[u]; X.mst()[i] = ms; X.offs()[i] = (uint16_t)sq[u].off; }
                 has_m[u] = i < cnt && sq[u].ml != 0u;
                 if (has_m[u] && sq[u].off > ms) ctl[C_BAD2] = 1u;  // OffsetOutOfBounds (decompress.rs:398-400)
                 if (!prev_ok && has_m[u] && ms - sq[u].off < OP0) ctl[C_NEEDPREV] = 1u;   // a match reaches into an earlier block of the chain
