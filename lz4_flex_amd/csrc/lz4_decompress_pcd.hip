@@ -68,7 +68,8 @@ struct Geo {
     static constexpr uint32_t L_BST = align_up(L_TOK + 2u * MAXSEQ, 16u);
     static constexpr uint32_t L_MST = align_up(L_BST + 4u * (BN + 1u), 16u);
     static constexpr uint32_t L_OFF = align_up(L_MST + 4u * BN, 16u);       // the batch's match offsets (u16)
-    static constexpr uint32_t L_DONE = align_up(L_OFF + 2u * BN, 16u);
+    static constexpr uint32_t L_TB = align_up(L_OFF + 2u * BN, 16u);       // per 64 bytes of the batch's output: the first sequence that starts at or behind them (u16)
+    static constexpr uint32_t L_DONE = align_up(L_TB + 2u * (WNEW / 64u + 2u), 16u);
     static constexpr uint32_t L_WSUM = L_DONE + 4u * align_up(BN / 32u, 4u);
     static constexpr uint32_t L_CTL = L_WSUM + 4u * align_up(NW * S, 4u);
     static constexpr uint32_t L_WIN = align_up(L_CTL + 4u * 32u, 16u);
@@ -262,6 +263,7 @@ struct Ctx {
     __device__ __forceinline__ lds_u32* bst() const { return (lds_u32*)(lds + G::L_BST); }
     __device__ __forceinline__ lds_u32* mst() const { return (lds_u32*)(lds + G::L_MST); }
     __device__ __forceinline__ lds_u16* offs() const { return (lds_u16*)(lds + G::L_OFF); }
+    __device__ __forceinline__ lds_u16* tb() const { return (lds_u16*)(lds + G::L_TB); }
     __device__ __forceinline__ lds_u32* done() const { return (lds_u32*)(lds + G::L_DONE); }
     __device__ __forceinline__ lds_u32* wsum() const { return (lds_u32*)(lds + G::L_WSUM); }
     __device__ __forceinline__ volatile lds_u32* ctl() const { return (volatile lds_u32*)(lds + G::L_CTL); }
@@ -444,14 +446,16 @@ struct Ctx {
         auto find = [&](bool want) {
             lo = 1u; hi = 0u;
             if (want && s1 > OP) {
+                // largest j < cnt with bst[j] <= a: from the first sequence that starts in a's 64 bytes (tb), forward -- two or three
+                // steps (a binary search over bst[] was 11 dependent LDS round trips, a twentieth of the kernel's time)
                 const uint32_t a0 = s0 > OP ? s0 : OP, a1 = s1 - 1u;
-                uint32_t jl = 0u, jh = 0u;
-#pragma unroll 1
-                for (uint32_t step = BN / 2u; step != 0u; step >>= 1) {    // largest j < cnt with bst[j] <= a
-                    const uint32_t cl = jl + step, ch = jh + step;
-                    if (cl < cnt && bst()[cl] <= a0) jl = cl;
-                    if (ch < cnt && bst()[ch] <= a1) jh = ch;
+                uint32_t jl = tb()[(a0 - OP) >> 6], jh = tb()[(a1 - OP) >> 6];
+                for (;;) {
+                    const bool ml_ = jl < cnt && bst()[jl] <= a0, mh_ = jh < cnt && bst()[jh] <= a1;
+                    if (!ml_ && !mh_) break;
+                    jl += ml_ ? 1u : 0u; jh += mh_ ? 1u : 0u;
                 }
+                jl -= 1u; jh -= 1u;                                        // (sequence 0 starts at OP <= a: never below 0)
                 if (jl < i) {                                              // (a source inside my own literals has no producer)
                     lo = jl;
                     hi = jh < i ? jh : i - 1u;
@@ -846,7 +850,13 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 const uint32_t i = u * G::T + tid;
                 const uint32_t ms = OP + ex[u] + sq[u].lit;        // where the match starts
                 if (i + 1u == cnt) ctl[C_TOTAL] = ex[u] + len[u];
-                if (i < cnt) { X.bst()[i] = OP + ex[u]; X.mst()[i] = ms; X.offs()[i] = (uint16_t)sq[u].off; }
+                if (i < cnt) {
+                    X.bst()[i] = OP + ex[u]; X.mst()[i] = ms; X.offs()[i] = (uint16_t)sq[u].off;
+                    // where does a position of the batch's output come from?  tb[k] = the first sequence that starts at or behind byte
+                    // 64 k: the sequence behind me, for every 64-byte boundary inside me (or at my end)
+                    if (i == 0u) X.tb()[0] = 0u;
+                    for (uint32_t k = (ex[u] >> 6) + 1u; (k << 6) <= ex[u] + len[u]; ++k) X.tb()[k] = (uint16_t)(i + 1u);
+                }
                 has_m[u] = i < cnt && sq[u].ml != 0u;
                 if (has_m[u] && sq[u].off > ms) ctl[C_BAD2] = 1u;  // OffsetOutOfBounds (decompress.rs:398-400)
                 if (!prev_ok && has_m[u] && ms - sq[u].off < OP0) ctl[C_NEEDPREV] = 1u;   // a match reaches into an earlier block of the chain

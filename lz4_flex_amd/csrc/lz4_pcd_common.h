@@ -47,7 +47,7 @@ constexpr uint32_t THREADS = 1024u;
 constexpr uint32_t SEQ_PER_LANE = 2u;
 constexpr uint32_t BATCH = THREADS * SEQ_PER_LANE;
 #ifndef LZ4P_HIST
-#define LZ4P_HIST 28672
+#define LZ4P_HIST 26624
 #endif
 #ifndef LZ4P_WNEW
 #define LZ4P_WNEW 49152
