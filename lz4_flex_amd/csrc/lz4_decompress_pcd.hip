@@ -58,7 +58,7 @@ struct Geo {
     static constexpr uint32_t MAX_ITERS = NP + 2u;
     static constexpr uint32_t KP = (HIST + 16u * T - 1u) / (16u * T);   // 16-byte pieces per thread when the history slides
     // LDS layout
-    static constexpr uint32_t L_CT = 0u;
+    static constexpr uint32_t L_CT = 16u;                         // (a walk's hop reads from the byte BEFORE its token: that byte exists for the tile's first one too)
     static constexpr uint32_t L_MARK = align_up(L_CT + CT + CM + 16u, 16u);
     static constexpr uint32_t L_ENT = L_MARK + 4u * MW;
     static constexpr uint32_t L_EXT = L_ENT + 4u * NP;
@@ -74,6 +74,7 @@ struct Geo {
     static constexpr uint32_t L_CTL = L_WSUM + 4u * align_up(NW * S, 4u);
     static constexpr uint32_t L_WIN = align_up(L_CTL + 4u * 32u, 16u);
     static constexpr uint32_t LDS_BYTES = L_WIN + WIN + 64u;
+    static_assert(4u * MW <= 2u * MAXSEQ, "the walks' scratch bitmap fits the token list's space");
     static_assert(CT % P == 0 && P % 32 == 0 && T % 64 == 0 && MW <= T && NP <= T && NP <= 64u * PPL && HIST % 16 == 0, "geometry");
     static_assert(LDS_BYTES <= 160u * 1024u, "LDS");
 };
@@ -175,37 +176,10 @@ __device__ __attribute__((noinline)) uint32_t walk_slow(const Rd<G>& rd, uint32_
     Seq s;
     return parse_seq<Rd<G>, false>(rd, ilen, p, s);
 }
-// One hop of a WALK from the token at p (cbase <= p < cbase + CT): the next token position, X_END or X_ERR -- parse_seq<.., false>.
-// A walk only needs where a sequence ENDS: token and literal length byte give that, except for the match length byte of a
-// token whose match nibble is 15, which lies right before the NEXT token -- so every hop reads the four bytes from p - 1 on
-// (ONE LDS round trip; seq_at needs two) and first checks that the previous hop's length byte, if it assumed one, is not 255
-// (prev255: then the previous sequence is walked again by the byte-wise path).  b15: this hop assumes such a byte at nx - 1.
-// Straight-line: the caller decides what applies (usual: nx is the next token).
-struct Hop { uint32_t nx; bool b15, usual, inl, prev255; };
-template <class G>
-__device__ __forceinline__ Hop hop_at(const Rd<G>& rd, uint32_t ilen, uint32_t staged, uint32_t p, uint32_t mark_addr, uint32_t& mark_word) {
-    const uint32_t r = p - rd.cbase;
-    const uint32_t base = (uint32_t)(uintptr_t)rd.ct;
-    const uint32_t ra = r != 0u ? r - 1u : 0u;                          // (the tile's first token has nothing before it)
-    uint64_t d01;
-    uint32_t mk;
-    asm volatile("ds_read_b32 %0, %1" : "=v"(mk) : "v"(mark_addr) : "memory");
-    asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(d01) : "v"(base + (ra & ~3u)) : "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d01), "+v"(mk) :: "memory");
-    mark_word = mk;
-    uint32_t w = __builtin_amdgcn_alignbyte((uint32_t)(d01 >> 32), (uint32_t)d01, ra & 3u);
-    w = r != 0u ? w : w << 8;                                            // byte 0: the byte before the token, 1: token, 2: literal length byte
-    Hop h;
-    h.inl = r + 8u <= staged;                                            // those bytes are staged
-    h.prev255 = (w & 0xFFu) == 0xFFu;
-    const uint32_t t = (w >> 8) & 0xFFu, lc = t >> 4, e1 = (w >> 16) & 0xFFu;
-    const uint32_t l15 = lc == 15u ? 1u : 0u;
-    const uint32_t q = p + 1u + l15 + lc + (l15 ? e1 : 0u);             // the offset's position
-    h.b15 = (t & 15u) == 15u;
-    h.usual = h.inl && !(l15 && e1 == 255u) && q + 3u < ilen;            // one length byte at most; offset, a length byte and one more byte exist
-    h.nx = q + 2u + (h.b15 ? 1u : 0u);
-    return h;
-}
+// A WALK's hop (the kernel's walk loop): where does the sequence whose token is at p end -- parse_seq<.., false>.  Token and
+// literal length byte give that, except for the match length byte of a token whose match nibble is 15, which lies right before
+// the NEXT token: so every hop reads the four bytes from p - 1 on (ONE LDS round trip; seq_at needs two) and first checks that
+// the previous hop's length byte, if it assumed one, is not 255 (then the previous sequence is walked again, byte-wise).
 
 // mark_addr: LDS byte address of a word that is fetched in the same round trip (the walk's "was this position marked before"),
 // or 0; its value comes back in *mark_word.
@@ -263,6 +237,7 @@ struct Ctx {
     __device__ __forceinline__ lds_u32* bst() const { return (lds_u32*)(lds + G::L_BST); }
     __device__ __forceinline__ lds_u32* mst() const { return (lds_u32*)(lds + G::L_MST); }
     __device__ __forceinline__ lds_u16* offs() const { return (lds_u16*)(lds + G::L_OFF); }
+    __device__ __forceinline__ lds_u32* nmk() const { return (lds_u32*)(lds + G::L_TOK); }   // a walk's marks until it ends (the token list's space: free while a tile is parsed)
     __device__ __forceinline__ lds_u16* tb() const { return (lds_u16*)(lds + G::L_TB); }
     __device__ __forceinline__ lds_u32* done() const { return (lds_u32*)(lds + G::L_DONE); }
     __device__ __forceinline__ lds_u32* wsum() const { return (lds_u32*)(lds + G::L_WSUM); }
@@ -648,7 +623,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
         X.load_tile(cbase);
         const uint32_t span = X.ilen - cbase;
         const uint32_t parts = span >= G::CT ? G::NP : (span + G::P - 1u) / G::P;
-        for (uint32_t w = tid; w < G::MW; w += G::T) X.marks()[w] = 0u;
+        for (uint32_t w = tid; w < G::MW; w += G::T) { X.marks()[w] = 0u; X.nmk()[w] = 0u; }
         const uint32_t staged = span < G::CT + G::CM ? span : G::CT + G::CM;      // bytes of the block in the LDS tile
         uint32_t my_e = cbase + tid * G::P;
         if (tid < parts) { X.ent()[tid] = my_e; X.ext()[tid] = X_ERR; }
@@ -666,73 +641,81 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 // assumed entry, meets no marks: the tile's are cleared).  So a part is walked once in full and then only as far
                 // as its chains differ -- a few sequences.
                 lds_u32* mk = X.marks() + tid * G::PW;
+                lds_u32* nk = X.nmk() + tid * G::PW;                    // this walk's marks (zero between walks)
                 const uint32_t pend = cbase + (tid + 1u) * G::P;
-                uint32_t nm[G::PW];
-#pragma unroll
-                for (uint32_t w = 0; w < G::PW; ++w) nm[w] = 0u;
-                // The loop is UNIFORM (every lane of the wavefront turns until the last one is through) and its body straight-line:
-                // written with per-lane breaks it was 250 instructions a hop, half of them exec-mask bookkeeping.  A lane whose
-                // chain has left the part with an unchecked length byte makes one more turn that only checks it.
-                uint32_t p = my_e, prev_p = my_e, x = 0u, mw = G::PW, mbit = 0u;
-                bool merged = false, p15 = false;                      // p15: the hop from prev_p assumed ONE match length byte, at p - 1
+                // One hop = one LDS round trip and ~50 instructions: the four bytes from the byte before the token (hop_at's layout),
+                // the part's old mark word in the same trip, the new mark set with an LDS OR (no per-word selects in registers),
+                // conditions as integers.  What a hop costs IS the parse: a round of walks lasts as long as its slowest lane's chain
+                // of hops (written with bool flags and the marks in registers: 120 instructions, 1 040 cycles a hop).
+                // Everything unusual -- a length byte of 255, the block's or the staged bytes' end, a second length byte found
+                // behind an assumed single one -- leaves through ONE wave-level test.
+                const uint32_t ctb = (uint32_t)(uintptr_t)rd.ct, mkb = (uint32_t)(uintptr_t)X.marks(), nkb = (uint32_t)(uintptr_t)X.nmk();
+                uint32_t p = my_e, prev_p = my_e, x = 0u, mrg = 0xFFFFFFFFu;   // mrg: where this walk fell into step with the old one (byte of the tile)
+                uint32_t p15 = 0u;                                      // 1: the hop from prev_p assumed ONE match length byte, at p - 1
                 bool act = true;
                 const unsigned long long pr_w0 = PCD_NOW();
-                uint32_t pr_rare = 0u;
                 while (act) {
+                    const uint32_t r = p - cbase, ra = r - 1u, wofs = (r >> 5) << 2;
+                    uint64_t d01;
+                    uint32_t oldw;
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(oldw) : "v"(mkb + wofs) : "memory");
+                    asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(d01) : "v"(ctb + (ra & ~3u)) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d01), "+v"(oldw) :: "memory");
+                    const uint32_t w = __builtin_amdgcn_alignbyte((uint32_t)(d01 >> 32), (uint32_t)d01, ra & 3u);   // byte 0: before the token, 1: token, 2: literal length byte
+                    const uint32_t lc = (w >> 12) & 15u, e1 = (w >> 16) & 0xFFu;
+                    const uint32_t l15 = lc == 15u ? 1u : 0u, b15 = (w & 0xF00u) == 0xF00u ? 1u : 0u;
+                    const uint32_t q = p + 1u + l15 + lc + (l15 ? e1 : 0u);         // the offset's position
+                    const uint32_t nx = q + 2u + b15;
+                    const uint32_t bit = 1u << (r & 31u);
                     const bool over = p >= pend;                       // the chain has left the part: p is the exit once p - 1 is checked
-                    if (over && !p15) { x = p; act = false; }
-                    const uint32_t pp = act ? p : cbase;               // (lanes that are through read something harmless)
-                    const uint32_t r = pp - cbase;
-                    const uint32_t wi = (r >> 5) - tid * G::PW, bit = 1u << (r & 31u);
-                    uint32_t oldw;                                     // (fetched together with the token's dwords)
-                    const Hop h = hop_at(rd, X.ilen, staged, pp, (uint32_t)(uintptr_t)(X.marks() + (r >> 5)), oldw);
+                    const bool inl = r + 8u <= staged;
+                    const bool prev255 = (w & 0xFFu) == 0xFFu;
+                    const bool usual = !(l15 != 0u && e1 == 255u) && q + 3u < X.ilen;
+                    const bool rare = !inl || (p15 != 0u && prev255) || (!over && !usual);
                     PCD_COUNT(24, 1)
-                    const bool rare = act && (!h.inl || (p15 && h.prev255) || (!over && !h.usual));
                     if (__any(rare)) {
-                        pr_rare += 1u;
                         if (rare) {
-                            const bool redo = p15 && (h.inl ? h.prev255 : rd(p - 1u) == 0xFFu);
+                            const bool redo = p15 != 0u && (inl ? prev255 : rd(p - 1u) == 0xFFu);
+                            p15 = 0u;
                             if (redo) {                                // p is not a token: the sequence before it is longer
                                 p = walk_slow(rd, X.ilen, prev_p);
                                 if (p >= X_ERR) { x = p; act = false; }
                             } else if (over) {
                                 x = p; act = false;
                             } else if ((oldw & bit) != 0u) {
-                                merged = true; mw = wi; mbit = r & 31u; act = false;
+                                mrg = r; act = false;
                             } else {
-#pragma unroll
-                                for (uint32_t w = 0; w < G::PW; ++w) nm[w] |= w == wi ? bit : 0u;
-                                const uint32_t nx = h.usual ? h.nx : walk_slow(rd, X.ilen, p);
+                                __hip_atomic_fetch_or((lds_u32*)(uintptr_t)(nkb + wofs), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                                const uint32_t n2 = (inl && usual) ? nx : walk_slow(rd, X.ilen, p);
                                 prev_p = p;
-                                if (nx >= X_ERR) { x = nx; act = false; } else p = nx;
+                                if (n2 >= X_ERR) { x = n2; act = false; } else { p = n2; p15 = (inl && usual) ? b15 : 0u; }
                             }
-                            p15 = act && !redo && !over && h.usual && h.b15;
                         }
                     }
-                    if (act && !rare) {
-                        if (over) {                                    // the length byte before the exit is an ordinary one
+                    if (!rare) {
+                        if (over) {                                    // (the length byte before the exit is an ordinary one)
                             x = p; act = false;
                         } else if ((oldw & bit) != 0u) {
-                            merged = true; mw = wi; mbit = r & 31u; act = false;
+                            mrg = r; act = false;
                         } else {
-#pragma unroll
-                            for (uint32_t w = 0; w < G::PW; ++w) nm[w] |= w == wi ? bit : 0u;
+                            __hip_atomic_fetch_or((lds_u32*)(uintptr_t)(nkb + wofs), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                             prev_p = p;
-                            p15 = h.b15;
-                            p = h.nx;                                  // (usual: a real position, below X_ERR)
+                            p15 = b15;
+                            p = nx;                                    // (usual: a real position, below X_ERR)
                         }
                     }
                 }
-                PCD_COUNT(25, PCD_NOW() - pr_w0) PCD_COUNT(23, pr_rare) (void)pr_rare;
-                if (merged) {
+                PCD_COUNT(25, PCD_NOW() - pr_w0)
+                // the part's marks: this walk's, and behind the point where it fell into step the old walk's (whose exit stands)
+                const bool merged = mrg != 0xFFFFFFFFu;
+                const uint32_t mw = merged ? (mrg >> 5) - tid * G::PW : G::PW, mbit = mrg & 31u;
 #pragma unroll
-                    for (uint32_t w = 0; w < G::PW; ++w) {
-                        const uint32_t old = mk[w];
-                        mk[w] = w < mw ? nm[w] : (w == mw ? (nm[w] | (old & (0xFFFFFFFFu << mbit))) : old);
-                    }
-                } else {
-#pragma unroll
-                    for (uint32_t w = 0; w < G::PW; ++w) mk[w] = nm[w];
+                for (uint32_t w = 0; w < G::PW; ++w) {
+                    const uint32_t nw = nk[w], old = mk[w];
+                    nk[w] = 0u;
+                    mk[w] = w < mw ? nw : (w == mw ? (nw | (old & (0xFFFFFFFFu << mbit))) : old);
+                }
+                if (!merged) {
                     exit_changed = X.ext()[tid] != x;              // (a first walk: the slot holds X_ERR ... and an entry that really
                     X.ext()[tid] = x;                              //  leads to X_ERR again changes nothing: the chain dies there either way)
                     exit_changed = exit_changed || it == 0u;
