@@ -412,7 +412,6 @@ struct Ctx {
                                                          uint32_t cnt_) const {
         const uint32_t OP = (uint32_t)__builtin_amdgcn_readfirstlane((int)OP_), Lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)Lo_),
                        cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_);
-        constexpr uint32_t BN = G::BN;
         const uint32_t ms = OP + exu + s.lit;
         uint32_t s0 = ms - s.off;                                          // source start (hm: off <= ms)
         uint32_t s1 = s0 + s.ml < ms ? s0 + s.ml : ms;                     // source end outside its own output
@@ -535,7 +534,7 @@ struct Ctx {
             }
             if (__any(ready)) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // the producers' bytes behind their DONE bits
-                if (ready && inl2) {
+                if (ready && inl2) {     // (16 bytes a step: grouping the loads as above makes this loop, and with it every level of the batch's dependency chains, a third slower)
                     for (uint32_t k = 0u; k < nfull; ++k) st16l(dstp + 16u * k, ld16l(srcp + 16u * k));
                     if (rem != 0u) st_exact(dstp + 16u * nfull, ld16l(srcp + 16u * nfull), rem);
                 }
@@ -653,7 +652,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                 uint32_t p = my_e, prev_p = my_e, x = 0u, mrg = 0xFFFFFFFFu;   // mrg: where this walk fell into step with the old one (byte of the tile)
                 uint32_t p15 = 0u;                                      // 1: the hop from prev_p assumed ONE match length byte, at p - 1
                 bool act = true;
-                const unsigned long long pr_w0 = PCD_NOW();
+                const unsigned long long pr_w0 = PCD_NOW(); (void)pr_w0;
                 while (act) {
                     const uint32_t r = p - cbase, ra = r - 1u, wofs = (r >> 5) << 2;
                     uint64_t d01;
