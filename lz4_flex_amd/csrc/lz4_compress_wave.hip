@@ -1123,8 +1123,8 @@ __device__ __forceinline__ void item_draw(const CompressArgs& a, uint32_t* wctr,
 // prof (nullable, tools only): cycle sums per role, [0] indexer busy, [1] indexer at barriers, [2] workers matching,
 // [3] workers at the barrier behind matching, [4] placing, [5] loading the next window, [6] at the barrier behind loading,
 // [7] windows
-__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) lz4_compress_wave_kernel(const CompressArgs a, uint8_t* __restrict__ ws,
-                                                                    uint32_t* __restrict__ carry, unsigned long long* __restrict__ prof, int32_t redo, uint32_t carry_spins) {
+__device__ __forceinline__ void wave_body(const CompressArgs& a, uint8_t* __restrict__ ws, uint32_t* __restrict__ carry,
+                                          unsigned long long* __restrict__ prof, const int32_t redo, const uint32_t carry_spins) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
     if ((uint32_t)(uintptr_t)lds != 0u) {
@@ -1283,6 +1283,17 @@ __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6,
     }
 }
 
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) lz4_compress_wave_kernel(const CompressArgs a, uint8_t* __restrict__ ws,
+                                                                    uint32_t* __restrict__ carry, unsigned long long* __restrict__ prof, uint32_t carry_spins) {
+    wave_body(a, ws, carry, prof, 0, carry_spins);
+}
+// the launch behind a window-mode launch (a kernel of its own so that profiles tell the two apart): block mode, only blocks
+// left with status `redo`
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) lz4_compress_wave_redo_kernel(const CompressArgs a, uint8_t* __restrict__ ws,
+                                                                                                                     int32_t redo) {
+    wave_body(a, ws, nullptr, nullptr, redo, CARRY_SPINS);
+}
+
 }  // namespace wave
 
 // cand[] slots and segment bodies per workgroup, then the window-carry ring and window counter per block for batches of fewer
@@ -1297,8 +1308,11 @@ hipError_t launch_compress_wave(const CompressArgs& a, void* workspace, int n_wo
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(have & bit)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wave::lz4_compress_wave_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)wave::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wave::lz4_compress_wave_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)wave::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(wave::lz4_compress_wave_redo_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)wave::LDS_BYTES);
         if (e != hipSuccess) return e;
         have |= bit;
     }
@@ -1311,15 +1325,14 @@ hipError_t launch_compress_wave(const CompressArgs& a, void* workspace, int n_wo
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(wave::lz4_compress_wave_kernel, dim3((uint32_t)n_workgroups), dim3(wave::THREADS), wave::LDS_BYTES, s, a,
-                       (uint8_t*)workspace, carry, prof, 0, carry_wait ? wave::CARRY_SPINS : 1u);
+                       (uint8_t*)workspace, carry, prof, carry_wait ? wave::CARRY_SPINS : 1u);
 #ifndef LZ4W_EXP_NO_REDO     // (tools: shows what the second launch is for)
     if (carry != nullptr && hipGetLastError() == hipSuccess) {
         // A window that gave up waiting for its predecessor's carry (every wait is bounded: a GPU shared with another process, a
         // debugger) left its block with status 66.  Those blocks are encoded again by their own workgroup, window after window,
         // with the carry in LDS: the same bytes, no waiting, and no valid input turns into an error.  Nothing to do: ~10 us.
         const uint32_t g = a.n < (uint32_t)n_workgroups ? a.n : (uint32_t)n_workgroups;
-        hipLaunchKernelGGL(wave::lz4_compress_wave_kernel, dim3(g), dim3(wave::THREADS), wave::LDS_BYTES, s, a, (uint8_t*)workspace,
-                           (uint32_t*)nullptr, (unsigned long long*)nullptr, 66, wave::CARRY_SPINS);
+        hipLaunchKernelGGL(wave::lz4_compress_wave_redo_kernel, dim3(g), dim3(wave::THREADS), wave::LDS_BYTES, s, a, (uint8_t*)workspace, 66);
     }
 #endif
     return hipGetLastError();

@@ -11,7 +11,7 @@ mkdir -p $OUT
 for c in $CONFIGS; do
   extra=""
   [ "$c" = "5" ] && extra="--steps 3 --warmup 1"
-  timeout 300 python bench.py --config $c $extra > $OUT/bench_line_config$c.json 2> $OUT/bench_config$c.err
+  timeout 300 python bench.py --config $c > $OUT/bench_line_config$c.json 2> $OUT/bench_config$c.err      # (the bench line: default steps)
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_config$c -o t -- python bench.py --config $c --no-cpu-baseline $extra > $OUT/trace_config$c.log 2>&1
   if [ "$c" = "2" ]; then
     for only in compress decompress; do
