@@ -79,7 +79,7 @@ def roof(alg_bytes, t):
             "traffic": None}
 
 
-def attach_traffic(kernels, n, mode):
+def attach_traffic(kernels, n, mode, config=2):
     """measured HBM bytes per launch (separate rocprofv3 --pmc passes, corrected per MI355X_MICROARCH.md), recorded in
     profiles/traffic.json together with the round and the counter files they came from"""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -90,7 +90,7 @@ def attach_traffic(kernels, n, mode):
             tr = json.load(f)
         for k in kernels:
             key = k + ("_" + mode if k == "compress" else "")
-            e = tr.get(key) or tr.get(k)
+            e = tr.get("config%d_%s" % (config, k)) if config != 2 else (tr.get(key) or tr.get(k))
             # kernel_key = the kernel's plain name (the "kernel" field may carry template arguments and a description)
             if e and kernels[k]["roofline"] and e.get("blocks") == n and e.get("kernel_key", e.get("kernel")) == kernels[k]["kernel"]:
                 kernels[k]["roofline"]["traffic"] = e["hbm_bytes_per_launch"]
@@ -272,7 +272,7 @@ def run_blocks(args, env):
                                             5: "lz4_decompress_wave_kernel", 4: "lz4_decompress_split_kernel", 1: "lz4_decompress_blocks_kernel"}[dv],
                                  "ms_per_launch": round(t_d * 1e3, 4), "MiB_per_s": round(total / 1048576 / t_d, 1),
                                  "roofline": roof(alg_bytes, t_d)}
-    attach_traffic(kernels, n, args.compress_mode)
+    attach_traffic(kernels, n, args.compress_mode, args.config)
     dominant = max(kernels, key=lambda k: kernels[k]["ms_per_launch"])
     out = {
         "metric": "MiB/s compress+decompress round trip, 1 GiB of 64 KiB JSON blocks per GPU (LZ4 block format)" if args.config == 2
