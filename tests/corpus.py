@@ -154,3 +154,76 @@ def adversarial_blocks():
         d = bytes(rnd.getrandbits(2) for _ in range(n))
         cases.append((O.compress(d), n))
     return cases
+
+
+def synthetic_block(rnd, target):
+    """(compressed, plain): an LZ4 block written sequence by sequence, not by an encoder -- matches aim at what a greedy encoder
+    rarely produces in bulk: the interior of earlier matches (copies of copies of copies, the chains the workgroup decoder
+    relinks), the bytes straddling two sequences, their own output (offsets 1..8), the block's first bytes, literal runs and
+    matches of every length class (one and several length bytes).  The plain text is produced with the format's byte-wise
+    semantics right here; the CPU suite checks it against the oracle."""
+    out, comp, seqs = bytearray(), bytearray(), []
+
+    def put_len(v):
+        while v >= 255:
+            comp.append(255)
+            v -= 255
+        comp.append(v)
+
+    while len(out) < target:
+        r = rnd.random()
+        lit = 0 if r < 0.3 else rnd.randint(1, 8) if r < 0.8 else rnd.randint(9, 40) if r < 0.95 else rnd.randint(100, 600)
+        if not out and lit == 0:
+            lit = 1
+        r = rnd.random()
+        ml = rnd.randint(4, 8) if r < 0.4 else rnd.randint(9, 30) if r < 0.8 else rnd.randint(31, 100) if r < 0.95 else rnd.randint(300, 3000)
+        pos = len(out) + lit
+        r = rnd.random()
+        recent = seqs[-40:]
+        if r < 0.15:
+            off = rnd.randint(1, 8)                                   # its own output: periodic
+        elif r < 0.65 and recent:
+            ms_j, ml_j = rnd.choice(recent)                           # inside an earlier match: a copy of a copy
+            if rnd.random() < 0.7 and ml_j > ml:
+                start = ms_j + rnd.randint(0, ml_j - ml)              # entirely inside it
+            else:
+                start = ms_j + rnd.randint(0, ml_j - 1)
+            off = pos - start
+        elif r < 0.8 and recent:
+            ms_j, ml_j = rnd.choice(recent)                           # straddling the end of an earlier match
+            off = pos - (ms_j + ml_j - rnd.randint(1, 3))
+        elif r < 0.85:
+            off = pos                                                 # the block's first byte
+        else:
+            off = rnd.randint(1, 65535)
+        off = max(1, min(off, pos, 65535))
+        tok = (min(lit, 15) << 4) | min(ml - 4, 15)
+        comp.append(tok)
+        if lit >= 15:
+            put_len(lit - 15)
+        lits = bytes(rnd.getrandbits(8) for _ in range(lit))
+        comp += lits
+        out += lits
+        comp += bytes((off & 0xFF, off >> 8))
+        if ml - 4 >= 15:
+            put_len(ml - 4 - 15)
+        start = len(out) - off
+        if off >= ml:
+            out += out[start:start + ml]
+        else:
+            for k in range(ml):
+                out.append(out[start + k])
+        seqs.append((pos, ml))
+    tail = bytes(rnd.getrandbits(8) for _ in range(rnd.randint(5, 30)))   # the last sequence: literals only
+    comp.append(min(len(tail), 15) << 4)
+    if len(tail) >= 15:
+        put_len(len(tail) - 15)
+    comp += tail
+    out += tail
+    return bytes(comp), bytes(out)
+
+
+def synthetic_blocks(seed=77, sizes=(150000,) * 24 + (5000,) * 24 + (1 << 20,) * 2):
+    import random
+    rnd = random.Random(seed)
+    return [synthetic_block(rnd, n) for n in sizes]

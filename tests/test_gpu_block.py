@@ -123,6 +123,45 @@ def test_adversarial_batch_all_decoders(blk, lanes):
         assert out[o + k:o + k + 64].tobytes() == b"\xA5" * 64, "block %d wrote behind its sink" % i
 
 
+@pytest.mark.parametrize("lanes", DECODERS)
+def test_synthetic_copy_chain_blocks_all_decoders(blk, lanes):
+    """50 hand-written blocks (corpus.synthetic_blocks: matches that aim INTO earlier matches -- copies of copies, what the
+    workgroup decoder relinks --, at the bytes straddling two sequences, at their own output, at the block's first byte; every
+    length class) and the same blocks cut short / with a sink a few bytes short: every decoder kernel == the oracle"""
+    from lz4_flex_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    cases = []
+    for comp, plain in corpus.synthetic_blocks():
+        cases.append((comp, len(plain)))
+        if len(plain) < 200000:
+            cases.append((comp[:len(comp) * 2 // 3], len(plain)))
+            cases.append((comp, len(plain) - 3))
+    want = [O.decompress(c, k) for c, k in cases]
+    assert sum(w[0] == "ok" for w in want) >= 50
+    inb = np.frombuffer(b"".join(c for c, _ in cases) + bytes(64), dtype=np.uint8)
+    in_off = np.cumsum([0] + [len(c) for c, _ in cases[:-1]])
+    out_off = np.cumsum([0] + [k + 64 for _, k in cases[:-1]])
+    caps = [k for _, k in cases]
+    out = np.full(int(out_off[-1]) + caps[-1] + 64, 0xA5, dtype=np.uint8)
+    ctx = C.c_void_p()
+    assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
+    _select_decoder(lib, ctx, lanes)
+    try:
+        ol, st, det = blk.decompress_batch(inb, list(in_off), [len(c) for c, _ in cases], out, list(out_off), caps, ctx=ctx)
+    finally:
+        lib.lz4flex_ctx_destroy(ctx)
+    for i, ((c, k), w) in enumerate(zip(cases, want)):
+        o = int(out_off[i])
+        if w[0] == "ok":
+            assert st[i] == 0 and ol[i] == len(w[1]) and out[o:o + len(w[1])].tobytes() == w[1], (i, len(c), k, int(st[i]), int(ol[i]))
+        else:
+            assert O.ERR_NAMES.get(int(st[i])) == w[0], (i, len(c), k, int(st[i]), w[0])
+            if w[0] == "OutputTooSmall":
+                assert (int(det[i][0]), int(det[i][1])) == tuple(w[1]), (i, det[i], w[1])
+        assert out[o + k:o + k + 64].tobytes() == b"\xA5" * 64, "block %d wrote behind its sink" % i
+
+
 # ---------------------------------------------------------------- fixtures
 @pytest.mark.parametrize("stem", corpus.FIXTURES)
 def test_fixture_decode_bit_exact(blk, stem):
