@@ -446,8 +446,16 @@ struct Ctx {
         // third of the levels away (JSON tiles 109 -> 74 per batch, log lines 28 -> 19; two rounds: 56 / 15) and costs one more
         // search.  Measured, 0 / 1 / 2 / 3 rounds: 256 JSON blocks 0.198 / 0.169 / 0.157 / 0.155 ms, 64 x 1 MiB JSON 2.18 / 1.74 /
         // 1.61 / 1.63, 256 x 4 MiB log blocks 5.47 / 5.51 / 5.88 / 6.31 (shallow chains: the searches cost more than the levels).
+        // So one round always, and further ones only where they pay: while at least LZ4P_RELINK_MIN of the wavefront's 64 matches
+        // would relink (the share falls round by round -- JSON 52 / 37 / 25 %, log lines 43 / 25 / 13 %, text 35 / 17 / 7 %: a
+        // second round on most JSON wavefronts, rarely elsewhere).  Measured with a floor of 12 / 20 / 28 lanes against one fixed
+        // round: 256 JSON blocks 0.138 / 0.140 / 0.143 against 0.150 ms, 64 x 1 MiB JSON 1.42 / 1.45 / 1.49 against 1.59, 256 x 4 MiB log
+        // blocks 5.14 / 4.97 / 4.84 against 4.78.
 #ifndef LZ4P_RELINK
-#define LZ4P_RELINK 1
+#define LZ4P_RELINK 3
+#endif
+#ifndef LZ4P_RELINK_MIN
+#define LZ4P_RELINK_MIN 28
 #endif
 #pragma unroll 1
         for (uint32_t rr = 0u; rr < LZ4P_RELINK; ++rr) {
@@ -455,7 +463,7 @@ struct Ctx {
             uint32_t mj = 0u, ej = 0u, oj = 0u;
             if (rl) { mj = mst()[lo]; ej = bst()[lo + 1u]; oj = offs()[lo]; }          // (lo < i: sequence lo + 1 exists)
             rl = rl && s0 >= mj && s1 <= ej;
-            if (!__any(rl)) break;
+            if ((uint32_t)__builtin_popcountll(__ballot(rl)) < (rr == 0u ? 1u : (uint32_t)LZ4P_RELINK_MIN)) break;
             if (rl) { s0 -= oj; s1 -= oj; }
             uint32_t lo2 = lo, hi2 = hi;
             find(rl);
