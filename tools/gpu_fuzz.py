@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""A longer random session than the test suite's (GPU box; tools, not a test): structured random inputs (fragments repeated at
+random distances, runs, random bytes, text) of 0 .. 3 MiB are compressed by both encoder modes (scalar entry point), checked
+with the oracle's decoder and -- the default mode -- against the encoder's scalar model, then decoded by every decoder kernel
+in one batch per round (the oracle's result is the reference: bytes, length, status), also cut short and with short sinks.
+usage: python tools/gpu_fuzz.py [--seconds 60] [--seed 1]"""
+import argparse
+import ctypes as C
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+
+def make_input(rnd):
+    r = rnd.random()
+    n = rnd.randint(0, 200) if r < 0.15 else rnd.randint(200, 70000) if r < 0.6 else rnd.randint(70000, 400000) if r < 0.9 else rnd.randint(400000, 3 << 20)
+    out = bytearray()
+    frags = [bytes(rnd.getrandbits(8) for _ in range(rnd.randint(1, 64))) for _ in range(rnd.randint(1, 30))]
+    alphabet = rnd.choice([256, 256, 16, 4, 2])
+    while len(out) < n:
+        k = rnd.random()
+        if k < 0.35:
+            out += rnd.choice(frags)
+        elif k < 0.55 and out:
+            d = rnd.randint(1, min(len(out), 70000))
+            m = rnd.randint(4, 300)
+            for _ in range(m):
+                out.append(out[-d])
+        elif k < 0.65:
+            out += bytes([rnd.getrandbits(8)]) * rnd.randint(1, 2000)
+        elif k < 0.7:
+            out += np.random.default_rng(rnd.getrandbits(32)).integers(0, alphabet, rnd.randint(1, 5000), dtype=np.uint8).tobytes()
+        else:
+            out += bytes(rnd.getrandbits(8) % alphabet for _ in range(rnd.randint(1, 40)))
+    return bytes(out[:n])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    import oracle_api as O
+    import wave_model as W
+    from lz4_flex_amd import _lib as L, block
+    lib = L.load()
+    rnd = random.Random(args.seed)
+    decoders = [(1, 0), (4, 8), (4, 32), (4, 64), (5, 0), (6, 0), (7, 0), (8, 0)]
+    t_end = time.time() + args.seconds
+    rounds = inputs = blocks = 0
+    while time.time() < t_end:
+        rounds += 1
+        cases = []
+        for _ in range(24):
+            d = make_input(rnd)
+            inputs += 1
+            for mode in (0, 1):
+                assert lib.lz4flex_set_tuning(None, b"compress_mode", mode) == 0
+                c = block.compress(d) if hasattr(block, "compress") else None
+                if c is None:
+                    cap = int(lib.lz4flex_get_maximum_output_size(len(d)))
+                    out = C.create_string_buffer(cap)
+                    r = lib.lz4flex_compress_into(d, len(d), out, cap)
+                    assert r >= 0, (r, L.last_error())
+                    c = out.raw[:r]
+                assert O.decompress(c, len(d)) == ("ok", d), ("encoder mode %d: the oracle does not return the input" % mode, len(d))
+                if mode == 0:
+                    assert c == W.compress(d), ("default encoder != its model", len(d))
+                else:
+                    assert c == O.compress(d), ("exact encoder != the reference's bytes", len(d))
+                cases.append((c, len(d)))
+                if len(c) > 4:
+                    cases.append((c[:rnd.randint(1, len(c) - 1)], len(d)))
+                    cases.append((c, max(0, len(d) - rnd.randint(1, 40))))
+        assert lib.lz4flex_set_tuning(None, b"compress_mode", 0) == 0
+        want = [O.decompress(c, k) for c, k in cases]
+        inb = np.frombuffer(b"".join(c for c, _ in cases) + bytes(64), dtype=np.uint8)
+        in_off = np.cumsum([0] + [len(c) for c, _ in cases[:-1]])
+        out_off = np.cumsum([0] + [k + 64 for _, k in cases[:-1]])
+        caps = [k for _, k in cases]
+        for variant, bpw in decoders:
+            out = np.full(int(out_off[-1]) + caps[-1] + 64, 0xA5, dtype=np.uint8)
+            ctx = C.c_void_p()
+            assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
+            assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", variant) == 0
+            if bpw:
+                assert lib.lz4flex_set_tuning(ctx, b"decompress_blocks_per_wg", bpw) == 0
+            ol, st, det = block.decompress_batch(inb, list(in_off), [len(c) for c, _ in cases], out, list(out_off), caps, ctx=ctx)
+            lib.lz4flex_ctx_destroy(ctx)
+            for i, ((c, k), w) in enumerate(zip(cases, want)):
+                o = int(out_off[i])
+                if w[0] == "ok":
+                    assert st[i] == 0 and ol[i] == len(w[1]) and out[o:o + len(w[1])].tobytes() == w[1], ("decoder", variant, bpw, i, len(c), k, int(st[i]), int(ol[i]))
+                else:
+                    assert O.ERR_NAMES.get(int(st[i])) == w[0], ("decoder", variant, bpw, i, len(c), k, int(st[i]), w[0])
+                assert out[o + k:o + k + 64].tobytes() == b"\xA5" * 64, ("decoder wrote behind a sink", variant, bpw, i)
+            blocks += len(cases)
+    print("gpu_fuzz: seed %d, %d rounds, %d inputs through both encoders, %d block decodes through 8 decoder kernels: all equal the oracle" % (args.seed, rounds, inputs, blocks))
+
+
+if __name__ == "__main__":
+    main()
