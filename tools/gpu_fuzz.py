@@ -41,11 +41,69 @@ def make_input(rnd):
     return bytes(out[:n])
 
 
+def frames(args):
+    """the frame layer: random options x random write / read chunking, both compress modes, against the oracle's FrameEncoder /
+    FrameDecoder restatement (exact mode: the frame's bytes; default mode: the oracle decodes it) and back"""
+    import io
+    import oracle_api as O
+    from lz4_flex_amd import block, frame as F
+    rnd = random.Random(args.seed)
+    t_end = time.time() + args.seconds
+    n = 0
+    sizes = {4: F.BlockSize.Max64KB, 5: F.BlockSize.Max256KB, 6: F.BlockSize.Max1MB, 7: F.BlockSize.Max4MB}
+    while time.time() < t_end:
+        d = make_input(rnd)
+        bs = rnd.choice([4, 4, 5, 6, 7])
+        linked, bc, cc = rnd.random() < 0.4, rnd.random() < 0.3, rnd.random() < 0.3
+        for mode in ("fast", "exact"):
+            block.set_compress_mode(mode)
+            fi = F.FrameInfo(block_size=sizes[bs], block_mode=F.BlockMode.Linked if linked else F.BlockMode.Independent,
+                             block_checksums=bc, content_checksum=cc)
+            sink = io.BytesIO()
+            enc = F.FrameEncoder(sink, fi)
+            pos = 0
+            chunks = []
+            flushed = False
+            while pos < len(d):
+                k = rnd.choice([1, 7, 4096, 65536, 65537, 1 << 20, len(d)])
+                k = min(k, len(d) - pos)
+                enc.write(d[pos:pos + k])
+                chunks.append(k)
+                pos += k
+                if rnd.random() < 0.05:
+                    enc.flush()
+                    flushed = True
+            enc.finish()
+            fr = sink.getvalue()
+            if mode == "exact" and not flushed and len(chunks) <= 4096:      # the reference's bytes, block for block
+                want = O.frame_compress(d, chunks=chunks, block_mode=1 if linked else 0, block_size=bs, block_checksums=int(bc), content_checksum=int(cc))[1]
+                assert fr == want, ("exact mode: frame != the oracle's FrameEncoder", bs, linked, bc, cc, len(d), len(chunks))
+            rc, back, used = O.frame_decompress(fr, len(d))
+            assert rc == 0 and back == d and used == len(fr), ("the oracle's FrameDecoder does not return the input", mode, bs, linked, bc, cc, len(d))
+            dec = F.FrameDecoder(io.BytesIO(fr))
+            got = bytearray()
+            while True:
+                part = dec.read(rnd.choice([1, 100, 65536, 1 << 20]))
+                if not part:
+                    break
+                got += part
+            assert bytes(got) == d, ("FrameDecoder", mode, bs, linked, bc, cc, len(d))
+            assert F.decompress_frame(fr, len(d))[0] == d
+            n += 1
+        block.set_compress_mode("fast")
+        ref = O.frame_compress(d, block_mode=1 if linked else 0, block_size=bs, block_checksums=int(bc), content_checksum=int(cc))[1]
+        assert F.decompress_frame(ref, len(d))[0] == d, ("a frame written by the oracle", bs, linked, bc, cc, len(d))
+    print("gpu_fuzz --frames: seed %d, %d frames written (random options, chunking, both modes), each decoded by the oracle and by both front ends; %d oracle-written frames decoded" % (args.seed, n, n // 2))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--frames", action="store_true")
     args = ap.parse_args()
+    if args.frames:
+        return frames(args)
     import oracle_api as O
     import wave_model as W
     from lz4_flex_amd import _lib as L, block
