@@ -227,7 +227,9 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  *   (16; 8/32/64 in -DLZ4FLEX_ALL_VARIANTS builds, variant 1); exact encoder: "compress_lanes" (8/16 lanes of a wavefront per
  *   block), "compress_variant" (1 = group encoder + emitter wavefront; 3 = group encoder alone, -DLZ4FLEX_ALL_VARIANTS builds);
  *   "decompress_second_pass" (tests: 0 leaves the blocks that variants 5..8 hand to the reference-order kernel marked with
- *   status 0x7F000001 instead of decoding them again); "compress_carry_wait" (tests: 0 = a 64 KiB window of the throughput
+ *   status 0x7F000001 instead of decoding them again); "decompress_pcd_pair" (variants 7 / 8: 1 = batches of at most 128 LARGE
+ *   blocks get a parser and a copier workgroup per block -- parse and copy of a block overlap, a single huge block uses two
+ *   CUs' worth of time instead of one; 0 = never; 2 = every batch of at most 128 blocks: tests); "compress_carry_wait" (tests: 0 = a 64 KiB window of the throughput
  *   encoder that has to wait for the window before it -- few, large blocks: a block's windows run on different workgroups --
  *   gives up at once instead of after a fraction of a second; such a block is encoded again by the launch that follows, to
  *   the same bytes: a time-sliced GPU costs time, never an error). */

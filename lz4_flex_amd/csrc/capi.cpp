@@ -47,6 +47,11 @@ struct lz4flex_ctx {
     int comp_lanes = 8;           // lanes per block, encode
     int comp_mode = 0;            // 0 = throughput ("wave") encoder, own parse (default); 1 = reference-exact encoder (lz4_flex's bytes)
     int comp_variant = 1;         // reference-exact encoder: 1 = group encoder + emitter wave (default), 3 = group encoder alone
+    uint8_t* pcd_ws = nullptr;    // workgroup decoder, small batches: a parser and a copier workgroup per block hand token lists over through this (lz4_device.h pair_ws); one per context, ordered across streams like wave_ws
+    hipEvent_t pcd_done = nullptr;
+    hipStream_t pcd_last = nullptr;
+    bool pcd_used = false;
+    int dec_pcd_pair = 1;         // 1: two workgroups per block for batches of few large blocks; 0: never, 2: whenever the batch is small enough (tests, measurements)
     uint32_t* chain_ws = nullptr; // chained decode batches (Linked frames): one "done" word per block, CHAIN_WS_BLOCKS of them
     void* wave_ws = nullptr;      // wave encoder workspace: wave_wgs persistent workgroups; allocated by lz4flex_ctx_create
     unsigned long long* wave_prof = nullptr;   // tools: per-role cycle counters of the wave encoder (lz4flex_debug_wave_prof)
@@ -70,7 +75,8 @@ static constexpr uint32_t PCD_MAX_BLOCKS = LZ4FLEX_PCD_MAX_BLOCKS;
 static constexpr uint32_t CHAIN_WS_BLOCKS = 65536u;      // blocks per chained decode batch (LZ4FLEX_MEM_CHAINED)
 
 // the decoders for blocks without dictionary / prefix
-static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressArgs& a, hipStream_t s, bool big_blocks = false) {
+static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a_, hipStream_t s, bool big_blocks = false) {
+    DecompressArgs a = a_;
     // 0: by batch shape.  Up to ~5 000 blocks the wave decoder (a wavefront per block: a block is done in half the time the
     // split decoder's serial chain needs, and blocks larger than 64 KiB stay tolerable); larger batches have enough blocks
     // to fill the chip with one chain per lane, which costs half the instructions per byte.  tools/wave_bench.py --dec, JSON
@@ -90,8 +96,25 @@ static hipError_t launch_decompress_fast(const lz4flex_ctx* c, const DecompressA
         // one block per wavefront (6: per pair of wavefronts; 7 / 8: per workgroup); blocks it marks (errors, sinks too small) are
         // decoded again in the reference's order
         constexpr int32_t REDO = 0x7F000001;
+        bool pair = false;
+        if (v >= 7 && (c->dec_pcd_pair == 2 || (c->dec_pcd_pair == 1 && big_blocks)) && c->pcd_ws && a.n <= PCD_PAIR_MAX_BLOCKS) {
+            // few LARGE blocks: a parser and a copier workgroup each (half the CUs would idle otherwise; a block of one tile has
+            // nothing to overlap and would only pay the hand-over: 64 KiB JSON blocks 0.144 -> 0.156 ms).  2 = always (tests).  The hand-over workspace is the
+            // context's: launches on different streams are ordered by an event, as the encoder's are
+            if (c->pcd_used && s != c->pcd_last) { const hipError_t w = hipStreamWaitEvent(s, c->pcd_done, 0); if (w != hipSuccess) return w; }
+            const hipError_t m = hipMemsetAsync(c->pcd_ws, 0, 64ull * a.n, s);
+            if (m != hipSuccess) return m;
+            a.pair_ws = c->pcd_ws;
+            pair = true;
+        }
         hipError_t e = v >= 7 ? launch_decompress_pcd(a, REDO, s, v == 8) : (v == 6 ? launch_decompress_wave_pair(a, REDO, s) : launch_decompress_wave(a, REDO, s));
         if (e != hipSuccess) return e;
+        if (pair) {
+            e = hipEventRecord(c->pcd_done, s);
+            if (e != hipSuccess) return e;
+            c->pcd_last = s; c->pcd_used = true;
+            a.pair_ws = nullptr;
+        }
         if (!c->dec_second_pass) return hipSuccess;
         DecompressArgs r = a;
         r.only_status = REDO;
@@ -223,6 +246,8 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->wave_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&c->chain_ws, 4u * CHAIN_WS_BLOCKS);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->pcd_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->pcd_ws, decompress_pcd_pair_ws_bytes());
     (void)hipSetDevice(prev);
     if (e != hipSuccess) {
         const int rc = hip_fail(e, "ctx_create");
@@ -239,6 +264,8 @@ void lz4flex_ctx_destroy(lz4flex_ctx* c) {
     if (c->wave_ws) (void)hipFree(c->wave_ws);
     if (c->wave_done) (void)hipEventDestroy(c->wave_done);
     if (c->chain_ws) (void)hipFree(c->chain_ws);
+    if (c->pcd_ws) (void)hipFree(c->pcd_ws);
+    if (c->pcd_done) (void)hipEventDestroy(c->pcd_done);
     if (c->wave_prof) (void)hipFree(c->wave_prof);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_pay) (void)hipHostFree(c->h_pay);
@@ -298,6 +325,11 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         c->dec_second_pass = value;
         return 0;
     }
+    if (!strcmp(key, "decompress_pcd_pair")) {
+        if (value < 0 || value > 2) return -LZ4FLEX_E_INVALID_ARG;
+        c->dec_pcd_pair = value;
+        return 0;
+    }
     if (!strcmp(key, "compress_carry_wait")) {
         if (value != 0 && value != 1) return -LZ4FLEX_E_INVALID_ARG;
         c->comp_carry_wait = value;
@@ -326,6 +358,7 @@ int lz4flex_get_tuning(lz4flex_ctx* c, const char* key) {
     if (!strcmp(key, "compress_mode")) return c->comp_mode;
     if (!strcmp(key, "compress_variant")) return c->comp_variant;
     if (!strcmp(key, "compress_carry_wait")) return c->comp_carry_wait;
+    if (!strcmp(key, "decompress_pcd_pair")) return c->dec_pcd_pair;
     if (!strcmp(key, "compress_lanes")) return c->comp_lanes;
     if (!strcmp(key, "decompress_variant")) return c->dec_variant;
     if (!strcmp(key, "decompress_second_pass")) return c->dec_second_pass;

@@ -107,6 +107,19 @@ __device__ unsigned long long g_pcd_prof[32];
 // 7 matches (polling), 8 write-back + slide, 9 giant sequences; counts: 16 tiles, 17 rounds, 18 batches, 19 sequences, 20 giants,
 // 21 / 22 turns of thread 0's polling loop with / without a ready match, 23 matches copied by thread 0's whole wavefront
 
+// ---- roles.  With fewer blocks than half the CUs a block gets TWO workgroups: the PARSER walks the tiles (it needs nothing but the
+// compressed stream) and hands every tile's token list to the COPIER through a ring of RING slots in memory; the copier never
+// walks.  Parse and copy of a block overlap (the parse was a fifth of a block's time), and one huge block -- the scalar
+// decompress_into -- no longer leaves 255 CUs idle with 1.  Layout of DecompressArgs::pair_ws: 64 control bytes per block (u32:
+// [k] slot k holds tile number [k] - 1, [3] tiles consumed, [4 + 3 k ..] slot k's tile start, token count, tile exit, [13] the
+// copier has left), then
+// RING slots of token lists per block.  Hand-over: MI355X_MICROARCH.md's valid forms (plain stores, barrier, one lane: agent
+// release fence, s_waitcnt, relaxed flag store / one relaxed poll, agent acquire, barrier, plain loads); workgroups are
+// dispatched in index order and a block's two are neighbours, so whatever is resident makes progress; every wait is bounded
+// all the same (a block that gives up is decoded by the reference-order kernel).
+constexpr uint32_t PAIR_RING = 3u;
+constexpr uint32_t PAIR_CTRL = 64u;
+constexpr uint32_t PAIR_TOKB = (2u * MAXSEQ + 255u) / 256u * 256u;      // (the production geometry's; the test geometry's lists are shorter)
 enum : uint32_t { C_EXIT = 0, C_CUT = 1, C_TOTAL = 2, C_BAD = 3, C_G_SRC = 4, C_G_LIT = 5, C_G_ML = 6, C_G_OFF = 7, C_TIMEOUT = 8, C_BAD2 = 9,
                   C_NEEDPREV = 10, C_PREV = 11 };
 
@@ -592,7 +605,9 @@ struct Ctx {
 template <class G>
 __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs a, int32_t redo_code) {
     extern __shared__ __attribute__((aligned(16))) uint8_t pcd_lds[];
-    const uint32_t b = blockIdx.x;
+    const bool paired = a.pair_ws != nullptr;
+    const uint32_t b = paired ? blockIdx.x >> 1 : blockIdx.x;
+    const uint32_t role = paired ? 1u + (blockIdx.x & 1u) : 0u;     // 0: the block's only workgroup, 1: its parser, 2: its copier
     if (b >= a.n) return;
     Ctx<G> X;
     X.lds = (lds_u8*)pcd_lds;
@@ -606,12 +621,15 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
     const uint32_t tid = X.tid, lane = X.lane;
     volatile lds_u32* ctl = X.ctl();
     if (X.ilen == 0u) {                                           // decompress.rs:207-209: the reference-order kernel reports it
-        if (tid == 0u) {
+        if (tid == 0u && role != 1u) {
             a.status[b] = redo_code; a.out_len[b] = 0u;
             if (a.chain_done != nullptr) __hip_atomic_store(a.chain_done + b, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
+    uint32_t* const pcw = paired ? (uint32_t*)(a.pair_ws + (size_t)PAIR_CTRL * b) : nullptr;                      // this block's control words
+    uint8_t* const ptok = paired ? a.pair_ws + (size_t)PAIR_CTRL * PCD_PAIR_MAX_BLOCKS + (size_t)PAIR_TOKB * PAIR_RING * b : nullptr;
+    uint32_t tile_no = 0u;
     if (tid < 32u) ctl[tid] = 0u;
     // prefix mode (Linked frames): the sink already holds OP0 bytes that matches may refer to; in a chained batch they are being
     // written by the earlier blocks of the batch
@@ -626,18 +644,46 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
     PCD_PROF_DECL
 
     while (!ended) {
+        uint32_t tile_exit = X_ERR, ntok = 0u;
+        if (role == 2u) {
+            // ---- copier of a pair: the tile comes parsed.  Wait for slot tile_no % RING, take the token list, give the slot back
+            const uint32_t k = tile_no % PAIR_RING;
+            if (tid == 0u) {
+                const unsigned long long t0 = wall_clock64();
+                uint32_t ok = 1u;
+                while (__hip_atomic_load(pcw + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tile_no + 1u) {
+                    if (wall_clock64() - t0 > 1000000000ull) { ok = 0u; break; }      // 10 s
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                ctl[C_G_SRC] = pcw[4u + 3u * k]; ctl[C_G_LIT] = pcw[5u + 3u * k]; ctl[C_G_ML] = pcw[6u + 3u * k];
+                ctl[C_PREV] = ok;
+            }
+            __syncthreads();
+            const bool ok = ctl[C_PREV] != 0u;
+            cbase = ctl[C_G_SRC]; ntok = ctl[C_G_LIT]; tile_exit = ctl[C_G_ML];
+            __syncthreads();                                       // (the control words are written again below)
+            if (!ok || tile_exit == X_ERR || ntok > G::MAXSEQ) { bad = true; break; }
+            X.load_tile(cbase);
+            const uint8_t* src = ptok + (size_t)PAIR_TOKB * k;
+            for (uint32_t o = 16u * tid; o < 2u * ntok; o += 16u * G::T) st16l((lds_u8*)X.tok() + o, ld16g(src + o));
+            __syncthreads();
+            if (tid == 0u) __hip_atomic_store(pcw + 3, tile_no + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (everybody's loads have landed: their values are in LDS)
+        } else {
         // ================================================================ PARSE one tile
         X.load_tile(cbase);
+        }
         const uint32_t span = X.ilen - cbase;
         const uint32_t parts = span >= G::CT ? G::NP : (span + G::P - 1u) / G::P;
-        for (uint32_t w = tid; w < G::MW; w += G::T) { X.marks()[w] = 0u; X.nmk()[w] = 0u; }
+        if (role != 2u) for (uint32_t w = tid; w < G::MW; w += G::T) { X.marks()[w] = 0u; X.nmk()[w] = 0u; }
         const uint32_t staged = span < G::CT + G::CM ? span : G::CT + G::CM;      // bytes of the block in the LDS tile
+        const Rd<G> rd{X.ct(), X.gin, cbase};
+        if (role != 2u) {
         uint32_t my_e = cbase + tid * G::P;
         if (tid < parts) { X.ent()[tid] = my_e; X.ext()[tid] = X_ERR; }
         bool dirty = tid < parts;
         if (tid == 0u) ctl[C_EXIT] = X_ERR;
         __syncthreads();
-        const Rd<G> rd{X.ct(), X.gin, cbase};
         bool settled = false;
         PCD_TICK(0) PCD_COUNT(16, 1)
         for (uint32_t it = 0u; it < G::MAX_ITERS; ++it) {
@@ -744,13 +790,11 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
             PCD_TICK(2)
             if (!any_dirty) { settled = true; break; }
         }
-        const uint32_t tile_exit = ctl[C_EXIT];
-        if (!settled || tile_exit == X_ERR) { bad = true; break; }     // (uniform)
-        ended = tile_exit == X_END;
-
+        tile_exit = ctl[C_EXIT];
+        if (!settled) tile_exit = X_ERR;
+        if (tile_exit != X_ERR) {
         // ---- the tile's sequences: set bits of the live parts, in order
-        uint32_t ntok;
-        {
+
             uint32_t word = 0u;
             if (tid < G::MW) {
                 const uint32_t part = tid / G::PW;
@@ -765,6 +809,38 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
         }
         __syncthreads();
         PCD_TICK(3)
+        if (role == 1u) {
+            // ---- parser of a pair: hand the tile over (an X_ERR exit too: the copier gives the block to the reference-order kernel)
+            const uint32_t k = tile_no % PAIR_RING;
+            if (tid == 0u) {
+                const unsigned long long t0 = wall_clock64();
+                uint32_t ok = 1u;
+                while (tile_no - __hip_atomic_load(pcw + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= PAIR_RING) {
+                    if (__hip_atomic_load(pcw + 13, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > 1000000000ull) { ok = 0u; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                ctl[C_PREV] = ok;
+            }
+            __syncthreads();
+            if (ctl[C_PREV] == 0u) return;                          // the copier is gone (it has given the block up, or will)
+            uint8_t* dst = ptok + (size_t)PAIR_TOKB * k;
+            for (uint32_t o = 16u * tid; o < 2u * ntok; o += 16u * G::T) st16g(dst + o, ld16l((const lds_u8*)X.tok() + o));
+            __syncthreads();                                       // every thread's stores precede the fence below
+            if (tid == 0u) {
+                pcw[4u + 3u * k] = cbase; pcw[5u + 3u * k] = ntok; pcw[6u + 3u * k] = tile_exit;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(pcw + k, tile_no + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tile_exit >= X_ERR) return;                         // X_END: the last tile; X_ERR: nothing to parse behind it
+            cbase = tile_exit;
+            tile_no += 1u;
+            __syncthreads();                                       // the tile's LDS is free
+            continue;
+        }
+        }
+        if (tile_exit == X_ERR) { bad = true; break; }             // (uniform)
+        ended = tile_exit == X_END;
 
         // ================================================================ COPY: batches of consecutive sequences
         // A batch is up to S sequences per lane: sequence i of the batch belongs to lane i mod T, slot i / T -- the phases whose cost
@@ -915,9 +991,11 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
         }
         if (bad) break;
         cbase = tile_exit;
+        tile_no += 1u;
         __syncthreads();                                           // the tile's LDS is free
     }
     PCD_PROF_FLUSH
+    if (role == 2u && tid == 0u) __hip_atomic_store(pcw + 13, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a parser still waiting for a slot goes home)
     if (a.chain_done != nullptr) {
         // my bytes are complete: say so once every earlier block has (a waiter wants ALL of its prefix), or pass the failure on
         __syncthreads();                                           // every thread's stores precede the fence below
@@ -948,7 +1026,7 @@ static hipError_t launch_geo(const DecompressArgs& a, int32_t redo_code, hipStre
             have |= bit;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(a.n), dim3(G::T), G::LDS_BYTES, s, a, redo_code);
+    hipLaunchKernelGGL(kern, dim3(a.pair_ws != nullptr ? 2u * a.n : a.n), dim3(G::T), G::LDS_BYTES, s, a, redo_code);
     return hipGetLastError();
 }
 
@@ -957,8 +1035,13 @@ static hipError_t launch_geo(const DecompressArgs& a, int32_t redo_code, hipStre
 // one workgroup per block; blocks it marks (status redo_code) are decoded again by launch_decompress (only_status = redo_code).
 // test_geometry: the small geometry (2 KiB tiles, 64-byte parts, 128 lanes, 0.5 + 1 KiB window) that puts every kind of boundary
 // inside small inputs -- tests only.
+size_t decompress_pcd_pair_ws_bytes() {
+    return (size_t)PCD_PAIR_MAX_BLOCKS * (pcd::PAIR_CTRL + (size_t)pcd::PAIR_TOKB * pcd::PAIR_RING);
+}
+
 hipError_t launch_decompress_pcd(const DecompressArgs& a, int32_t redo_code, hipStream_t s, bool test_geometry) {
     if (a.n == 0u) return hipSuccess;
+    if (a.pair_ws != nullptr && a.n > PCD_PAIR_MAX_BLOCKS) return hipErrorInvalidValue;
     if (a.dict_base != nullptr) return hipErrorInvalidValue;   // external dictionary: lz4_decompress.hip
     return test_geometry ? pcd::launch_geo<pcd::GeoTest>(a, redo_code, s) : pcd::launch_geo<pcd::GeoProd>(a, redo_code, s);
 }

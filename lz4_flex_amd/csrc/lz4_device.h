@@ -33,7 +33,13 @@ struct DecompressArgs {
     // one output region and block i's prefix [.., out_pos[i]) is what blocks 0..i-1 of this batch write (Linked frames,
     // src/frame/decompress.rs:195-222,280-306).  chain_done[i] becomes 1 (done, and every block before it) or 2 (given up).
     uint32_t* chain_done;
+    // lz4_decompress_pcd_kernel: nullable.  Set (n <= PCD_PAIR_MAX_BLOCKS, the first 64 n bytes zero before the launch) => every block
+    // gets TWO workgroups: one parses its tiles and hands the token lists over through this workspace, the other copies
+    // (lz4_decompress_pcd.hip "roles"); decompress_pcd_pair_ws_bytes() bytes
+    uint8_t* pair_ws;
 };
+constexpr uint32_t PCD_PAIR_MAX_BLOCKS = 128u;
+size_t decompress_pcd_pair_ws_bytes();
 
 struct CompressArgs {
     const uint8_t* in_base;

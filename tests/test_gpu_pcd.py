@@ -28,11 +28,13 @@ def env():
     return lib, block
 
 
-def _ctx(lib, variant, second_pass=1):
+def _ctx(lib, variant, second_pass=1, pair=None):
     ctx = C.c_void_p()
     assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
     assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", variant) == 0
     assert lib.lz4flex_set_tuning(ctx, b"decompress_second_pass", second_pass) == 0
+    if pair is not None:      # 0: one workgroup per block; 2: a parser and a copier workgroup per block in every batch of <= 128 blocks
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_pcd_pair", pair) == 0
     return ctx
 
 
@@ -66,10 +68,12 @@ def big_inputs():
     ]
 
 
+@pytest.mark.parametrize("pair", [0, 2])
 @pytest.mark.parametrize("variant", [7, 8])
-def test_large_blocks_every_encoder(env, variant):
+def test_large_blocks_every_encoder(env, variant, pair):
     """blocks of up to 4 MiB from the reference encoder (oracle), C liblz4 and this library's throughput encoder (model): bytes ==
-    oracle, nothing behind the sink, also with a sink larger than needed"""
+    oracle, nothing behind the sink, also with a sink larger than needed.  With one workgroup per block and with a parser and a
+    copier workgroup per block (the token lists travel through the context's workspace)"""
     lib, block = env
     comps, caps, plains = [], [], []
     for name, d in big_inputs():
@@ -78,11 +82,12 @@ def test_large_blocks_every_encoder(env, variant):
             comps += [c, c]
             caps += [len(d), len(d) + 777]
             plains += [d, d]
-    ctx = _ctx(lib, variant)
+    ctx = _ctx(lib, variant, pair=pair)
     try:
         out, out_off, ol, st, det = _batch(block, ctx, comps, caps)
     finally:
         lib.lz4flex_ctx_destroy(ctx)
+    assert len(comps) <= 128
     for i, d in enumerate(plains):
         o = int(out_off[i])
         assert st[i] == 0 and ol[i] == len(d), (i, int(st[i]), int(ol[i]), len(d))
@@ -134,6 +139,44 @@ def test_first_pass_marks_exactly_what_the_model_calls_irregular(env, variant):
             assert O.ERR_NAMES.get(int(st[i])) == w[0], (i, int(st[i]), w[0])
             if w[0] == "OutputTooSmall":
                 assert (int(det[i][0]), int(det[i][1])) == tuple(w[1])
+
+
+@pytest.mark.parametrize("variant", [7, 8])
+def test_two_workgroups_per_block_on_the_adversarial_batch(env, variant):
+    """the adversarial blocks (every prefix, corruptions, short sinks ...) in launches of <= 128 blocks with a parser and a copier
+    workgroup per block: an irregular tile reaches the copier as such, the copier hands the block to the reference-order kernel:
+    bytes, error variants and OutputTooSmall{expected, actual} == the oracle; twice through the same context (the workspace is
+    reused) -- and a chained batch (a Linked frame written by the oracle) through the default context in that mode"""
+    lib, block = env
+    cases = corpus.adversarial_blocks()[::3] + corpus.synthetic_blocks(sizes=(150000,) * 3 + (5000,) * 5)
+    cases = [(c, k if isinstance(k, int) else len(k)) for c, k in cases]
+    ctx = _ctx(lib, variant, pair=2)
+    try:
+        for rep in range(2):
+            for at in range(0, len(cases), 128):
+                part = cases[at:at + 128]
+                want = [O.decompress(c, k) for c, k in part]
+                out, out_off, ol, st, det = _batch(block, ctx, [c for c, _ in part], [k for _, k in part])
+                for i, w in enumerate(want):
+                    o = int(out_off[i])
+                    if w[0] == "ok":
+                        assert st[i] == 0 and ol[i] == len(w[1]) and out[o:o + ol[i]].tobytes() == w[1], (at + i, int(st[i]))
+                    else:
+                        assert O.ERR_NAMES.get(int(st[i])) == w[0], (at + i, int(st[i]), w[0])
+                        if w[0] == "OutputTooSmall":
+                            assert (int(det[i][0]), int(det[i][1])) == tuple(w[1])
+                    assert out[o + part[i][1]:o + part[i][1] + 64].tobytes() == b"\xA5" * 64
+    finally:
+        lib.lz4flex_ctx_destroy(ctx)
+    if variant == 7:
+        from lz4_flex_amd import frame as F
+        data = (O.fixture_plain("compression_66k_JSON") * 12)[:700000]
+        fr = O.frame_compress(data, block_mode=1, block_size=4)[1]
+        assert lib.lz4flex_set_tuning(None, b"decompress_pcd_pair", 2) == 0
+        try:
+            assert F.decompress_frame(fr, len(data))[0] == data
+        finally:
+            assert lib.lz4flex_set_tuning(None, b"decompress_pcd_pair", 1) == 0
 
 
 def test_scalar_decompress_into_of_large_blocks_uses_the_workgroup_decoder(env):

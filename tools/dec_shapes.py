@@ -73,7 +73,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 assert lib.lz4flex_decompress_batch(ctx, p(comp), p(comp_off), p(clen), n, p(back), p(in_off), p(in_len), p(blen), p(bst),
-                                                    None, L.MEM_DEVICE, stream) == 0, L.last_error()
+                                                    None, L.MEM_DEVICE | (L.MEM_BIG_BLOCKS if B > 131072 else 0), stream) == 0, L.last_error()   # (the hint a caller of large blocks gives: include/lz4flex_amd.h)
                 e1.record()
                 torch.cuda.synchronize()
                 if r:
@@ -87,7 +87,7 @@ def main():
                 pv = (C.c_ulonglong * 32)()
                 lib.lz4flex_debug_pcd_prof(None, 1)
                 assert lib.lz4flex_decompress_batch(ctx, p(comp), p(comp_off), p(clen), n, p(back), p(in_off), p(in_len), p(blen), p(bst),
-                                                    None, L.MEM_DEVICE, stream) == 0
+                                                    None, L.MEM_DEVICE | (L.MEM_BIG_BLOCKS if B > 131072 else 0), stream) == 0
                 torch.cuda.synchronize()
                 lib.lz4flex_debug_pcd_prof(pv, 0)
                 pv = list(pv)
