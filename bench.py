@@ -267,7 +267,7 @@ def run_blocks(args, env):
         kernels["compress"] = {"kernel": kname, "ms_per_launch": round(t_c * 1e3, 4), "MiB_per_s": round(total / 1048576 / t_c, 1),
                                "roofline": roof(alg_bytes, t_c)}
     if args.only in ("both", "decompress"):
-        dv = args.decompress_variant or (7 if n <= 768 else (6 if n <= 2304 else (5 if n <= 5120 else 4)))   # capi.cpp launch_decompress_fast's choice by batch size
+        dv = args.decompress_variant or (7 if n <= 1024 else (6 if n <= 2304 else (5 if n <= 5120 else 4)))   # capi.cpp launch_decompress_fast's choice by batch size
         kernels["decompress"] = {"kernel": {7: "lz4_decompress_pcd_kernel", 8: "lz4_decompress_pcd_kernel", 6: "lz4_decompress_wave_pair_kernel",
                                             5: "lz4_decompress_wave_kernel", 4: "lz4_decompress_split_kernel", 1: "lz4_decompress_blocks_kernel"}[dv],
                                  "ms_per_launch": round(t_d * 1e3, 4), "MiB_per_s": round(total / 1048576 / t_d, 1),

@@ -132,7 +132,7 @@ int64_t lz4flex_decompress_size_prepended_with_dict(const uint8_t *in, size_t in
 /* OR into mem_kind for DEVICE batches that may hold blocks > 64 KiB: the lengths live in device memory where the host cannot see
  * them (HOST batches detect it themselves).  compress, reference-exact mode: selects the u32 hash table; decompress: a hint
  * that the blocks are large, so any number of them goes to the one-workgroup-per-block decoder (lz4_decompress_pcd.hip), which
- * otherwise serves batches of up to 768 blocks.  Results do not depend on the hint. */
+ * otherwise serves batches of up to 1 024 blocks.  Results do not depend on the hint. */
 #define LZ4FLEX_MEM_BIG_BLOCKS 0x100
 
 /* OR into mem_kind for lz4flex_decompress_batch_ex with ext->out_pos: the batch is a CHAIN -- every block has the same out_off,

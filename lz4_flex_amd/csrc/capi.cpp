@@ -69,7 +69,7 @@ struct lz4flex_ctx {
 };
 
 #ifndef LZ4FLEX_PCD_MAX_BLOCKS
-#define LZ4FLEX_PCD_MAX_BLOCKS 768
+#define LZ4FLEX_PCD_MAX_BLOCKS 1024
 #endif
 static constexpr uint32_t PCD_MAX_BLOCKS = LZ4FLEX_PCD_MAX_BLOCKS;
 static constexpr uint32_t CHAIN_WS_BLOCKS = 65536u;      // blocks per chained decode batch (LZ4FLEX_MEM_CHAINED)
@@ -86,9 +86,9 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
     // block: 256 / 1 024 / 2 048 blocks 0.45 / 0.52 / 0.65 ms against 0.73 / 0.75 / 0.82 with one wavefront
     // up to PCD_MAX_BLOCKS blocks, or blocks known to be large: a whole workgroup per block, token chain and copies parallel INSIDE
     // the block (lz4_decompress_pcd.hip) -- the only decoder here whose time for a block is not the length of the block's chain.
-    // tools/dec_shapes.py, JSON tiles (its worst case: 60-85 dependent matches per batch), 256 / 512 / 1 024 blocks: 0.20 / 0.38 /
-    // 0.73 ms against 0.44 / 0.49 / 0.52 (pair of wavefronts per block); 1 024 text / log blocks 0.88 / 0.46 against 1.03 / 0.58;
-    // 256 x 4 MiB log blocks: 5.5 ms against 28.8; one 16 MiB block: 21.2 ms against 113.  768 = three workgroups per CU.
+    // tools/dec_shapes.py, JSON tiles (its worst case: the deepest dependency chains), 256 / 512 / 1 024 / 2 304 blocks: 0.15 / 0.28 /
+    // 0.52 / 1.13 ms against 0.45 / 0.49 / 0.52 / 0.71 (pair of wavefronts per block); 1 024 text / log blocks 0.81 / 0.42 against
+    // 1.02 / 0.58; 256 x 4 MiB log blocks: 4.9 ms against 28.8; one 16 MiB block: 14.6 ms against 113.  1 024 = four workgroups per CU.
     int v = c->dec_variant != 0 ? c->dec_variant
                                 : ((a.n <= PCD_MAX_BLOCKS || big_blocks) ? 7 : (a.n <= 2304u ? 6 : (a.n <= 5120u ? 5 : 4)));
     if (a.out_pos != nullptr && v != 8) v = 7;           // prefix mode (Linked frames): only the workgroup decoder knows it
