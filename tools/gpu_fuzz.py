@@ -109,7 +109,9 @@ def main():
     from lz4_flex_amd import _lib as L, block
     lib = L.load()
     rnd = random.Random(args.seed)
-    decoders = [(1, 0), (4, 8), (4, 32), (4, 64), (5, 0), (6, 0), (7, 0), (8, 0)]
+    # (decompress_variant, blocks per workgroup of the split decoder | for 7 / 8: 2 = a parser and a copier workgroup per block, in
+    # launches of 100 blocks)
+    decoders = [(1, 0), (4, 8), (4, 32), (4, 64), (5, 0), (6, 0), (7, 0), (8, 0), (7, 2), (8, 2)]
     t_end = time.time() + args.seconds
     rounds = inputs = blocks = 0
     while time.time() < t_end:
@@ -147,9 +149,18 @@ def main():
             ctx = C.c_void_p()
             assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
             assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", variant) == 0
-            if bpw:
-                assert lib.lz4flex_set_tuning(ctx, b"decompress_blocks_per_wg", bpw) == 0
-            ol, st, det = block.decompress_batch(inb, list(in_off), [len(c) for c, _ in cases], out, list(out_off), caps, ctx=ctx)
+            lens = [len(c) for c, _ in cases]
+            if variant >= 7 and bpw == 2:
+                assert lib.lz4flex_set_tuning(ctx, b"decompress_pcd_pair", 2) == 0
+                ol, st = np.zeros(len(cases), dtype=np.uint32), np.zeros(len(cases), dtype=np.int32)
+                for at in range(0, len(cases), 100):
+                    e = min(at + 100, len(cases))
+                    o2, s2, _d2 = block.decompress_batch(inb, list(in_off[at:e]), lens[at:e], out, list(out_off[at:e]), caps[at:e], ctx=ctx)
+                    ol[at:e], st[at:e] = o2, s2
+            else:
+                if bpw:
+                    assert lib.lz4flex_set_tuning(ctx, b"decompress_blocks_per_wg", bpw) == 0
+                ol, st, det = block.decompress_batch(inb, list(in_off), lens, out, list(out_off), caps, ctx=ctx)
             lib.lz4flex_ctx_destroy(ctx)
             for i, ((c, k), w) in enumerate(zip(cases, want)):
                 o = int(out_off[i])
@@ -159,7 +170,7 @@ def main():
                     assert O.ERR_NAMES.get(int(st[i])) == w[0], ("decoder", variant, bpw, i, len(c), k, int(st[i]), w[0])
                 assert out[o + k:o + k + 64].tobytes() == b"\xA5" * 64, ("decoder wrote behind a sink", variant, bpw, i)
             blocks += len(cases)
-    print("gpu_fuzz: seed %d, %d rounds, %d inputs through both encoders, %d block decodes through 8 decoder kernels: all equal the oracle" % (args.seed, rounds, inputs, blocks))
+    print("gpu_fuzz: seed %d, %d rounds, %d inputs through both encoders, %d block decodes through 8 decoder kernels (the workgroup decoder also with two workgroups per block): all equal the oracle" % (args.seed, rounds, inputs, blocks))
 
 
 if __name__ == "__main__":
