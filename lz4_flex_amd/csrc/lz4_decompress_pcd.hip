@@ -7,22 +7,26 @@
 // lanes decodes a block, and both halves of the reference's loop are parallel inside the block:
 //
 //   PARSE (the token chain, decompress.rs:244-332).  The compressed stream is consumed in tiles of 32 KiB staged in LDS; a tile
-//   is cut into 128 parts of 256 bytes and lane k walks part k from an ASSUMED entry (the part's first byte), marking the
+//   is cut into 256 parts of 128 bytes and lane k walks part k from an ASSUMED entry (the part's first byte), marking the
 //   token positions it visits in an LDS bitmap and noting where its chain leaves the part.  A chain started at a wrong byte
 //   falls into step with the true chain after a few sequences, and two chains that share a position are identical from
 //   there on.  One wavefront then follows the exits from part 0 (whose entry is true) by pointer jumping: the exit of a live
-//   part is the true entry of the part it lands in.  Parts whose entry changed are walked again; this repeats until nothing
-//   changes (1.8 walks per part on the benchmark data; NP + 1 rounds at worst).  The set bits of the live parts are the
-//   tile's sequences, in order.  No lane needs the output position.
+//   part is the true entry of the part it lands in.  Parts whose entry changed are walked again, only as far as their new chain
+//   differs from the old one; this repeats until nothing changes (3 rounds on the benchmark data; NP + 1 at worst).  The set
+//   bits of the live parts are the tile's sequences, in order.  No lane needs the output position, and a hop of a walk is ONE
+//   LDS round trip (see the walk loop).
 //
-//   COPY (decompress.rs:334-437).  Sequences are executed 1 024 at a time, one lane each: token re-parsed from the LDS tile, a
-//   block-wide prefix sum of literal + match lengths places all of them at once in an LDS WINDOW of the output (16 KiB of
-//   history + up to 32 KiB new bytes); all literals are copied at once; a match waits until the sequences that produce its
-//   source bytes (a range of the batch found by binary search over the start positions) have set their DONE bits, then copies
-//   16 bytes at a time and sets its own.  Wavefronts poll independently: a dependency costs an LDS round trip, not a barrier.
+//   COPY (decompress.rs:334-437).  Sequences are executed 2 048 at a time, two per lane: token re-parsed from the LDS tile, a
+//   block-wide prefix sum of literal + match lengths places all of them at once in an LDS WINDOW of the output (26 KiB of
+//   history + up to 48 KiB new bytes); all literals are copied at once; a match whose whole source lies inside an earlier match
+//   of the batch is RELINKED to that match's source; a match then waits until the sequences that produce its source bytes
+//   (found through a table of the first sequence per 64 output bytes) have set their DONE bits, copies 16 bytes at a time and
+//   sets its own.  Wavefronts poll independently: a dependency costs an LDS round trip, not a barrier.
 //   Long / overlapping / window-straddling matches and long literal runs are copied by a whole wavefront (non-overlapping
 //   steps of doubling size for periodic matches); a sequence longer than the window is executed alone by the whole workgroup
 //   on the output itself.  The window is written back 16 bytes per lane after every batch.
+//
+//   ROLES.  A batch of few large blocks gets two workgroups per block: one parses, the other copies (see "roles" below).
 //
 // It diagnoses nothing: any irregularity (every DecompressError of src/block/mod.rs:82-98, a sink too small, an offset behind
 // the output, a tile that does not settle) marks the block, and lz4_decompress_blocks_kernel decodes it again in the
