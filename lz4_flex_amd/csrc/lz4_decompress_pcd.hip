@@ -82,7 +82,7 @@ struct Geo {
     static_assert(CT % P == 0 && P % 32 == 0 && T % 64 == 0 && MW <= T && NP <= T && NP <= 64u * PPL && HIST % 16 == 0, "geometry");
     static_assert(LDS_BYTES <= 160u * 1024u, "LDS");
 };
-using GeoProd = Geo<CT, CM, P, THREADS, SEQ_PER_LANE, HIST, WNEW>;   // lz4_pcd_common.h: 32 KiB tiles, 128-byte parts, 1 024 lanes x 2 sequences, 48 + 32 KiB window
+using GeoProd = Geo<CT, CM, P, THREADS, SEQ_PER_LANE, HIST, WNEW>;   // lz4_pcd_common.h: 32 KiB tiles, 128-byte parts, 1 024 lanes x 2 sequences, 26 + 48 KiB window
 using GeoTest = Geo<2048u, 256u, 64u, 128u, 2u, 512u, 1024u>;        // tests: boundaries of every kind inside small inputs
 
 // control words in LDS.  A word is written on one side of a barrier and read on the other: C_BAD (a sequence that does not parse) is

@@ -25,7 +25,7 @@ namespace pcd {
 // EXIT, a position in a later part).  A chain that starts at the wrong byte falls into step with the true chain after a few
 // sequences (median 15-25 bytes), and two chains that share a position are identical from there on.  So: follow
 // the exits from part 0 -- exit of part 0 = true entry of the part it lands in, and so on --, re-walk every part whose
-// entry changed, and repeat until nothing changes (usually two walks).  Parts a sequence jumps over hold no token: dead.
+// entry changed, and repeat until nothing changes (three rounds on real data).  Parts a sequence jumps over hold no token: dead.
 // Then the set bits of the live parts ARE the tile's sequences, in order.
 constexpr uint32_t CT = 32768u;           // compressed bytes per tile
 constexpr uint32_t CM = 1024u;            // bytes behind the tile that are staged with it (a walk's last sequence reads past the tile)

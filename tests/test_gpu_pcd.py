@@ -2,7 +2,7 @@
 copies parallel INSIDE the block) on the shapes it exists for -- few, large blocks -- and against its host model.
 
 Checker: the oracle (lz4_flex's decoder restated).  Both geometries of the kernel run everything: the production one (32 KiB
-tiles, 1 024 sequences per batch, 16 + 32 KiB window) and the test one (2 KiB tiles, 128 sequences, 0.5 + 1 KiB window), which
+tiles, 2 048 sequences per batch, 26 + 48 KiB window) and the test one (2 KiB tiles, 256 sequences, 0.5 + 1 KiB window), which
 puts tile / part / batch / window boundaries and the giant-sequence path inside ordinary inputs.  The generic decoder matrix
 of test_gpu_block.py (KATs, the 2 490-block adversarial batch, mixed batches) runs both geometries too (DECODERS -7, -8)."""
 import ctypes as C
