@@ -151,7 +151,7 @@ int lz4flex_frame_compress_sharded(lz4flex_ctx* ctx, void* nccl_comm, int rank, 
         TRY_HIP(hipMemcpyAsync(st.data(), d + o_st, 4ull * n, hipMemcpyDeviceToHost, s));
         TRY_HIP(hipMemcpyAsync(&seg_bytes, d + o_seg_off + 8ull * n, 8, hipMemcpyDeviceToHost, s));
         TRY_HIP(hipStreamSynchronize(s));
-        for (uint32_t i = 0; i < n; i++) if (st[i] != 0) return -LZ4FLEX_FE_COMPRESSION;
+        for (uint32_t i = 0; i < n; i++) if (st[i] != 0) seg_bytes = ~0ull;       // (said to everybody below: a rank that left now would leave the others waiting in the exchange)
     }
     // ---- 1) all-gather of the segment sizes, 2) exclusive prefix sum
     std::vector<uint64_t> all((size_t)world, 0);
@@ -164,6 +164,7 @@ int lz4flex_frame_compress_sharded(lz4flex_ctx* ctx, void* nccl_comm, int rank, 
     } else {
         all[0] = seg_bytes;
     }
+    for (int r = 0; r < world; r++) if (all[(size_t)r] == ~0ull) return -LZ4FLEX_FE_COMPRESSION;       // every rank sees the same sizes: all leave here
     uint8_t hdr[19];
     const int64_t hl = lz4flex_frame_info_write(info, hdr, sizeof hdr);
     if (hl < 0) return (int)hl;
@@ -172,9 +173,19 @@ int lz4flex_frame_compress_sharded(lz4flex_ctx* ctx, void* nccl_comm, int rank, 
     for (int r = 0; r < world; r++) { off[(size_t)r] = at; at += all[(size_t)r]; }
     const uint64_t total = at + 4;                                   // + EndMark (frame/compress.rs:222-224)
     if (frame_len) *frame_len = rank == root ? total : 0;
+    // ---- the root's verdict on its buffer reaches every rank before anybody sends (a root that left alone would leave the
+    // senders waiting)
+    uint64_t go = (rank != root || (frame && frame_cap >= total)) ? 1 : 0;
+    if (world > 1) {
+        uint64_t* dsz = sizes.as<uint64_t>();
+        TRY_HIP(hipMemcpyAsync(dsz, &go, 8, hipMemcpyHostToDevice, s));
+        TRY_NCCL(rccl().Broadcast(dsz, dsz, 1, NCCL_U64, root, nccl_comm, s));
+        TRY_HIP(hipMemcpyAsync(&go, dsz, 8, hipMemcpyDeviceToHost, s));
+        TRY_HIP(hipStreamSynchronize(s));
+    }
+    if (!go) return -LZ4FLEX_FE_OUTPUT_FULL;
     // ---- 3) variable-size gather to the root
     if (rank == root) {
-        if (!frame || frame_cap < total) return -LZ4FLEX_FE_OUTPUT_FULL;
         uint8_t* f = (uint8_t*)frame;
         TRY_HIP(hipMemcpyAsync(f, hdr, (size_t)hl, hipMemcpyHostToDevice, s));
         TRY_HIP(hipMemsetAsync(f + total - 4, 0, 4, s));
