@@ -333,8 +333,10 @@ int lz4flex_frame_walk_device(const void *frame, uint64_t frame_len, uint32_t he
  * temporaries).  Linked frames, content checksums / sizes and BlockSize::Auto do not shard: -LZ4FLEX_E_UNSUPPORTED /
  * -LZ4FLEX_E_INVALID_ARG.  Verdicts that depend on the data or on one rank's buffers (a block that failed to compress, a frame
  * that does not parse, a root buffer too small) reach every rank before the exchange they would break: all ranks return the
- * same code and nobody is left waiting.  With more than one rank these entry points have been compiled and linked against RCCL but not run
- * (no multi-GPU node was available to this build); lz4_flex_amd/sharded.py is the same exchange over torch.distributed. */
+ * same code and nobody is left waiting.  With more than one rank these entry points have run against a mock communicator
+ * (ranks as threads on one device: tests/test_gpu_sharded_native.py; LZ4FLEX_RCCL_LIB names the library that provides the
+ * ncclXxx entry points, RCCL by default), never against RCCL on several GPUs (no multi-GPU node was available to this build);
+ * lz4_flex_amd/sharded.py is the same exchange over torch.distributed. */
 /* bytes a rank's segment can take at most (and the root must be able to receive from it) */
 uint64_t lz4flex_frame_segment_bound(uint64_t local_len, const lz4flex_frame_info *info);
 /* local[0 .. local_len): this rank's blocks (a multiple of the block size except on the last rank); first_block: the global

@@ -18,6 +18,8 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -43,7 +45,11 @@ constexpr int NCCL_U8 = 1, NCCL_U64 = 5;
 const Rccl& rccl() {
     static Rccl r = [] {
         Rccl x;
-        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        // LZ4FLEX_RCCL_LIB: another library with the six ncclXxx entry points (a site's own build of RCCL; tests/sim/mock_rccl.cpp --
+        // ranks as threads of one process on one device, which RCCL itself refuses)
+        void* h = nullptr;
+        if (const char* own = getenv("LZ4FLEX_RCCL_LIB")) h = dlopen(own, RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (!h) return x;
         x.AllGather = (decltype(x.AllGather))dlsym(h, "ncclAllGather");
@@ -75,8 +81,13 @@ struct DevBuf {                       // a device allocation that frees itself
     template <class T> T* as() const { return (T*)p; }
 };
 
-#define TRY_HIP(e) do { if ((e) != hipSuccess) return -LZ4FLEX_E_HIP; } while (0)
-#define TRY_NCCL(e) do { if ((e) != 0) return -LZ4FLEX_E_HIP; } while (0)
+// (LZ4FLEX_TRACE=1: which call failed, on stderr -- these paths have no other way to say so)
+static int failed(const char* what, int line, int code) {
+    if (getenv("LZ4FLEX_TRACE")) fprintf(stderr, "lz4flex sharded.cpp:%d: %s failed (%d)\n", line, what, code);
+    return -LZ4FLEX_E_HIP;
+}
+#define TRY_HIP(e) do { const hipError_t e_ = (e); if (e_ != hipSuccess) return failed("HIP call", __LINE__, (int)e_); } while (0)
+#define TRY_NCCL(e) do { const int e_ = (e); if (e_ != 0) return failed("RCCL call", __LINE__, e_); } while (0)
 #define TRY_RC(e) do { const int rc_ = (e); if (rc_) return rc_; } while (0)
 
 // contiguous block ranges [lo, hi) per rank, sizes differ by at most one (lz4_flex_amd/sharded.py partition)
