@@ -1038,10 +1038,10 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
 }
 
 // the current window into LDS: the worker threads, 16 B per thread and load, four loads in flight per thread
-__device__ __attribute__((noinline)) void load_window(const uint8_t* __restrict__ g_, uint32_t wl_, lds_u8* lds, uint32_t tid) {
+__device__ __attribute__((noinline)) void load_window(const uint8_t* __restrict__ g_, uint32_t wl_, uint32_t rd_n_, lds_u8* lds, uint32_t tid) {
     constexpr uint32_t NT = 64u * WORKERS;
     const g_u8* __restrict__ g = uni_gptr<const g_u8>(g_);
-    const uint32_t wl = uni(wl_);
+    const uint32_t wl = uni(wl_), rd_n = uni(rd_n_);                     // rd_n: the block's bytes from the window's first one on (>= wl)
     const uint32_t mis = (uint32_t)((16u - ((uintptr_t)g & 15u)) & 15u);    // bytes up to the first 16 B boundary
     const uint32_t head = mis < wl ? mis : wl;
     if (tid < head) lds[L_WIN + tid] = g[tid];
@@ -1064,7 +1064,11 @@ __device__ __attribute__((noinline)) void load_window(const uint8_t* __restrict_
     }
     const uint32_t done = head + 16u * nvec;
     if (tid < wl - done) lds[L_WIN + done + tid] = g[done + tid];
-    if (tid < 64u) lds[L_WIN + wl + tid] = 0;                               // slack read by the 16-byte compares
+    // 64 bytes of slack behind the window, read by the head test and the 16-byte compares of its last positions: the block's next
+    // bytes where it goes on (a head is a position whose 4 bytes equal its candidate's -- the last three positions of a window
+    // that is not the block's last look past it, and with zeros there they were heads for the model and not for the kernel:
+    // one head more or less decides whether a superstep is halved; found by tools/gpu_fuzz.py), zeros behind the block's end
+    if (tid < 64u) lds[L_WIN + wl + tid] = wl + tid < rd_n ? g[wl + tid] : (uint8_t)0;
 }
 
 struct Item {
@@ -1186,7 +1190,7 @@ __device__ __forceinline__ void wave_body(const CompressArgs& a, uint8_t* __rest
     };
     auto do_load = [&](const Item& t) {
         if (t.skip) return;
-        load_window(a.in_base + t.in_off + (size_t)win_base(t), win_len(t), lds, threadIdx.x);
+        load_window(a.in_base + t.in_off + (size_t)win_base(t), win_len(t), t.len - win_base(t), lds, threadIdx.x);
     };
 
     // (sums are kept in registers and added to prof[] once, when the workgroup is done: an atomic per tick made the

@@ -176,3 +176,19 @@ def _window_mode_batch(blk, L):
             got = bytes(outb[out_off[k]:out_off[k] + int(ol[k])])
             assert got == W.compress(b), (k, len(b))
             assert O.decompress(got, len(b)) == ("ok", b), k
+
+
+def test_wave_encoder_heads_at_a_window_end(blk):
+    """found by tools/gpu_fuzz.py (seed 31): a 139 612-byte block whose second window ends in positions that are heads -- their
+    4 bytes reach past the window -- and holds 129 heads in its last 256 positions: the model halved that superstep, the kernel
+    (zeros behind the window in LDS: three heads fewer) did not and cut a long match at 84 bytes.  Valid either way; the
+    kernel must equal its model.  The window's slack now holds the block's next bytes."""
+    import os
+    import zlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", "fuzz_window_end_heads.zlib"), "rb") as f:
+        d = zlib.decompress(f.read())
+    assert len(d) == 139612
+    c = blk.compress(d)
+    assert O.decompress(c, len(d)) == ("ok", d)
+    assert c == W.compress(d)

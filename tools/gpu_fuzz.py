@@ -130,9 +130,14 @@ def main():
                     assert r >= 0, (r, L.last_error())
                     c = out.raw[:r]
                 assert O.decompress(c, len(d)) == ("ok", d), ("encoder mode %d: the oracle does not return the input" % mode, len(d))
-                if mode == 0:
-                    assert c == W.compress(d), ("default encoder != its model", len(d))
-                else:
+                if mode == 0 and c != W.compress(d):
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    with open(os.path.join(ROOT, "gpurun_out", "fuzz_fail_input.bin"), "wb") as f:
+                        f.write(d)
+                    with open(os.path.join(ROOT, "gpurun_out", "fuzz_fail_gpu.lz4"), "wb") as f:
+                        f.write(c)
+                    raise AssertionError(("default encoder != its model (input and GPU output written to gpurun_out/fuzz_fail_*)", len(d)))
+                if mode == 1:
                     assert c == O.compress(d), ("exact encoder != the reference's bytes", len(d))
                 cases.append((c, len(d)))
                 if len(c) > 4:
