@@ -78,3 +78,17 @@ def test_model_ratio_close_to_reference_encoder():
     j = O.fixture_plain("compression_66k_JSON")
     tiles = (j * 3)[1000:1000 + 65536]
     assert len(W.compress(tiles)) <= len(O.compress(tiles))
+
+
+def test_model_on_the_window_end_fixture():
+    """the input tools/gpu_fuzz.py found (heads at the last positions of a window that is not the block's last): the model's block is
+    a valid LZ4 block for the reference's decoder and for liblz4 (the GPU suite pins kernel == model on it)"""
+    import os
+    import zlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", "fuzz_window_end_heads.zlib"), "rb") as f:
+        d = zlib.decompress(f.read())
+    c = W.compress(d)
+    assert O.decompress(c, len(d)) == ("ok", d)
+    assert O.c_decompress(c, len(d)) == d
+    assert len(c) == 41666
