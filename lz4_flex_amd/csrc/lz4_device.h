@@ -54,6 +54,17 @@ struct CompressArgs {
     uint32_t n;
 };
 
+// plan / replay decoder (lz4_decompress_plan.hip, lz4_decompress_replay.hip; record format: lz4_plan_common.h)
+namespace plan { struct BlockPlan; }
+struct ReplayArgs {
+    const uint8_t* in_base;
+    uint8_t* out_base;
+    const plan::BlockPlan* plans;   // n per-block headers
+    const uint32_t* words;          // the plan array
+    uint32_t n;
+};
+hipError_t launch_replay(const ReplayArgs& a, hipStream_t s);
+
 hipError_t launch_decompress(const DecompressArgs& a, int lanes_per_block, hipStream_t s);
 // one block per wavefront (lz4_decompress_wave.hip); irregular blocks are left with status redo_code for a second pass of
 // launch_decompress (only_status = redo_code), which decodes them in the reference's check order
