@@ -75,27 +75,28 @@ def _vregs(tok):
     return {int(m.group(1))} if m else set()
 
 
-def check_async_loads(isa_lines):
-    """The encoder's indexer issues its window loads as inline assembly, several chunks ahead, and waits for them with
-    hand-counted `s_waitcnt vmcnt(N)` (marked "lz4w-load" / "lz4w-wait <registers>").  The compiler does not know these
-    registers are in flight: an instruction that reads, copies or spills one between the load and its wait would move garbage,
-    silently.  Returns (ok, message, loads, waits) for a `hipcc -S` listing of that file."""
+def check_async_loads(isa_lines, tag="lz4w"):
+    """The encoder's indexer (tag "lz4w") and the replay decoder (tag "lz4r") issue loads as inline assembly, several steps
+    ahead, and wait for them with hand-counted `s_waitcnt vmcnt(N)` (marked "<tag>-load" / "<tag>-wait <registers>").  The
+    compiler does not know these registers are in flight: an instruction that reads, copies or spills one between the load and
+    its wait would move garbage, silently.  Returns (ok, message, loads, waits) for a `hipcc -S` listing of that file."""
+    load_mark, wait_mark = tag + "-load", tag + "-wait"
     in_flight = {}          # register -> line number of the load
     n_loads = n_waits = 0
     for ln, line in enumerate(isa_lines, 1):
         code = line.split(";")[0].strip()
-        if "lz4w-load" in line:
+        if load_mark in line:
             n_loads += 1
-            dst = re.search(r"global_load_dword(?:x4)?\s+(v\[\d+:\d+\]|v\d+),\s*(v\[\d+:\d+\])", code)
+            dst = re.search(r"global_load_dword(?:x[24])?\s+(v\[\d+:\d+\]|v\d+),\s*(v\[\d+:\d+\])", code)
             if not dst:
                 return False, "line %d: unexpected form of a marked load: %s" % (ln, line.strip()), n_loads, n_waits
             for r in _vregs(dst.group(1)):      # (the address registers may alias the destination: read at issue)
                 in_flight[r] = ln
             continue
-        if "lz4w-wait" in line:
+        if wait_mark in line:
             n_waits += 1
             named = set()
-            for tok in re.findall(r"v\[\d+:\d+\]|\bv\d+\b", line.split("lz4w-wait")[1]):
+            for tok in re.findall(r"v\[\d+:\d+\]|\bv\d+\b", line.split(wait_mark)[1]):
                 named |= _vregs(tok)
             if not named:
                 return False, "line %d: a wait that names no register: %s" % (ln, line.strip()), n_loads, n_waits
@@ -124,16 +125,40 @@ WAVE_SRC = "lz4_compress_wave.hip"
 PLAIN_LOADS = "-DLZ4W_PLAIN_LOADS"     # the indexer's loads as ordinary C++ loads: slower (the compiler sinks them to their use), always right
 
 
-def wave_isa(extra_flags=()):
-    """the `hipcc -S` listing (device code) of the throughput encoder with the build's flags"""
-    out = os.path.join(BDIR, "wave_check.s")
+REPLAY_SRC = "lz4_decompress_replay.hip"
+REPLAY_PLAIN_LOADS = "-DLZ4R_PLAIN_LOADS"   # the replay decoder's loads in every lane, waited for by the compiler: slower, always right
+
+
+def file_isa(src, extra_flags=()):
+    """the `hipcc -S` listing (device code) of one source file with the build's flags"""
+    out = os.path.join(BDIR, src.rsplit(".", 1)[0] + "_check.s")
     os.makedirs(BDIR, exist_ok=True)
-    cmd = [_hipcc()] + [f for f in FLAGS if f != "-fPIC"] + list(extra_flags) + ["-x", "hip", "--cuda-device-only", "-S", os.path.join(CSRC, WAVE_SRC), "-o", out]
+    cmd = [_hipcc()] + [f for f in FLAGS if f != "-fPIC"] + list(extra_flags) + ["-x", "hip", "--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", out]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
-        raise RuntimeError("hipcc -S failed on %s:\n%s" % (WAVE_SRC, r.stdout.decode(errors="replace")))
+        raise RuntimeError("hipcc -S failed on %s:\n%s" % (src, r.stdout.decode(errors="replace")))
     with open(out) as f:
         return f.read().splitlines()
+
+
+def wave_isa(extra_flags=()):
+    """the listing of the throughput encoder"""
+    return file_isa(WAVE_SRC, extra_flags)
+
+
+def replay_isa(extra_flags=()):
+    """the listing of the replay decoder"""
+    return file_isa(REPLAY_SRC, extra_flags)
+
+
+def replay_extra_flags():
+    """[] when this toolchain leaves the replay kernel's in-flight registers alone, else [REPLAY_PLAIN_LOADS]"""
+    ok, msg, loads, waits = check_async_loads(replay_isa(), "lz4r")
+    if ok and loads >= 48 and waits >= 24:
+        return []
+    print("lz4_flex_amd.build: %s: the hand-scheduled loads of the replay decoder are not safe with this compiler (%s); "
+          "building it with %s" % (REPLAY_SRC, msg or "markers missing: %d loads, %d waits" % (loads, waits), REPLAY_PLAIN_LOADS), file=sys.stderr)
+    return [REPLAY_PLAIN_LOADS]
 
 
 def wave_extra_flags():
@@ -150,14 +175,14 @@ def wave_extra_flags():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    wave_flags = wave_extra_flags()
+    per_file = {WAVE_SRC: wave_extra_flags(), REPLAY_SRC: replay_extra_flags()}
     hipcc = _hipcc()
     os.makedirs(BDIR, exist_ok=True)
     sh = source_hash()
     objs, procs = [], []
     for src in sources():
         obj = os.path.join(BDIR, src + ".o")
-        cmd = [hipcc] + FLAGS + (wave_flags if src == WAVE_SRC else []) + ['-DLZ4FLEX_BUILD_ID="%s"' % sh, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + per_file.get(src, []) + ['-DLZ4FLEX_BUILD_ID="%s"' % sh, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -27,27 +27,69 @@ typedef uint8_t __attribute__((address_space(3))) lds_u8;
 
 // four lines of K_END: what a lane group without a block (batch tail, irregular block) replays
 #define LZ4R_E4 END_REC, END_REC, END_REC, END_REC
-#define LZ4R_E28 LZ4R_E4, LZ4R_E4, LZ4R_E4, LZ4R_E4, LZ4R_E4, LZ4R_E4, LZ4R_E4
-__device__ __attribute__((aligned(16))) uint32_t g_end_lines[(END_LINES + 1u) * LINE_WORDS] = {LZ4R_E28, LZ4R_E28, LZ4R_E28, LZ4R_E28};
-#undef LZ4R_E28
+#define LZ4R_E24 LZ4R_E4, LZ4R_E4, LZ4R_E4, LZ4R_E4, LZ4R_E4, LZ4R_E4
+__device__ __attribute__((aligned(16))) uint32_t g_end_lines[(END_LINES + 1u) * LINE_WORDS] = {LZ4R_E24, LZ4R_E24, LZ4R_E24, LZ4R_E24};
+#undef LZ4R_E24
 #undef LZ4R_E4
-static_assert(END_LINES == 3u && LINE_WORDS == 28u, "g_end_lines");
+static_assert(END_LINES == 3u && LINE_WORDS == 24u, "g_end_lines");
 __device__ __attribute__((aligned(64))) uint8_t g_replay_pad[64];   // the sink / source of lane groups without a block
 
 #ifndef LZ4R_GROUPS_PER_WAVE
 #define LZ4R_GROUPS_PER_WAVE 16
 #endif
-constexpr uint32_t GPW = LZ4R_GROUPS_PER_WAVE;     // lane groups per wavefront in use (16: every lane; 8: half of them -- twice the wavefronts per block, the other SIMD-resident wavefront runs while one waits)
+constexpr uint32_t GPW = LZ4R_GROUPS_PER_WAVE;     // lane groups per wavefront in use (16: every lane; measured with 8 -- twice the wavefronts, half the lanes each: 1.8 times slower, a step's cost is its instructions, not its lanes)
 constexpr uint32_t NB = 4u * GPW;        // blocks per workgroup (four wavefronts)
 constexpr uint32_t G = 4u;               // lanes per block
 constexpr uint32_t LW = LINE_WORDS / G;  // words of a line per lane
-static_assert(G * LANE_B == PIECE && LINE_WORDS == G * LW && LOOKAHEAD == LINE_WORDS && LW == 7u, "geometry");
+static_assert(G * LANE_B == PIECE && LINE_WORDS == G * LW && LOOKAHEAD == LINE_WORDS && LW == 6u && LOOKAHEAD % FLUSH_EVERY == 0u, "geometry");
 
+// Memory sources are requested LOOKAHEAD steps before their use, by the lanes that need them only (a 16-byte load costs the
+// CU's texture path the same whether its bytes are wanted or not, and every wavefront pays for every lane: the first
+// version loaded in every lane at every step and spent a quarter of its time there).  hipcc cannot express that -- it waits
+// for a conditional load where it is issued, and it counts the loads it knows about -- so the loads of this kernel's loop are
+// inline assembly with hand-counted waits: "lz4r-load" under an execution mask that always contains lane 0 (an instruction
+// without any active lane might not count), "lz4r-wait <registers>" = s_waitcnt vmcnt(N) with N = the marked loads issued
+// since (loads and stores the compiler adds in between only make the wait stricter).  Nothing may touch the destination
+// registers between load and wait, which the compiler does not know: lz4_flex_amd/build.py checks exactly that on the ISA it
+// ships (check_async_loads, also run by tests/test_isa_checks.py) and builds with -DLZ4R_PLAIN_LOADS -- every lane loads,
+// the compiler waits -- if a toolchain ever breaks it.
 struct Slot {
     uint32_t r;     // the record
     u32x4 v;        // its bytes, if they come from memory (K_LIT, K_FAR)
 };
-struct LineRegs { uint32_t w[LW]; };
+
+__device__ __forceinline__ void slot_load(u32x4& dst, const uint8_t* p, uint64_t mask) {
+#ifdef LZ4R_PLAIN_LOADS
+    __builtin_memcpy(&dst, p, 16);
+#else
+    uint64_t save;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %3\n\tglobal_load_dwordx4 %0, %2, off ; lz4r-load\n\ts_mov_b64 exec, %1"
+                 : "+v"(dst), "=&s"(save) : "v"(p), "s"(mask) : "memory");    // "+v": the slot keeps its registers from turn to turn (no copies of registers in flight)
+#endif
+}
+template <int N>
+__device__ __forceinline__ void slot_wait(u32x4& v) {
+#ifndef LZ4R_PLAIN_LOADS
+    asm volatile("s_waitcnt vmcnt(%1) ; lz4r-wait %0" : "+v"(v) : "n"(N) : "memory");
+#endif
+}
+// a line of the plan in flight: LW words per lane
+struct LineFlight { u32x4 a; uint64_t b; };
+__device__ __forceinline__ void line_issue(LineFlight& l, const uint32_t* p) {
+#ifdef LZ4R_PLAIN_LOADS
+    __builtin_memcpy(&l.a, p, 16);
+    __builtin_memcpy(&l.b, p + 4, 8);
+#else
+    asm volatile("global_load_dwordx4 %0, %2, off ; lz4r-load\n\tglobal_load_dwordx2 %1, %2, off offset:16 ; lz4r-load"
+                 : "+v"(l.a), "+v"(l.b) : "v"(p) : "memory");
+#endif
+}
+template <int N>
+__device__ __forceinline__ void line_wait(LineFlight& l) {
+#ifndef LZ4R_PLAIN_LOADS
+    asm volatile("s_waitcnt vmcnt(%2) ; lz4r-wait %0 %1" : "+v"(l.a), "+v"(l.b) : "n"(N) : "memory");
+#endif
+}
 
 template <uint32_t K>
 __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
@@ -55,81 +97,72 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
 }
 
 struct Lane {
-    const uint8_t* in_l;     // the compressed block
-    const uint8_t* idle;     // what a lane without a source reads: its own 16 bytes of the plan line that is being fetched anyway
-    const uint8_t* out_rd;   // the block's sink (far sources)
+    const uint8_t* in_l;     // the compressed block + 16 g
+    const uint8_t* out_rd;   // the block's sink + 16 g (far sources)
     uint8_t* out_wr;         // the block's sink + 16 g
     lds_u8* ring_l;          // the block's ring + 16 g
     uint32_t g16;            // 16 g
-    uint32_t g16d;           // 16 g until the block's K_END, then 0xFFFFFFFF: `g16d < n` is "this lane moves bytes of the piece"
-    uint32_t op;             // output position
-    uint32_t F;              // lines below F have left the ring (a multiple of 64)
-    uint32_t pF;             // a line that was read from the ring in the previous step and goes to memory in this one
-    uint32_t pend;
-    u32x4 y;
-
-    // request the bytes of record r (if they come from memory).  Lanes the piece does not reach read where the piece's first
-    // lane reads, records without a load read the lane's part of the plan line in flight: neither costs a memory transaction.
-    // (One 64-byte pad for every idle lane of the chip was 2.3 times slower than the whole kernel: same bank, same channel.)
-    __device__ __forceinline__ void front(Slot& s, uint32_t r) {
-        const uint32_t kind = r >> 30;
-        const uint32_t n = ((r >> 24) & 63u) + 1u;
-#ifdef LZ4R_EXP_FARNEAR     // timing experiment (wrong output): far sources at most 4 KiB behind the block's start
-        const uint32_t field = kind == K_FAR ? (r & 0xFFFu) : (r & 0xFFFFFFu);
-#else
-        const uint32_t field = r & 0xFFFFFFu;
+#ifdef LZ4R_PLAIN_LOADS
+    const uint8_t* idle;
 #endif
-        const uint32_t lane_off = g16 < n ? g16 : 0u;
-        const uint8_t* p = kind == K_FAR ? out_rd : in_l;
-        p = (kind - 1u) < 2u ? p + (field + lane_off) : idle;
-#ifdef LZ4R_EXP_NOLOAD      // timing experiments only (wrong output): no memory sources
+    uint32_t op;             // output position
+    uint32_t F;              // lines below F are in memory (a multiple of 64)
+
+    // request the bytes of record r, in the lanes that will move them (an instruction whose mask is empty still counts)
+    __device__ __forceinline__ void front(Slot& s, uint32_t r) {
+        const uint32_t n = r >> N_SHIFT;
+        const uint32_t kind = (r >> KIND_SHIFT) & 3u;
+#ifdef LZ4R_EXP_FARNEAR     // timing experiment (wrong output): far sources at most 4 KiB behind the block's start
+        const uint32_t field = kind == K_FAR ? (r & 0xFFFu) : (r & MAX_FIELD);
+#else
+        const uint32_t field = r & MAX_FIELD;
+#endif
+        const uint8_t* p = (kind == K_FAR ? out_rd : in_l) + field;
+#ifdef LZ4R_PLAIN_LOADS
+        p = (kind - 1u) < 2u ? (g16 < n ? p : p - g16) : idle;      // every lane loads: lanes the piece does not reach read where its first lane reads, records without a source their part of the plan line that was fetched last
+        __builtin_memcpy(&s.v, p, 16);
+#elif defined(LZ4R_EXP_NOLOAD)      // timing experiments only (wrong output): no memory sources
         asm volatile("" :: "v"(p));
         s.v = u32x4{r, r, r, r};
 #else
-        __builtin_memcpy(&s.v, p, 16);
+        slot_load(s.v, p, __builtin_amdgcn_ballot_w64((kind - 1u) < 2u) & __builtin_amdgcn_ballot_w64(g16 < n));
 #endif
         s.r = r;
     }
-    // execute a record: the read half (near sources come from the ring) ...
-    __device__ __forceinline__ void back_read(const Slot& s, u32x4& x, uint32_t& n, bool& active) {
+    // execute a record: near sources come from the ring, the bytes go to the ring
+    __device__ __forceinline__ void back(Slot& s) {
         const uint32_t r = s.r;
-        n = r >= END_REC ? 0u : ((r >> 24) & 63u) + 1u;
-        g16d = r >= END_REC ? 0xFFFFFFFFu : g16d;
-        active = g16d < n;
-        x = s.v;
+        const uint32_t n = r >> N_SHIFT;
+        const bool active = g16 < n;                 // (K_END: n = 0)
+        slot_wait<LOOKAHEAD + 1>(s.v);               // marked loads since this slot's: the other LOOKAHEAD - 1 slots and the two halves of a line
+        u32x4 x = s.v;
 #ifndef LZ4R_EXP_NORING
-        if (active && r < (K_LIT << 30)) __builtin_memcpy(&x, (const void*)(ring_l + (r & MASK)), 16);
-#endif
-    }
-    // ... the line the previous step took out of the ring goes to memory (one full-line write per 64 bytes of output instead
-    // of one partial write per piece: the memory system counts transactions, not bytes) ...
-    __device__ __forceinline__ void store_pending() {
-#ifndef LZ4R_EXP_NOSTORE
-        if (pend) __builtin_memcpy(out_wr + pF, &y, 16);
-#endif
-    }
-    // ... and the write half: the bytes go to the ring; a 64-byte line this piece completed is read back, 16 aligned bytes per
-    // lane, for the next step's store
-    __device__ __forceinline__ void back_write(const u32x4& x, uint32_t n, bool active) {
-#ifndef LZ4R_EXP_NORING
+        if (active && (r & KIND_MASK) == 0u) __builtin_memcpy(&x, (const void*)(ring_l + (r & MASK)), 16);
         if (active) __builtin_memcpy((void*)(ring_l + (op & MASK)), &x, 16);
+#else
+        asm volatile("" :: "v"(x));
 #endif
         op += n;
-        const uint32_t fl = op & ~(PIECE - 1u);
-        pend = fl != F;              // pieces are at most PIECE bytes: exactly one line, [F, F + 64)
-        if (pend) {
+    }
+    // every FLUSH_EVERY steps: the 64-byte lines of the output that are complete leave the ring, 16 aligned bytes per lane -- one
+    // full-line write per 64 bytes of output (the first version stored every piece where it ended: the memory system counts
+    // transactions, and so does the wavefront: a store instruction costs it as much as a load)
+    __device__ __forceinline__ void flush() {
+        while (F + PIECE <= op) {
 #ifndef LZ4R_EXP_NORING
-            y = *reinterpret_cast<const u32x4 __attribute__((address_space(3)))*>(ring_l + (F & MASK));
+            const u32x4 y = *reinterpret_cast<const u32x4 __attribute__((address_space(3)))*>(ring_l + (F & MASK));
 #else
-            y = x;
+            const u32x4 y = u32x4{F, op, F, op};
 #endif
-            pF = F;
-            F = fl;
+#ifndef LZ4R_EXP_NOSTORE
+            __builtin_memcpy(out_wr + F, &y, 16);
+#else
+            asm volatile("" :: "v"(y));
+#endif
+            F += PIECE;
         }
     }
 };
-
-__device__ __forceinline__ void load_line(LineRegs& l, const uint32_t* p) { __builtin_memcpy(l.w, p, 4u * LW); }
 
 __global__ void __launch_bounds__(256) lz4_replay_kernel(ReplayArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
@@ -144,40 +177,62 @@ __global__ void __launch_bounds__(256) lz4_replay_kernel(ReplayArgs a) {
     const bool live = valid && bp.flags == 0u;
     Lane L;
     L.g16 = LANE_B * g;
-    L.g16d = L.g16;
-    L.in_l = live ? a.in_base + bp.in_off : g_replay_pad;
-    L.out_rd = live ? a.out_base + bp.out_off : g_replay_pad;
+    L.in_l = (live ? a.in_base + bp.in_off : g_replay_pad) + L.g16;
+    L.out_rd = (live ? a.out_base + bp.out_off : g_replay_pad) + L.g16;
     L.out_wr = (live ? a.out_base + bp.out_off : g_replay_pad) + L.g16;
     L.ring_l = lds + j * RING_STRIDE + L.g16;
-    L.op = 0u; L.F = 0u; L.pF = 0u; L.pend = 0u; L.y = u32x4{0u, 0u, 0u, 0u};
+    L.op = 0u; L.F = 0u;
     // the plan: LW words per lane and line
     const uint32_t* lp = (live ? a.words + bp.first_word : g_end_lines) + LW * g;
     Slot sl[LOOKAHEAD];
-    LineRegs line, next;
-    load_line(line, lp);
-    load_line(next, lp + LINE_WORDS);
-    L.idle = (const uint8_t*)lp;
-    lp += 2u * LINE_WORDS;
-    // prologue: request the bytes of the first line's records
-#define LZ4R_FRONT(i) L.front(sl[i], quad_bcast<(i) / LW>(line.w[(i) % LW]))
-#define LZ4R_ALL(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20) \
-                    M(21) M(22) M(23) M(24) M(25) M(26) M(27)
-#define LZ4R_PRO(i) LZ4R_FRONT(i);
-    LZ4R_ALL(LZ4R_PRO)
+    for (uint32_t i = 0; i < LOOKAHEAD; ++i) sl[i].v = u32x4{0u, 0u, 0u, 0u};
+    // two lines of the plan in registers: the one whose records are being looked at, and the one in flight behind it.  They
+    // swap roles every LOOKAHEAD steps, in two copies of the loop body: a single set of registers would have to be copied
+    // when a line lands, and the compiler is free to place that copy before the wait.
+    LineFlight fa, fb;
+    fa.a = u32x4{0u, 0u, 0u, 0u}; fa.b = 0ull;
+    fb.a = u32x4{0u, 0u, 0u, 0u}; fb.b = 0ull;
+#define LZ4R_WORD(f, k) ((k) == 0 ? f.a.x : (k) == 1 ? f.a.y : (k) == 2 ? f.a.z : (k) == 3 ? f.a.w : (k) == 4 ? (uint32_t)f.b : (uint32_t)(f.b >> 32))
+#define LZ4R_FRONT(f, i) L.front(sl[i], quad_bcast<(i) / LW>(LZ4R_WORD(f, (i) % LW)));
+#define LZ4R_ALL(M, f) M(f, 0) M(f, 1) M(f, 2) M(f, 3) M(f, 4) M(f, 5) M(f, 6) M(f, 7) M(f, 8) M(f, 9) M(f, 10) M(f, 11) M(f, 12) M(f, 13) M(f, 14) \
+                       M(f, 15) M(f, 16) M(f, 17) M(f, 18) M(f, 19) M(f, 20) M(f, 21) M(f, 22) M(f, 23)
+#define LZ4R_STEP(f, i) L.back(sl[i]); if ((i) % FLUSH_EVERY == FLUSH_EVERY - 1u) L.flush(); LZ4R_FRONT(f, i)
+    // a turn: `cur` (the line behind the one being executed) has had LOOKAHEAD steps to arrive; `nxt` (the one behind that)
+    // starts now (a finished block stays inside its K_END lines)
+#define LZ4R_TURN(cur, nxt)                                             \
+    line_wait<LOOKAHEAD>(cur);                                          \
+    LZ4R_IDLE()                                                         \
+    lp += done ? 0u : LINE_WORDS;                                       \
+    line_issue(nxt, lp);                                                \
+    LZ4R_ALL(LZ4R_STEP, cur)                                            \
+    done = (sl[LOOKAHEAD - 1u].r & KIND_MASK) == KIND_MASK;   /* the line just requested ends in K_END: the block's last record is behind us */ \
+    if (__all(done_exec)) break;                                        \
+    done_exec = done;
+#ifdef LZ4R_PLAIN_LOADS
+#define LZ4R_IDLE() L.idle = (const uint8_t*)lp;
+#else
+#define LZ4R_IDLE()
+#endif
+    bool done = false, done_exec = false;
+    line_issue(fa, lp);
+    line_wait<0>(fa);
+    LZ4R_IDLE()
+    lp += LINE_WORDS;
+    line_issue(fb, lp);                                  // the second line: on its way while the first one's sources are requested
+    LZ4R_ALL(LZ4R_FRONT, fa)                             // prologue: request the bytes of the first line's records
     for (;;) {
-        line = next;                             // the line behind the one being executed
-        load_line(next, lp);                     // and the one behind that: on its way for LOOKAHEAD steps
-        L.idle = (const uint8_t*)lp;
-        lp += L.g16d == 0xFFFFFFFFu ? 0u : LINE_WORDS;   // (a finished block stays inside its K_END lines)
-#define LZ4R_STEP(i) { u32x4 x; uint32_t n; bool act; L.back_read(sl[i], x, n, act); LZ4R_FRONT(i); L.store_pending(); L.back_write(x, n, act); }
-        LZ4R_ALL(LZ4R_STEP)
-        if (__all(L.g16d == 0xFFFFFFFFu)) break;
+        LZ4R_TURN(fb, fa)
+        LZ4R_TURN(fa, fb)
     }
-    L.store_pending();
+#ifndef LZ4R_PLAIN_LOADS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // requests still in flight own their registers until they land
+#endif
+#undef LZ4R_TURN
+#undef LZ4R_IDLE
 #undef LZ4R_STEP
-#undef LZ4R_PRO
 #undef LZ4R_ALL
 #undef LZ4R_FRONT
+#undef LZ4R_WORD
     // the bytes behind the last full line leave the ring, then the tail: the block's last few pieces, byte by byte in memory
     // (exact reads, exact writes)
     if (live && g == 0u) {

@@ -13,7 +13,7 @@
 // array of 4-byte records; the REPLAY kernel walks that array, four lanes per block, ~30 instructions per record, and does
 // nothing else.  The serial part of a block is then as short as it can be made.
 //
-// Record (u32):  [31:30] kind   [29:24] n - 1 (1..64 bytes)   [23:0] field
+// Record (u32):  [31:25] n (1..64 bytes; 0 in K_END)   [24:23] kind   [22:0] field
 //   K_NEAR  match piece whose source is still in the block's LDS ring: field = ring address of the source (11 bits)
 //   K_LIT   literal piece: field = position of the bytes in the compressed block
 //   K_FAR   match piece whose source has left the ring: field = absolute output position of the source
@@ -51,20 +51,22 @@ constexpr uint32_t NEAR_MAX = W - 64u;
 // records in between write LOOKAHEAD * PIECE bytes: NEAR_MAX - 64 must exceed that.  LOOKAHEAD is as deep as that allows:
 // the loads of a wavefront return in order, so every load has to be LOOKAHEAD steps' worth of time away from its use or the
 // slowest one (a far source that left the L2: one to two microseconds) sets the pace of all of them
-constexpr uint32_t LOOKAHEAD = 28u;
-// (+ the bytes of the line that is not complete yet + the 16-byte granules of the read)
-static_assert(LOOKAHEAD * PIECE + 63u + 64u <= NEAR_MAX, "far sources must be stored before they are requested");
-constexpr uint32_t LINE_WORDS = 28u;     // records per 112-byte line of the plan (one line per LOOKAHEAD steps and group: 28 bytes per lane)
+constexpr uint32_t LOOKAHEAD = 24u;
+constexpr uint32_t FLUSH_EVERY = 4u;     // steps between the write-backs of a block's complete 64-byte lines
+// (+ what FLUSH_EVERY steps may leave in the ring + the line that is not complete yet + the 16-byte granules of the read)
+static_assert((LOOKAHEAD - 1u + FLUSH_EVERY) * PIECE + 63u + 64u <= NEAR_MAX, "far sources must be stored before they are requested");
+constexpr uint32_t LINE_WORDS = 24u;     // records per 96-byte line of the plan (one line per LOOKAHEAD steps and group: 24 bytes per lane)
 constexpr uint32_t END_LINES = 3u;       // lines of K_END behind the last record (the replay kernel fetches two lines ahead)
-constexpr uint32_t MAX_FIELD = (1u << 24) - 1u;
+constexpr uint32_t MAX_FIELD = (1u << 23) - 1u;   // positions a record can name: blocks (compressed and decoded) below 8 MiB
 
 constexpr uint32_t K_NEAR = 0u, K_LIT = 1u, K_FAR = 2u, K_END = 3u;
-PLAN_FN uint32_t rec(uint32_t kind, uint32_t n, uint32_t field) { return (kind << 30) | ((n - 1u) << 24) | field; }
-PLAN_FN uint32_t rec_kind(uint32_t r) { return r >> 30; }
-PLAN_FN uint32_t rec_n(uint32_t r) { return ((r >> 24) & 63u) + 1u; }
-PLAN_FN uint32_t rec_field(uint32_t r) { return r & 0xFFFFFFu; }
+constexpr uint32_t N_SHIFT = 25u, KIND_SHIFT = 23u, KIND_MASK = 3u << KIND_SHIFT;
+PLAN_FN uint32_t rec(uint32_t kind, uint32_t n, uint32_t field) { return (n << N_SHIFT) | (kind << KIND_SHIFT) | field; }
+PLAN_FN uint32_t rec_kind(uint32_t r) { return (r >> KIND_SHIFT) & 3u; }
+PLAN_FN uint32_t rec_n(uint32_t r) { return r >> N_SHIFT; }
+PLAN_FN uint32_t rec_field(uint32_t r) { return r & MAX_FIELD; }
 // tail records (executed byte by byte, in global memory): K_LIT as above, K_FAR with field = the match OFFSET
-constexpr uint32_t END_REC = (K_END << 30);
+constexpr uint32_t END_REC = (K_END << KIND_SHIFT);   // n = 0: no lane moves a byte
 
 // Per-block header the plan kernel leaves for the replay kernel (32 bytes).
 struct BlockPlan {

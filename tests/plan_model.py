@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "sim", "plan_model.cpp")
 HDRS = [os.path.join(ROOT, "lz4_flex_amd", "csrc", h) for h in ("lz4_pcd_common.h", "lz4_plan_common.h")]
 SO = os.path.join(ROOT, "tests", "sim", "libplan_model.so")
-LINE_WORDS, END_LINES, W = 28, 3, 2048
+LINE_WORDS, END_LINES, W = 24, 3, 2048
 
 _m = None
 
