@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "sim", "plan_model.cpp")
 HDRS = [os.path.join(ROOT, "lz4_flex_amd", "csrc", h) for h in ("lz4_pcd_common.h", "lz4_plan_common.h")]
 SO = os.path.join(ROOT, "tests", "sim", "libplan_model.so")
-LINE_WORDS, END_LINES, W = 24, 3, 2048
+TURN_WORDS, END_TURNS, W = 96, 3, 2048
 
 _m = None
 
@@ -25,22 +25,22 @@ def lib():
         m.plan_replay.restype = C.c_int
         m.plan_replay.argtypes = [C.c_char_p, C.c_uint32, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32]
         m.plan_compile_batch.restype = C.c_int64
-        m.plan_compile_batch.argtypes = [C.c_void_p] * 5 + [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        m.plan_compile_batch.argtypes = [C.c_void_p] * 5 + [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
         _m = m
     return _m
 
 
 def compile_block(comp, cap):
-    """-> None (irregular block) or dict(words, n_main, tail_word, n_tail, E)"""
+    """-> None (irregular block) or dict(words, n_steps, tail_word, n_tail, E)"""
     comp = bytes(comp)
-    max_words = 8 * len(comp) + cap // 8 + 256
+    max_words = 16 * len(comp) + cap // 4 + 1024
     words = (C.c_uint32 * max_words)()
-    n_main, tail_word, n_tail, E = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
-    r = lib().plan_compile(comp, len(comp), cap, words, max_words, C.byref(n_main), C.byref(tail_word), C.byref(n_tail), C.byref(E))
+    n_steps, tail_word, n_tail, E = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    r = lib().plan_compile(comp, len(comp), cap, words, max_words, C.byref(n_steps), C.byref(tail_word), C.byref(n_tail), C.byref(E))
     assert r >= 0, "plan does not fit %d words" % max_words
     if r == 0:
         return None
-    return dict(words=words, n_words=int(r), n_main=n_main.value, tail_word=tail_word.value, n_tail=n_tail.value, E=E.value)
+    return dict(words=words, n_words=int(r), n_steps=n_steps.value, tail_word=tail_word.value, n_tail=n_tail.value, E=E.value)
 
 
 def replay(comp, plan, cap):

@@ -32,9 +32,13 @@ struct Rd {
 };
 
 struct VecSink {
-    std::vector<uint32_t> mainv, tailv;
+    std::vector<uint32_t> steps;     // 4 words per step
+    std::vector<uint32_t> tailv;
     uint32_t tail_op = 0u, main_bytes = 0u;
-    void main(uint32_t r) { mainv.push_back(r); main_bytes += rec_n(r); }
+    void step(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+        steps.push_back(w0); steps.push_back(w1); steps.push_back(w2); steps.push_back(w3);
+        main_bytes += rec_n(w0) + rec_n(w1) + rec_n(w2) + rec_n(w3);
+    }
     void tail(uint32_t r) { if (tailv.empty()) tail_op = main_bytes; tailv.push_back(r); }
 };
 
@@ -57,7 +61,8 @@ int compile_block(const uint8_t* in, uint32_t in_len, uint32_t cap, VecSink& sin
             p = nx;
         }
     }
-    Emit e{0u, (uint32_t)E, in_len, 0u};
+    Emit e;
+    emit_init(e, in_len);
     uint32_t p = 0;
     for (;;) {
         pcd::Seq s;
@@ -67,31 +72,39 @@ int compile_block(const uint8_t* in, uint32_t in_len, uint32_t cap, VecSink& sin
         if (nx == pcd::X_END) break;
         p = nx;
     }
+    emit_end(e, sink);
     if (e.op != (uint32_t)E || sink.tailv.size() > MAX_TAIL) return 1;
     if (sink.tailv.empty()) sink.tail_op = sink.main_bytes;
     *E_out = (uint32_t)E;
     return 0;
 }
 
-uint32_t padded_main_words(uint32_t n_main) {   // records + K_END up to the line's end + END_LINES lines of K_END
-    const uint32_t with_end = n_main + 1u;
-    return (with_end + LINE_WORDS - 1u) / LINE_WORDS * LINE_WORDS + END_LINES * LINE_WORDS;
+// steps + a step of K_END, padded with K_END to whole turns, + END_TURNS turns of K_END
+uint32_t padded_turns(uint32_t n_steps) { return (n_steps + 1u + TURN_STEPS - 1u) / TURN_STEPS + END_TURNS; }
+
+// the kernel's layout: lz4_plan_common.h word_of
+void lay_out(const VecSink& s, uint32_t* words) {
+    const uint32_t n_steps = (uint32_t)(s.steps.size() / 4u);
+    const uint32_t total = padded_turns(n_steps) * TURN_STEPS;
+    for (uint32_t st = 0; st < total; ++st)
+        for (uint32_t g = 0; g < G; ++g) words[word_of(st, g)] = st < n_steps ? s.steps[4u * st + g] : END_REC;
 }
 
 }  // namespace
 
 extern "C" {
 
-// words: [main records | K_END padding | tail records]; returns total words written, 0 = irregular block, -1 = no room
-int64_t plan_compile(const uint8_t* in, uint32_t in_len, uint32_t cap, uint32_t* words, uint32_t max_words, uint32_t* n_main,
+// words: [turns: steps, then K_END | tail records]; returns total words written, 0 = irregular block, -1 = no room
+int64_t plan_compile(const uint8_t* in, uint32_t in_len, uint32_t cap, uint32_t* words, uint32_t max_words, uint32_t* n_steps,
                      uint32_t* tail_word, uint32_t* n_tail, uint32_t* E) {
     VecSink s;
     if (compile_block(in, in_len, cap, s, E)) return 0;
-    const uint32_t pm = padded_main_words((uint32_t)s.mainv.size());
+    const uint32_t ns = (uint32_t)(s.steps.size() / 4u);
+    const uint32_t pm = padded_turns(ns) * TURN_WORDS;
     if (pm + s.tailv.size() > max_words) return -1;
-    for (uint32_t i = 0; i < pm; ++i) words[i] = i < s.mainv.size() ? s.mainv[i] : END_REC;
+    lay_out(s, words);
     for (size_t i = 0; i < s.tailv.size(); ++i) words[pm + i] = s.tailv[i];
-    *n_main = (uint32_t)s.mainv.size();
+    *n_steps = ns;
     *tail_word = pm;
     *n_tail = (uint32_t)s.tailv.size();
     return (int64_t)(pm + s.tailv.size());
@@ -102,79 +115,82 @@ int plan_replay(const uint8_t* in, uint32_t in_len, const uint32_t* words, uint3
                 uint8_t* out, uint32_t cap) {
     if (E > cap) return -1;
     std::vector<uint8_t> ring(RING_STRIDE, 0xEE);
-    std::vector<uint8_t> written(E + 1u, 0);      // which output bytes have been stored (final value or not)
-    struct Slot { uint32_t r; uint8_t v[4][16]; };
+    std::vector<uint8_t> written(E + 1u, 0);         // which output bytes are in memory
+    std::vector<uint8_t> ringfinal(E + 128u, 0);     // is the ring's copy of this output position the final byte
+    struct Slot { uint32_t r[G]; uint8_t v[G][16]; };
     std::vector<Slot> slots(LOOKAHEAD);
     uint32_t op = 0, F = 0;
-    bool done = false;
-    std::vector<uint8_t> ringfinal(E + 128u, 0);   // is the ring's copy of this output position the final byte
-    auto fe = [&](uint32_t idx, Slot& sl) -> int {      // request the record's bytes
-        const uint32_t r = words[idx];
-        sl.r = r;
-        const uint32_t kind = rec_kind(r), n = rec_n(r), field = rec_field(r);
-        for (uint32_t g = 0; g < 4u; ++g) {
-            const uint32_t lane_off = 16u * g < n ? 16u * g : 0u;
+    auto word = [&](uint32_t step, uint32_t g) { return words[word_of(step, g)]; };
+    auto fe = [&](uint32_t step, Slot& sl) -> int {      // request the step's bytes
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint32_t r = word(step, g);
+            sl.r[g] = r;
+            const uint32_t kind = rec_kind(r), n = rec_n(r), field = rec_field(r);
+            memset(sl.v[g], 0xAB, 16);
+            if (n == 0u) continue;
             if (kind == K_LIT) {
-                if (field + lane_off + 16u > in_len) return -2;                 // a lane reads behind the compressed block
-                memcpy(sl.v[g], in + field + lane_off, 16);
+                if (field + 16u > in_len) return -2;                            // a lane reads behind the compressed block
+                memcpy(sl.v[g], in + field, 16);
             } else if (kind == K_FAR) {
-                if (field + lane_off + 16u > E) return -3;
-                for (uint32_t k = 0; k < 16u; ++k)
-                    if (16u * g < n && lane_off + k < n && written[field + lane_off + k] != 2) return -4;   // a byte the piece needs is not final yet
-                memcpy(sl.v[g], out + field + lane_off, 16);
-            } else {
-                memset(sl.v[g], 0xAB, 16);                                     // (idle lanes read plan words)
+                if (field + 16u > E) return -3;
+                for (uint32_t k = 0; k < n; ++k) if (written[field + k] != 2) return -4;   // a byte the lane needs is not in memory yet
+                memcpy(sl.v[g], out + field, 16);
             }
         }
         return 0;
     };
-    // prologue: the first LOOKAHEAD records
     for (uint32_t i = 0; i < LOOKAHEAD; ++i) { const int e = fe(i, slots[i]); if (e) return e; }
     uint32_t idx = 0;
-    while (!done) {
+    for (;;) {
         Slot& sl = slots[idx % LOOKAHEAD];
-        const uint32_t r = sl.r, kind = rec_kind(r), n = rec_n(r), field = rec_field(r);
-        if (kind == K_END) { done = true; break; }
-        // back end: all lanes read, then all lanes write
-        uint8_t x[4][16];
-        for (uint32_t g = 0; g < 4u; ++g) {
-            if (16u * g >= n) continue;
-            if (kind == K_NEAR) {
-                const uint32_t a = field + 16u * g;
+        if (rec_kind(sl.r[0]) == K_END) {
+            for (uint32_t g = 0; g < G; ++g) if (sl.r[g] != END_REC) return -16;
+            break;
+        }
+        // all lanes read ...
+        uint8_t x[G][16];
+        uint32_t total = 0;
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint32_t r = sl.r[g], n = rec_n(r);
+            if (n > 16u) return -17;
+            if (n != 0u && rec_rel(r) != total) return -18;       // lanes in ascending, gapless order
+            total += n;
+            if (n == 0u) continue;
+            if (rec_kind(r) == K_NEAR) {
+                const uint32_t a = rec_field(r);
                 if (a + 16u > RING_STRIDE) return -5;
                 memcpy(x[g], &ring[a], 16);
             } else {
                 memcpy(x[g], sl.v[g], 16);
             }
         }
-        const uint32_t d = op & MASK;
-        for (uint32_t g = 0; g < 4u; ++g) {      // (lanes of a piece never overlap: 16-byte strides)
-            if (16u * g >= n) continue;
-            if (d + 16u * g + 16u > RING_STRIDE) return -6;
-            memcpy(&ring[d + 16u * g], x[g], 16);
-            for (uint32_t k = 0; k < 16u && op + 16u * g + k < E + 64u; ++k) {
-                const uint32_t pos = op + 16u * g + k;
-                if (pos < ringfinal.size()) ringfinal[pos] = (16u * g + k < n) ? 1 : 0;
+        // ... then write in lane order, 16 bytes each
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint32_t r = sl.r[g], n = rec_n(r);
+            if (n == 0u) continue;
+            const uint32_t pos = op + rec_rel(r), d = pos & MASK;
+            if (d + 16u > RING_STRIDE) return -6;
+            if (d + n > W) return -19;                             // the lane's own bytes never wrap
+            memcpy(&ring[d], x[g], 16);
+            for (uint32_t k = 0; k < 16u; ++k) if (pos + k < ringfinal.size()) ringfinal[pos + k] = k < n ? 1 : 0;
+        }
+        op += total;
+        if (idx % FLUSH_EVERY == FLUSH_EVERY - 1u) {
+            while (F + PIECE <= op) {
+                if (F + PIECE > E) return -7;                                       // a store behind the block's output
+                for (uint32_t k = 0; k < PIECE; ++k) {
+                    if (!ringfinal[F + k]) return -8;                               // a byte that is not final leaves the ring
+                    out[F + k] = ring[(F + k) & MASK];
+                    written[F + k] = 2;
+                }
+                F += PIECE;
             }
         }
-        op += n;
-        const uint32_t fl = op & ~(PIECE - 1u);
-        if (fl != F) {
-            if (fl != F + PIECE) return -15;
-            if (F + PIECE > E) return -7;                                       // a store behind the block's output
-            for (uint32_t k = 0; k < PIECE; ++k) {
-                if (!ringfinal[F + k]) return -8;                               // a byte that is not final leaves the ring
-                out[F + k] = ring[(F + k) & MASK];
-                written[F + k] = 2;
-            }
-            F = fl;
-        }
-        // front end for the record LOOKAHEAD ahead
         const int e = fe(idx + LOOKAHEAD, slots[idx % LOOKAHEAD]);
         if (e) return e;
         idx++;
     }
-    // the bytes behind the last full line, then the tail: byte by byte in global memory
+    // every complete line that is still in the ring, the bytes behind the last full line, then the tail: byte by byte in global memory
     for (uint32_t k = F; k < op; ++k) {
         if (!ringfinal[k]) return -8;
         out[k] = ring[k & MASK];
@@ -203,11 +219,12 @@ int plan_replay(const uint8_t* in, uint32_t in_len, const uint32_t* words, uint3
 }
 
 // plans for n blocks in the kernel's layout.  plans: n BlockPlan records (32 bytes each); words: the plan array; returns words used
-// (first_word of every block is a multiple of LINE_WORDS), or -1 when max_words is too small.  Irregular blocks get flags = 1 and no records.
+// (first_word of every block is a multiple of TURN_WORDS), or -1 when max_words is too small.  Irregular blocks get flags = 1 and no records.
 int64_t plan_compile_batch(const uint8_t* in_base, const uint64_t* in_off, const uint32_t* in_len, const uint64_t* out_off,
-                           const uint32_t* out_cap, uint32_t n, void* plans, uint32_t* words, uint64_t max_words, uint32_t* out_len) {
+                           const uint32_t* out_cap, uint32_t n, void* plans, uint32_t* words, uint64_t max_words, uint32_t* out_len,
+                           uint64_t* n_steps_total) {
     BlockPlan* bp = (BlockPlan*)plans;
-    uint64_t w = 0;
+    uint64_t w = 0, steps = 0;
     for (uint32_t b = 0; b < n; ++b) {
         VecSink s;
         uint32_t E = 0;
@@ -215,10 +232,11 @@ int64_t plan_compile_batch(const uint8_t* in_base, const uint64_t* in_off, const
         bp[b].first_word = (uint32_t)w; bp[b].tail_word = 0u; bp[b].tail_op = 0u; bp[b].n_tail = 0u; bp[b].flags = 0u;
         out_len[b] = 0u;
         if (compile_block(in_base + in_off[b], in_len[b], out_cap[b], s, &E)) { bp[b].flags = 1u; continue; }
-        const uint32_t pm = padded_main_words((uint32_t)s.mainv.size());
-        const uint64_t total = ((uint64_t)pm + s.tailv.size() + LINE_WORDS - 1u) / LINE_WORDS * LINE_WORDS;
+        const uint32_t ns = (uint32_t)(s.steps.size() / 4u);
+        const uint32_t pm = padded_turns(ns) * TURN_WORDS;
+        const uint64_t total = ((uint64_t)pm + s.tailv.size() + TURN_WORDS - 1u) / TURN_WORDS * TURN_WORDS;
         if (w + total > max_words || w + total > 0xFFFFFFFFull) return -1;
-        for (uint32_t i = 0; i < pm; ++i) words[w + i] = i < s.mainv.size() ? s.mainv[i] : END_REC;
+        lay_out(s, words + w);
         for (size_t i = 0; i < s.tailv.size(); ++i) words[w + pm + i] = s.tailv[i];
         for (uint64_t i = pm + s.tailv.size(); i < total; ++i) words[w + i] = END_REC;
         bp[b].tail_word = (uint32_t)(w + pm);
@@ -226,7 +244,9 @@ int64_t plan_compile_batch(const uint8_t* in_base, const uint64_t* in_off, const
         bp[b].tail_op = s.tail_op;
         out_len[b] = E;
         w += total;
+        steps += ns;
     }
+    if (n_steps_total) *n_steps_total = steps;
     return (int64_t)w;
 }
 

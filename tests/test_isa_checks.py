@@ -66,3 +66,38 @@ def test_no_spills_inside_the_hot_functions(isa):
         inside = [body[i].strip() for i in spill_lines if first_loop < i < last_branch and "Folded" in body[i]]
         # tolerate reloads of loop-invariant pointers, never stores (a store inside a loop is a live value being spilled)
         assert not [l for l in inside if "scratch_store" in l], (fn, inside[:5])
+
+
+# ---- the replay decoder (lz4_decompress_replay.hip): same discipline, tag "lz4r"
+@pytest.fixture(scope="module")
+def replay_isa():
+    from lz4_flex_amd import build
+    return build.replay_isa()
+
+
+def test_replay_async_loads_are_not_touched_before_their_wait(replay_isa):
+    from lz4_flex_amd import build
+    ok, msg, n_loads, n_waits = build.check_async_loads(replay_isa, "lz4r")
+    assert ok, msg
+    assert n_loads >= 48 and n_waits >= 24
+    assert build.replay_extra_flags() == []
+
+
+def test_the_check_sees_a_touched_replay_register(replay_isa):
+    from lz4_flex_amd import build
+    for i, line in enumerate(replay_isa):
+        if "lz4r-load" in line and "dwordx4" in line:
+            dst = re.search(r"global_load_dwordx4\s+v\[(\d+):(\d+)\]", line)
+            bad = replay_isa[:i + 2] + ["\tv_mov_b32_e32 v0, v%s" % dst.group(1)] + replay_isa[i + 2:]   # (behind the line that restores exec)
+            ok, msg, _l, _w = build.check_async_loads(bad, "lz4r")
+            assert not ok and "not waited for yet" in msg
+            return
+    raise AssertionError("no marked load in the listing")
+
+
+def test_replay_plain_load_fallback_compiles_without_hand_counted_waits():
+    from lz4_flex_amd import build
+    lines = build.replay_isa([build.REPLAY_PLAIN_LOADS])
+    assert not any("lz4r-load" in l or "lz4r-wait" in l for l in lines)
+    assert any("global_load_dwordx4" in l for l in lines)
+    build.replay_isa()      # (leave the default listing behind)

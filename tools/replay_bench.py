@@ -55,14 +55,16 @@ def main():
     h_len = clen.cpu().numpy().astype(np.uint32)
     h_ooff = in_off.cpu().numpy().astype(np.uint64)
     h_cap = np.full(n, B, dtype=np.uint32)
-    max_words = int(h_len.sum()) * 2 + n * 256
+    max_words = int(h_len.sum()) * 3 + n * 1024
     words = np.zeros(max_words, dtype=np.uint32)
     plans = np.zeros(n * 32, dtype=np.uint8)
     olen = np.zeros(n, dtype=np.uint32)
     vp = lambda a: C.c_void_p(a.ctypes.data)
-    used = M.lib().plan_compile_batch(vp(h_comp), vp(h_off), vp(h_len), vp(h_ooff), vp(h_cap), n, vp(plans), vp(words), max_words, vp(olen))
+    steps = C.c_uint64(0)
+    used = M.lib().plan_compile_batch(vp(h_comp), vp(h_off), vp(h_len), vp(h_ooff), vp(h_cap), n, vp(plans), vp(words), max_words, vp(olen),
+                                      C.byref(steps))
     assert used > 0 and int((olen != B).sum()) == 0, used
-    print("plans: %d words for %d blocks (%.1f per block), %.3f x the compressed bytes" % (used, n, used / n, used * 4 / h_len.sum()))
+    print("plans: %d words for %d blocks (%.1f steps per block), %.3f x the compressed bytes" % (used, n, steps.value / n, used * 4 / h_len.sum()))
     d_words = torch.from_numpy(words[:used + 64].copy()).to(dev)
     d_plans = torch.from_numpy(plans).to(dev)
     out = torch.zeros(n * B, dtype=torch.uint8, device=dev)
