@@ -52,7 +52,10 @@ struct lz4flex_ctx {
     hipStream_t pcd_last = nullptr;
     bool pcd_used = false;
     int dec_pcd_pair = 1;         // 1: two workgroups per block for batches of few large blocks; 0: never, 2: whenever the batch is small enough (tests, measurements)
-    uint32_t* chain_ws = nullptr; // chained decode batches (Linked frames): one "done" word per block, CHAIN_WS_BLOCKS of them
+    uint32_t* chain_ws = nullptr; // chained decode batches (Linked frames): one "done" word per block, CHAIN_WS_BLOCKS of them; one per context, ordered across streams like wave_ws
+    hipEvent_t chain_evt = nullptr;
+    hipStream_t chain_last = nullptr;
+    bool chain_used = false;
     void* wave_ws = nullptr;      // wave encoder workspace: wave_wgs persistent workgroups; allocated by lz4flex_ctx_create
     unsigned long long* wave_prof = nullptr;   // tools: per-role cycle counters of the wave encoder (lz4flex_debug_wave_prof)
     int wave_wgs = 0;
@@ -66,6 +69,8 @@ struct lz4flex_ctx {
     int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 4 = parser / copier split (lz4_decompress_split.hip), 5 / 6 = a wavefront / a pair of wavefronts per block (lz4_decompress_wave.hip), 7 = a workgroup per block (lz4_decompress_pcd.hip; 8: its test geometry)
     int comp_carry_wait = 1;      // tests: 0 = a window of the throughput encoder that has to wait for its predecessor's carry gives up at once (the block then takes the second launch)
     int dec_second_pass = 1;      // tests: 0 leaves the blocks a first-pass decoder marked (status 0x7F000001) instead of decoding them again
+    int chain_giveup = 0;         // tests: block chain_giveup - 1 of the next chained decode batches gives up without an error (the ordered second pass decodes it and everything behind it)
+    int fail_next_batch = 0;      // tests: the next N batch calls on this context fail before they launch anything (what an allocation failure looks like to the caller)
 };
 
 #ifndef LZ4FLEX_PCD_MAX_BLOCKS
@@ -118,7 +123,8 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
         if (!c->dec_second_pass) return hipSuccess;
         DecompressArgs r = a;
         r.only_status = REDO;
-        return launch_decompress(r, c->dec_lanes, s);
+        // a chained batch's marked blocks depend on each other: in chain order, not side by side
+        return r.chain_done ? launch_decompress_chain_redo(r, s) : launch_decompress(r, c->dec_lanes, s);
     }
     return launch_decompress_split(a, s, c->dec_blocks_per_wg);
 }
@@ -246,6 +252,7 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->wave_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&c->chain_ws, 4u * CHAIN_WS_BLOCKS);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->chain_evt, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->pcd_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&c->pcd_ws, decompress_pcd_pair_ws_bytes());
     (void)hipSetDevice(prev);
@@ -264,6 +271,7 @@ void lz4flex_ctx_destroy(lz4flex_ctx* c) {
     if (c->wave_ws) (void)hipFree(c->wave_ws);
     if (c->wave_done) (void)hipEventDestroy(c->wave_done);
     if (c->chain_ws) (void)hipFree(c->chain_ws);
+    if (c->chain_evt) (void)hipEventDestroy(c->chain_evt);
     if (c->pcd_ws) (void)hipFree(c->pcd_ws);
     if (c->pcd_done) (void)hipEventDestroy(c->pcd_done);
     if (c->wave_prof) (void)hipFree(c->wave_prof);
@@ -347,6 +355,16 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
     if (!strcmp(key, "compress_lanes")) {
         if (value != 8 && value != 16) return -LZ4FLEX_E_INVALID_ARG;
         c->comp_lanes = value;
+        return 0;
+    }
+    if (!strcmp(key, "debug_chain_giveup")) {
+        if (value < 0) return -LZ4FLEX_E_INVALID_ARG;
+        c->chain_giveup = value;
+        return 0;
+    }
+    if (!strcmp(key, "debug_fail_next_batch")) {                 // tests/test_gpu_sharded_native.py: one rank's call-level failure
+        if (value < 0) return -LZ4FLEX_E_INVALID_ARG;
+        c->fail_next_batch = value;
         return 0;
     }
     return -LZ4FLEX_E_INVALID_ARG;
@@ -495,6 +513,7 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
         if (chained) {
             HIP_TRY(hipMemsetAsync(c->chain_ws, 0, 4ull * n, s));
             a.chain_done = c->chain_ws;
+            a.debug_giveup = (uint32_t)c->chain_giveup;
         }
         le = ((c->dec_variant != 1 || chained) && !has_dict) ? launch_decompress_fast(c, a, s, big) : launch_decompress(a, c->dec_lanes, s);
     }
@@ -594,10 +613,17 @@ static int run_device_batch(lz4flex_ctx* c, bool compress, const void* in_base, 
         a.dict_len = ext ? ext->dict_len : nullptr;
         a.out_len = out_len; a.status = status; a.detail = detail; a.n = n;
         if (chained && n) {
+            // the "done" words are the context's: two chained batches on different streams would clear and poll the same flags
+            //  -- a launch on another stream than the previous one waits for it first
+            if (c->chain_used && s != c->chain_last) HIP_TRY(hipStreamWaitEvent(s, c->chain_evt, 0));
             HIP_TRY(hipMemsetAsync(c->chain_ws, 0, 4ull * n, s));
             a.chain_done = c->chain_ws;
         }
         le = ((c->dec_variant != 1 || chained) && !a.dict_base) ? launch_decompress_fast(c, a, s, big_hint != 0) : launch_decompress(a, c->dec_lanes, s);
+        if (le == hipSuccess && chained && n) {
+            HIP_TRY(hipEventRecord(c->chain_evt, s));
+            c->chain_last = s; c->chain_used = true;
+        }
     }
     if (le != hipSuccess) return hip_fail(le, "kernel launch");
     return 0;
@@ -622,6 +648,7 @@ int lz4flex_compress_batch(lz4flex_ctx* ctx, const void* in_base, const uint64_t
     int rc;
     if (!ctx && (rc = default_ctx(&ctx))) return rc;
     if (n && (!in_off || !in_len || !out_off || !out_cap || !out_len || !status)) return -LZ4FLEX_E_INVALID_ARG;
+    if (ctx->fail_next_batch > 0) { ctx->fail_next_batch--; g_last_error = "debug_fail_next_batch"; return -LZ4FLEX_E_HIP; }
     if (mem_kind == LZ4FLEX_MEM_HOST)
         return run_host_batch(ctx, true, (const uint8_t*)in_base, in_off, in_len, flags, n, (uint8_t*)out_base, out_off,
                               out_cap, out_len, status, nullptr, nullptr);
@@ -638,6 +665,7 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx* ctx, const void* in_base, const uin
     int rc;
     if (!ctx && (rc = default_ctx(&ctx))) return rc;
     if (n && (!in_off || !in_len || !out_off || !out_cap || !out_len || !status)) return -LZ4FLEX_E_INVALID_ARG;
+    if (ctx->fail_next_batch > 0) { ctx->fail_next_batch--; g_last_error = "debug_fail_next_batch"; return -LZ4FLEX_E_HIP; }
     lz4flex_decompress_ext_ e{};
     if (ext) { e.dict_base = ext->dict_base; e.dict_off = ext->dict_off; e.dict_len = ext->dict_len; e.out_pos = ext->out_pos; }
     const bool chained = (mem_kind & LZ4FLEX_MEM_CHAINED) != 0;

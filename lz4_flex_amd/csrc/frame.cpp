@@ -602,7 +602,9 @@ struct lz4flex_frame_decoder {
         bool saw_end = false, raw_tail = false;
         size_t raw_at = 0, raw_len = 0;
         const size_t out_budget = std::max<size_t>(batch_bytes, mbs) * (batch_auto ? 4u : 1u);
-        while (in_off.size() < max_blocks && (in_off.empty() || (in_off.size() + 1) * mbs <= out_budget)) {
+        // (sink positions are 32-bit: an explicit batch size of 4 GiB or more must not wrap them)
+        const size_t pos_blocks = (size_t)((0xFFFFFFFFull - carry) / mbs) - 1u;
+        while (in_off.size() < std::min(max_blocks, pos_blocks) && (in_off.empty() || (in_off.size() + 1) * mbs <= out_budget)) {
             uint8_t bi[4];
             const int rc = read_exact(bi, 4);
             if (rc != 0) {
@@ -635,8 +637,14 @@ struct lz4flex_frame_decoder {
         std::vector<uint64_t> zero_off(nb, 0);
         size_t first = 0;
         bool failed = false;
+        // A launch assumes full blocks; the blocks behind a short one have to be decoded again from their real position.  A
+        // frame of many short blocks (a flush() after every small write) would cost a launch and a re-decode of everything
+        // behind it per block if every launch took the whole rest of the run: the run length is cut to a quarter whenever a
+        // short block invalidates the blocks behind it and doubles again while launches end clean -- launches and decoded
+        // blocks stay linear in the number of blocks.
+        size_t run = nb;
         while (first < nb) {
-            const size_t m = nb - first;
+            const size_t m = std::min(run, nb - first);
             for (size_t k = 0; k < m; k++) {
                 pos[k] = (uint32_t)(carry + produced_total + k * mbs);
                 cap[k] = pos[k] + (uint32_t)mbs;
@@ -660,6 +668,7 @@ struct lz4flex_frame_decoder {
                 produced_total += out_len[i];
                 if (out_len[i] != mbs) { k++; break; }        // the blocks behind a short one were given a wrong position
             }
+            run = k < m ? std::max<size_t>(1, m / 4) : std::min(nb, 2 * m);
             first += k;
             if (failed) break;
         }

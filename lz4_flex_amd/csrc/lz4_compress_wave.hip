@@ -1330,8 +1330,10 @@ hipError_t launch_compress_wave(const CompressArgs& a, void* workspace, int n_wo
     }
     hipLaunchKernelGGL(wave::lz4_compress_wave_kernel, dim3((uint32_t)n_workgroups), dim3(wave::THREADS), wave::LDS_BYTES, s, a,
                        (uint8_t*)workspace, carry, prof, carry_wait ? wave::CARRY_SPINS : 1u);
+    const hipError_t first = hipGetLastError();      // (reading it clears it: a failed first launch must not be reported as success)
+    if (first != hipSuccess) return first;
 #ifndef LZ4W_EXP_NO_REDO     // (tools: shows what the second launch is for)
-    if (carry != nullptr && hipGetLastError() == hipSuccess) {
+    if (carry != nullptr) {
         // A window that gave up waiting for its predecessor's carry (every wait is bounded: a GPU shared with another process, a
         // debugger) left its block with status 66.  Those blocks are encoded again by their own workgroup, window after window,
         // with the carry in LDS: the same bytes, no waiting, and no valid input turns into an error.  Nothing to do: ~10 us.

@@ -230,6 +230,47 @@ __global__ void __launch_bounds__(256) lz4_decompress_blocks_kernel(DecompressAr
     }
 }
 
+// Second pass behind a CHAINED batch (Linked frames: block i's prefix is what blocks 0..i-1 of the batch write).  The marked blocks
+// of such a batch cannot be decoded side by side -- block k + 1 would read block k's last 64 KiB while block k is being written
+// again (status 0, wrong bytes) -- so ONE wavefront decodes them one after the other, in chain order.  Slow, and only
+// ever busy when a first-pass block gave up for a non-error reason (a time-sliced or oversubscribed GPU) or the frame is corrupt.
+__global__ void __launch_bounds__(64) lz4_decompress_chain_redo_kernel(DecompressArgs a) {
+    constexpr int G = 16;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t b0 = 0u; b0 < a.n; b0 += 64u) {
+        const uint32_t bi = b0 + lane;
+        const bool marked = bi < a.n && a.status[bi] == a.only_status;
+        uint64_t m = __builtin_amdgcn_ballot_w64(marked);
+        while (m != 0ull) {
+            const uint32_t b = b0 + (uint32_t)__builtin_ctzll(m);
+            m &= m - 1ull;
+            if (lane < (uint32_t)G) {
+                uint32_t produced = 0u;
+                uint64_t expected = 0u;
+                const uint32_t cap = a.out_cap[b];
+                const int32_t st = decode_block<G, false>(a.in_base + a.in_off[b], a.in_len[b], a.out_base + a.out_off[b], a.out_pos ? a.out_pos[b] : 0u,
+                                                          cap, nullptr, 0u, lane, &produced, &expected);
+                if (lane == 0u) {
+                    a.status[b] = st;
+                    a.out_len[b] = st == 0 ? produced : 0u;
+                    if (a.detail) {
+                        a.detail[2u * b] = st == LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL ? expected : 0u;
+                        a.detail[2u * b + 1u] = st == LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL ? (uint64_t)cap : 0u;
+                    }
+                }
+            }
+            __threadfence();      // the next block of the chain reads what this one wrote
+        }
+    }
+}
+
+hipError_t launch_decompress_chain_redo(const DecompressArgs& a, hipStream_t s) {
+    if (a.n == 0u) return hipSuccess;
+    if (a.dict_base != nullptr || a.only_status == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lz4_decompress_chain_redo_kernel, dim3(1), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
 template <int G, bool USE_DICT>
 static hipError_t launch_g(const DecompressArgs& a, hipStream_t s) {
     const uint32_t blocks_per_wg = 256u / G;

@@ -643,7 +643,8 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
     uint32_t cbase = 0u;       // the tile's first byte: a true token position
     uint32_t OP = OP0;         // output position: everything before it is written back
     uint32_t hist = 0u;        // window bytes [0, hist) hold output [OP - hist, OP)
-    bool ended = false, bad = false;
+    bool ended = false, bad = a.debug_giveup == b + 1u;      // (tests: a block that gives up without an error of its own)
+    if (bad) ended = true;
     __syncthreads();
     PCD_PROF_DECL
 

@@ -37,6 +37,8 @@ struct DecompressArgs {
     // gets TWO workgroups: one parses its tiles and hands the token lists over through this workspace, the other copies
     // (lz4_decompress_pcd.hip "roles"); decompress_pcd_pair_ws_bytes() bytes
     uint8_t* pair_ws;
+    // lz4_decompress_pcd_kernel, tests only: block debug_giveup - 1 of a chained batch gives up as if a wait had timed out (0: none)
+    uint32_t debug_giveup;
 };
 constexpr uint32_t PCD_PAIR_MAX_BLOCKS = 128u;
 size_t decompress_pcd_pair_ws_bytes();
@@ -66,6 +68,8 @@ struct ReplayArgs {
 hipError_t launch_replay(const ReplayArgs& a, hipStream_t s);
 
 hipError_t launch_decompress(const DecompressArgs& a, int lanes_per_block, hipStream_t s);
+// the second pass of a CHAINED batch: the blocks whose status equals a.only_status, one after the other in chain order (one wavefront)
+hipError_t launch_decompress_chain_redo(const DecompressArgs& a, hipStream_t s);
 // one block per wavefront (lz4_decompress_wave.hip); irregular blocks are left with status redo_code for a second pass of
 // launch_decompress (only_status = redo_code), which decodes them in the reference's check order
 hipError_t launch_decompress_wave(const DecompressArgs& a, int32_t redo_code, hipStream_t s);

@@ -121,11 +121,14 @@ int lz4flex_frame_compress_sharded(lz4flex_ctx* ctx, void* nccl_comm, int rank, 
     hipStream_t s = (hipStream_t)hip_stream;
     const uint32_t n = (uint32_t)((local_len + bs - 1) / bs);
     const uint64_t stride = (lz4flex_get_maximum_output_size(bs) + 63) / 64 * 64;
-    // ---- this rank's blocks -> its segment, on the device
+    // ---- this rank's blocks -> its segment, on the device.  No rank may leave before a collective its peers will enter: whatever
+    // fails in this phase (an allocation, a launch, a block) is SAID in the size all-gather below (seg_bytes = ~0) and every rank
+    // returns there, this one with its own code.  The one thing that has to work first is the buffer the exchange itself uses.
     DevBuf comp, desc, seg, sizes;
     uint64_t seg_bytes = 0;
-    TRY_HIP(seg.alloc(lz4flex_frame_segment_bound(local_len, info)));
     TRY_HIP(sizes.alloc(8ull * (size_t)world + 8));
+    const int local_rc = [&]() -> int {
+    TRY_HIP(seg.alloc(lz4flex_frame_segment_bound(local_len, info)));
     if (n) {
         TRY_HIP(comp.alloc(stride * n));
         // descriptor arrays: in_off, comp_off, seg_off (n + 1) [u64]; in_len, cap, comp_len, status, flags [u32]; scratch 16 n
@@ -162,8 +165,11 @@ int lz4flex_frame_compress_sharded(lz4flex_ctx* ctx, void* nccl_comm, int rank, 
         TRY_HIP(hipMemcpyAsync(st.data(), d + o_st, 4ull * n, hipMemcpyDeviceToHost, s));
         TRY_HIP(hipMemcpyAsync(&seg_bytes, d + o_seg_off + 8ull * n, 8, hipMemcpyDeviceToHost, s));
         TRY_HIP(hipStreamSynchronize(s));
-        for (uint32_t i = 0; i < n; i++) if (st[i] != 0) seg_bytes = ~0ull;       // (said to everybody below: a rank that left now would leave the others waiting in the exchange)
+        for (uint32_t i = 0; i < n; i++) if (st[i] != 0) return -LZ4FLEX_FE_COMPRESSION;
     }
+    return 0;
+    }();
+    if (local_rc) seg_bytes = ~0ull - (uint64_t)(uint32_t)(-local_rc);    // the code travels with the verdict: every rank returns the same one
     // ---- 1) all-gather of the segment sizes, 2) exclusive prefix sum
     std::vector<uint64_t> all((size_t)world, 0);
     if (world > 1) {
@@ -175,7 +181,8 @@ int lz4flex_frame_compress_sharded(lz4flex_ctx* ctx, void* nccl_comm, int rank, 
     } else {
         all[0] = seg_bytes;
     }
-    for (int r = 0; r < world; r++) if (all[(size_t)r] == ~0ull) return -LZ4FLEX_FE_COMPRESSION;       // every rank sees the same sizes: all leave here
+    for (int r = 0; r < world; r++)
+        if (all[(size_t)r] > ~0ull - 0x10000ull) return -(int)(uint32_t)(~0ull - all[(size_t)r]);       // every rank sees the same sizes: all leave here, with the first failing rank's code
     uint8_t hdr[19];
     const int64_t hl = lz4flex_frame_info_write(info, hdr, sizeof hdr);
     if (hl < 0) return (int)hl;
@@ -227,7 +234,9 @@ int lz4flex_frame_decompress_sharded(lz4flex_ctx* ctx, void* nccl_comm, int rank
     DevBuf d_off, d_word, d_info, d_meta;
     TRY_HIP(d_meta.alloc(32));
     uint32_t hdr_len = 0;
-    if (rank == root) {
+    // (as in the encoder: a call that fails on the root before the broadcast below is said IN that broadcast -- meta[3] --, the
+    // root does not leave its peers waiting)
+    const int root_rc = rank != root ? 0 : [&]() -> int {
         if (!frame || frame_bytes < 7) meta[3] = LZ4FLEX_FE_IO;
         else {
             uint8_t h[19] = {0};
@@ -262,14 +271,16 @@ int lz4flex_frame_decompress_sharded(lz4flex_ctx* ctx, void* nccl_comm, int rank
                 meta[2] = fi.block_checksums ? 1 : 0;
             }
         }
-    }
+        return 0;
+    }();
+    if (root_rc && !meta[3]) meta[3] = (uint64_t)(-root_rc);
     if (world > 1) {
         TRY_HIP(hipMemcpyAsync(d_meta.p, meta, 32, hipMemcpyHostToDevice, s));
         TRY_NCCL(rccl().Broadcast(d_meta.p, d_meta.p, 4, NCCL_U64, root, nccl_comm, s));
         TRY_HIP(hipMemcpyAsync(meta, d_meta.p, 32, hipMemcpyDeviceToHost, s));
         TRY_HIP(hipStreamSynchronize(s));
     }
-    if (meta[3]) return -(int)meta[3];
+    if (meta[3]) return root_rc ? root_rc : -(int)meta[3];
     const uint64_t nb = meta[0];
     const size_t bs = block_bytes((int)meta[1]);
     const bool has_bc = meta[2] != 0;

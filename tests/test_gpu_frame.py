@@ -58,6 +58,37 @@ def test_decode_linked_frames(fr, i):   # Linked DECODE on GPU (prefix + ext-dic
     assert _dec(fr, O.c_frame_compress(data, independent=False)) == data
 
 
+@pytest.mark.parametrize("giveup", [1, 2, 7, 11])
+def test_linked_frame_with_a_block_that_gives_up(fr, giveup, exact_encoder):
+    """A block of a chained batch that gives up WITHOUT an error of its own (a bounded wait that ran out: a time-sliced GPU) leaves
+    itself and every block behind it to the second pass, which decodes a chain's blocks one after the other in chain order -- side
+    by side, block k + 1 would read block k's last 64 KiB while it is being written again.  Linked frames of the
+    oracle's encoder (blocks that do refer to their predecessors), 64 KiB blocks, give-up forced through the library's test hook;
+    and a frame of short blocks (a flush() after every small write: the run length of the launches adapts)."""
+    from lz4_flex_amd import _lib
+    lib = _lib.load()
+    data = (O.fixture_plain("compression_66k_JSON") * 12)[:780000]
+    f = O.frame_compress(data, block_mode=1, block_size=4)[1]
+    assert lib.lz4flex_set_tuning(None, b"debug_chain_giveup", giveup) == 0
+    try:
+        assert _dec(fr, f) == data
+    finally:
+        assert lib.lz4flex_set_tuning(None, b"debug_chain_giveup", 0) == 0
+    chunks = [3000 + 977 * (i % 13) for i in range(90)]
+    small = data[:sum(chunks)]
+    buf = io.BytesIO()
+    e = fr.FrameEncoder.with_frame_info(fr.FrameInfo(block_mode=fr.BlockMode.Linked, block_size=fr.BlockSize.Max64KB), buf)
+    at = 0
+    for n in chunks:
+        e.write(small[at:at + n]); e.flush()                       # 90 short blocks, each referring to its predecessors
+        at += n
+    e.finish()
+    f2 = buf.getvalue()
+    rc, back, _used = O.frame_decompress(f2, len(small))
+    assert rc == 0 and back == small
+    assert _dec(fr, f2) == small
+
+
 @pytest.mark.parametrize("stem", corpus.FIXTURES)
 def test_fixtures(fr, stem):
     data = O.fixture_plain(stem)

@@ -128,6 +128,11 @@ def test_frame_across_ranks_through_the_c_abi(env, world, mode, bs_code, n_block
         return lib.lz4flex_frame_compress_sharded(ctxs[r], comms[r], r, world, 0, C.c_void_p(src.data_ptr() + a), max(b - a, 0), lo, C.byref(fic),
                                                   C.c_void_p(small.data_ptr()) if r == 0 else None, 64 if r == 0 else 0, C.byref(flens[r]), None)
     assert _run(world, comp_small) == [-L.FE_OUTPUT_FULL] * world
+    # ---- a call-level failure on ONE rank before the size all-gather (an allocation or a launch that fails: here the batch call,
+    # through the library's test hook): the rank says so IN the all-gather, nobody is left waiting, everybody returns its code
+    assert lib.lz4flex_set_tuning(ctxs[0], b"debug_fail_next_batch", 1) == 0
+    assert _run(world, comp) == [-L.E_HIP] * world
+    assert _run(world, comp) == [0] * world                       # (and the communicator is still usable)
     assert mock.mock_world_errors(wptr) == 0, "a collective was called with different arguments on different ranks, or a send met a receive of another size"
     for ctx in ctxs:
         lib.lz4flex_ctx_destroy(ctx)
