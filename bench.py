@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 BLOCK = 65536
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
-ROUND = 3               # stamped into the traffic figure's provenance
+ROUND = 4               # stamped into the traffic figure's provenance
 
 
 def median(xs):
@@ -304,9 +304,31 @@ def run_blocks(args, env):
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(src, comp, comp_off, comp_len, n, args.compress_mode)
+            stash = {}
+            out["cpu_baseline"] = cpu_baseline(src, comp, comp_off, comp_len, n, args.compress_mode, stash)
+            # north_star's decompress contract is "bit-exact on the reference's own block bytes": the timed loop above decodes the
+            # GPU encoder's blocks, so the decoder is timed once more on the ORACLE-encoded workload (= lz4_flex's bytes), after
+            # the timed region, events on the launch stream, and checked against the source
+            h_out, h_out_len = stash["oracle_blocks"]
+            comp.copy_(torch.from_numpy(h_out).to(dev))
+            comp_len.copy_(torch.from_numpy(h_out_len.astype("int32")).to(dev))
+            back.zero_()
+            do_decompress()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); do_decompress(); e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            assert int((d_status != 0).sum().item()) == 0 and torch.equal(back, src), "reference-encoded blocks: decode mismatch"
+            out["decompress_ref_blocks_ms"] = round(median(ts), 4)
+            out["decompress_ref_blocks"] = ("all %d blocks encoded by the oracle (lz4_flex's encoder restated: %d compressed bytes), decoded on the "
+                                            "GPU, median of 5 launches, output == source" % (n, int(h_out_len.sum())))
         except Exception as e:   # the baseline is a report, never a reason to lose the GPU line
-            out["cpu_baseline"] = {"error": repr(e)}
+            out.setdefault("cpu_baseline", {"error": repr(e)})
+            out["decompress_ref_blocks_ms"] = None
+            out["decompress_ref_blocks"] = "failed: %r" % (e,)
     return out
 
 
@@ -400,10 +422,23 @@ def run_linked_frame(args, env):
         state["back"] = F.decompress_frame(fr, len(data))[0]
 
     elapsed = timed(args, env, step)
+    oracle_checked = None
     if not args.no_verify:
         assert state["back"] == data
+        # the reference's FrameDecoder (oracle restatement) over the frame the GPU wrote, once, after the timed loop
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_api as O
+        rc, back, used = O.frame_decompress(state["frame"], len(data))
+        assert rc == 0 and back == data and used == len(state["frame"]), "the reference's FrameDecoder (oracle) does not return the data"
+        oracle_checked = "frame (%d bytes) decoded by the oracle's FrameDecoder == the data" % len(state["frame"])
     total = len(data) * world
     alg = len(data) + len(state["frame"])
+    base = {"note": "--no-cpu-baseline"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            base = cpu_baseline_linked(data)
+        except Exception as e:
+            base = {"error": repr(e)}
     return {
         "metric": "MiB/s frame compress + decompress, BlockLinked 64 KiB blocks, host buffers",
         "value": round((total / 1048576) / (elapsed / args.steps), 2), "unit": "MiB/s", "n_gpus": world, "steps": args.steps,
@@ -419,8 +454,8 @@ def run_linked_frame(args, env):
                    "blocks": n, "compress_mode": args.compress_mode},
         "ratio": round(len(state["frame"]) / len(data), 5),
         "roofline": dict(roof(alg, elapsed / args.steps), kernel=("lz4_compress_chain_kernel" if exact else "lz4_compress_wave_kernel") + " + lz4_decompress_pcd_kernel (chained batch)"),
-        "verified": "NOT VERIFIED" if args.no_verify else "frame round trip bit-exact",
-        "cpu_baseline": {"note": "not timed for this stress configuration (see --config 2)"},
+        "verified": "NOT VERIFIED" if args.no_verify else "frame round trip bit-exact; " + oracle_checked,
+        "cpu_baseline": base,
     }
 
 
@@ -525,7 +560,7 @@ def _baseline_dict(res, topo, sample):
     return out
 
 
-def cpu_baseline(src, comp, comp_off, comp_len, n, mode):
+def cpu_baseline(src, comp, comp_off, comp_len, n, mode, stash=None):
     """Times oracle/ (kind 'port': lz4_flex is Rust, no toolchain here) and the system liblz4 on the same bytes as the GPU: the
     whole batch on all host threads / all physical cores, an eighth of it on one thread; then the ORACLE's decoder (= lz4_flex's,
     restated) decodes EVERY block the GPU encoder wrote and must return the input."""
@@ -535,6 +570,8 @@ def cpu_baseline(src, comp, comp_off, comp_len, n, mode):
     h_src = src[:ns * BLOCK].cpu().numpy()
     stride = int(comp_off[1].item()) if n > 1 else 72128
     res, topo, h_out, h_out_len = _time_codecs(O, h_src, ns, BLOCK, stride)
+    if stash is not None:
+        stash["oracle_blocks"] = (h_out, h_out_len)      # the oracle port's output of its last compress pass: every block, at the GPU's stride
     g_len = comp_len[:ns].cpu().numpy().astype(np.uint32)
     g = comp[:ns * stride].cpu().numpy()
     if mode == "exact":                            # the reference-exact encoder: same sizes and bytes as the oracle
@@ -559,6 +596,57 @@ def cpu_baseline(src, comp, comp_off, comp_len, n, mode):
     d["oracle_ratio"] = round(res[("oracle_port", topo[0])][3], 5)
     d["gpu_blocks_decoded_by_oracle"] = int(ns)
     return d
+
+
+def cpu_baseline_linked(data):
+    """config 5: the oracle's FrameEncoder + FrameDecoder (lz4_flex's, restated) on the same bytes, Linked 64 KiB blocks: one thread
+    on one frame (a Linked frame is one dependency chain: that is its CPU speed), and every hardware thread on a frame each
+    (what the host does with many such streams).  Passes of >= 0.3 s, best of 3."""
+    import threading
+    O = _oracle_fresh()
+    hw, phys = host_topology()
+    rc, fr = O.frame_compress(data, block_mode=1, block_size=4)
+    assert rc == 0
+    assert O.frame_decompress(fr, len(data))[1] == data
+    o = O.lib()
+    fi = O.frame_info(block_mode=1, block_size=4)
+    cap = len(data) + len(data) // 100 + (len(data) // 65536 + 2) * 16 + 64
+
+    def one_pass(reps):          # the oracle's C entry points on preallocated buffers: no Python copies inside the timed passes
+        out = C.create_string_buffer(cap)
+        back = C.create_string_buffer(len(data))
+        used = C.c_size_t(0)
+        d = O.ErrDetail()
+        for _ in range(reps):
+            n = o.lz4o_frame_compress(data, len(data), None, 0, C.byref(fi), out, cap, C.byref(d))
+            m = o.lz4o_frame_decompress(out, n, back, len(data), C.byref(used), C.byref(d))
+            assert n == len(fr) and m == len(data)
+
+    def rate(threads):
+        reps, best = 1, 0.0
+        for attempt in range(8):
+            th = [threading.Thread(target=one_pass, args=(reps,)) for _ in range(threads)]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            dt = time.perf_counter() - t0
+            if dt >= 0.3:
+                best = max(best, threads * reps * len(data) / 1048576 / dt)
+                if attempt >= 4:
+                    break
+            else:
+                reps = max(reps + 1, int(reps * 0.4 / max(dt, 1e-3)))
+        return best
+    one = rate(1)
+    allc = rate(hw)
+    return {"value": round(one, 1), "unit": "MiB/s", "cores": 1, "kind": "port",
+            "sample": "the same %d bytes, one Linked frame of 64 KiB blocks: oracle FrameEncoder + FrameDecoder round trip on ONE thread (a Linked frame is one "
+                      "dependency chain); passes of >= 0.3 s, best of 3; oracle rebuilt on this node with gcc -O3 -march=native" % len(data),
+            "all_threads": {"threads": hw, "round_trip_MiB_per_s": round(allc, 1),
+                            "note": "every hardware thread encodes + decodes its own copy of the frame (ctypes calls release the GIL)"},
+            "host": {"hardware_threads": hw, "physical_cores": phys}, "oracle_ratio": round(len(fr) / len(data), 5)}
 
 
 def cpu_baseline_buffer(buf, bs):

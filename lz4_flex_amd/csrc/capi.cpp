@@ -95,7 +95,7 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
     // 0.52 / 1.13 ms against 0.45 / 0.49 / 0.52 / 0.71 (pair of wavefronts per block); 1 024 text / log blocks 0.81 / 0.42 against
     // 1.02 / 0.58; 256 x 4 MiB log blocks: 4.9 ms against 28.8; one 16 MiB block: 14.6 ms against 113.  1 024 = four workgroups per CU.
     int v = c->dec_variant != 0 ? c->dec_variant
-                                : ((a.n <= PCD_MAX_BLOCKS || big_blocks) ? 7 : (a.n <= 2304u ? 6 : (a.n <= 5120u ? 5 : 4)));
+                                : ((a.n <= PCD_MAX_BLOCKS || big_blocks) ? 7 : (a.n <= DISPATCH_WAVE_PAIR_MAX ? 6 : (a.n <= DISPATCH_WAVE_MAX ? 5 : 4)));
     if (a.out_pos != nullptr && v != 8) v = 7;           // prefix mode (Linked frames): only the workgroup decoder knows it
     if (v >= 5 && v <= 8) {
         // one block per wavefront (6: per pair of wavefronts; 7 / 8: per workgroup); blocks it marks (errors, sinks too small) are
@@ -372,6 +372,14 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
 
 int lz4flex_get_tuning(lz4flex_ctx* c, const char* key) {
     if (!key) return -LZ4FLEX_E_INVALID_ARG;
+    // the batch sizes at which the default decoder dispatch changes kernel or geometry (lz4_device.h), in ascending order; the
+    // list ends where the key is refused.  tests/test_gpu_block.py builds its size matrix from it.
+    if (!strncmp(key, "dispatch_threshold_", 19)) {
+        const uint32_t t[] = {PCD_PAIR_MAX_BLOCKS, PCD_MAX_BLOCKS, DISPATCH_WAVE_PAIR_MAX, DISPATCH_SPLIT_16, DISPATCH_WAVE_MAX, DISPATCH_SPLIT_32, DISPATCH_SPLIT_64};
+        const int i = atoi(key + 19);
+        if (i < 0 || i >= (int)(sizeof t / sizeof t[0]) || (key[19] < '0' || key[19] > '9')) return -LZ4FLEX_E_INVALID_ARG;
+        return (int)t[i];
+    }
     if (!c) { const int rc = default_ctx(&c); if (rc) return rc; }
     if (!strcmp(key, "compress_mode")) return c->comp_mode;
     if (!strcmp(key, "compress_variant")) return c->comp_variant;

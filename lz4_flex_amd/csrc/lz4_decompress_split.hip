@@ -494,7 +494,7 @@ hipError_t launch_decompress_split(const DecompressArgs& a, hipStream_t s, int b
     if (a.n == 0u) return hipSuccess;
     if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;   // dictionary / prefix: v1 kernel
     if (blocks_per_wg == 0)
-        blocks_per_wg = a.n >= 64u * 256u ? 64 : (a.n >= 32u * 256u ? 32 : (a.n >= 16u * 256u ? 16 : 8));
+        blocks_per_wg = a.n >= DISPATCH_SPLIT_64 ? 64 : (a.n >= DISPATCH_SPLIT_32 ? 32 : (a.n >= DISPATCH_SPLIT_16 ? 16 : 8));
     switch (blocks_per_wg) {
         case 64: return v5::launch_cfg<v5::LayoutBig, 64, LZ4S_G, LZ4S_WB, LZ4S_NS>(a, s);
         case 32: return v5::launch_cfg<v5::LayoutBig, 32, 8, 4, 4>(a, s);

@@ -41,6 +41,15 @@ struct DecompressArgs {
     uint32_t debug_giveup;
 };
 constexpr uint32_t PCD_PAIR_MAX_BLOCKS = 128u;
+// The batch sizes at which launch_decompress_fast (capi.cpp) changes decoder and launch_decompress_split its geometry: ONE
+// table, read by the dispatch AND (through lz4flex_get_tuning "dispatch_threshold_<i>") by the tests, whose decoder matrix is
+// every threshold and its successor -- a threshold edit cannot leave a size class untested (a wrong result lived a round in
+// batches of 5 121 ... 16 383 blocks because one geometry was never run on real data).
+constexpr uint32_t DISPATCH_WAVE_PAIR_MAX = 2304u;   // <= : a pair of wavefronts per block (above LZ4FLEX_PCD_MAX_BLOCKS)
+constexpr uint32_t DISPATCH_WAVE_MAX = 5120u;        // <= : a wavefront per block; above: the split decoder
+constexpr uint32_t DISPATCH_SPLIT_16 = 16u * 256u;   // split decoder: >= this many blocks 16 per workgroup, below 8
+constexpr uint32_t DISPATCH_SPLIT_32 = 32u * 256u;
+constexpr uint32_t DISPATCH_SPLIT_64 = 64u * 256u;
 size_t decompress_pcd_pair_ws_bytes();
 
 struct CompressArgs {

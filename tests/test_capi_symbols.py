@@ -91,3 +91,18 @@ def test_stale_library_is_detected(lib_path):
             with open(victim, "wb") as f:
                 f.write(orig)
     assert not build.needs_build()
+
+
+def test_dispatch_thresholds_are_readable_without_a_device():
+    """the decoder dispatch's batch-size table (lz4_device.h) through lz4flex_get_tuning: ascending, ends where the key is refused --
+    tests/test_gpu_dispatch_matrix.py builds its size matrix from it"""
+    from lz4_flex_amd import _lib
+    lib = _lib.load()
+    ts = []
+    for i in range(32):
+        v = lib.lz4flex_get_tuning(None, b"dispatch_threshold_%d" % i)
+        if v < 0:
+            break
+        ts.append(v)
+    assert len(ts) >= 5 and ts == sorted(ts) and ts[-1] == 16384
+    assert lib.lz4flex_get_tuning(None, b"dispatch_threshold_x") < 0
