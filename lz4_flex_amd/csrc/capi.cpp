@@ -69,6 +69,14 @@ struct lz4flex_ctx {
     int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 4 = parser / copier split (lz4_decompress_split.hip), 5 / 6 = a wavefront / a pair of wavefronts per block (lz4_decompress_wave.hip), 7 = a workgroup per block (lz4_decompress_pcd.hip; 8: its test geometry)
     int comp_carry_wait = 1;      // tests: 0 = a window of the throughput encoder that has to wait for its predecessor's carry gives up at once (the block then takes the second launch)
     int dec_second_pass = 1;      // tests: 0 leaves the blocks a first-pass decoder marked (status 0x7F000001) instead of decoding them again
+    // plan / replay decoder (lz4_decompress_plan.hip, lz4_decompress_replay.hip): the copy plans of a batch, plan_slot_words() words per
+    // block + a 32-byte header each.  Grows with the largest batch seen (a hipMalloc -- a device synchronisation -- in the first such
+    // call and whenever a larger batch arrives; never shrinks); one per context, ordered across streams like wave_ws.
+    uint8_t* plan_ws = nullptr;
+    size_t plan_cap = 0;
+    hipEvent_t plan_done = nullptr;
+    hipStream_t plan_last = nullptr;
+    bool plan_used = false;
     int chain_giveup = 0;         // tests: block chain_giveup - 1 of the next chained decode batches gives up without an error (the ordered second pass decodes it and everything behind it)
     int fail_next_batch = 0;      // tests: the next N batch calls on this context fail before they launch anything (what an allocation failure looks like to the caller)
 };
@@ -97,6 +105,42 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
     int v = c->dec_variant != 0 ? c->dec_variant
                                 : ((a.n <= PCD_MAX_BLOCKS || big_blocks) ? 7 : (a.n <= DISPATCH_WAVE_PAIR_MAX ? 6 : (a.n <= DISPATCH_WAVE_MAX ? 5 : 4)));
     if (a.out_pos != nullptr && v != 8) v = 7;           // prefix mode (Linked frames): only the workgroup decoder knows it
+    if (v == 9) {
+        // plan / replay: every block is turned into a copy plan (one wavefront per block, everything that is parallel), then the
+        // plans are replayed (four lanes per block, the serial rest); blocks without a plan (errors, sinks too small, oversized) go
+        // to the reference-order kernel
+        constexpr int32_t REDO = 0x7F000001;
+        const size_t slot = plan_slot_words();
+        const size_t need = (size_t)a.n * (slot * 4u + 32u) + 256u;
+        if (need > c->plan_cap) {
+            if (c->plan_used) { const hipError_t w = hipEventSynchronize(c->plan_done); if (w != hipSuccess) return w; }
+            if (c->plan_ws) (void)hipFree(c->plan_ws);
+            c->plan_ws = nullptr; c->plan_cap = 0;
+            const hipError_t m = hipMalloc((void**)&c->plan_ws, need);
+            if (m != hipSuccess) return m;
+            c->plan_cap = need;
+        }
+        if (c->plan_used && s != c->plan_last) { const hipError_t w = hipStreamWaitEvent(s, c->plan_done, 0); if (w != hipSuccess) return w; }
+        PlanArgs pa;
+        pa.in_base = a.in_base; pa.in_off = a.in_off; pa.in_len = a.in_len; pa.out_off = a.out_off; pa.out_cap = a.out_cap;
+        pa.plans = (plan::BlockPlan*)c->plan_ws;
+        pa.words = (uint32_t*)(c->plan_ws + (((size_t)a.n * 32u + 255u) & ~(size_t)255u));
+        pa.out_len = a.out_len; pa.status = a.status; pa.n = a.n; pa.slot_words = (uint32_t)slot; pa.redo_code = REDO;
+        hipError_t e = launch_plan(pa, s);
+        if (e != hipSuccess) return e;
+        ReplayArgs ra;
+        ra.in_base = a.in_base; ra.out_base = a.out_base; ra.plans = pa.plans; ra.words = pa.words; ra.n = a.n;
+        e = launch_replay(ra, s);
+        if (e != hipSuccess) return e;
+        e = hipEventRecord(c->plan_done, s);
+        if (e != hipSuccess) return e;
+        c->plan_last = s; c->plan_used = true;
+        if (a.detail) { const hipError_t z = hipMemsetAsync(a.detail, 0, 16ull * a.n, s); if (z != hipSuccess) return z; }
+        if (!c->dec_second_pass) return hipSuccess;
+        DecompressArgs r = a;
+        r.only_status = REDO;
+        return launch_decompress(r, c->dec_lanes, s);
+    }
     if (v >= 5 && v <= 8) {
         // one block per wavefront (6: per pair of wavefronts; 7 / 8: per workgroup); blocks it marks (errors, sinks too small) are
         // decoded again in the reference's order
@@ -253,6 +297,7 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->wave_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&c->chain_ws, 4u * CHAIN_WS_BLOCKS);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->chain_evt, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->plan_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->pcd_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&c->pcd_ws, decompress_pcd_pair_ws_bytes());
     (void)hipSetDevice(prev);
@@ -272,6 +317,8 @@ void lz4flex_ctx_destroy(lz4flex_ctx* c) {
     if (c->wave_done) (void)hipEventDestroy(c->wave_done);
     if (c->chain_ws) (void)hipFree(c->chain_ws);
     if (c->chain_evt) (void)hipEventDestroy(c->chain_evt);
+    if (c->plan_ws) (void)hipFree(c->plan_ws);
+    if (c->plan_done) (void)hipEventDestroy(c->plan_done);
     if (c->pcd_ws) (void)hipFree(c->pcd_ws);
     if (c->pcd_done) (void)hipEventDestroy(c->pcd_done);
     if (c->wave_prof) (void)hipFree(c->wave_prof);
@@ -324,7 +371,7 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "decompress_variant")) {
-        if (value != 0 && value != 1 && (value < 4 || value > 8)) return -LZ4FLEX_E_INVALID_ARG;
+        if (value != 0 && value != 1 && (value < 4 || value > 9)) return -LZ4FLEX_E_INVALID_ARG;
         c->dec_variant = value;
         return 0;
     }

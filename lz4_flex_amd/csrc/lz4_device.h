@@ -75,6 +75,22 @@ struct ReplayArgs {
     uint32_t n;
 };
 hipError_t launch_replay(const ReplayArgs& a, hipStream_t s);
+struct PlanArgs {
+    const uint8_t* in_base;
+    const uint64_t* in_off;
+    const uint32_t* in_len;
+    const uint64_t* out_off;
+    const uint32_t* out_cap;
+    plan::BlockPlan* plans;         // n per-block headers (written)
+    uint32_t* words;                // the plan array: slot_words per block (written)
+    uint32_t* out_len;
+    int32_t* status;                // 0, or redo_code: the block has no plan (irregular) and is left to the reference-order kernel
+    uint32_t n;
+    uint32_t slot_words;
+    int32_t redo_code;
+};
+size_t plan_slot_words();
+hipError_t launch_plan(const PlanArgs& a, hipStream_t s);
 
 hipError_t launch_decompress(const DecompressArgs& a, int lanes_per_block, hipStream_t s);
 // the second pass of a CHAINED batch: the blocks whose status equals a.only_status, one after the other in chain order (one wavefront)

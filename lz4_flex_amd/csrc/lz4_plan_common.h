@@ -101,11 +101,15 @@ struct Emit {
     uint32_t lanes;     // lanes taken
     uint32_t bytes;     // bytes they move
     uint32_t start;     // output position of the step's first byte
-    uint32_t w[G];
+    uint32_t w0, w1, w2, w3;    // (four names, not an array: an array indexed by `lanes` lives in scratch memory on the device)
 };
+static_assert(G == 4u, "Emit");
 PLAN_FN void emit_init(Emit& e, uint32_t in_len) {
     e.op = 0u; e.in_len = in_len; e.tail = 0u; e.lanes = 0u; e.bytes = 0u; e.start = 0u;
-    for (uint32_t g = 0; g < G; ++g) e.w[g] = NOP_REC;
+    e.w0 = e.w1 = e.w2 = e.w3 = NOP_REC;
+}
+PLAN_FN void emit_set(Emit& e, uint32_t lane, uint32_t r) {
+    e.w0 = lane == 0u ? r : e.w0; e.w1 = lane == 1u ? r : e.w1; e.w2 = lane == 2u ? r : e.w2; e.w3 = lane == 3u ? r : e.w3;
 }
 
 PLAN_FN uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
@@ -114,8 +118,8 @@ PLAN_FN uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 template <class Sink>
 PLAN_FN void close_step(Emit& e, Sink& sink) {
     if (e.lanes != 0u) {
-        sink.step(e.w[0], e.w[1], e.w[2], e.w[3]);
-        for (uint32_t g = 0; g < G; ++g) e.w[g] = NOP_REC;
+        sink.step(e.w0, e.w1, e.w2, e.w3);
+        e.w0 = e.w1 = e.w2 = e.w3 = NOP_REC;
         e.lanes = 0u; e.bytes = 0u;
     }
 }
@@ -130,7 +134,7 @@ PLAN_FN void put_piece(Emit& e, uint32_t kind, uint32_t m, uint32_t src, Sink& s
     for (uint32_t j = 0; j < need; ++j) {
         const uint32_t nj = min_u32(LANE_B, m - LANE_B * j);
         const uint32_t f = kind == K_NEAR ? ((src & MASK) + LANE_B * j) : src + LANE_B * j;
-        e.w[e.lanes + j] = rec(kind, nj, e.bytes + LANE_B * j, f);
+        emit_set(e, e.lanes + j, rec(kind, nj, e.bytes + LANE_B * j, f));
     }
     e.lanes += need; e.bytes += m; e.op += m;
 }
