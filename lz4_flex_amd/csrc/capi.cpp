@@ -14,6 +14,7 @@
 
 #include "../../include/lz4flex_amd.h"
 #include "lz4_device.h"
+#include "lz4_plan_common.h"
 
 using namespace lz4flex_dev;
 
@@ -129,7 +130,7 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
         hipError_t e = launch_plan(pa, s);
         if (e != hipSuccess) return e;
         ReplayArgs ra;
-        ra.in_base = a.in_base; ra.out_base = a.out_base; ra.plans = pa.plans; ra.words = pa.words; ra.n = a.n;
+        ra.in_base = a.in_base; ra.out_base = a.out_base; ra.plans = pa.plans; ra.words = pa.words; ra.n = a.n; ra.max_turns = (uint32_t)(slot / plan::TURN_WORDS) + 2u;
         e = launch_replay(ra, s);
         if (e != hipSuccess) return e;
         e = hipEventRecord(c->plan_done, s);

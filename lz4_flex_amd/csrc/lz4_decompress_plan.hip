@@ -42,14 +42,21 @@ constexpr uint32_t PB = 64u;             // bytes per part
 constexpr uint32_t NPART = PT / PB;      // 64: one per lane
 constexpr uint32_t PMARGIN = 128u;       // bytes behind the tile staged with it (a walk's last sequence reads past its part; beyond: global memory)
 constexpr uint32_t DCAP = 22u;           // descriptors per part: a sequence with a match is at least 3 bytes
-constexpr uint32_t PCAP = 8u;            // ... and of a second walk before it lands on the first one (else the part is walked afresh)
+constexpr uint32_t PCAP = 6u;            // ... and of a second walk before it lands on the first one (else the part is walked afresh)
 constexpr uint32_t PLAN_SLOT_WORDS = 14336u; // words of the plan array per block (56 KiB: 2 x a JSON block's plan; a block whose plan outgrows it is irregular)
 constexpr uint32_t MAX_TAIL_SLOT = 64u;  // tail records a block's slot has room for (a tail is the block's last < 16 compressed bytes' worth of pieces)
+// LDS.  Lane k reads part k of the tile, its descriptor lists, over and over: every per-lane area is laid out at an ODD dword stride
+// so that the 64 lanes hit 64 different banks (a tile stored flat puts lanes k and k + 4 on the same bank: 16-way conflicts on every
+// read; the first version spent most of its time there).  The tile: 4 bytes of padding behind every 64-byte part; the descriptor
+// lists: the two words of a descriptor in two arrays of (capacity + 1) dwords per lane.
+constexpr uint32_t TILE_PARTS = (PT + PMARGIN) / PB;
 constexpr uint32_t LDS_TILE = 0u;
-constexpr uint32_t LDS_DESC = PT + PMARGIN;
-constexpr uint32_t LDS_PRE = LDS_DESC + NPART * DCAP * 8u;
-constexpr uint32_t LDS_BYTES = LDS_PRE + NPART * PCAP * 8u;
-static_assert(NPART == 64u && LDS_DESC % 16u == 0u, "geometry");
+constexpr uint32_t TILE_LDS = TILE_PARTS * (PB + 4u);
+constexpr uint32_t MSTRIDE = DCAP + 1u, PSTRIDE = PCAP + 1u;          // dwords per lane
+constexpr uint32_t LDS_MA = TILE_LDS, LDS_MB = LDS_MA + NPART * MSTRIDE * 4u, LDS_PA = LDS_MB + NPART * MSTRIDE * 4u, LDS_PB = LDS_PA + NPART * PSTRIDE * 4u;
+constexpr uint32_t LDS_BYTES = LDS_PB + NPART * PSTRIDE * 4u;
+static_assert(NPART == 64u && MSTRIDE % 2u == 1u && PSTRIDE % 2u == 1u && (PT + PMARGIN) % PB == 0u, "geometry");
+__device__ __forceinline__ uint32_t tile_at(uint32_t r) { return r + 4u * (r / PB); }          // LDS offset of tile byte r
 
 // a sequence, 8 bytes: a = token position relative to the tile (13 bits) | literal length << 13 (16 bits); b = offset | match length << 16
 // (match length 0: the block's last sequence).  Literal and match lengths beyond 65 535 make a block irregular.
@@ -74,9 +81,18 @@ struct Reader {
     uint32_t t0;
     __device__ __forceinline__ uint32_t operator()(uint32_t pos) const {
         const uint32_t r = pos - t0;
-        return r < PT + PMARGIN ? (uint32_t)tile[r] : (uint32_t)g[pos];
+        return r < PT + PMARGIN ? (uint32_t)tile[tile_at(r)] : (uint32_t)g[pos];
     }
     __device__ __forceinline__ uint32_t u32(uint32_t pos) const { return (*this)(pos) | ((*this)(pos + 1u) << 8) | ((*this)(pos + 2u) << 16) | ((*this)(pos + 3u) << 24); }
+};
+
+// a lane's descriptor lists (main: a first walk's; pre: a second walk's, up to where it meets the first)
+struct Lists {
+    lds_u32* ma; lds_u32* mb; lds_u32* pa; lds_u32* pb;
+    __device__ __forceinline__ Desc main(uint32_t i) const { return Desc{ma[i], mb[i]}; }
+    __device__ __forceinline__ Desc pre(uint32_t i) const { return Desc{pa[i], pb[i]}; }
+    __device__ __forceinline__ void set_main(uint32_t i, const Desc& d) const { ma[i] = d.x; mb[i] = d.y; }
+    __device__ __forceinline__ void set_pre(uint32_t i, const Desc& d) const { pa[i] = d.x; pb[i] = d.y; }
 };
 
 struct CountSinkD {
@@ -89,13 +105,39 @@ struct StoreSinkD {
     uint32_t* tailw;         // the block's tail records
     uint32_t at;             // next step
     uint32_t n_tail;
+    // one 16-byte store per step, STEP-major; the block's layout (lz4_plan_common.h word_of: four steps x four lanes, lane-major)
+    // is made by transposing whole groups of four steps afterwards -- four scattered 4-byte stores per step were a memory
+    // transaction each, and half of the kernel's time
     __device__ __forceinline__ void step(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
-        uint32_t* p = words + 16u * (at / 4u) + at % 4u;      // lz4_plan_common.h word_of
-        p[0] = w0; p[4] = w1; p[8] = w2; p[12] = w3;
+        const u32x4 v = u32x4{w0, w1, w2, w3};
+#ifdef LZ4P_EXP_NOSTORE      // timing experiments only
+        asm volatile("" :: "v"(v), "v"(words + 4u * at));
+#else
+        __builtin_memcpy(words + 4u * at, &v, 16);
+#endif
         at++;
     }
     __device__ __forceinline__ void tail(uint32_t r) { tailw[n_tail++] = r; }
 };
+
+// groups [g0, g1) of four steps: step-major (as written) -> lane-major (as the replay kernel reads them), in place, a lane per group
+__device__ __forceinline__ void transpose_groups(uint32_t* words, uint32_t g0, uint32_t g1, uint32_t lane) {
+#ifdef LZ4P_EXP_NOTRANSPOSE  // timing experiments only
+    return;
+#endif
+    for (uint32_t g = g0 + lane; g < g1; g += 64u) {
+        u32x4 r0, r1, r2, r3;
+        uint32_t* p = words + 16u * g;
+        // (sc1: served by the L2.  The 128-byte line a group shares with its neighbour may sit in this CU's L1 from the neighbour's
+        // transposition a tile ago, without the steps stored since)
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(p) : "memory");
+        const u32x4 c0 = u32x4{r0.x, r1.x, r2.x, r3.x}, c1 = u32x4{r0.y, r1.y, r2.y, r3.y}, c2 = u32x4{r0.z, r1.z, r2.z, r3.z},
+                    c3 = u32x4{r0.w, r1.w, r2.w, r3.w};
+        __builtin_memcpy(p, &c0, 16); __builtin_memcpy(p + 4, &c1, 16); __builtin_memcpy(p + 8, &c2, 16); __builtin_memcpy(p + 12, &c3, 16);
+    }
+}
 
 struct PartState {
     uint32_t from;       // where the walk whose descriptors stand began (X_ERR: none yet)
@@ -112,8 +154,7 @@ struct PartState {
 // position is marked.  Else: to the prefix list, until a marked position is reached (the main list stands from there); a walk that
 // needs more than PCAP descriptors starts again as a FIRST walk.
 template <bool FIRST>
-__device__ __forceinline__ void walk_part(const Reader& rd, uint32_t ilen, uint32_t p, uint32_t part0, uint32_t part_end, Desc __attribute__((address_space(3)))* mainl,
-                                          Desc __attribute__((address_space(3)))* prel, PartState& s) {
+__device__ __forceinline__ void walk_part(const Reader& rd, uint32_t ilen, uint32_t p, uint32_t part0, uint32_t part_end, const Lists& L, PartState& s) {
     const uint32_t entry = p;
     uint32_t n = 0u;
     uint64_t marks = 0ull;
@@ -131,12 +172,43 @@ __device__ __forceinline__ void walk_part(const Reader& rd, uint32_t ilen, uint3
             if (n == PCAP) break;                                 // (no room: walk the part afresh, below)
         }
         pcd::Seq q;
-        const uint32_t nx = pcd::parse_seq(rd, ilen, p, q);
+        uint32_t nx;
+        // The plain sequence -- literal length in the token or one more byte, match length in the token or one more byte, literals and
+        // match bytes inside the staged window, 16 bytes of block left behind the token: everything parse_seq checks holds or is
+        // checked here -- costs two LDS round trips: the 8 bytes at the token, the 8 bytes behind the literals, each out of three
+        // aligned dwords.  Anything else goes through parse_seq -- rarely: a lane on that path holds up the other 63 (the first
+        // version took it for 8 % of the sequences, i.e. in every hop of every wavefront, with four lanes working on average).
+        {
+            const uint32_t r = p - rd.t0;
+            uint32_t ra = r & ~3u;
+            uint32_t d0 = *(const lds_u32*)(rd.tile + tile_at(ra)), d1 = *(const lds_u32*)(rd.tile + tile_at(ra + 4u)),
+                     d2 = *(const lds_u32*)(rd.tile + tile_at(ra + 8u));
+            uint32_t sh = r & 3u;
+            const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+            const uint32_t t = lo & 0xFFu, mn = t & 15u;
+            const uint32_t e1 = (lo >> 8) & 0xFFu;
+            const uint32_t lit = (t >> 4) < 15u ? (t >> 4) : 15u + e1;
+            const uint32_t lsrc = p + ((t >> 4) < 15u ? 1u : 2u);
+            const uint32_t r1 = lsrc + lit - rd.t0;                       // where the offset is
+            bool fast = !((t >> 4) == 15u && e1 == 255u) && r1 + 12u <= PT + PMARGIN && lsrc + lit + 16u <= ilen;
+            ra = fast ? (r1 & ~3u) : 0u;
+            d0 = *(const lds_u32*)(rd.tile + tile_at(ra)); d1 = *(const lds_u32*)(rd.tile + tile_at(ra + 4u));
+            sh = r1 & 3u;
+            const uint32_t w1 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+            const uint32_t off = w1 & 0xFFFFu, e2 = (w1 >> 16) & 0xFFu;
+            fast = fast && off != 0u && !(mn == 15u && e2 == 255u);
+            if (fast) {
+                q.lit_src = lsrc; q.lit = lit; q.off = off; q.ml = 4u + mn + (mn == 15u ? e2 : 0u);
+                nx = lsrc + lit + 2u + (mn == 15u ? 1u : 0u);
+            } else {
+                nx = pcd::parse_seq(rd, ilen, p, q);
+            }
+        }
         if (nx == pcd::X_ERR) { exit_ = X_ERR; break; }
         if (n == DCAP) { exit_ = X_ERR; break; }                  // (cannot happen: a sequence with a match is at least 3 bytes)
         if (q.lit > 0xFFFFu || q.ml > 0xFFFFu) s.big = 1u;
         const Desc d = Desc{(p - rd.t0) | (q.lit << 13), q.off | (q.ml << 16)};
-        if (FIRST) mainl[n] = d; else prel[n] = d;
+        if (FIRST) L.set_main(n, d); else L.set_pre(n, d);
         marks |= 1ull << (p - part0);
         n++;
         if (nx == pcd::X_END) { exit_ = X_END; break; }
@@ -159,12 +231,10 @@ __device__ __forceinline__ uint32_t lit_src_of(uint32_t tok, uint32_t lit) { ret
 
 // the emitter over a part's true sequences.  off <= position is the reference's check :398-402.
 template <class Sink>
-__device__ __forceinline__ void emit_part(const PartState& s, const Desc __attribute__((address_space(3)))* mainl, const Desc __attribute__((address_space(3)))* prel,
-                                          uint32_t t0, Emit& e, Sink& sink, uint32_t& bad) {
+__device__ __forceinline__ void emit_part(const PartState& s, const Lists& L, uint32_t t0, Emit& e, Sink& sink, uint32_t& bad) {
     const uint32_t total = s.np + (s.cnt - s.h);
     for (uint32_t i = 0u; i < total; ++i) {
-        Desc d;
-        if (i < s.np) d = prel[i]; else d = mainl[s.h + (i - s.np)];
+        const Desc d = i < s.np ? L.pre(i) : L.main(s.h + (i - s.np));
         const uint32_t tok = t0 + (d.x & 0x1FFFu), lit = d.x >> 13, off = d.y & 0xFFFFu, ml = d.y >> 16;
         emit_literals(e, lit_src_of(tok, lit), lit, sink);
         if (ml != 0u) {
@@ -180,8 +250,9 @@ __global__ void __launch_bounds__(64) lz4_plan_kernel(PlanArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t plan_lds[];
     lds_u8* lds = (lds_u8*)plan_lds;
     const uint32_t lane = threadIdx.x;
-    Desc __attribute__((address_space(3)))* mainl = (Desc __attribute__((address_space(3)))*)(lds + LDS_DESC) + lane * DCAP;
-    Desc __attribute__((address_space(3)))* prel = (Desc __attribute__((address_space(3)))*)(lds + LDS_PRE) + lane * PCAP;
+    Lists L;
+    L.ma = (lds_u32*)(lds + LDS_MA) + lane * MSTRIDE; L.mb = (lds_u32*)(lds + LDS_MB) + lane * MSTRIDE;
+    L.pa = (lds_u32*)(lds + LDS_PA) + lane * PSTRIDE; L.pb = (lds_u32*)(lds + LDS_PB) + lane * PSTRIDE;
     for (uint32_t b = blockIdx.x; b < a.n; b += gridDim.x) {
         const uint8_t* gin = a.in_base + a.in_off[b];
         const uint32_t ilen = a.in_len[b];
@@ -193,6 +264,7 @@ __global__ void __launch_bounds__(64) lz4_plan_kernel(PlanArgs a) {
         uint32_t entry = 0u;         // the next tile's first true token position
         uint32_t OP = 0u;            // decoded bytes in front of it
         uint32_t steps = 0u;         // steps written
+        uint32_t gdone = 0u;         // groups of four steps already in their final layout
         uint32_t n_tail = 0u;
         bool ended = false;
         while (!bad && !ended) {
@@ -207,7 +279,7 @@ __global__ void __launch_bounds__(64) lz4_plan_kernel(PlanArgs a) {
                     for (uint32_t k = 0u; k < 16u; ++k) if (t0 + o + k < ilen) w[k / 4u] |= (uint32_t)gin[t0 + o + k] << (8u * (k % 4u));
                     v = u32x4{w[0], w[1], w[2], w[3]};
                 }
-                *reinterpret_cast<u32x4 __attribute__((address_space(3)))*>(lds + LDS_TILE + o) = v;
+                __builtin_memcpy((void*)(lds + LDS_TILE + tile_at(o)), &v, 16);      // (16 bytes never straddle a part)
             }
             __builtin_amdgcn_s_barrier();
             Reader rd;
@@ -220,27 +292,52 @@ __global__ void __launch_bounds__(64) lz4_plan_kernel(PlanArgs a) {
             s.from = X_ERR; s.exit = X_ERR; s.main_exit = X_ERR; s.cnt = 0u; s.h = 0u; s.np = 0u; s.marks = 0ull; s.big = 0u;
             // ---- 1. first walks: the entry's lane from the tile's entry, the lanes behind it from their part's first byte
             const uint32_t entry_lane = (entry - t0) / PB;
-            if (has_part && lane >= entry_lane) walk_part<true>(rd, ilen, lane == entry_lane ? entry : part0, part0, part_end, mainl, prel, s);
-            // ---- 2. / 3. follow the exits from the entry (a part whose walk began elsewhere is taken to leave where that walk left: true
-            // once the chains have met); lanes whose walk began elsewhere walk again; until a whole pass finds nothing to do
+            if (has_part && lane >= entry_lane) walk_part<true>(rd, ilen, lane == entry_lane ? entry : part0, part0, part_end, L, s);
+#if defined(LZ4P_EXP_STOP) && LZ4P_EXP_STOP == 1      // timing experiments only: the phases of a tile, cut off one by one
+            if (s.exit == X_END) ended = true;
+            entry = (uint32_t)__builtin_amdgcn_readlane((int)s.exit, 63);
+            if (entry == X_ERR || entry == X_END || t0 + PT >= ilen) ended = true; else entry = t0 + PT;
+            continue;
+#endif
+            // ---- 2. / 3. which parts does the true chain visit, and where does it enter them?  Every part points at the part its
+            // exit lies in (a part whose walk began elsewhere is taken to leave where that walk left: true once the chains have met);
+            // the parts reachable from the entry's are found by pointer jumping (six rounds of ds_bpermute instead of a scalar walk
+            // over up to 64 lanes), each takes the exit of the path part before it as its entry.  Lanes whose walk began elsewhere walk again; until
+            // a whole pass finds nothing to do.
             uint32_t my_entry = X_ERR;       // this part's true entry (X_ERR: no sequence of the true chain begins here)
             uint32_t tile_exit = X_ERR;
             for (uint32_t round = 0u; round < NPART + 2u; ++round) {
-                my_entry = X_ERR;
-                uint32_t pos = entry;
-                tile_exit = X_ERR;
-                for (uint32_t hop = 0u; hop <= NPART; ++hop) {              // (uniform: pos is the same in every lane)
-                    if (pos == X_END || pos == X_ERR || pos >= t0 + PT) { tile_exit = pos; break; }
-                    const uint32_t j = (pos - t0) / PB;
-                    if (lane == j) my_entry = pos;
-                    pos = (uint32_t)__builtin_amdgcn_readlane((int)s.exit, (int)j);
+                const bool inside = s.exit != X_END && s.exit != X_ERR && s.exit < t0 + PT;
+                const uint32_t nxt = inside ? (s.exit - t0) / PB : 64u;               // 64: the chain leaves the tile (or ends, or fails) here
+                // reach = the parts on the path from this one (itself included), jump = 2^i steps ahead
+                uint64_t reach = 1ull << lane;
+                uint32_t jump = nxt;
+#pragma unroll
+                for (uint32_t i = 0u; i < 6u; ++i) {
+                    const uint32_t src = (jump < 64u ? jump : lane) * 4u;
+                    const uint32_t rlo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)(uint32_t)reach);
+                    const uint32_t rhi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)(uint32_t)(reach >> 32));
+                    const uint32_t j2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)jump);
+                    if (jump < 64u) { reach |= ((uint64_t)rhi << 32) | rlo; jump = j2; }
                 }
+                const uint64_t path = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(reach >> 32), (int)entry_lane) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)reach, (int)entry_lane);
+                const bool on_path = ((path >> lane) & 1ull) != 0ull;
+                // a part on the path is entered where the path part before it leaves (the chain only moves forward: the path part before
+                // it is its predecessor)
+                const uint64_t before = path & ((1ull << lane) - 1ull);
+                const uint32_t pred = before != 0ull ? 63u - (uint32_t)__builtin_clzll(before) : lane;
+                const uint32_t pulled = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pred * 4u), (int)s.exit);
+                my_entry = lane == entry_lane ? entry : (on_path && before != 0ull ? pulled : X_ERR);
+                // the last part on the path says where the chain leaves the tile
+                const uint32_t last = 63u - (uint32_t)__builtin_clzll(path);
+                tile_exit = (uint32_t)__builtin_amdgcn_readlane((int)s.exit, (int)last);
                 const bool need = my_entry != X_ERR && s.from != my_entry;
                 if (!__any(need)) break;
                 if (need) {
-                    if (s.from != X_ERR && s.cnt != 0u) walk_part<false>(rd, ilen, my_entry, part0, part_end, mainl, prel, s);
+                    if (s.from != X_ERR && s.cnt != 0u) walk_part<false>(rd, ilen, my_entry, part0, part_end, L, s);
                     else s.from = X_ERR;
-                    if (s.from == X_ERR) walk_part<true>(rd, ilen, my_entry, part0, part_end, mainl, prel, s);
+                    if (s.from == X_ERR) walk_part<true>(rd, ilen, my_entry, part0, part_end, L, s);
                 }
                 tile_exit = X_ERR;                                           // (not final: the next pass says)
             }
@@ -248,13 +345,16 @@ __global__ void __launch_bounds__(64) lz4_plan_kernel(PlanArgs a) {
             if (tile_exit == X_ERR) { bad = 2u; break; }
             const bool live = my_entry != X_ERR;
             if (__any(live && s.big != 0u)) { bad = 3u; break; }
+#if defined(LZ4P_EXP_STOP) && LZ4P_EXP_STOP == 2
+            if (tile_exit == X_END) ended = true; else entry = tile_exit;
+            continue;
+#endif
             // ---- 4. output positions, step counts, steps
             uint32_t U = 0u;
             if (live) {
                 const uint32_t total = s.np + (s.cnt - s.h);
                 for (uint32_t i = 0u; i < total; ++i) {
-                    Desc d;
-                    if (i < s.np) d = prel[i]; else d = mainl[s.h + (i - s.np)];
+                    const Desc d = i < s.np ? L.pre(i) : L.main(s.h + (i - s.np));
                     U += (d.x >> 13) + (d.y >> 16);
                 }
             }
@@ -270,7 +370,7 @@ __global__ void __launch_bounds__(64) lz4_plan_kernel(PlanArgs a) {
             uint32_t tail_in = n_tail != 0u ? 1u : 0u;
             if (live) {
                 emit_init(e, ilen); e.op = my_op; e.tail = tail_in;
-                emit_part(s, mainl, prel, t0, e, cs, lane_bad);
+                emit_part(s, L, t0, e, cs, lane_bad);
             }
             if (tail_in == 0u) {
                 const uint64_t tm = __builtin_amdgcn_ballot_w64(live && cs.n_tail != 0u);
@@ -280,11 +380,16 @@ __global__ void __launch_bounds__(64) lz4_plan_kernel(PlanArgs a) {
                         tail_in = 1u;
                         cs.n_steps = 0u; cs.n_tail = 0u;
                         emit_init(e, ilen); e.op = my_op; e.tail = 1u;
-                        emit_part(s, mainl, prel, t0, e, cs, lane_bad);
+                        emit_part(s, L, t0, e, cs, lane_bad);
                     }
                 }
             }
             if (__any(lane_bad != 0u)) { bad = 5u; break; }
+#if defined(LZ4P_EXP_STOP) && LZ4P_EXP_STOP == 3
+            steps += cs.n_steps & 1u;
+            if (tile_exit == X_END) ended = true; else entry = tile_exit;
+            continue;
+#endif
             const uint32_t sincl = wave_incl_add(cs.n_steps);
             const uint32_t tile_steps = (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
             const uint32_t tincl = wave_incl_add(cs.n_tail);
@@ -294,20 +399,27 @@ __global__ void __launch_bounds__(64) lz4_plan_kernel(PlanArgs a) {
             if (live) {
                 StoreSinkD ss; ss.words = words; ss.tailw = tailw; ss.at = steps + sincl - cs.n_steps; ss.n_tail = n_tail + tincl - cs.n_tail;
                 emit_init(e, ilen); e.op = my_op; e.tail = tail_in;
-                emit_part(s, mainl, prel, t0, e, ss, lane_bad);
+                emit_part(s, L, t0, e, ss, lane_bad);
             }
             steps += tile_steps;
             n_tail += tile_tail;
             OP += tileU;
+            // the groups of four steps that are complete now get their final layout (the lanes' stores first: other lanes read them)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            transpose_groups(words, gdone, steps / 4u, lane);
+            gdone = steps / 4u;
             if (tile_exit == X_END) ended = true; else entry = tile_exit;
         }
         // ---- the block's end: K_END up to whole turns + END_TURNS, header, verdict
         const uint32_t turns = (steps + 1u + TURN_STEPS - 1u) / TURN_STEPS + END_TURNS;
         if (!bad) {
-            for (uint32_t st = steps * G + lane; st < turns * TURN_STEPS * G; st += 64u) {
-                const uint32_t step = st / G, g = st % G;
-                words[16u * (step / 4u) + 4u * g + step % 4u] = END_REC;
-            }
+            // K_END: every word of these steps is the same, the layout does not matter; the group the last real step shares with them does
+            const u32x4 endv = u32x4{END_REC, END_REC, END_REC, END_REC};
+            for (uint32_t st = steps + lane; st < turns * TURN_STEPS; st += 64u) __builtin_memcpy(words + 4u * st, &endv, 16);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            transpose_groups(words, gdone, (steps + 3u) / 4u, lane);
         }
         if (lane == 0u) {
             // the bytes the steps move: everything but the tail's

@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(256) lz4_replay_kernel(ReplayArgs a) {
 #endif
     LZ4R_TURN(LZ4R_FRONT)                                // prologue: request the bytes of the first turn's records; w: the second turn's
     done = (sl[LOOKAHEAD - 1u].r & KIND_MASK) == KIND_MASK;
-    for (;;) {
+    for (uint32_t turn = 0u; turn < a.max_turns; ++turn) {   // (bounded: a damaged plan costs time, not the GPU)
         LZ4R_IDLE()
         lp += done ? 0u : TURN_WORDS;                    // (a block that is about to finish stays inside its K_END turns)
         LZ4R_TURN(LZ4R_STEP)
@@ -300,5 +300,6 @@ extern "C" int lz4flex_debug_replay(const void* in_base, void* out_base, const v
     a.plans = (const lz4flex_dev::plan::BlockPlan*)plans;
     a.words = (const uint32_t*)words;
     a.n = n;
+    a.max_turns = 1u << 16;
     return (int)lz4flex_dev::launch_replay(a, (hipStream_t)stream);
 }

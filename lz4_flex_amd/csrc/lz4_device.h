@@ -73,6 +73,7 @@ struct ReplayArgs {
     const plan::BlockPlan* plans;   // n per-block headers
     const uint32_t* words;          // the plan array
     uint32_t n;
+    uint32_t max_turns;             // no block's plan is longer than this many turns (a plan without its K_END must not hang the kernel)
 };
 hipError_t launch_replay(const ReplayArgs& a, hipStream_t s);
 struct PlanArgs {
