@@ -80,7 +80,9 @@ struct Copier {
 #ifdef LZ4FLEX_PROFILE_PHASES
     uint32_t pr_piece, pr_idle, pr_blocked;
 #endif
-    enum : uint32_t { K_NONE = 0, K_MAINT = 1, K_RARE = R_RARE, K_CAREFUL = R_CAREFUL, K_FINISH = R_FINISH };
+    enum : uint32_t { K_NONE = 0, K_MAINT = 1, K_RARE = R_RARE, K_CAREFUL = R_CAREFUL, K_FINISH = R_FINISH, K_LONG = 8 };
+    static constexpr uint32_t LONG_LIT = 1024u, LONG_KEEP = 256u;     // literal runs from LONG_LIT bytes on: all but the last LONG_KEEP (+ < 64) bytes go memory to memory
+    static_assert(OUT_H + 16u + 64u <= LONG_LIT - LONG_KEEP - 64u, "the window is rebuilt from the run itself");
     struct Slot { uint32_t n, dst, msrc, glob; word_t v; };
     static __device__ __forceinline__ word_t ldw(const uint8_t* p) { word_t v; __builtin_memcpy(&v, p, WB); return v; }
 
@@ -114,6 +116,32 @@ struct Copier {
         }
         for (uint32_t p = fnew + g; p < op; p += G) gout[p] = lout[p - L0];
         F = op;
+    }
+    // A long literal run (incompressible data: a 64 KiB block is ONE run; round 3: 3.2 ms per GiB through 64-byte pieces and the LDS
+    // buffer) goes memory to memory, 16 bytes per lane and 4 loads in flight, up to LONG_KEEP bytes before its end; the rest -- the end
+    // of the block may be there -- goes the usual way.  The LDS buffer is written back first and rebuilt behind the bulk from the
+    // run's own bytes (512 bytes of history + the granule that is not complete), with the invariants flush_slide() leaves.
+    __device__ void bulk_literals() {
+        final_flush();
+        const uint32_t n = (lit_rem - LONG_KEEP) & ~63u;
+        const uint8_t* src = gin + lit_src;
+        uint8_t* dst = gout + op;
+        uint32_t i = 16u * g;
+        for (; i + 192u < n; i += 256u) {
+            u32x4 v0, v1, v2, v3;
+            __builtin_memcpy(&v0, src + i, 16); __builtin_memcpy(&v1, src + i + 64u, 16); __builtin_memcpy(&v2, src + i + 128u, 16); __builtin_memcpy(&v3, src + i + 192u, 16);
+            __builtin_memcpy(dst + i, &v0, 16); __builtin_memcpy(dst + i + 64u, &v1, 16); __builtin_memcpy(dst + i + 128u, &v2, 16); __builtin_memcpy(dst + i + 192u, &v3, 16);
+        }
+        for (; i < n; i += 64u) { u32x4 v; __builtin_memcpy(&v, src + i, 16); __builtin_memcpy(dst + i, &v, 16); }
+        op += n; lit_src += n; lit_rem -= n;
+        F = op & ~15u;
+        L0 = F > OUT_H ? F - OUT_H : 0u;
+        const uint32_t have = op - L0;                              // <= OUT_H + 15 <= n: every byte of it is a byte of this run
+        const uint8_t* h = gin + lit_src - have;
+        for (uint32_t k = 16u * g; k < have; k += 16u * G) {        // (the last granule reads a few of the run's remaining bytes: there are LONG_KEEP of them)
+            u32x4 v; __builtin_memcpy(&v, h + k, 16);
+            *reinterpret_cast<u32x4 __attribute__((address_space(3)))*>(lout + k) = v;
+        }
     }
     // literals with exact source bounds (the block's last literals end at its last byte)
     __device__ void generic_literals(uint32_t s, uint32_t n) {
@@ -195,7 +223,8 @@ struct Copier {
         lit_rem = pop ? e.y : lit_rem;
         ml_rem = pop ? e.z : ml_rem;
         moff = pop ? (e.w & 0xFFFFu) : moff;
-        const uint32_t kind = pop ? e.w >> 16 : 0u;      // R_RARE / R_CAREFUL / R_FINISH == K_*: generic code in service()
+        uint32_t kind = pop ? e.w >> 16 : 0u;            // R_RARE / R_CAREFUL / R_FINISH == K_*: generic code in service()
+        kind = (pop && kind == 0u && e.y >= LONG_LIT) ? (uint32_t)K_LONG : kind;      // a long literal run: service() moves its bulk memory to memory
         blocked |= kind;
         head = pop ? head + 1u : head;
         e = q.get(head);                                  // next record (complete iff head != snap); its latency overlaps this step
@@ -252,6 +281,7 @@ struct Copier {
     __device__ __forceinline__ void service() {
         if (done) return;
         if (out_space() < FLUSH_AT) flush_slide();
+        if (lit_rem >= LONG_LIT && (blocked == K_LONG || blocked == K_CAREFUL || blocked == K_FINISH)) bulk_literals();
         if (blocked == K_RARE) {   // a periodic match; the record's literals (if any) go first
             generic_literals(lit_src, lit_rem);
             lit_rem = 0u;

@@ -163,6 +163,53 @@ def test_synthetic_copy_chain_blocks_all_decoders(blk, lanes):
         assert out[o + k:o + k + 64].tobytes() == b"\xA5" * 64, "block %d wrote behind its sink" % i
 
 
+@pytest.mark.parametrize("lanes", DECODERS)
+def test_long_literal_runs_all_decoders(blk, lanes):
+    """literal runs around the length from which the split decoder moves them memory to memory (lz4_decompress_split.hip,
+    LONG_LIT = 1024, in 64-byte steps up to 256 bytes before the run's end) -- in the middle of a block, as its first bytes,
+    as its last literals -- each followed by matches that aim into the run: at its last bytes (the rebuilt LDS window), a
+    little more than 512 bytes back (the first bytes memory holds alone) and at its first byte; plus the same blocks cut
+    short and with a sink a few bytes short: every decoder kernel == the oracle"""
+    from lz4_flex_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    text = O.fixture_plain("compression_65k")
+    cases = []
+    for L in (960, 1023, 1024, 1025, 1087, 1088, 1089, 1279, 1280, 1343, 2048, 5000, 40000, 65000):
+        noise = rng.integers(0, 256, L, dtype=np.uint8).tobytes()
+        tail = noise[-100:] + text[:40] + noise[-700:-560] + text[40:60] + noise[:90] + text[100:400]
+        for plain in (text[:3000] + noise + tail, noise + tail, text[:500] + noise + tail + noise[: L // 2] + bytes(rng.integers(0, 256, L, dtype=np.uint8)),
+                      text[:777] + noise):
+            plain = plain[:65536 * 2]
+            comp = O.compress(plain)
+            cases.append((comp, len(plain)))
+            cases.append((comp[:len(comp) - 300], len(plain)))
+            cases.append((comp, len(plain) - 3))
+    want = [O.decompress(c, k) for c, k in cases]
+    inb = np.frombuffer(b"".join(c for c, _ in cases) + bytes(64), dtype=np.uint8)
+    in_off = np.cumsum([0] + [len(c) for c, _ in cases[:-1]])
+    out_off = np.cumsum([0] + [k + 64 for _, k in cases[:-1]])
+    caps = [k for _, k in cases]
+    out = np.full(int(out_off[-1]) + caps[-1] + 64, 0xA5, dtype=np.uint8)
+    ctx = C.c_void_p()
+    assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
+    _select_decoder(lib, ctx, lanes)
+    try:
+        ol, st, det = blk.decompress_batch(inb, list(in_off), [len(c) for c, _ in cases], out, list(out_off), caps, ctx=ctx)
+    finally:
+        lib.lz4flex_ctx_destroy(ctx)
+    for i, ((c, k), w) in enumerate(zip(cases, want)):
+        o = int(out_off[i])
+        if w[0] == "ok":
+            assert st[i] == 0 and ol[i] == len(w[1]) and out[o:o + len(w[1])].tobytes() == w[1], (i, len(c), k, int(st[i]), int(ol[i]))
+        else:
+            assert O.ERR_NAMES.get(int(st[i])) == w[0], (i, len(c), k, int(st[i]), w[0])
+            if w[0] == "OutputTooSmall":
+                assert (int(det[i][0]), int(det[i][1])) == tuple(w[1]), (i, det[i], w[1])
+        assert out[o + k:o + k + 64].tobytes() == b"\xA5" * 64, "block %d wrote behind its sink" % i
+
+
 # ---------------------------------------------------------------- fixtures
 @pytest.mark.parametrize("stem", corpus.FIXTURES)
 def test_fixture_decode_bit_exact(blk, stem):

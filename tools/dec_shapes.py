@@ -44,6 +44,11 @@ def main():
             src = workloads.json_tiles(O.fixture_plain("compression_65k"), n * B, device=dev)
         elif data == "log":
             src = workloads.log_stream(0, n * B, device=dev)
+        elif data == "mixed":          # 8 KiB of JSON, 8 KiB of noise, ...: long literal runs between matches
+            src = workloads.json_tiles(O.fixture_plain("compression_66k_JSON"), n * B, device=dev)
+            noise = torch.randint(0, 256, (n * B,), dtype=torch.uint8, device=dev)
+            sel = ((torch.arange(n * B, device=dev) >> 13) & 1).bool()
+            src = torch.where(sel, noise, src)
         elif data == "zeros":
             src = torch.zeros(n * B, dtype=torch.uint8, device=dev)
         else:
