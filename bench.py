@@ -406,8 +406,9 @@ def run_sharded_frame(args, env):
 def run_linked_frame(args, env):
     torch, dev, world, rank, block = (env[k] for k in ("torch", "dev", "world", "rank", "block"))
     from lz4_flex_amd import frame as F, workloads
-    # fast (default): the Linked frame holds independently parsed blocks, one compress launch per batch; exact: the
-    # reference's bytes, one dependency chain on the device.  Decoding: one chained launch per batch of blocks either way.
+    # fast (default): every block's matches reach into the 32 KiB of the stream in front of it (LZ4FLEX_BLOCK_HISTORY: the history is
+    # input, so the blocks still encode in one launch); exact: the reference's bytes, one dependency chain on the device.
+    # Decoding: one chained launch per batch of blocks either way -- the frame carries dependencies either way.
     block.set_compress_mode(args.compress_mode)
     exact = args.compress_mode == "exact"
     n = args.blocks or 64
@@ -433,10 +434,10 @@ def run_linked_frame(args, env):
         oracle_checked = "frame (%d bytes) decoded by the oracle's FrameDecoder == the data" % len(state["frame"])
     total = len(data) * world
     alg = len(data) + len(state["frame"])
-    # BASELINE calls this configuration a sequential-dependency stress.  In compress_mode fast the frame's blocks are parsed on their
-    # own (a valid Linked frame in which no block refers to another): the timed figure above is NOT a dependency-carrying frame.  So
-    # the same data also goes through the reference-exact chain encoder (lz4_flex's bytes: every block refers to its predecessors) and
-    # back, outside the timed loop, and that round trip is reported next to it -- it is what "BlockLinked" costs on this design.
+    # BASELINE calls this configuration a sequential-dependency stress.  Since round 4 the timed frame IS dependency-carrying in
+    # compress_mode fast too (every block but the first refers to its predecessor's bytes; round 3's blocks were parsed on their
+    # own).  The same data also goes through the reference-exact chain encoder (lz4_flex's bytes) and back, outside the timed loop:
+    # that is what the reference's own byte stream costs on this design.
     dep = None
     if rank == 0 and not exact and not args.no_verify:
         try:
@@ -445,7 +446,7 @@ def run_linked_frame(args, env):
             back_x = F.decompress_frame(fr_x, len(data))[0]; torch.cuda.synchronize(); t2 = time.perf_counter()
             assert back_x == data
             rc_o, fr_o = O.frame_compress(data, block_mode=1, block_size=4)
-            dep = {"what": "the same data through the reference-exact chain encoder (blocks that DO refer to their predecessors) and the chained decoder, one pass, untimed warm caches",
+            dep = {"what": "the same data through the reference-exact chain encoder (lz4_flex's own bytes) and the chained decoder, one pass, untimed warm caches",
                    "compress_ms": round((t1 - t0) * 1e3, 2), "decompress_ms": round((t2 - t1) * 1e3, 2),
                    "round_trip_MiB_per_s": round(len(data) / 1048576 / (t2 - t0), 2), "ratio": round(len(fr_x) / len(data), 5),
                    "frame_equals_oracle_FrameEncoder": bool(rc_o == 0 and fr_o == fr_x)}
@@ -469,7 +470,8 @@ def run_linked_frame(args, env):
                                "decoded by ONE chained launch (lz4_decompress_pcd_kernel: every block's token chain at once; a block waits for its "
                                "predecessors only where a match reaches behind its start)" +
                                ("; compress_mode exact: the chain encoder does too (the reference's bytes)" if exact else
-                                "; compress_mode fast: the encoder parses every block on its own (one launch, a valid Linked frame, the Independent frame's ratio)") +
+                                "; compress_mode fast: one encoder launch, every block's matches reach up to 64 KiB back into the blocks before it "
+                                "(32 KiB of history in front of each block, windows advancing by 32 KiB): a dependency-carrying frame, ratio below the reference's") +
                                "; host buffers (PCIe included)",
                    "blocks": n, "compress_mode": args.compress_mode},
         "ratio": round(len(state["frame"]) / len(data), 5),

@@ -160,6 +160,14 @@ int64_t lz4flex_decompress_size_prepended_with_dict(const uint8_t *in, size_t in
 /* bits 1|0: block k>0 of an Independent frame: same table, every entry unreachable, position 0
  * is probed (src/frame/compress.rs:357-367, src/block/compress.rs:353-359,422-429) */
 #define LZ4FLEX_BLOCK_FRAME_CONTINUATION 3u
+/* bits 8..31, any compress_mode's flag word: h bytes of the SAME STREAM lie in front of the block, readable at
+ * in_base[in_off[i] - h .. in_off[i]) -- block k > 0 of a Linked frame (src/frame/compress.rs:280-299,327-356: the reference
+ * keeps the previous 64 KiB of input as the next block's dictionary).  The throughput encoder then lets the block's matches
+ * reach into them: with h >= 32 768 every position sees between 32 and 64 KiB of the stream behind it (a smaller h is not
+ * used), all blocks of the batch still encode side by side, and the block can only be decoded behind those bytes (a Linked
+ * frame, LZ4FLEX_MEM_CHAINED, or lz4flex_decompress_batch_ex with them as out_pos prefix / dictionary).  compress_mode exact
+ * ignores the bits: the reference's bytes for dependent blocks come from lz4flex_compress_chains. */
+#define LZ4FLEX_BLOCK_HISTORY(h) ((uint32_t)(h) << 8)
 
 /* Compress n independent blocks.  Block i reads in_base[in_off[i] .. +in_len[i]] and writes at
  * out_base[out_off[i] ..], capacity out_cap[i] (must be >= get_maximum_output_size(in_len[i]),

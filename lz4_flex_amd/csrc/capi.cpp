@@ -563,7 +563,15 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
     (void)hipGetDevice(&prev);
     HIP_TRY(hipSetDevice(c->device));
     struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
-    if (n <= SMALL_BATCH_BLOCKS && !ext && !chained) {
+    // LZ4FLEX_BLOCK_HISTORY: the bytes in front of a block travel with it
+    uint64_t hist_lo = ~0ull;
+    if (compress && flags)
+        for (uint32_t i = 0; i < n; i++) {
+            const uint64_t h = flags[i] >> 8;
+            if (h > in_off[i]) return -LZ4FLEX_E_INVALID_ARG;
+            if (h) hist_lo = std::min<uint64_t>(hist_lo, in_off[i] - h);
+        }
+    if (n <= SMALL_BATCH_BLOCKS && !ext && !chained && hist_lo == ~0ull) {
         size_t bytes = 0;
         for (uint32_t i = 0; i < n; i++) bytes += (size_t)in_len[i] + out_cap[i];
         if (bytes <= SMALL_BATCH_BYTES) return run_host_small(c, compress, in_base, in_off, in_len, flags, n, out_base, out_off, out_cap, out_len, status, detail);
@@ -571,6 +579,7 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
 
     HostBatch hb;
     hb.in_span = span_of(in_off, in_len, n);
+    if (hist_lo < hb.in_span.lo) hb.in_span.lo = hist_lo;
     hb.out_span = span_of(out_off, out_cap, n);
     const bool has_dict = ext && ext->dict_base && ext->dict_off && ext->dict_len;
     const bool has_pos = ext && ext->out_pos;

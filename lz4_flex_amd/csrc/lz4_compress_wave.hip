@@ -68,6 +68,19 @@ __host__ __device__ constexpr uint32_t seg_longest() {
     return m;
 }
 constexpr uint32_t SEG = seg_longest();   // longest segment
+constexpr uint32_t HIST = WINDOW / 2u;      // history in front of a block (see Item)
+// Start of segment j (0 .. WORKERS) of a window whose first `skip` positions are history.  Without history in front of the block
+// the segments are the fixed ones, clipped (only an anchored last window has skip != 0); with it (skip >= HIST in every window)
+// the eight segments share the parsed part in the same proportions -- clipped, half of the workers would have nothing to do.
+// Starts other than `skip` itself are multiples of 512.
+__device__ __forceinline__ uint32_t seg_start(uint32_t j, uint32_t skip, bool hmode) {
+    if (!hmode) return seg_lo(j) > skip ? seg_lo(j) : skip;
+    if (j == 0u) return skip;
+    if (j >= WORKERS) return WINDOW;
+    const uint32_t v = (skip + (WINDOW - skip) * (seg_lo(j) / 512u) / 128u) & ~511u;
+    return v > skip ? v : skip;
+}
+
 constexpr uint32_t CAP = 1024u;           // longest match a head counts
 constexpr uint32_t SKIPD = 64u;           // a position buried this deep in a running match is not evaluated
 constexpr uint32_t CARRY_SLOTS = 16u;        // per block: a ring of {out_pos, pend, window} records, one cache line each
@@ -925,7 +938,7 @@ __device__ __forceinline__ void put_len_header(g_u8* dst, uint32_t lit, uint32_t
 
 // Place segment w of the current window (after the barrier: every worker's SegMeta is final).
 __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8_t* __restrict__ gin_, uint32_t blk_len_, uint32_t win_idx_, bool last_win_,
-                              uint32_t wl_, uint32_t wbase_, uint32_t wskip_, const uint8_t* body_, uint8_t* gout_, uint32_t carry_slot_, uint32_t w_, uint32_t lane,
+                              uint32_t wl_, uint32_t wbase_, uint32_t wskip_, bool hmode_, const uint8_t* body_, uint8_t* gout_, uint32_t carry_slot_, uint32_t w_, uint32_t lane,
                               uint32_t* out_len_, int32_t* status_, uint32_t* gcarry_, uint32_t iter_, uint32_t spins_max_) {
     const g_u8* __restrict__ gin = uni_gptr<const g_u8>(gin_);
     const g_u8* body = uni_gptr<const g_u8>(body_);
@@ -935,7 +948,7 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
     const uint32_t blk_len = uni(blk_len_), win_idx = uni(win_idx_), wl = uni(wl_), carry_slot = uni(carry_slot_), w = uni(w_);
     const uint32_t wbase = uni(wbase_), wskip = uni(wskip_);       // the window's first byte in the block; its first wskip positions are history
     const uint32_t spins_max = uni(spins_max_);                    // CARRY_SPINS (tests: 1 -- a window gives up at once)
-    const bool last_win = uni((uint32_t)last_win_) != 0u;
+    const bool last_win = uni((uint32_t)last_win_) != 0u, hmode = uni((uint32_t)hmode_) != 0u;
     const lds_u32* mp = (const lds_u32*)(lds + L_META);
     lds_u32* cp = (lds_u32*)(lds + L_META) + 5u * WORKERS;          // BlkCarry[2]
     // Where this window's output starts and how many literals the block has pending: from the previous window, which this
@@ -978,7 +991,7 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
         }
     }
     auto seg_at = [&](uint32_t j) -> uint32_t {                     // start of segment j, clipped to the parsed part of the window
-        const uint32_t v = seg_lo(j) > wskip ? seg_lo(j) : wskip;
+        const uint32_t v = seg_start(j, wskip, hmode);
         return v < wl ? v : wl;
     };
     auto seg_len = [&](uint32_t j) -> uint32_t { return seg_at(j + 1u) - seg_at(j); };
@@ -1071,20 +1084,42 @@ __device__ __attribute__((noinline)) void load_window(const uint8_t* __restrict_
     if (tid < 64u) lds[L_WIN + wl + tid] = wl + tid < rd_n ? g[wl + tid] : (uint8_t)0;
 }
 
+// History (a Linked frame's blocks, src/frame/compress.rs:280-299,327-356: the reference keeps the previous 64 KiB of the stream as
+// the next block's dictionary): a block whose flags promise >= HIST readable bytes of the stream in front of it
+// (LZ4FLEX_BLOCK_HISTORY, include/lz4flex_amd.h) is encoded as the item [block - HIST, block + len): `len` and `in_off` below are
+// the ITEM's, its first `hist` positions are history only (indexed and loaded, never parsed or emitted), and its windows advance
+// by HIST instead of WINDOW, so every parsed position has between 32 and 64 KiB of the stream behind it in its window -- the
+// anchored-last-window mechanism, applied to every window.  All blocks of a launch still encode side by side: the history
+// is INPUT, nothing waits.  Price: every byte is indexed and loaded twice (the indexer, 160 k of a window's 300 k cycles,
+// becomes the longer half).
 struct Item {
-    uint32_t blk, win, nwin, len, skip;
+    uint32_t blk, win, nwin, len, skip, hist;
     uint64_t in_off;
 };
-
+// window geometry: window t.win covers [win_base, win_base + win_len) of the item and parses [win_from, that end)
+__device__ __forceinline__ uint32_t win_stride(const Item& t) { return t.hist != 0u ? HIST : WINDOW; }
+// the LAST window of an item longer than a window is anchored at the item's end and overlaps the window before it, so the tail can
+// match backwards like the reference's (src/block/compress.rs:403-405: the window is the previous 64 KiB; a 66 675-byte block is
+// 65 536 + 1 139 bytes)
+__device__ __forceinline__ uint32_t win_base(const Item& t) { return (t.win + 1u == t.nwin && t.len > WINDOW) ? t.len - WINDOW : t.win * win_stride(t); }
+__device__ __forceinline__ uint32_t win_from(const Item& t) { return t.win == 0u ? t.hist : (t.win - 1u) * win_stride(t) + WINDOW; }
+__device__ __forceinline__ uint32_t win_skip(const Item& t) { return win_from(t) - win_base(t); }
+__device__ __forceinline__ uint32_t win_len(const Item& t) {
+    const uint32_t base = win_base(t);
+    return t.len > base ? (t.len - base < WINDOW ? t.len - base : WINDOW) : 0u;
+}
 __device__ __forceinline__ void item_load(const CompressArgs& a, Item& it) {
     // first window of block it.blk (or invalid)
-    it.win = 0u; it.nwin = 0u; it.len = 0u; it.skip = 0u; it.in_off = 0ull;
+    it.win = 0u; it.nwin = 0u; it.len = 0u; it.skip = 0u; it.hist = 0u; it.in_off = 0ull;
     if (it.blk >= a.n) return;
     const uint32_t len = a.in_len[it.blk];
     const uint32_t cap = a.out_cap[it.blk];
-    it.len = len;
-    it.in_off = a.in_off[it.blk];
-    it.nwin = len == 0u ? 1u : (uint32_t)(((uint64_t)len + WINDOW - 1u) / WINDOW);
+    const uint32_t h = (a.flags != nullptr && (a.flags[it.blk] >> 8) >= HIST && len != 0u && len <= 0xFFFFFFFFu - HIST) ? HIST : 0u;
+    it.hist = h;
+    it.len = len + h;
+    it.in_off = a.in_off[it.blk] - h;
+    it.nwin = h != 0u ? (it.len <= WINDOW ? 1u : 1u + (it.len - WINDOW + HIST - 1u) / HIST)
+                      : (len == 0u ? 1u : (uint32_t)(((uint64_t)len + WINDOW - 1u) / WINDOW));
     const uint64_t need = 20ull + (uint64_t)len * 110ull / 100ull;   // get_maximum_output_size, compress.rs:588-590
     if ((uint64_t)cap < need) { it.skip = 1u; it.nwin = 1u; }
 }
@@ -1169,18 +1204,6 @@ __device__ __forceinline__ void wave_body(const CompressArgs& a, uint8_t* __rest
     if (it.blk >= a.n) return;
     uint32_t k = 0u;
 
-    // Window t.win of a block starts at t.win * 64 KiB -- except the LAST window of a block that is longer than 64 KiB: it is
-    // anchored at the block's end (base = len - 64 KiB) and overlaps the window before it.  Its first win_skip positions are
-    // history only (indexed and loaded, not parsed), so the block's tail can match backwards like the reference's
-    // (src/block/compress.rs:403-405: the window is the previous 64 KiB; a 66 675-byte block is 65 536 + 1 139 bytes).
-    auto win_base = [](const Item& t) -> uint32_t {
-        return (t.win + 1u == t.nwin && t.len > WINDOW) ? t.len - WINDOW : t.win * WINDOW;
-    };
-    auto win_skip = [&](const Item& t) -> uint32_t { return t.win * WINDOW - win_base(t); };
-    auto win_len = [&](const Item& t) -> uint32_t {
-        const uint32_t base = win_base(t);
-        return t.len > base ? (t.len - base < WINDOW ? t.len - base : WINDOW) : 0u;
-    };
     auto do_index = [&](const Item& t, uint32_t slot) {
         if (t.skip) return;
         const uint32_t base = win_base(t), wl = win_len(t);
@@ -1231,8 +1254,8 @@ __device__ __forceinline__ void wave_body(const CompressArgs& a, uint8_t* __rest
             if (ix.blk < a.n) do_index(ix, (k + 1u) & 1u);
         } else if (!it.skip) {
             const uint32_t base = win_base(it), skip = win_skip(it);
-            uint32_t s0 = seg_lo(w) > skip ? seg_lo(w) : skip;
-            uint32_t s1 = seg_lo(w + 1u) > skip ? seg_lo(w + 1u) : skip;
+            uint32_t s0 = seg_start(w, skip, it.hist != 0u);
+            uint32_t s1 = seg_start(w + 1u, skip, it.hist != 0u);
             s0 = s0 < wl ? s0 : wl;
             s1 = s1 < wl ? s1 : wl;
             const uint32_t act_abs = it.len >= 12u ? it.len - 11u : 0u;
@@ -1260,7 +1283,7 @@ __device__ __forceinline__ void wave_body(const CompressArgs& a, uint8_t* __rest
             if (it.skip) {
                 if (threadIdx.x == 0u) { a.out_len[it.blk] = 0u; a.status[it.blk] = LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL; }
             } else {
-                place_segment(lds, a.in_base + it.in_off, it.len, it.win, last_win, wl, win_base(it), win_skip(it), bodies + (size_t)w * BODY_STRIDE,
+                place_segment(lds, a.in_base + it.in_off, it.len, it.win, last_win, wl, win_base(it), win_skip(it), it.hist != 0u, bodies + (size_t)w * BODY_STRIDE,
                               a.out_base + a.out_off[it.blk], k & 1u, w, lane, a.out_len + it.blk, a.status + it.blk,
                               wmode ? carry + CARRY_DWORDS * (size_t)it.blk : nullptr, k + 1u, carry_spins);
             }

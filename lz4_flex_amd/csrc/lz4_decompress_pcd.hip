@@ -608,6 +608,7 @@ struct Ctx {
 
 template <class G>
 __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs a, int32_t redo_code) {
+    constexpr uint32_t SPLAT_MAX = G::WIN - 32u < 4096u ? G::WIN - 32u : 4096u;       // periods the giant-match path repeats from LDS
     extern __shared__ __attribute__((aligned(16))) uint8_t pcd_lds[];
     const bool paired = a.pair_ws != nullptr;
     const uint32_t b = paired ? blockIdx.x >> 1 : blockIdx.x;
@@ -899,6 +900,28 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                         prev_ok = true;
                     }
                     uint32_t donem = 0u;
+                    if (g_off <= SPLAT_MAX) {
+                        // a short period (offset 1: a run of one byte, decompress_safe.rs:311-313): the period, and 16 bytes of its
+                        // repetition, go to the (unused) window once; every thread then stores 16 bytes of the pattern per turn,
+                        // read from the window at its position's phase -- stores only, instead of log2(ml / off) rounds of
+                        // memory-to-memory copies with a barrier each (16 x 4 MiB of zeros: 6 GB/s in round 3)
+                        const uint8_t* pat = X.gout + OP - g_off;
+                        for (uint32_t o = tid; o < g_off + 16u; o += G::T) X.win()[o] = pat[o % g_off];
+                        __syncthreads();
+                        uint32_t phase = (16u * tid) % g_off;
+                        const uint32_t hop = (16u * G::T) % g_off;
+                        uint8_t* dstp = X.gout + OP;
+                        for (uint32_t o = 16u * tid; o < g_ml; o += 16u * G::T) {
+                            const u32x4 v = ld16l(X.win() + phase);
+                            const uint32_t mrem = g_ml - o;
+                            if (mrem >= 16u) st16g(dstp + o, v);
+                            else for (uint32_t j = 0; j < mrem; ++j) dstp[o + j] = (uint8_t)byte_of(v, j);
+                            phase += hop;
+                            phase -= phase >= g_off ? g_off : 0u;
+                        }
+                        donem = g_ml;
+                        __syncthreads();
+                    }
                     while (donem < g_ml) {
                         const uint32_t room = donem + g_off;
                         const uint32_t n = g_ml - donem < room ? g_ml - donem : room;

@@ -81,7 +81,10 @@ struct Copier {
     uint32_t pr_piece, pr_idle, pr_blocked;
 #endif
     enum : uint32_t { K_NONE = 0, K_MAINT = 1, K_RARE = R_RARE, K_CAREFUL = R_CAREFUL, K_FINISH = R_FINISH, K_LONG = 8 };
-    static constexpr uint32_t LONG_LIT = 1024u, LONG_KEEP = 256u;     // literal runs from LONG_LIT bytes on: all but the last LONG_KEEP (+ < 64) bytes go memory to memory
+#ifndef LZ4S_LONG_MLP
+#define LZ4S_LONG_MLP 8
+#endif
+    static constexpr uint32_t LONG_LIT = 1024u, LONG_KEEP = 256u, LONG_MLP = LZ4S_LONG_MLP;     // literal runs from LONG_LIT bytes on: all but the last LONG_KEEP (+ < 64) bytes go memory to memory, LONG_MLP loads in flight per lane
     static_assert(OUT_H + 16u + 64u <= LONG_LIT - LONG_KEEP - 64u, "the window is rebuilt from the run itself");
     struct Slot { uint32_t n, dst, msrc, glob; word_t v; };
     static __device__ __forceinline__ word_t ldw(const uint8_t* p) { word_t v; __builtin_memcpy(&v, p, WB); return v; }
@@ -118,7 +121,7 @@ struct Copier {
         F = op;
     }
     // A long literal run (incompressible data: a 64 KiB block is ONE run; round 3: 3.2 ms per GiB through 64-byte pieces and the LDS
-    // buffer) goes memory to memory, 16 bytes per lane and 4 loads in flight, up to LONG_KEEP bytes before its end; the rest -- the end
+    // buffer) goes memory to memory, 16 bytes per lane and LONG_MLP loads in flight, up to LONG_KEEP bytes before its end; the rest -- the end
     // of the block may be there -- goes the usual way.  The LDS buffer is written back first and rebuilt behind the bulk from the
     // run's own bytes (512 bytes of history + the granule that is not complete), with the invariants flush_slide() leaves.
     __device__ void bulk_literals() {
@@ -127,10 +130,12 @@ struct Copier {
         const uint8_t* src = gin + lit_src;
         uint8_t* dst = gout + op;
         uint32_t i = 16u * g;
-        for (; i + 192u < n; i += 256u) {
-            u32x4 v0, v1, v2, v3;
-            __builtin_memcpy(&v0, src + i, 16); __builtin_memcpy(&v1, src + i + 64u, 16); __builtin_memcpy(&v2, src + i + 128u, 16); __builtin_memcpy(&v3, src + i + 192u, 16);
-            __builtin_memcpy(dst + i, &v0, 16); __builtin_memcpy(dst + i + 64u, &v1, 16); __builtin_memcpy(dst + i + 128u, &v2, 16); __builtin_memcpy(dst + i + 192u, &v3, 16);
+        for (; i + 64u * (LONG_MLP - 1u) < n; i += 64u * LONG_MLP) {
+            u32x4 v[LONG_MLP];
+#pragma unroll
+            for (uint32_t k = 0; k < LONG_MLP; ++k) __builtin_memcpy(&v[k], src + i + 64u * k, 16);
+#pragma unroll
+            for (uint32_t k = 0; k < LONG_MLP; ++k) __builtin_memcpy(dst + i + 64u * k, &v[k], 16);
         }
         for (; i < n; i += 64u) { u32x4 v; __builtin_memcpy(&v, src + i, 16); __builtin_memcpy(dst + i, &v, 16); }
         op += n; lit_src += n; lit_rem -= n;

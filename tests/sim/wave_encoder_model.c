@@ -38,7 +38,9 @@ typedef struct {
     uint32_t nseg;   /* segments per 64 KiB window (the kernel's worker wavefronts); boundaries are multiples of 512 */
     uint32_t cap;    /* longest match a head counts */
     uint32_t skipd;  /* a position buried this deep in a running match is not evaluated */
+    uint32_t hist;   /* 0, or HIST: `in` starts HIST bytes before the block (a Linked frame's previous bytes); they are history only */
 } lz4w_params;
+#define HIST (WINDOW / 2u)
 
 static inline uint32_t ld32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 
@@ -47,16 +49,24 @@ static inline uint32_t ld32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); re
  * before it.  Only the positions behind that window's end ("newfrom") are parsed; the overlap is history (it is indexed
  * again, and matches may start in it).  Without this a 66 675-byte block would be 65 536 + 1 139 bytes with no history for
  * the tail, and the reference's ratio pin for its JSON fixture (tests/tests.rs:168-170) fails. */
-static uint32_t win_count(uint32_t n) { return (n + WINDOW - 1) / WINDOW; }
-static uint32_t win_base(uint32_t n, uint32_t wi) { return (wi + 1 == win_count(n) && n > WINDOW) ? n - WINDOW : wi * WINDOW; }
+/* With history in front of the block (hist == HIST; `n` counts it) the windows advance by HIST instead of WINDOW, so every parsed
+ * position has 32 to 64 KiB of the stream behind it in its window. */
+static uint32_t win_count(uint32_t n, uint32_t hist) {
+    if (hist) return n <= WINDOW ? 1 : 1 + (n - WINDOW + HIST - 1) / HIST;
+    return (n + WINDOW - 1) / WINDOW;
+}
+static uint32_t win_base(uint32_t n, uint32_t wi, uint32_t hist) {
+    return (wi + 1 == win_count(n, hist) && n > WINDOW) ? n - WINDOW : wi * (hist ? HIST : WINDOW);
+}
+static uint32_t win_from(uint32_t wi, uint32_t hist) { return wi == 0 ? hist : (wi - 1) * (hist ? HIST : WINDOW) + WINDOW; }   /* parsed from here on */
 
 /* index pass: d[p] for every p (0 = no candidate).  The table is cleared at every window start, so a candidate never lies
  * before its position's window; steps of 64 positions are counted from the window's base. */
-void lz4w_index(const uint8_t *in, uint32_t n, uint16_t *d) {
+void lz4w_index(const uint8_t *in, uint32_t n, uint16_t *d, uint32_t hist) {
     uint16_t *tab = (uint16_t *)calloc(1u << HBITS, 2);
     for (uint32_t p = 0; p < n; p++) d[p] = 0;
-    for (uint32_t wi = 0; wi < win_count(n); wi++) {
-        const uint32_t base = win_base(n, wi), newfrom = wi * WINDOW;
+    for (uint32_t wi = 0; wi < win_count(n, hist); wi++) {
+        const uint32_t base = win_base(n, wi, hist), newfrom = win_from(wi, hist);
         const uint32_t wend = (n - base < WINDOW) ? n : base + WINDOW;
         memset(tab, 0, 2u << HBITS);
         for (uint32_t b = base; b < wend; b += WAVE) {
@@ -101,18 +111,30 @@ static int is_head(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_
  * compacts the heads of a superstep into the 64 lanes of its wavefront, 64 heads at a time), else 128. */
 size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_params *P, lz4w_seq *seqs) {
     size_t ns = 0;
-    uint32_t anchor = 0;
+    const uint32_t hist = P->hist;
+    uint32_t anchor = hist;
     uint32_t best[256], own[256];
-    const uint32_t nwin = win_count(n);
+    const uint32_t nwin = win_count(n, hist);
     for (uint32_t sj = 0; sj < nwin * P->nseg; sj++) {
-        const uint32_t wbase = win_base(n, sj / P->nseg);          /* candidates must lie in the segment's 64 KiB window */
-        const uint32_t newfrom = (sj / P->nseg) * WINDOW;          /* an anchored last window: the positions before this are history */
+        const uint32_t wbase = win_base(n, sj / P->nseg, hist);    /* candidates must lie in the segment's 64 KiB window */
+        const uint32_t newfrom = win_from(sj / P->nseg, hist);     /* the window's positions before this are history */
         const uint32_t wj = sj % P->nseg;
         /* eight segments are 16 17 17 17 15 16 15 15 groups of 512 long (later segments cost more per position: the kernel's
          * workers finish together), any other count tiles the window evenly */
         static const uint32_t lo8[9] = {0, 16, 33, 50, 67, 82, 98, 113, 128};
         uint32_t s0 = wbase + 512u * (P->nseg == 8 ? lo8[wj] : (128u * wj) / P->nseg);
         uint32_t s1 = wbase + 512u * (P->nseg == 8 ? lo8[wj + 1] : (128u * (wj + 1)) / P->nseg);
+        if (hist) {
+            /* with history the segments share the PARSED part of the window in the same proportions (clipped, half of the
+             * kernel's workers would idle); starts other than the first are multiples of 512 */
+            const uint32_t skip = newfrom - wbase;
+            const uint32_t g0 = (s0 - wbase) / 512u, g1 = (s1 - wbase) / 512u;
+            uint32_t r0 = (skip + (WINDOW - skip) * g0 / 128u) & ~511u, r1 = (skip + (WINDOW - skip) * g1 / 128u) & ~511u;
+            if (wj == 0 || r0 < skip) r0 = skip;
+            if (r1 < skip) r1 = skip;
+            if (wj + 1 == P->nseg) r1 = WINDOW;
+            s0 = wbase + r0; s1 = wbase + r1;
+        }
         if (s0 < newfrom) s0 = newfrom;
         if (s1 < newfrom) s1 = newfrom;
         if (s0 > n) s0 = n;
@@ -195,7 +217,7 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
 size_t lz4w_compress(const uint8_t *in, uint32_t n, uint8_t *out, const lz4w_params *P, uint32_t *n_seq) {
     uint16_t *d = (uint16_t *)calloc((size_t)n + WAVE, 2);
     lz4w_seq *seqs = (lz4w_seq *)malloc(sizeof(lz4w_seq) * ((size_t)n / 4 + 2));
-    if (n) lz4w_index(in, n, d);
+    if (n) lz4w_index(in, n, d, P->hist);
     const size_t ns = n ? lz4w_parse(in, n, d, P, seqs) : 0;
     size_t o = 0;
     if (n == 0) { out[o++] = 0; }

@@ -62,6 +62,8 @@ def big_inputs():
         ("random 300 KB (one literal run longer than the window)", bytes(rnd.getrandbits(8) for _ in range(300000))),
         ("period 3 / 7 / 20 / 300 runs", b"abc" * 40000 + bytes(range(7)) * 20000 + bytes(rnd.getrandbits(8) for _ in range(20)) * 9000
          + bytes(rnd.getrandbits(8) for _ in range(300)) * 700),
+        ("periods around the limits of the giant-match splat (1 504 in the test geometry, 4 096 in production)",
+         b"".join(bytes(rnd.getrandbits(8) for _ in range(q)) * (70000 // q + 2) for q in (1, 2, 16, 17, 64, 1503, 1504, 1505, 4095, 4096, 4097))),
         ("mixed: random, zeros, text, random", bytes(rnd.getrandbits(8) for _ in range(50000)) + bytes(200000) + t + bytes(rnd.getrandbits(8) for _ in range(70000)) + j),
         ("two-letter alphabet (chains rarely meet: many rounds per tile)", bytes(rnd.choice(b"ab") for _ in range(120000))),
         ("tiny", b"q"), ("empty", b""), ("13 zeros", bytes(13)),

@@ -192,3 +192,76 @@ def test_wave_encoder_heads_at_a_window_end(blk):
     c = blk.compress(d)
     assert O.decompress(c, len(d)) == ("ok", d)
     assert c == W.compress(d)
+
+
+def _history_batch(blk, L, sizes, seed):
+    """blocks cut from ONE stream; flags promise the bytes in front of a block as history (LZ4FLEX_BLOCK_HISTORY): 0, fewer than
+    the encoder uses (ignored), exactly HIST, more.  Every block == model (which gets the same 32 KiB in front), and the oracle
+    decodes it behind the previous 64 KiB of the stream as dictionary"""
+    rnd = random.Random(seed)
+    j = O.fixture_plain("compression_66k_JSON")
+    t = O.fixture_plain("compression_65k")
+    total = sum(sizes)
+    stream = b""
+    while len(stream) < total:
+        src = j if rnd.random() < 0.6 else t
+        ph = rnd.randrange(len(src))
+        stream += (src * 2)[ph:ph + rnd.choice([3000, 20000, 66000, 100000])]
+    stream = stream[:total]
+    in_len = list(sizes)
+    in_off = [int(x) for x in np.concatenate([[0], np.cumsum(in_len)[:-1]])]
+    hist = []
+    for k, o in enumerate(in_off):
+        h = [0, 1000, 32767, 32768, 32768, 40000, 65536, 65536][k % 8]
+        hist.append(min(h, o))
+    flags = [(h << 8) | (k % 4) for k, h in enumerate(hist)]              # (the low bits mean nothing to the throughput encoder)
+    cap = [O.max_out(n) for n in in_len]
+    out_off = [int(x) for x in np.concatenate([[0], np.cumsum(cap)[:-1]])]
+    src_buf = np.frombuffer(stream, dtype=np.uint8).copy()
+    outb = np.full(sum(cap) + 64, 0xEE, dtype=np.uint8)
+    ol, st = blk.compress_batch(src_buf, in_off, in_len, outb, out_off, cap, flags=flags)
+    assert not st.any()
+    used = 0
+    step = max(1, len(sizes) // 150)
+    for k, (o, n) in enumerate(zip(in_off, in_len)):
+        got = bytes(outb[out_off[k]:out_off[k] + int(ol[k])])
+        b = stream[o:o + n]
+        with_h = hist[k] >= W.HIST and n > 0
+        used += with_h
+        if k % step == 0 or n > 65536:
+            want = W.compress(stream[o - W.HIST:o + n], hist=W.HIST) if with_h else W.compress(b)
+            assert got == want, (k, o, n, hist[k])
+        assert O.decompress(got, n, dict_data=stream[max(0, o - 65536):o] if with_h else None) == ("ok", b), (k, o, n)
+    assert used >= len(sizes) // 3
+    return stream, in_off, in_len, ol, outb, out_off
+
+
+@pytest.mark.parametrize("carry_wait", [1, 0])
+def test_wave_encoder_history_few_blocks(blk, carry_wait):
+    """fewer blocks than workgroups (windows dealt out, carries through the workspace; carry_wait 0: through the second launch)"""
+    from lz4_flex_amd import _lib as L
+    lib = L.load()
+    sizes = [65536, 65536, 65536, 1, 11, 12, 13, 100, 65536, 40000, 70000, 262144, 65535, 65537, 98304, 32768, 32769, 1048576 + 5, 65536, 5, 65536,
+             4 * 1048576, 65536, 131072, 65536, 1000]
+    assert lib.lz4flex_set_tuning(None, b"compress_carry_wait", carry_wait) == 0
+    try:
+        _history_batch(blk, L, sizes, 31)
+    finally:
+        assert lib.lz4flex_set_tuning(None, b"compress_carry_wait", 1) == 0
+
+
+def test_wave_encoder_history_many_blocks(blk):
+    """more blocks than workgroups (a workgroup walks the windows of its blocks in order, the carry stays in LDS)"""
+    from lz4_flex_amd import _lib as L
+    rnd = random.Random(8)
+    sizes = [rnd.choice([65536, 65536, 65536, 16384, 50000, 70000, 131072]) for _ in range(1400)]
+    _history_batch(blk, L, sizes, 32)
+
+
+def test_history_must_lie_inside_the_input(blk):
+    """a host batch whose flags promise more bytes than lie in front of the block is refused (-E_INVALID_ARG)"""
+    from lz4_flex_amd import _lib as L, block
+    src = np.zeros(70000, dtype=np.uint8)
+    out = np.zeros(O.max_out(65536) + 64, dtype=np.uint8)
+    with pytest.raises(block.DeviceError):
+        blk.compress_batch(src, [1000], [65536], out, [0], [O.max_out(65536)], flags=[40000 << 8])

@@ -92,3 +92,21 @@ def test_model_on_the_window_end_fixture():
     assert O.decompress(c, len(d)) == ("ok", d)
     assert O.c_decompress(c, len(d)) == d
     assert len(c) == 41666
+
+
+def test_history_in_front_of_a_block():
+    """hist = HIST (a Linked frame's block, LZ4FLEX_BLOCK_HISTORY): the block alone is emitted, its matches reach into the 32 KiB
+    in front of it, the oracle decodes it behind those bytes as dictionary; every length class around the window arithmetic;
+    and the ratio of a stream cut into 64 KiB blocks beats the reference's own Linked frame"""
+    j = O.fixture_plain("compression_66k_JSON")
+    H = W.HIST
+    for L in (1, 5, 11, 12, 13, 100, 4096, 32767, 32768, 32769, 65535, 65536, 65537, 100000, 262144, 300001):
+        s = (j * 6)[:H + L]
+        c = W.compress(s, hist=H)
+        assert O.decompress(c, L, dict_data=s[:H]) == ("ok", s[H:]), L
+    stream = (j * 8)[:6 * 65536]
+    with_h = sum(len(W.compress(stream[max(0, b - H):b + 65536], hist=H if b else 0)) for b in range(0, len(stream), 65536))
+    alone = sum(len(W.compress(stream[b:b + 65536])) for b in range(0, len(stream), 65536))
+    rc, ref = O.frame_compress(stream, block_size=4, block_mode=1)
+    assert rc == 0
+    assert with_h < alone and with_h < len(ref) - 50, (with_h, alone, len(ref))

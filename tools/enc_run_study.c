@@ -7,7 +7,7 @@ int main(int argc, char** argv) {
     FILE* f = fopen(argv[1], "rb"); static uint8_t buf[1 << 24]; uint32_t n = fread(buf, 1, sizeof buf, f); fclose(f);
     if (n > 65536) n = 65536;
     uint16_t* d = calloc(n + 64, 2);
-    lz4w_index(buf, n, d);
+    lz4w_index(buf, n, d, 0);
     // per position: eq
     uint8_t* eq = calloc(n + 64, 1);
     for (uint32_t p = 0; p + 12 <= n; p++) eq[p] = d[p] && p >= d[p] && ld32(buf + p) == ld32(buf + p - d[p]);
