@@ -106,6 +106,17 @@ static int is_head(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_
     return ld32(in + p) == ld32(in + p - dp);                     /* the candidate's first 4 bytes match (p <= n - 12: readable) */
 }
 
+/* encode_seqs' first act: among the `cnt` sequences of one call (seqs[from ...]), a sequence without literals whose match has
+ * its predecessor's distance continues that match -- the two are one.  The sequences behind the call move down. */
+static size_t merge_batch(lz4w_seq *seqs, size_t from, size_t cnt, size_t ns) {
+    size_t o = from;
+    for (size_t i = from; i < ns; i++) {
+        if (i > from && i < from + cnt && seqs[i].lit_len == 0 && seqs[i].off == seqs[o - 1].off) { seqs[o - 1].mlen += seqs[i].mlen; continue; }
+        seqs[o++] = seqs[i];
+    }
+    return o;
+}
+
 /* parse of one block; returns the number of sequences (the last one has mlen == 0: final literals).
  * A segment is walked in "supersteps": 256 positions at a time when they hold at most 128 heads (the kernel
  * compacts the heads of a superstep into the 64 lanes of its wavefront, 64 heads at a time), else 128. */
@@ -142,6 +153,7 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
         if (s0 == s1) continue;
         uint32_t mend = (n >= 5) ? ((s1 < n - 5) ? s1 : n - 5) : 0;         /* matches end here at the latest */
         if (mend > wbase + 65535u) mend = wbase + 65535u;                    /* ends are 16-bit window-relative numbers */
+        size_t batch_from = ns, npend = 0;   /* the sequences waiting in the kernel's lanes for a full wavefront (encode_seqs takes <= 64 at a time) */
         uint32_t carry = 0;    /* the match that reaches furthest so far in this segment: window-relative end << 16 | distance */
         uint32_t cursor = s0;
         uint32_t b = wbase + ((s0 - wbase) & ~255u);              /* supersteps are aligned in the window; positions before s0 are no heads */
@@ -206,7 +218,13 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
             }
             if (cursor < e1) cursor = e1;                /* (not reached: the loop runs until cursor >= e1) */
             b = e1;
+            const size_t nsel = ns - (batch_from + npend);
+            if (npend + nsel > 64) {                     /* no room in the lanes: the waiting ones are encoded, the new ones wait */
+                ns = merge_batch(seqs, batch_from, npend, ns);
+                batch_from = ns - nsel; npend = nsel;
+            } else npend += nsel;
         }
+        ns = merge_batch(seqs, batch_from, npend, ns);   /* the segment's end: the rest is encoded */
     }
     seqs[ns].lit_start = anchor; seqs[ns].lit_len = n - anchor; seqs[ns].off = 0; seqs[ns].mlen = 0;
     ns++;

@@ -39,6 +39,12 @@ def cases():
     out.append(b"".join(bytes([rnd.getrandbits(8)]) * rnd.randint(1, 700) for _ in range(300)))
     out.append((bytes(range(256)) * 300)[:70001])
     out.append(bytes(rnd.getrandbits(8) for _ in range(20)) * 4000)       # period 20: every step full of same-bucket lanes
+    # adjacent matches of one distance are merged inside an encode_seqs call (round 4): runs of every length around the 1 024-byte cap
+    # and around 64 sequences per call, runs separated by single literals, long runs in a block of several windows
+    out.append(b"".join(bytes([65 + k % 20]) * n for k, n in enumerate([1023, 1024, 1025, 2047, 2048, 2049, 5000, 8192, 8193, 20000])))
+    out.append(b"".join(bytes([rnd.getrandbits(8)]) * rnd.choice([1100, 2100, 3000]) + bytes([rnd.getrandbits(8)]) for _ in range(40)))
+    out.append(bytes(70000) + b"xyz" * 30000 + bytes(200000))
+    out.append((b"0123456789abcdef" * 8192)[:131072 + 5])
     return out
 
 
