@@ -81,10 +81,7 @@ struct Copier {
     uint32_t pr_piece, pr_idle, pr_blocked;
 #endif
     enum : uint32_t { K_NONE = 0, K_MAINT = 1, K_RARE = R_RARE, K_CAREFUL = R_CAREFUL, K_FINISH = R_FINISH, K_LONG = 8 };
-#ifndef LZ4S_LONG_MLP
-#define LZ4S_LONG_MLP 8
-#endif
-    static constexpr uint32_t LONG_LIT = 1024u, LONG_KEEP = 256u, LONG_MLP = LZ4S_LONG_MLP;     // literal runs from LONG_LIT bytes on: all but the last LONG_KEEP (+ < 64) bytes go memory to memory, LONG_MLP loads in flight per lane
+    static constexpr uint32_t LONG_LIT = 1024u, LONG_KEEP = 256u;     // literal runs from LONG_LIT bytes on: all but the last LONG_KEEP (+ < 64) bytes go memory to memory
     static_assert(OUT_H + 16u + 64u <= LONG_LIT - LONG_KEEP - 64u, "the window is rebuilt from the run itself");
     struct Slot { uint32_t n, dst, msrc, glob; word_t v; };
     static __device__ __forceinline__ word_t ldw(const uint8_t* p) { word_t v; __builtin_memcpy(&v, p, WB); return v; }
@@ -121,32 +118,38 @@ struct Copier {
         F = op;
     }
     // A long literal run (incompressible data: a 64 KiB block is ONE run; round 3: 3.2 ms per GiB through 64-byte pieces and the LDS
-    // buffer) goes memory to memory, 16 bytes per lane and LONG_MLP loads in flight, up to LONG_KEEP bytes before its end; the rest -- the end
+    // buffer) goes memory to memory, 16 bytes per lane and four loads in flight, up to LONG_KEEP bytes before its end; the rest -- the end
     // of the block may be there -- goes the usual way.  The LDS buffer is written back first and rebuilt behind the bulk from the
     // run's own bytes (512 bytes of history + the granule that is not complete), with the invariants flush_slide() leaves.
+    // The copy is a function of its own (not inlined: its registers would be the kernel's -- inlined, the hot loop spilled and
+    // JSON blocks took 1.74 instead of 1.64 ms).
+    static __device__ __attribute__((noinline)) void bulk_copy(const uint8_t* src, uint8_t* dst, uint32_t n, uint32_t g, lds_u8* lds_dst,
+                                                               const uint8_t* hist, uint32_t have) {
+        typedef __attribute__((address_space(1))) uint8_t g_u8;      // (named: a pointer that crossed a call is flat)
+        typedef u32x4 __attribute__((aligned(1))) u32x4_u;
+        typedef __attribute__((address_space(1))) u32x4_u g_u32x4_u;
+        const g_u8* s1 = (const g_u8*)src;
+        g_u8* d1 = (g_u8*)dst;
+        auto ld = [&](uint32_t o) -> u32x4 { return *reinterpret_cast<const g_u32x4_u*>(s1 + o); };
+        auto st = [&](uint32_t o, const u32x4& v) { *reinterpret_cast<g_u32x4_u*>(d1 + o) = v; };
+        uint32_t i = 16u * g;
+        for (; i + 192u < n; i += 256u) {                           // four loads in flight per lane (eight: no faster, sixteen: slower)
+            const u32x4 v0 = ld(i), v1 = ld(i + 64u), v2 = ld(i + 128u), v3 = ld(i + 192u);
+            st(i, v0); st(i + 64u, v1); st(i + 128u, v2); st(i + 192u, v3);
+        }
+        for (; i < n; i += 64u) st(i, ld(i));
+        const g_u8* h1 = (const g_u8*)hist;
+        for (uint32_t k = 16u * g; k < have; k += 16u * G)          // (the last granule reads a few of the run's remaining bytes: there are LONG_KEEP of them)
+            *reinterpret_cast<u32x4 __attribute__((address_space(3)))*>(lds_dst + k) = *reinterpret_cast<const g_u32x4_u*>(h1 + k);
+    }
     __device__ void bulk_literals() {
         final_flush();
         const uint32_t n = (lit_rem - LONG_KEEP) & ~63u;
-        const uint8_t* src = gin + lit_src;
-        uint8_t* dst = gout + op;
-        uint32_t i = 16u * g;
-        for (; i + 64u * (LONG_MLP - 1u) < n; i += 64u * LONG_MLP) {
-            u32x4 v[LONG_MLP];
-#pragma unroll
-            for (uint32_t k = 0; k < LONG_MLP; ++k) __builtin_memcpy(&v[k], src + i + 64u * k, 16);
-#pragma unroll
-            for (uint32_t k = 0; k < LONG_MLP; ++k) __builtin_memcpy(dst + i + 64u * k, &v[k], 16);
-        }
-        for (; i < n; i += 64u) { u32x4 v; __builtin_memcpy(&v, src + i, 16); __builtin_memcpy(dst + i, &v, 16); }
-        op += n; lit_src += n; lit_rem -= n;
-        F = op & ~15u;
-        L0 = F > OUT_H ? F - OUT_H : 0u;
-        const uint32_t have = op - L0;                              // <= OUT_H + 15 <= n: every byte of it is a byte of this run
-        const uint8_t* h = gin + lit_src - have;
-        for (uint32_t k = 16u * g; k < have; k += 16u * G) {        // (the last granule reads a few of the run's remaining bytes: there are LONG_KEEP of them)
-            u32x4 v; __builtin_memcpy(&v, h + k, 16);
-            *reinterpret_cast<u32x4 __attribute__((address_space(3)))*>(lout + k) = v;
-        }
+        const uint32_t op2 = op + n, f2 = op2 & ~15u, l2 = f2 > OUT_H ? f2 - OUT_H : 0u;
+        const uint32_t have = op2 - l2;                             // <= OUT_H + 15 <= n: every byte of it is a byte of this run
+        bulk_copy(gin + lit_src, gout + op, n, g, lout, gin + lit_src + n - have, have);
+        op = op2; lit_src += n; lit_rem -= n;
+        F = f2; L0 = l2;
     }
     // literals with exact source bounds (the block's last literals end at its last byte)
     __device__ void generic_literals(uint32_t s, uint32_t n) {
@@ -213,7 +216,13 @@ struct Copier {
     // Once per NS-step iteration: make sure NS pieces fit into the output buffer, touch the next line of the compressed
     // stream ahead of the parser.
     __device__ __forceinline__ void iteration_begin() {
+        // (a long literal run is noticed HERE, once per iteration, some pieces after its record was popped: the same test at the pop,
+        // one compare and one select per step, made JSON blocks 6 % slower -- 1.72 instead of 1.62 ms)
+#ifdef LZ4S_EXP_NOLONG    // (timing experiments: round 3's line)
         if ((done | blocked) == 0u && out_space() < NS * PIECE + 64u) blocked = K_MAINT;
+#else
+        if ((done | blocked) == 0u) blocked = lit_rem >= LONG_LIT ? (uint32_t)K_LONG : (out_space() < NS * PIECE + 64u ? (uint32_t)K_MAINT : (uint32_t)K_NONE);
+#endif
         pf_acc += pf_v;                                   // the touch issued one iteration ago (long complete)
         const bool pf = pf_next < lit_src + PF_AHEAD;
         const uint32_t pos = pf_next + (128u / G) * g;
@@ -228,8 +237,7 @@ struct Copier {
         lit_rem = pop ? e.y : lit_rem;
         ml_rem = pop ? e.z : ml_rem;
         moff = pop ? (e.w & 0xFFFFu) : moff;
-        uint32_t kind = pop ? e.w >> 16 : 0u;            // R_RARE / R_CAREFUL / R_FINISH == K_*: generic code in service()
-        kind = (pop && kind == 0u && e.y >= LONG_LIT) ? (uint32_t)K_LONG : kind;      // a long literal run: service() moves its bulk memory to memory
+        const uint32_t kind = pop ? e.w >> 16 : 0u;      // R_RARE / R_CAREFUL / R_FINISH == K_*: generic code in service()
         blocked |= kind;
         head = pop ? head + 1u : head;
         e = q.get(head);                                  // next record (complete iff head != snap); its latency overlaps this step
