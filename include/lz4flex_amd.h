@@ -229,16 +229,19 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  * "compress_mode": 0 = throughput encoder (default; lz4_compress_wave.hip: a valid LZ4 block with this library's own
  *   parse -- any LZ4 decoder returns the input; ratio within a percent of the reference's, usually better), 1 = the
  *   reference's exact bytes (src/block/compress.rs:318-489 restated; about 3x slower).  Blocks with a dictionary / prefix
- *   always use the exact encoder.  A Linked frame (src/frame/compress.rs:261-371) written in mode 0 holds independently
- *   parsed blocks -- a valid Linked frame that any decoder returns to the input, with the Independent frame's ratio and one
- *   launch per batch of blocks; in mode 1 it holds the reference's bytes (one dependency chain, milliseconds per block).
+ *   always use the exact encoder.  A Linked frame (src/frame/compress.rs:261-371) written in mode 0 holds blocks whose matches
+ *   reach up to 64 KiB back into the blocks before them (LZ4FLEX_BLOCK_HISTORY below: 32 KiB of the stream in front of every
+ *   block are its history) -- a dependency-carrying Linked frame that any decoder returns to the input, with a ratio below the
+ *   reference's and still one launch per batch of blocks; in mode 1 it holds the reference's bytes (one dependency chain,
+ *   milliseconds per block).
  *   Environment: LZ4FLEX_COMPRESS_MODE=exact|fast.
  * Kernel selection, for measurements only (every choice produces the same bytes / lengths / error variants):
  * "decompress_variant": 0 = by batch size (default), 7 = one block per WORKGROUP, token chain and copies parallel inside the
  *   block (lz4_decompress_pcd.hip: few, large blocks; 8 = the same with its small test geometry), 5 = one block per wavefront
  *   (lz4_decompress_wave.hip), 6 = the same with a parser and an executor wavefront per block, 4 = parser /
- *   copier split decoder (large batches), 1 = decoder whose window lives in HBM/L2 (always used for dictionary /
- *   prefix blocks); "decompress_blocks_per_wg" (variant 4: 0 = by batch size, 8/16/32/64); "decompress_lanes"
+ *   copier split decoder (large batches), 9 = plan / replay (lz4_decompress_plan.hip + lz4_decompress_replay.hip: a parallel
+ *   parse per block writes a copy plan, a parse-free copier executes it; an experiment -- slower than 0 on every shape
+ *   measured), 1 = decoder whose window lives in HBM/L2 (always used for dictionary / prefix blocks); "decompress_blocks_per_wg" (variant 4: 0 = by batch size, 8/16/32/64); "decompress_lanes"
  *   (16; 8/32/64 in -DLZ4FLEX_ALL_VARIANTS builds, variant 1); exact encoder: "compress_lanes" (8/16 lanes of a wavefront per
  *   block), "compress_variant" (1 = group encoder + emitter wavefront; 3 = group encoder alone, -DLZ4FLEX_ALL_VARIANTS builds);
  *   "decompress_second_pass" (tests: 0 leaves the blocks that variants 5..8 hand to the reference-order kernel marked with
