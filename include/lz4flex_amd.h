@@ -237,7 +237,8 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  *   Environment: LZ4FLEX_COMPRESS_MODE=exact|fast.
  * Kernel selection, for measurements only (every choice produces the same bytes / lengths / error variants):
  * "decompress_variant": 0 = by batch size (default), 7 = one block per WORKGROUP, token chain and copies parallel inside the
- *   block (lz4_decompress_pcd.hip: few, large blocks; 8 = the same with its small test geometry), 5 = one block per wavefront
+ *   block (lz4_decompress_pcd.hip: few, large blocks; 8 = the same with its small test geometry, 10 / 11 = with 256 / 512 lanes
+ *   per block: what 0 picks for 513 ... 1 024 / 257 ... 512 blocks), 5 = one block per wavefront
  *   (lz4_decompress_wave.hip), 6 = the same with a parser and an executor wavefront per block, 4 = parser /
  *   copier split decoder (large batches), 9 = plan / replay (lz4_decompress_plan.hip + lz4_decompress_replay.hip: a parallel
  *   parse per block writes a copy plan, a parse-free copier executes it; an experiment -- slower than 0 on every shape

@@ -82,10 +82,7 @@ struct lz4flex_ctx {
     int fail_next_batch = 0;      // tests: the next N batch calls on this context fail before they launch anything (what an allocation failure looks like to the caller)
 };
 
-#ifndef LZ4FLEX_PCD_MAX_BLOCKS
-#define LZ4FLEX_PCD_MAX_BLOCKS 1024
-#endif
-static constexpr uint32_t PCD_MAX_BLOCKS = LZ4FLEX_PCD_MAX_BLOCKS;
+static constexpr uint32_t PCD_MAX_BLOCKS = DISPATCH_PCD_256;     // up to here the default dispatch takes the workgroup decoder
 static constexpr uint32_t CHAIN_WS_BLOCKS = 65536u;      // blocks per chained decode batch (LZ4FLEX_MEM_CHAINED)
 
 // the decoders for blocks without dictionary / prefix
@@ -102,10 +99,15 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
     // the block (lz4_decompress_pcd.hip) -- the only decoder here whose time for a block is not the length of the block's chain.
     // tools/dec_shapes.py, JSON tiles (its worst case: the deepest dependency chains), 256 / 512 / 1 024 / 2 304 blocks: 0.15 / 0.28 /
     // 0.52 / 1.13 ms against 0.45 / 0.49 / 0.52 / 0.71 (pair of wavefronts per block); 1 024 text / log blocks 0.81 / 0.42 against
-    // 1.02 / 0.58; 256 x 4 MiB log blocks: 4.9 ms against 28.8; one 16 MiB block: 14.6 ms against 113.  1 024 = four workgroups per CU.
+    // 1.02 / 0.58; 256 x 4 MiB log blocks: 4.9 ms against 28.8; one 16 MiB block: 14.6 ms against 113.  Round 4: from 257 blocks on
+    // with 512 lanes per block, from 513 on with 256 (more workgroups per CU; pcd_geo below): 512 / 1 024 JSON blocks 0.23 / 0.38 ms.
     int v = c->dec_variant != 0 ? c->dec_variant
                                 : ((a.n <= PCD_MAX_BLOCKS || big_blocks) ? 7 : (a.n <= DISPATCH_WAVE_PAIR_MAX ? 6 : (a.n <= DISPATCH_WAVE_MAX ? 5 : 4)));
     if (a.out_pos != nullptr && v != 8) v = 7;           // prefix mode (Linked frames): only the workgroup decoder knows it
+    // the workgroup decoder's geometry by batch size (lz4_decompress_pcd.hip GeoMid*: smaller workgroups, more of them per CU); large
+    // blocks and chains keep the full workgroup (a chain is one block at a time, a large block wants the long tiles)
+    int pcd_geo = v == 8 ? 1 : (v == 10 ? 2 : (v == 11 ? 3 : 0));
+    if (c->dec_variant == 0 && v == 7 && !big_blocks && a.out_pos == nullptr && a.n > DISPATCH_PCD_1024) pcd_geo = a.n <= DISPATCH_PCD_512 ? 3 : 2;
     if (v == 9) {
         // plan / replay: every block is turned into a copy plan (one wavefront per block, everything that is parallel), then the
         // plans are replayed (four lanes per block, the serial rest); blocks without a plan (errors, sinks too small, oversized) go
@@ -142,12 +144,12 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
         r.only_status = REDO;
         return launch_decompress(r, c->dec_lanes, s);
     }
-    if (v >= 5 && v <= 8) {
+    if ((v >= 5 && v <= 8) || v == 10 || v == 11) {
         // one block per wavefront (6: per pair of wavefronts; 7 / 8: per workgroup); blocks it marks (errors, sinks too small) are
         // decoded again in the reference's order
         constexpr int32_t REDO = 0x7F000001;
         bool pair = false;
-        if (v >= 7 && (c->dec_pcd_pair == 2 || (c->dec_pcd_pair == 1 && big_blocks)) && c->pcd_ws && a.n <= PCD_PAIR_MAX_BLOCKS) {
+        if (v >= 7 && v <= 8 && (c->dec_pcd_pair == 2 || (c->dec_pcd_pair == 1 && big_blocks)) && c->pcd_ws && a.n <= PCD_PAIR_MAX_BLOCKS) {
             // few LARGE blocks: a parser and a copier workgroup each (half the CUs would idle otherwise; a block of one tile has
             // nothing to overlap and would only pay the hand-over: 64 KiB JSON blocks 0.144 -> 0.156 ms).  2 = always (tests).  The hand-over workspace is the
             // context's: launches on different streams are ordered by an event, as the encoder's are
@@ -157,7 +159,7 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
             a.pair_ws = c->pcd_ws;
             pair = true;
         }
-        hipError_t e = v >= 7 ? launch_decompress_pcd(a, REDO, s, v == 8) : (v == 6 ? launch_decompress_wave_pair(a, REDO, s) : launch_decompress_wave(a, REDO, s));
+        hipError_t e = v >= 7 ? launch_decompress_pcd(a, REDO, s, pcd_geo) : (v == 6 ? launch_decompress_wave_pair(a, REDO, s) : launch_decompress_wave(a, REDO, s));
         if (e != hipSuccess) return e;
         if (pair) {
             e = hipEventRecord(c->pcd_done, s);
@@ -279,7 +281,7 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
 #ifdef LZ4FLEX_ALL_VARIANTS
     if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v == 1 || v == 3) c->comp_variant = v; }
 #endif
-    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v == 0 || v == 1 || (v >= 4 && v <= 8)) c->dec_variant = v; }
+    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v == 0 || v == 1 || (v >= 4 && v <= 11)) c->dec_variant = v; }
     int prev = 0;
     (void)hipGetDevice(&prev);
     e = hipSetDevice(device);
@@ -372,7 +374,7 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "decompress_variant")) {
-        if (value != 0 && value != 1 && (value < 4 || value > 9)) return -LZ4FLEX_E_INVALID_ARG;
+        if (value != 0 && value != 1 && (value < 4 || value > 11)) return -LZ4FLEX_E_INVALID_ARG;
         c->dec_variant = value;
         return 0;
     }
@@ -423,7 +425,7 @@ int lz4flex_get_tuning(lz4flex_ctx* c, const char* key) {
     // the batch sizes at which the default decoder dispatch changes kernel or geometry (lz4_device.h), in ascending order; the
     // list ends where the key is refused.  tests/test_gpu_block.py builds its size matrix from it.
     if (!strncmp(key, "dispatch_threshold_", 19)) {
-        const uint32_t t[] = {PCD_PAIR_MAX_BLOCKS, PCD_MAX_BLOCKS, DISPATCH_WAVE_PAIR_MAX, DISPATCH_SPLIT_16, DISPATCH_WAVE_MAX, DISPATCH_SPLIT_32, DISPATCH_SPLIT_64};
+        const uint32_t t[] = {PCD_PAIR_MAX_BLOCKS, DISPATCH_PCD_1024, DISPATCH_PCD_512, DISPATCH_PCD_256, DISPATCH_WAVE_PAIR_MAX, DISPATCH_SPLIT_16, DISPATCH_WAVE_MAX, DISPATCH_SPLIT_32, DISPATCH_SPLIT_64};
         const int i = atoi(key + 19);
         if (i < 0 || i >= (int)(sizeof t / sizeof t[0]) || (key[19] < '0' || key[19] > '9')) return -LZ4FLEX_E_INVALID_ARG;
         return (int)t[i];

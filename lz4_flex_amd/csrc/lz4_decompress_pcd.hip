@@ -84,6 +84,14 @@ struct Geo {
 };
 using GeoProd = Geo<CT, CM, P, THREADS, SEQ_PER_LANE, HIST, WNEW>;   // lz4_pcd_common.h: 32 KiB tiles, 128-byte parts, 1 024 lanes x 2 sequences, 26 + 48 KiB window
 using GeoTest = Geo<2048u, 256u, 64u, 128u, 2u, 512u, 1024u>;        // tests: boundaries of every kind inside small inputs
+// Medium batches (round 4).  The kernel is a chain of latencies with the CU's issue slots mostly empty, and the production geometry
+// fits ONE workgroup per CU: from 257 blocks on the batch runs in rounds.  Fewer lanes and less LDS per block make a block slower
+// (JSON block alone: 1 024 lanes 0.14 ms, 512 lanes 0.20, 256 lanes 0.30, 128 lanes 0.50) and the CU hold more of them: 512 lanes and
+// 53 KB -- two per CU -- win for 257 ... 512 blocks (JSON 512 blocks: 0.23 instead of 0.28 ms), 256 lanes and 29 KB -- four per CU --
+// for 513 ... 1 024 (1 024 blocks: 0.38 instead of 0.52); above that a pair of wavefronts per block is ahead
+// (profiles/r04_decoder_shapes.txt; capi.cpp launch_decompress_fast holds the thresholds).
+using GeoMid512 = Geo<8192u, 1024u, 64u, 512u, 2u, 8192u, 16384u>;
+using GeoMid256 = Geo<4096u, 512u, 64u, 256u, 2u, 6144u, 8192u>;
 
 // control words in LDS.  A word is written on one side of a barrier and read on the other: C_BAD (a sequence that does not parse) is
 // written before the batch's first barrier and read behind it, C_BAD2 (an offset behind the output) before the second one --
@@ -1061,17 +1069,21 @@ static hipError_t launch_geo(const DecompressArgs& a, int32_t redo_code, hipStre
 }  // namespace pcd
 
 // one workgroup per block; blocks it marks (status redo_code) are decoded again by launch_decompress (only_status = redo_code).
-// test_geometry: the small geometry (2 KiB tiles, 64-byte parts, 128 lanes, 0.5 + 1 KiB window) that puts every kind of boundary
-// inside small inputs -- tests only.
+// geometry 1: the small geometry (2 KiB tiles, 64-byte parts, 128 lanes, 0.5 + 1 KiB window) that puts every kind of boundary
+// inside small inputs -- tests only; 2 / 3: the medium-batch geometries (GeoMid256 / GeoMid512).
 size_t decompress_pcd_pair_ws_bytes() {
     return (size_t)PCD_PAIR_MAX_BLOCKS * (pcd::PAIR_CTRL + (size_t)pcd::PAIR_TOKB * pcd::PAIR_RING);
 }
 
-hipError_t launch_decompress_pcd(const DecompressArgs& a, int32_t redo_code, hipStream_t s, bool test_geometry) {
+hipError_t launch_decompress_pcd(const DecompressArgs& a, int32_t redo_code, hipStream_t s, int geometry) {
     if (a.n == 0u) return hipSuccess;
     if (a.pair_ws != nullptr && a.n > PCD_PAIR_MAX_BLOCKS) return hipErrorInvalidValue;
     if (a.dict_base != nullptr) return hipErrorInvalidValue;   // external dictionary: lz4_decompress.hip
-    return test_geometry ? pcd::launch_geo<pcd::GeoTest>(a, redo_code, s) : pcd::launch_geo<pcd::GeoProd>(a, redo_code, s);
+    if (geometry == 2 || geometry == 3) {
+        if (a.pair_ws != nullptr) return hipErrorInvalidValue;
+        return geometry == 2 ? pcd::launch_geo<pcd::GeoMid256>(a, redo_code, s) : pcd::launch_geo<pcd::GeoMid512>(a, redo_code, s);
+    }
+    return geometry == 1 ? pcd::launch_geo<pcd::GeoTest>(a, redo_code, s) : pcd::launch_geo<pcd::GeoProd>(a, redo_code, s);
 }
 
 }  // namespace lz4flex_dev

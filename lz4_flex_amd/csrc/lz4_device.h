@@ -45,7 +45,10 @@ constexpr uint32_t PCD_PAIR_MAX_BLOCKS = 128u;
 // table, read by the dispatch AND (through lz4flex_get_tuning "dispatch_threshold_<i>") by the tests, whose decoder matrix is
 // every threshold and its successor -- a threshold edit cannot leave a size class untested (a wrong result lived a round in
 // batches of 5 121 ... 16 383 blocks because one geometry was never run on real data).
-constexpr uint32_t DISPATCH_WAVE_PAIR_MAX = 2304u;   // <= : a pair of wavefronts per block (above LZ4FLEX_PCD_MAX_BLOCKS)
+constexpr uint32_t DISPATCH_PCD_1024 = 256u;         // <= : a workgroup of 1 024 lanes per block (one per CU); also for large blocks and chains at any count
+constexpr uint32_t DISPATCH_PCD_512 = 512u;          // <= : 512 lanes per block (two per CU)
+constexpr uint32_t DISPATCH_PCD_256 = 1024u;         // <= : 256 lanes per block (four per CU; 1 280 blocks already run in two rounds)
+constexpr uint32_t DISPATCH_WAVE_PAIR_MAX = 2304u;   // <= : a pair of wavefronts per block
 constexpr uint32_t DISPATCH_WAVE_MAX = 5120u;        // <= : a wavefront per block; above: the split decoder
 constexpr uint32_t DISPATCH_SPLIT_16 = 16u * 256u;   // split decoder: >= this many blocks 16 per workgroup, below 8
 constexpr uint32_t DISPATCH_SPLIT_32 = 32u * 256u;
@@ -103,7 +106,7 @@ hipError_t launch_decompress_wave_pair(const DecompressArgs& a, int32_t redo_cod
 hipError_t launch_decompress_split(const DecompressArgs& a, hipStream_t s, int blocks_per_wg = 0);   // parser / copier wavefronts, no dict/prefix
 // one WORKGROUP per block, token chain and copies parallel inside the block (lz4_decompress_pcd.hip: few, large blocks); irregular
 // blocks are left with status redo_code like behind launch_decompress_wave.  test_geometry: tiny tiles / batches (tests only)
-hipError_t launch_decompress_pcd(const DecompressArgs& a, int32_t redo_code, hipStream_t s, bool test_geometry = false);
+hipError_t launch_decompress_pcd(const DecompressArgs& a, int32_t redo_code, hipStream_t s, int geometry = 0);   // 0 production (1 024 lanes), 1 tests, 2 / 3 medium batches (256 / 512 lanes)
 hipError_t launch_compress(const CompressArgs& a, int variant, hipStream_t s);
 // throughput ("wave") encoder, lz4_compress_wave.hip: persistent workgroups, `workspace` holds
 // compress_wave_workspace_bytes(n_workgroups) bytes (cand[] slots + segment bodies, L2 / Infinity Cache resident)

@@ -70,8 +70,7 @@ def big_inputs():
     ]
 
 
-@pytest.mark.parametrize("pair", [0, 2])
-@pytest.mark.parametrize("variant", [7, 8])
+@pytest.mark.parametrize("variant,pair", [(7, 0), (7, 2), (8, 0), (8, 2), (10, 0), (11, 0)])
 def test_large_blocks_every_encoder(env, variant, pair):
     """blocks of up to 4 MiB from the reference encoder (oracle), C liblz4 and this library's throughput encoder (model): bytes ==
     oracle, nothing behind the sink, also with a sink larger than needed.  With one workgroup per block and with a parser and a
@@ -99,7 +98,7 @@ def test_large_blocks_every_encoder(env, variant, pair):
             assert out[o + len(d):o + caps[i]].tobytes() == b"\xA5" * (caps[i] - len(d)), "block %d wrote behind its end" % i
 
 
-@pytest.mark.parametrize("variant", [7, 8])
+@pytest.mark.parametrize("variant", [7, 8, 10, 11])
 def test_first_pass_marks_exactly_what_the_model_calls_irregular(env, variant):
     """kernel == model: without the second pass, the blocks the kernel leaves marked are exactly the ones tests/sim/pcd_model.cpp
     (same geometry) calls irregular, every other block is decoded (== oracle); with the second pass every result equals the
@@ -109,7 +108,9 @@ def test_first_pass_marks_exactly_what_the_model_calls_irregular(env, variant):
     rnd = random.Random(3)
     big = O.compress(bytes(rnd.choice(b"ab") for _ in range(60000)))
     cases += [(big, 60000), (big, 59990), (big[:-5], 60000)]
-    prm = M.defaults() if variant == 7 else M.Params(ct=2048, p=64, batch=256, hist=512, wnew=1024, max_iters=34)
+    prm = {7: M.defaults(), 8: M.Params(ct=2048, p=64, batch=256, hist=512, wnew=1024, max_iters=34),
+           10: M.Params(ct=4096, p=64, batch=512, hist=6144, wnew=8192, max_iters=66),        # GeoMid256 (513 ... 1 024 blocks by default)
+           11: M.Params(ct=8192, p=64, batch=1024, hist=8192, wnew=16384, max_iters=130)}[variant]   # GeoMid512 (257 ... 512 blocks)
     model = [M.decode(c, k, prm, seed=i)[0] for i, (c, k) in enumerate(cases)]
     want = [O.decompress(c, k) for c, k in cases]
     comps, caps = [c for c, _ in cases], [k for _, k in cases]
