@@ -175,7 +175,7 @@ def main():
                     assert O.ERR_NAMES.get(int(st[i])) == w[0], ("decoder", variant, bpw, i, len(c), k, int(st[i]), w[0])
                 assert out[o + k:o + k + 64].tobytes() == b"\xA5" * 64, ("decoder wrote behind a sink", variant, bpw, i)
             blocks += len(cases)
-    print("gpu_fuzz: seed %d, %d rounds, %d inputs through both encoders, %d block decodes through 8 decoder kernels (the workgroup decoder also with two workgroups per block): all equal the oracle" % (args.seed, rounds, inputs, blocks))
+    print("gpu_fuzz: seed %d, %d rounds, %d inputs through both encoders, %d block decodes through %d decoder configurations (every kernel, the workgroup decoder in four geometries and with two workgroups per block): all equal the oracle" % (args.seed, rounds, inputs, blocks, len(decoders)))
 
 
 if __name__ == "__main__":
