@@ -242,7 +242,7 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  *   (lz4_decompress_wave.hip), 6 = the same with a parser and an executor wavefront per block, 4 = parser /
  *   copier split decoder (large batches), 9 = plan / replay (lz4_decompress_plan.hip + lz4_decompress_replay.hip: a parallel
  *   parse per block writes a copy plan, a parse-free copier executes it; an experiment -- slower than 0 on every shape
- *   measured), 1 = decoder whose window lives in HBM/L2 (always used for dictionary / prefix blocks); "decompress_blocks_per_wg" (variant 4: 0 = by batch size, 8/16/32/64); "decompress_lanes"
+ *   measured), 1 = decoder whose window lives in HBM/L2 (always used for dictionary / prefix blocks); "decompress_blocks_per_wg" (variant 4: 0 = 64, the default at every batch size; 8/16/32: the older narrow geometries, tests); "decompress_lanes"
  *   (16; 8/32/64 in -DLZ4FLEX_ALL_VARIANTS builds, variant 1); exact encoder: "compress_lanes" (8/16 lanes of a wavefront per
  *   block), "compress_variant" (1 = group encoder + emitter wavefront; 3 = group encoder alone, -DLZ4FLEX_ALL_VARIANTS builds);
  *   "decompress_second_pass" (tests: 0 leaves the blocks that variants 5..8 hand to the reference-order kernel marked with

@@ -66,7 +66,7 @@ struct lz4flex_ctx {
     hipEvent_t wave_done = nullptr;
     hipStream_t wave_last = nullptr;
     bool wave_used = false;
-    int dec_blocks_per_wg = 0;    // split decoder: blocks per workgroup (8/16/32/64), 0 = by batch size
+    int dec_blocks_per_wg = 0;    // split decoder: blocks per workgroup (8/16/32/64), 0 = 64
     int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 4 = parser / copier split (lz4_decompress_split.hip), 5 / 6 = a wavefront / a pair of wavefronts per block (lz4_decompress_wave.hip), 7 = a workgroup per block (lz4_decompress_pcd.hip; 8: its test geometry), 9 = plan / replay (lz4_decompress_plan.hip + lz4_decompress_replay.hip)
     int comp_carry_wait = 1;      // tests: 0 = a window of the throughput encoder that has to wait for its predecessor's carry gives up at once (the block then takes the second launch)
     int dec_second_pass = 1;      // tests: 0 leaves the blocks a first-pass decoder marked (status 0x7F000001) instead of decoding them again
@@ -425,7 +425,7 @@ int lz4flex_get_tuning(lz4flex_ctx* c, const char* key) {
     // the batch sizes at which the default decoder dispatch changes kernel or geometry (lz4_device.h), in ascending order; the
     // list ends where the key is refused.  tests/test_gpu_block.py builds its size matrix from it.
     if (!strncmp(key, "dispatch_threshold_", 19)) {
-        const uint32_t t[] = {PCD_PAIR_MAX_BLOCKS, DISPATCH_PCD_1024, DISPATCH_PCD_512, DISPATCH_PCD_256, DISPATCH_WAVE_PAIR_MAX, DISPATCH_SPLIT_16, DISPATCH_WAVE_MAX, DISPATCH_SPLIT_32, DISPATCH_SPLIT_64};
+        const uint32_t t[] = {PCD_PAIR_MAX_BLOCKS, DISPATCH_PCD_1024, DISPATCH_PCD_512, DISPATCH_PCD_256, DISPATCH_WAVE_PAIR_MAX, DISPATCH_WAVE_MAX, DISPATCH_SPLIT_FULL};
         const int i = atoi(key + 19);
         if (i < 0 || i >= (int)(sizeof t / sizeof t[0]) || (key[19] < '0' || key[19] > '9')) return -LZ4FLEX_E_INVALID_ARG;
         return (int)t[i];

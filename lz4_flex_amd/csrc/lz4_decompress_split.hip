@@ -536,8 +536,11 @@ static hipError_t launch_cfg(const DecompressArgs& a, hipStream_t s) {
 hipError_t launch_decompress_split(const DecompressArgs& a, hipStream_t s, int blocks_per_wg) {
     if (a.n == 0u) return hipSuccess;
     if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;   // dictionary / prefix: v1 kernel
-    if (blocks_per_wg == 0)
-        blocks_per_wg = a.n >= DISPATCH_SPLIT_64 ? 64 : (a.n >= DISPATCH_SPLIT_32 ? 32 : (a.n >= DISPATCH_SPLIT_16 ? 16 : 8));
+    // 0 = the default: 64 blocks per workgroup whatever the batch size.  The kernel takes as long as a workgroup's slowest block
+    // (1.62 ms for JSON blocks), and rounds 2 and 3 spread smaller batches over more, smaller workgroups (8 / 16 / 32 blocks each, the older
+    // 8-lanes-of-4-bytes copier): 8 193 ... 16 383 blocks then ran in two rounds or several workgroups per CU -- 1.92 ... 2.15 ms where 64
+    // per workgroup needs 1.62 ... 1.66 on half-empty chips (tools/split_geometry.py, profiles/r04_decoder_shapes.txt)
+    if (blocks_per_wg == 0) blocks_per_wg = 64;
     switch (blocks_per_wg) {
         case 64: return v5::launch_cfg<v5::LayoutBig, 64, LZ4S_G, LZ4S_WB, LZ4S_NS>(a, s);
         case 32: return v5::launch_cfg<v5::LayoutBig, 32, 8, 4, 4>(a, s);

@@ -50,9 +50,7 @@ constexpr uint32_t DISPATCH_PCD_512 = 512u;          // <= : 512 lanes per block
 constexpr uint32_t DISPATCH_PCD_256 = 1024u;         // <= : 256 lanes per block (four per CU; 1 280 blocks already run in two rounds)
 constexpr uint32_t DISPATCH_WAVE_PAIR_MAX = 2304u;   // <= : a pair of wavefronts per block
 constexpr uint32_t DISPATCH_WAVE_MAX = 5120u;        // <= : a wavefront per block; above: the split decoder
-constexpr uint32_t DISPATCH_SPLIT_16 = 16u * 256u;   // split decoder: >= this many blocks 16 per workgroup, below 8
-constexpr uint32_t DISPATCH_SPLIT_32 = 32u * 256u;
-constexpr uint32_t DISPATCH_SPLIT_64 = 64u * 256u;
+constexpr uint32_t DISPATCH_SPLIT_FULL = 64u * 256u;  // (not a change of kernel: from here on every CU holds a workgroup of the split decoder; the tests want this size too)
 size_t decompress_pcd_pair_ws_bytes();
 
 struct CompressArgs {
