@@ -123,33 +123,57 @@ struct Copier {
     // run's own bytes (512 bytes of history + the granule that is not complete), with the invariants flush_slide() leaves.
     // The copy is a function of its own (not inlined: its registers would be the kernel's -- inlined, the hot loop spilled and
     // JSON blocks took 1.74 instead of 1.64 ms).
-    static __device__ __attribute__((noinline)) void bulk_copy(const uint8_t* src, uint8_t* dst, uint32_t n, uint32_t g, lds_u8* lds_dst,
-                                                               const uint8_t* hist, uint32_t have) {
+    // The WHOLE WAVEFRONT copies one block's run at a time, 16 bytes per lane and load, four loads in flight (the wavefront's other
+    // blocks cannot step while one of them is served anyway: with only the block's own four lanes copying, a block with several
+    // long runs held its fifteen neighbours up for 30 us each time).  src / dst / n are wave-uniform.
+    static __device__ __attribute__((noinline)) void wave_bulk_copy(const uint8_t* src, uint8_t* dst, uint32_t n_, uint32_t lane) {
         typedef __attribute__((address_space(1))) uint8_t g_u8;      // (named: a pointer that crossed a call is flat)
         typedef u32x4 __attribute__((aligned(1))) u32x4_u;
         typedef __attribute__((address_space(1))) u32x4_u g_u32x4_u;
-        const g_u8* s1 = (const g_u8*)src;
-        g_u8* d1 = (g_u8*)dst;
+        const uint64_t sa = ((uint64_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)src >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)src);
+        const uint64_t da = ((uint64_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)dst >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)dst);
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_);
+        const g_u8* s1 = (const g_u8*)sa;
+        g_u8* d1 = (g_u8*)da;
         auto ld = [&](uint32_t o) -> u32x4 { return *reinterpret_cast<const g_u32x4_u*>(s1 + o); };
         auto st = [&](uint32_t o, const u32x4& v) { *reinterpret_cast<g_u32x4_u*>(d1 + o) = v; };
-        uint32_t i = 16u * g;
-        for (; i + 192u < n; i += 256u) {                           // four loads in flight per lane (eight: no faster, sixteen: slower)
-            const u32x4 v0 = ld(i), v1 = ld(i + 64u), v2 = ld(i + 128u), v3 = ld(i + 192u);
-            st(i, v0); st(i + 64u, v1); st(i + 128u, v2); st(i + 192u, v3);
+        uint32_t i = 16u * lane;
+        for (; i + 3072u < n; i += 4096u) {
+            const u32x4 v0 = ld(i), v1 = ld(i + 1024u), v2 = ld(i + 2048u), v3 = ld(i + 3072u);
+            st(i, v0); st(i + 1024u, v1); st(i + 2048u, v2); st(i + 3072u, v3);
         }
-        for (; i < n; i += 64u) st(i, ld(i));
+        for (; i < n; i += 1024u) st(i, ld(i));
+    }
+    // ... and a block's LDS buffer behind its run: 512 bytes of history + the granule that is not complete, from the run's own bytes
+    static __device__ __attribute__((noinline)) void bulk_rebuild(lds_u8* lds_dst, const uint8_t* hist, uint32_t have, uint32_t g) {
+        typedef __attribute__((address_space(1))) uint8_t g_u8;
+        typedef u32x4 __attribute__((aligned(1))) u32x4_u;
+        typedef __attribute__((address_space(1))) u32x4_u g_u32x4_u;
         const g_u8* h1 = (const g_u8*)hist;
         for (uint32_t k = 16u * g; k < have; k += 16u * G)          // (the last granule reads a few of the run's remaining bytes: there are LONG_KEEP of them)
             *reinterpret_cast<u32x4 __attribute__((address_space(3)))*>(lds_dst + k) = *reinterpret_cast<const g_u32x4_u*>(h1 + k);
     }
-    __device__ void bulk_literals() {
-        final_flush();
-        const uint32_t n = (lit_rem - LONG_KEEP) & ~63u;
-        const uint32_t op2 = op + n, f2 = op2 & ~15u, l2 = f2 > OUT_H ? f2 - OUT_H : 0u;
-        const uint32_t have = op2 - l2;                             // <= OUT_H + 15 <= n: every byte of it is a byte of this run
-        bulk_copy(gin + lit_src, gout + op, n, g, lout, gin + lit_src + n - have, have);
-        op = op2; lit_src += n; lit_rem -= n;
-        F = f2; L0 = l2;
+    // every lane of the wavefront calls this (want: this lane's block has a run to move)
+    __device__ void bulk_literals(bool want) {
+        if (want) final_flush();
+        const uint32_t n = want ? (lit_rem - LONG_KEEP) & ~63u : 0u;
+        const uint64_t sp = (uint64_t)(gin + lit_src), dp = (uint64_t)(gout + op);
+        const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        uint64_t m = __ballot(want && g == 0u);
+        while (m != 0ull) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1ull;
+            const uint64_t s = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(sp >> 32), (int)l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sp, (int)l);
+            const uint64_t d = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(dp >> 32), (int)l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dp, (int)l);
+            wave_bulk_copy((const uint8_t*)s, (uint8_t*)d, (uint32_t)__builtin_amdgcn_readlane((int)n, (int)l), lane);
+        }
+        if (want) {
+            const uint32_t op2 = op + n, f2 = op2 & ~15u, l2 = f2 > OUT_H ? f2 - OUT_H : 0u;
+            const uint32_t have = op2 - l2;                         // <= OUT_H + 15 <= n: every byte of it is a byte of this run
+            bulk_rebuild(lout, gin + lit_src + n - have, have, g);
+            op = op2; lit_src += n; lit_rem -= n;
+            F = f2; L0 = l2;
+        }
     }
     // literals with exact source bounds (the block's last literals end at its last byte)
     __device__ void generic_literals(uint32_t s, uint32_t n) {
@@ -292,9 +316,12 @@ struct Copier {
         if (WB * g < s.n) __builtin_memcpy((void*)(lout + s.dst + WB * g), &x, WB);
     }
     __device__ __forceinline__ void service() {
+        {
+            const bool want = done == 0u && lit_rem >= LONG_LIT && (blocked == K_LONG || blocked == K_CAREFUL || blocked == K_FINISH);
+            if (__any(want)) bulk_literals(want);              // (the whole wavefront: see wave_bulk_copy)
+        }
         if (done) return;
         if (out_space() < FLUSH_AT) flush_slide();
-        if (lit_rem >= LONG_LIT && (blocked == K_LONG || blocked == K_CAREFUL || blocked == K_FINISH)) bulk_literals();
         if (blocked == K_RARE) {   // a periodic match; the record's literals (if any) go first
             generic_literals(lit_src, lit_rem);
             lit_rem = 0u;
