@@ -235,6 +235,11 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  *   reference's and still one launch per batch of blocks; in mode 1 it holds the reference's bytes (one dependency chain,
  *   milliseconds per block).
  *   Environment: LZ4FLEX_COMPRESS_MODE=exact|fast.
+ * "compress_sliding_window" (throughput encoder): 1 (default) = the 64 KiB windows of a block LONGER than 64 KiB advance by
+ *   32 KiB, so every window start has 32 ... 64 KiB of the block behind it -- the reference's window slides continuously
+ *   (src/block/compress.rs:403-405); 4 MiB log blocks 0.3027 -> 0.2928 (the reference: 0.2947) at the price of indexing
+ *   every byte twice; 0 = windows advance by 64 KiB (faster, round 3's bytes).  Blocks of <= 64 KiB are one window either way.
+ *   Environment: LZ4FLEX_SLIDING_WINDOW=0|1.
  * Kernel selection, for measurements only (every choice produces the same bytes / lengths / error variants):
  * "decompress_variant": 0 = by batch size (default), 7 = one block per WORKGROUP, token chain and copies parallel inside the
  *   block (lz4_decompress_pcd.hip: few, large blocks; 8 = the same with its small test geometry, 10 / 11 = with 256 / 512 lanes

@@ -68,6 +68,7 @@ struct lz4flex_ctx {
     bool wave_used = false;
     int dec_blocks_per_wg = 0;    // split decoder: blocks per workgroup (8/16/32/64), 0 = 64
     int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 4 = parser / copier split (lz4_decompress_split.hip), 5 / 6 = a wavefront / a pair of wavefronts per block (lz4_decompress_wave.hip), 7 = a workgroup per block (lz4_decompress_pcd.hip; 8: its test geometry), 9 = plan / replay (lz4_decompress_plan.hip + lz4_decompress_replay.hip)
+    int comp_sliding = 1;         // throughput encoder: the windows of a block longer than 64 KiB advance by 32 KiB (every window start has history); 0 = by 64 KiB (round 3's bytes, faster)
     int comp_carry_wait = 1;      // tests: 0 = a window of the throughput encoder that has to wait for its predecessor's carry gives up at once (the block then takes the second launch)
     int dec_second_pass = 1;      // tests: 0 leaves the blocks a first-pass decoder marked (status 0x7F000001) instead of decoding them again
     // plan / replay decoder (lz4_decompress_plan.hip, lz4_decompress_replay.hip): the copy plans of a batch, plan_slot_words() words per
@@ -190,7 +191,9 @@ static int launch_compress_any(lz4flex_ctx* c, const CompressArgs& a, bool big, 
     if (c->comp_mode == 0) {
         if (!c->wave_ws || !c->wave_done) { g_last_error = "context without encoder workspace"; return -LZ4FLEX_E_INVALID_ARG; }
         if (c->wave_used && s != c->wave_last) HIP_TRY(hipStreamWaitEvent(s, c->wave_done, 0));
-        le = launch_compress_wave(a, c->wave_ws, c->wave_wgs, s, c->wave_prof, c->comp_carry_wait != 0);
+        CompressArgs aw = a;
+        aw.slide = c->comp_sliding != 0 ? 1u : 0u;
+        le = launch_compress_wave(aw, c->wave_ws, c->wave_wgs, s, c->wave_prof, c->comp_carry_wait != 0);
         if (le == hipSuccess) {
             HIP_TRY(hipEventRecord(c->wave_done, s));
             c->wave_last = s;
@@ -278,6 +281,7 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
     if (!c) return -LZ4FLEX_E_NOMEM;
     c->device = device;
     if (const char* e = getenv("LZ4FLEX_COMPRESS_MODE")) c->comp_mode = (!strcmp(e, "exact") || !strcmp(e, "1")) ? 1 : 0;
+    if (const char* e = getenv("LZ4FLEX_SLIDING_WINDOW")) c->comp_sliding = atoi(e) != 0 ? 1 : 0;
 #ifdef LZ4FLEX_ALL_VARIANTS
     if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v == 1 || v == 3) c->comp_variant = v; }
 #endif
@@ -393,6 +397,11 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         c->comp_carry_wait = value;
         return 0;
     }
+    if (!strcmp(key, "compress_sliding_window")) {
+        if (value != 0 && value != 1) return -LZ4FLEX_E_INVALID_ARG;
+        c->comp_sliding = value;
+        return 0;
+    }
     if (!strcmp(key, "compress_variant")) {
 #ifdef LZ4FLEX_ALL_VARIANTS
         if (value != 1 && value != 3) return -LZ4FLEX_E_INVALID_ARG;
@@ -434,6 +443,7 @@ int lz4flex_get_tuning(lz4flex_ctx* c, const char* key) {
     if (!strcmp(key, "compress_mode")) return c->comp_mode;
     if (!strcmp(key, "compress_variant")) return c->comp_variant;
     if (!strcmp(key, "compress_carry_wait")) return c->comp_carry_wait;
+    if (!strcmp(key, "compress_sliding_window")) return c->comp_sliding;
     if (!strcmp(key, "decompress_pcd_pair")) return c->dec_pcd_pair;
     if (!strcmp(key, "compress_lanes")) return c->comp_lanes;
     if (!strcmp(key, "decompress_variant")) return c->dec_variant;

@@ -1117,11 +1117,11 @@ __device__ __attribute__((noinline)) void load_window(const uint8_t* __restrict_
 // is INPUT, nothing waits.  Price: every byte is indexed and loaded twice (the indexer, 160 k of a window's 300 k cycles,
 // becomes the longer half).
 struct Item {
-    uint32_t blk, win, nwin, len, skip, hist;
+    uint32_t blk, win, nwin, len, skip, hist, slide;     // slide: the windows advance by HIST (history in front of the block, or CompressArgs::slide and a long block)
     uint64_t in_off;
 };
 // window geometry: window t.win covers [win_base, win_base + win_len) of the item and parses [win_from, that end)
-__device__ __forceinline__ uint32_t win_stride(const Item& t) { return t.hist != 0u ? HIST : WINDOW; }
+__device__ __forceinline__ uint32_t win_stride(const Item& t) { return t.slide != 0u ? HIST : WINDOW; }
 // the LAST window of an item longer than a window is anchored at the item's end and overlaps the window before it, so the tail can
 // match backwards like the reference's (src/block/compress.rs:403-405: the window is the previous 64 KiB; a 66 675-byte block is
 // 65 536 + 1 139 bytes)
@@ -1134,7 +1134,7 @@ __device__ __forceinline__ uint32_t win_len(const Item& t) {
 }
 __device__ __forceinline__ void item_load(const CompressArgs& a, Item& it) {
     // first window of block it.blk (or invalid)
-    it.win = 0u; it.nwin = 0u; it.len = 0u; it.skip = 0u; it.hist = 0u; it.in_off = 0ull;
+    it.win = 0u; it.nwin = 0u; it.len = 0u; it.skip = 0u; it.hist = 0u; it.slide = 0u; it.in_off = 0ull;
     if (it.blk >= a.n) return;
     const uint32_t len = a.in_len[it.blk];
     const uint32_t cap = a.out_cap[it.blk];
@@ -1142,7 +1142,10 @@ __device__ __forceinline__ void item_load(const CompressArgs& a, Item& it) {
     it.hist = h;
     it.len = len + h;
     it.in_off = a.in_off[it.blk] - h;
-    it.nwin = h != 0u ? (it.len <= WINDOW ? 1u : 1u + (it.len - WINDOW + HIST - 1u) / HIST)
+    // (sliding windows without history: every window start of a block longer than a window sees >= 32 KiB behind it, like the
+    // reference's continuously sliding window, src/block/compress.rs:403-405 -- 4 MiB log blocks 0.3027 -> 0.2928, the reference 0.2947)
+    it.slide = (h != 0u || (a.slide != 0u && len > WINDOW)) ? 1u : 0u;
+    it.nwin = it.slide != 0u ? (it.len <= WINDOW ? 1u : 1u + (it.len - WINDOW + HIST - 1u) / HIST)
                       : (len == 0u ? 1u : (uint32_t)(((uint64_t)len + WINDOW - 1u) / WINDOW));
     const uint64_t need = 20ull + (uint64_t)len * 110ull / 100ull;   // get_maximum_output_size, compress.rs:588-590
     if ((uint64_t)cap < need) { it.skip = 1u; it.nwin = 1u; }
@@ -1278,8 +1281,8 @@ __device__ __forceinline__ void wave_body(const CompressArgs& a, uint8_t* __rest
             if (ix.blk < a.n) do_index(ix, (k + 1u) & 1u);
         } else if (!it.skip) {
             const uint32_t base = win_base(it), skip = win_skip(it);
-            uint32_t s0 = seg_start(w, skip, it.hist != 0u);
-            uint32_t s1 = seg_start(w + 1u, skip, it.hist != 0u);
+            uint32_t s0 = seg_start(w, skip, it.slide != 0u);
+            uint32_t s1 = seg_start(w + 1u, skip, it.slide != 0u);
             s0 = s0 < wl ? s0 : wl;
             s1 = s1 < wl ? s1 : wl;
             const uint32_t act_abs = it.len >= 12u ? it.len - 11u : 0u;
@@ -1307,7 +1310,7 @@ __device__ __forceinline__ void wave_body(const CompressArgs& a, uint8_t* __rest
             if (it.skip) {
                 if (threadIdx.x == 0u) { a.out_len[it.blk] = 0u; a.status[it.blk] = LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL; }
             } else {
-                place_segment(lds, a.in_base + it.in_off, it.len, it.win, last_win, wl, win_base(it), win_skip(it), it.hist != 0u, bodies + (size_t)w * BODY_STRIDE,
+                place_segment(lds, a.in_base + it.in_off, it.len, it.win, last_win, wl, win_base(it), win_skip(it), it.slide != 0u, bodies + (size_t)w * BODY_STRIDE,
                               a.out_base + a.out_off[it.blk], k & 1u, w, lane, a.out_len + it.blk, a.status + it.blk,
                               wmode ? carry + CARRY_DWORDS * (size_t)it.blk : nullptr, k + 1u, carry_spins);
             }

@@ -64,6 +64,7 @@ struct CompressArgs {
     uint32_t* out_len;
     int32_t* status;
     uint32_t n;
+    uint32_t slide;            // throughput encoder: 1 = the windows of a block longer than 64 KiB advance by 32 KiB (lz4_compress_wave.hip Item)
 };
 
 // plan / replay decoder (lz4_decompress_plan.hip, lz4_decompress_replay.hip; record format: lz4_plan_common.h)

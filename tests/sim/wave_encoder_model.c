@@ -39,6 +39,7 @@ typedef struct {
     uint32_t cap;    /* longest match a head counts */
     uint32_t skipd;  /* a position buried this deep in a running match is not evaluated */
     uint32_t hist;   /* 0, or HIST: `in` starts HIST bytes before the block (a Linked frame's previous bytes); they are history only */
+    uint32_t slide;  /* 1: windows advance by HIST even without history in front of the block (every window start of a long block sees >= 32 KiB behind it) */
 } lz4w_params;
 #define HIST (WINDOW / 2u)
 
@@ -51,14 +52,16 @@ static inline uint32_t ld32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); re
  * the tail, and the reference's ratio pin for its JSON fixture (tests/tests.rs:168-170) fails. */
 /* With history in front of the block (hist == HIST; `n` counts it) the windows advance by HIST instead of WINDOW, so every parsed
  * position has 32 to 64 KiB of the stream behind it in its window. */
+static uint32_t g_slide;   /* (set by lz4w_compress from the parameters: hist != 0 or slide) */
 static uint32_t win_count(uint32_t n, uint32_t hist) {
-    if (hist) return n <= WINDOW ? 1 : 1 + (n - WINDOW + HIST - 1) / HIST;
+    (void)hist;
+    if (g_slide) return n <= WINDOW ? 1 : 1 + (n - WINDOW + HIST - 1) / HIST;
     return (n + WINDOW - 1) / WINDOW;
 }
 static uint32_t win_base(uint32_t n, uint32_t wi, uint32_t hist) {
-    return (wi + 1 == win_count(n, hist) && n > WINDOW) ? n - WINDOW : wi * (hist ? HIST : WINDOW);
+    return (wi + 1 == win_count(n, hist) && n > WINDOW) ? n - WINDOW : wi * (g_slide ? HIST : WINDOW);
 }
-static uint32_t win_from(uint32_t wi, uint32_t hist) { return wi == 0 ? hist : (wi - 1) * (hist ? HIST : WINDOW) + WINDOW; }   /* parsed from here on */
+static uint32_t win_from(uint32_t wi, uint32_t hist) { return wi == 0 ? hist : (wi - 1) * (g_slide ? HIST : WINDOW) + WINDOW; }   /* parsed from here on */
 
 /* index pass: d[p] for every p (0 = no candidate).  The table is cleared at every window start, so a candidate never lies
  * before its position's window; steps of 64 positions are counted from the window's base. */
@@ -135,8 +138,8 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
         static const uint32_t lo8[9] = {0, 16, 33, 50, 67, 82, 98, 113, 128};
         uint32_t s0 = wbase + 512u * (P->nseg == 8 ? lo8[wj] : (128u * wj) / P->nseg);
         uint32_t s1 = wbase + 512u * (P->nseg == 8 ? lo8[wj + 1] : (128u * (wj + 1)) / P->nseg);
-        if (hist) {
-            /* with history the segments share the PARSED part of the window in the same proportions (clipped, half of the
+        if (g_slide) {
+            /* with history (or sliding windows) the segments share the PARSED part of the window in the same proportions (clipped, half of the
              * kernel's workers would idle); starts other than the first are multiples of 512 */
             const uint32_t skip = newfrom - wbase;
             const uint32_t g0 = (s0 - wbase) / 512u, g1 = (s1 - wbase) / 512u;
@@ -235,6 +238,7 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
 size_t lz4w_compress(const uint8_t *in, uint32_t n, uint8_t *out, const lz4w_params *P, uint32_t *n_seq) {
     uint16_t *d = (uint16_t *)calloc((size_t)n + WAVE, 2);
     lz4w_seq *seqs = (lz4w_seq *)malloc(sizeof(lz4w_seq) * ((size_t)n / 4 + 2));
+    g_slide = (P->hist != 0 || P->slide != 0);
     if (n) lz4w_index(in, n, d, P->hist);
     const size_t ns = n ? lz4w_parse(in, n, d, P, seqs) : 0;
     size_t o = 0;

@@ -195,9 +195,33 @@ def test_wave_encoder_heads_at_a_window_end(blk):
     with open(os.path.join(here, "golden", "fuzz_window_end_heads.zlib"), "rb") as f:
         d = zlib.decompress(f.read())
     assert len(d) == 139612
-    c = blk.compress(d)
-    assert O.decompress(c, len(d)) == ("ok", d)
-    assert c == W.compress(d)
+    from lz4_flex_amd import _lib as L
+    lib = L.load()
+    try:
+        for slide in (0, 1):          # windows advancing by 64 KiB (where the fuzzer found it), and by 32 KiB (the default for long blocks)
+            assert lib.lz4flex_set_tuning(None, b"compress_sliding_window", slide) == 0
+            c = blk.compress(d)
+            assert O.decompress(c, len(d)) == ("ok", d)
+            assert c == W.compress(d, slide=slide)
+    finally:
+        assert lib.lz4flex_set_tuning(None, b"compress_sliding_window", 1) == 0
+
+
+def test_wave_encoder_sliding_windows_off(blk):
+    """"compress_sliding_window" 0: the windows of a long block advance by 64 KiB (round 3's bytes); blocks of every length class
+    == model with slide 0, decoded by the oracle"""
+    from lz4_flex_amd import _lib as L
+    lib = L.load()
+    j = O.fixture_plain("compression_66k_JSON")
+    assert lib.lz4flex_set_tuning(None, b"compress_sliding_window", 0) == 0
+    try:
+        for n in (65536, 65537, 66675, 98304, 131072 + 77, 300000, 1048576 + 5):
+            d = (j * 17)[:n]
+            c = blk.compress(d)
+            assert O.decompress(c, n) == ("ok", d)
+            assert c == W.compress(d, slide=0), n
+    finally:
+        assert lib.lz4flex_set_tuning(None, b"compress_sliding_window", 1) == 0
 
 
 def _history_batch(blk, L, sizes, seed):

@@ -88,10 +88,11 @@ def test_model_on_the_window_end_fixture():
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "golden", "fuzz_window_end_heads.zlib"), "rb") as f:
         d = zlib.decompress(f.read())
-    c = W.compress(d)
-    assert O.decompress(c, len(d)) == ("ok", d)
-    assert O.c_decompress(c, len(d)) == d
-    assert len(c) == 41631        # (41 666 before adjacent matches of one distance were merged, round 4)
+    for slide, size in ((0, 41631), (1, 40898)):      # windows that advance by 64 KiB (where the fuzzer found it) / by 32 KiB (the default for long blocks)
+        c = W.compress(d, slide=slide)
+        assert O.decompress(c, len(d)) == ("ok", d)
+        assert O.c_decompress(c, len(d)) == d
+        assert len(c) == size     # (41 666 before adjacent matches of one distance were merged, round 4)
 
 
 def test_history_in_front_of_a_block():

@@ -11,7 +11,7 @@ NSEG, CAP, SKIPD = 8, 1024, 64    # the kernel's constants (lz4_compress_wave.hi
 
 
 class Params(C.Structure):
-    _fields_ = [("nseg", C.c_uint32), ("cap", C.c_uint32), ("skipd", C.c_uint32), ("hist", C.c_uint32)]
+    _fields_ = [("nseg", C.c_uint32), ("cap", C.c_uint32), ("skipd", C.c_uint32), ("hist", C.c_uint32), ("slide", C.c_uint32)]
 
 
 _m = None
@@ -32,13 +32,15 @@ def lib():
 HIST = 32768                      # lz4_compress_wave.hip: HIST
 
 
-def compress(data, nseg=NSEG, cap=CAP, skipd=SKIPD, hist=0):
-    """hist: 0, or HIST -- `data` starts with HIST bytes of history (the stream in front of the block: a Linked frame), which are
+def compress(data, nseg=NSEG, cap=CAP, skipd=SKIPD, hist=0, slide=None):
+    """slide: None = the library's default; hist: 0, or HIST -- `data` starts with HIST bytes of history (the stream in front of the block: a Linked frame), which are
     not emitted; the result is the block alone and needs them as its dictionary"""
     data = bytes(data)
     assert hist == 0 or (hist == HIST and len(data) > hist)
     out = C.create_string_buffer(20 + len(data) * 110 // 100 + 16)
-    p = Params(nseg, cap, skipd, hist)
+    if slide is None:           # the library's default ("compress_sliding_window" 1): the windows of a block longer than 64 KiB advance by 32 KiB
+        slide = 1 if len(data) - hist > 65536 else 0
+    p = Params(nseg, cap, skipd, hist, slide)
     ns = C.c_uint32(0)
     n = lib().lz4w_compress(data, len(data), out, C.byref(p), C.byref(ns))
     return out.raw[:n]
