@@ -154,7 +154,13 @@ __device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { 
 __device__ __forceinline__ uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
 __device__ __forceinline__ uint32_t len_ext_bytes(uint32_t v) { return v >= 15u ? (v - 15u) / 255u + 1u : 0u; }   // compress.rs:237-247
 
-__device__ __forceinline__ uint32_t ffbl(uint32_t x) { return (uint32_t)(__ffs((int)x) - 1); }   // v_ffbl_b32: 0xFFFFFFFF for 0
+// v_ffbl_b32: index of the lowest set bit, 0xFFFFFFFF for 0.  As inline assembly: written as __ffs(x) - 1 hipcc guards the zero case
+// with a compare and a select per dword (first_diff: 22 vector instructions instead of 13, a tenth of the workers' instructions)
+#ifndef LZ4W_NO_HWFFBL
+__device__ __forceinline__ uint32_t ffbl(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+#else
+__device__ __forceinline__ uint32_t ffbl(uint32_t x) { return (uint32_t)(__ffs((int)x) - 1); }
+#endif
 // arguments of a non-inlined function arrive in VGPRs as flat pointers: make them scalar, global-address-space pointers
 template <typename G, typename T>
 __device__ __forceinline__ G* uni_gptr(T* p) {
@@ -575,6 +581,11 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
         const uint32_t f0 = ffbl(va.x ^ vc.x), f1 = ffbl(va.y ^ vc.y), f2 = ffbl(va.z ^ vc.z), f3 = ffbl(va.w ^ vc.w);   // 0xFFFFFFFF: equal
         return umin3(umin3(f0, f1 | 32u, f2 | 64u), f3 | 96u, 128u);        // f < 32 or all ones: "or" is "add" or keeps "none"
     };
+    auto first_diff32 = [](const u32x4& va0, const u32x4& vc0, const u32x4& va1, const u32x4& vc1) -> uint32_t {   // the same over 32 bytes: 256 if none
+        const uint32_t f0 = ffbl(va0.x ^ vc0.x), f1 = ffbl(va0.y ^ vc0.y), f2 = ffbl(va0.z ^ vc0.z), f3 = ffbl(va0.w ^ vc0.w);
+        const uint32_t f4 = ffbl(va1.x ^ vc1.x), f5 = ffbl(va1.y ^ vc1.y), f6 = ffbl(va1.z ^ vc1.z), f7 = ffbl(va1.w ^ vc1.w);
+        return umin3(umin3(umin3(umin3(f0, f1 | 32u, f2 | 64u), f3 | 96u, f4 | 128u), f5 | 160u, f6 | 192u), f7 | 224u, 256u);
+    };
 
     // One superstep of NS steps at b (a multiple of 64 NS); t_u = distances of step u.  false: more than 128 heads, nothing
     // was changed, the caller halves.
@@ -605,11 +616,22 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
         // (conditions are kept as 64-bit lane masks: a bool that is changed under a branch makes hipcc materialise it in a
         // VGPR and compare again)
         auto bal = [](bool c) -> uint64_t { return __builtin_amdgcn_ballot_w64(c); };
-        uint64_t K0 = bal(t0 != 0u) & bal(t0 != dpp_wave_shr1(t0, dlast)), K1 = 0ull, K2 = 0ull, K3 = 0ull;
-        if (NS > 1u) K1 = bal(t1 != 0u) & bal(t1 != dpp_wave_shr1(t1, rdlane(t0, 63u)));
+        uint64_t K0 = bal(t0 != dpp_wave_shr1(t0, dlast)), K1 = 0ull, K2 = 0ull, K3 = 0ull;
+        if (NS > 1u) K1 = bal(t1 != dpp_wave_shr1(t1, rdlane(t0, 63u)));
         if (NS > 2u) {
-            K2 = bal(t2 != 0u) & bal(t2 != dpp_wave_shr1(t2, rdlane(t1, 63u)));
-            K3 = bal(t3 != 0u) & bal(t3 != dpp_wave_shr1(t3, rdlane(t2, 63u)));
+            K2 = bal(t2 != dpp_wave_shr1(t2, rdlane(t1, 63u)));
+            K3 = bal(t3 != dpp_wave_shr1(t3, rdlane(t2, 63u)));
+        }
+        // "no candidate" is distance 0, and only two kinds of position carry it: the window's position 0 (never a head: its
+        // predecessor value is the initial dlast, 0 as well; with history in front of the segment the b < s0 branch below masks it)
+        // and the positions from the block's last match start on (>= mfl_end) -- so the test is paid in a block's last supersteps only
+#ifndef LZ4W_NO_EDGE_T0
+        if (b + 64u * NS > mfl_end)
+#endif
+        {
+            K0 &= bal(t0 != 0u);
+            if (NS > 1u) K1 &= bal(t1 != 0u);
+            if (NS > 2u) { K2 &= bal(t2 != 0u); K3 &= bal(t3 != 0u); }
         }
         if (b < s0) {
             // the segment starts inside this superstep (only the anchored last window of a block, see win_base): positions before
@@ -654,59 +676,63 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
                    hh2 = __builtin_amdgcn_inverse_ballot_w64(M2), hh3 = __builtin_amdgcn_inverse_ballot_w64(M3);
         // the match of one chunk's heads that reaches furthest: bestv[r] = best among heads 0..r of the chunk and everything
         // before it (cin); returns the best behind the chunk's last head
-        auto chunk_best = [&](const uint32_t hv, const bool isH, const uint32_t cin, uint32_t& bestv) -> uint32_t {
+        auto chunk_best = [&](const uint32_t hv, const uint64_t hmask, const uint32_t cin, uint32_t& bestv) -> uint32_t {
             const uint32_t p = hv >> 16, d = hv & 0xFFFFu;
-            // true match lengths of the heads (their first 4 bytes are known to match)
+            // true match lengths of the heads in the lanes of hmask (their first 4 bytes are known to match)
             uint32_t lim = __builtin_elementwise_sub_sat(mend, p);
             lim = lim < CAP ? lim : CAP;
             uint32_t k = 4u;
-            bool act = isH & (lim > 4u);
+            // The lanes still counting are a 64-bit lane mask in scalar registers (`am`), the loop below is uniform control flow
+            // around exec-masked bodies, and every condition becomes a mask by a ballot of ONE compare outside the masked body
+            // (a bool that is the AND of two compares, or that is set under a branch, goes through v_cndmask + v_cmp to be
+            // balloted; carried around the loop it also drags the round counter into a vector register).
+            uint64_t am = hmask & __builtin_amdgcn_ballot_w64(lim > 4u);
 #ifdef LZ4W_EXP_NOLEN
-            act = false;
+            am = 0ull;
 #endif
-            if (__builtin_amdgcn_ballot_w64(act) != 0ull) {
-                if (act) {                                          // 16 bytes, branch-free: most candidates end here
+            if (am != 0ull) {
+                uint32_t bits = 0u;
+                if (__builtin_amdgcn_inverse_ballot_w64(am)) {     // 16 bytes, branch-free: most candidates end here
                     u32x4 va, vc;
                     // (ten aligned dword reads + 8 v_alignbyte instead of two unaligned 16-byte reads: an unaligned LDS access
                     // takes the CU's LDS pipe for a cycle per active lane, and ~48 lanes are active here; 4.38 -> 4.25 ms.  The
                     // later rounds have few active lanes: there the unaligned reads are the cheaper ones, measured)
                     va = ld16a(p + 4u); vc = ld16a(p + 4u - d);
-                    const uint32_t bits = first_diff(va, vc);
+                    bits = first_diff(va, vc);
                     k = 4u + (bits >> 3);
-                    act = (bits == 128u) & (k < lim);
                 }
-                for (uint32_t rounds = 0u; __builtin_amdgcn_ballot_w64(act) != 0ull; ++rounds) {
-                    if (rounds == 2u) {
+                asm volatile("" : "+v"(bits));          // (the compare stays OUTSIDE the masked body: moved into it, its result comes back through v_cndmask + v_cmp)
+                am = __builtin_amdgcn_ballot_w64(bits == 128u) & __builtin_amdgcn_ballot_w64(k < lim);
+                for (uint32_t rounds = 0u; am != 0ull; ++rounds) {
+                    if (rounds == 2u && (uint32_t)__builtin_popcountll(am) >= LONGN) {       // (a handful of long matches is ordinary data: no check)
                         // Heads still matching after LONGK bytes.  In a run (zeros, a repeated record) EVERY position is one, and 64
                         // lanes reading unaligned to the cap keep the LDS pipe busy for 16 ms per GiB: a head followed within NEARP
                         // positions by another such head stays at LONGK bytes (it starts just before a match that is at least as
                         // long as it is known to be); the last one of such a group goes on.
                         static_assert(LONGK == 4u + 16u + 2u * 32u, "the check sits behind the third compare round");
-                        const uint64_t am = __builtin_amdgcn_ballot_w64(act);
-                        if ((uint32_t)__builtin_popcountll(am) >= LONGN) {       // (a handful of long matches is ordinary data: no check)
                         const uint64_t above = (am >> lane) >> 1;                                      // active lanes behind this one, bit 0 = lane + 1
                         const uint32_t next = lane + 1u + ctz64(above | (1ull << 63));                 // the next active lane (anything if none)
                         const uint32_t pn = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((next & 63u) << 2), (int)p);
-                        act = act & ((above == 0ull) | (pn - p > NEARP));
-                        if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
-                        }
+                        am &= __builtin_amdgcn_ballot_w64(above == 0ull) | __builtin_amdgcn_ballot_w64(pn - p > NEARP);
+                        if (am == 0ull) break;
                     }
-                    if (act) {                                      // 32 bytes per further round
+                    bits = 0u;
+                    if (__builtin_amdgcn_inverse_ballot_w64(am)) {      // 32 bytes per further round
                         const lds_u8* ap = win + p + k;
                         u32x4 va0, vc0, va1, vc1;
                         __builtin_memcpy(&va0, (const void*)ap, 16);
                         __builtin_memcpy(&vc0, (const void*)(ap - d), 16);
                         __builtin_memcpy(&va1, (const void*)(ap + 16), 16);
                         __builtin_memcpy(&vc1, (const void*)(ap - d + 16), 16);
-                        const uint32_t d0 = first_diff(va0, vc0), d1 = first_diff(va1, vc1);
-                        const uint32_t bits = d0 < 128u ? d0 : 128u + d1;
+                        bits = first_diff32(va0, vc0, va1, vc1);
                         k += bits >> 3;
-                        act = (bits == 256u) & (k < lim);
                     }
+                    asm volatile("" : "+v"(bits));
+                    am = __builtin_amdgcn_ballot_w64(bits == 256u) & __builtin_amdgcn_ballot_w64(k < lim);
                 }
             }
             k = k < lim ? k : lim;
-            const uint32_t own_e = (isH & (k >= 4u)) ? hv + (k << 16) : 0u;      // (p + k) << 16 | d
+            const uint32_t own_e = __builtin_amdgcn_inverse_ballot_w64(hmask & __builtin_amdgcn_ballot_w64(k >= 4u)) ? hv + (k << 16) : 0u;      // (p + k) << 16 | d
             bestv = wave_incl_max(own_e);
             bestv = bestv > cin ? bestv : cin;
             return rdlane(bestv, 63u);
@@ -725,12 +751,12 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
             if (hh0) cmp[r0] = (p0 << 16) | t0;
             if (NS > 1u) if (hh1) cmp[r1] = (p1 << 16) | t1;
             if (NS > 2u) { if (hh2) cmp[r2] = (p2 << 16) | t2; if (hh3) cmp[r3] = (p3 << 16) | t3; }
-            const bool isH = lane < H;
+            const uint64_t hmask = H >= 64u ? ~0ull : (1ull << H) - 1ull;      // lanes 0 .. H - 1
             uint32_t hv = 0u;
-            if (isH) hv = cmp[lane];
+            if (__builtin_amdgcn_inverse_ballot_w64(hmask)) hv = cmp[lane];
             uint32_t bestv;
             const uint32_t cin = carry;
-            carry = chunk_best(hv, isH, cin, bestv);
+            carry = chunk_best(hv, hmask, cin, bestv);
             const uint32_t bestsh = dpp_wave_shr1(bestv, cin);      // the same before head r, i.e. with r heads passed
             LZ4W_TICK(1)
             auto best_at = [&](uint32_t ri) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ri << 2), (int)bestsh); };
@@ -755,15 +781,15 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
             if (hh1 && r1 < 64u) cmp[r1] = (p1 << 16) | t1;
             if (NS > 2u) { if (hh2 && r2 < 64u) cmp[r2] = (p2 << 16) | t2; if (hh3 && r3 < 64u) cmp[r3] = (p3 << 16) | t3; }
             uint32_t hv = cmp[lane], bestv;
-            const uint32_t cmid = chunk_best(hv, true, carry, bestv);
+            const uint32_t cmid = chunk_best(hv, ~0ull, carry, bestv);
             best[1u + lane] = bestv;
             if (hh0 && r0 >= 64u) cmp[r0 - 64u] = (p0 << 16) | t0;
             if (hh1 && r1 >= 64u) cmp[r1 - 64u] = (p1 << 16) | t1;
             if (NS > 2u) { if (hh2 && r2 >= 64u) cmp[r2 - 64u] = (p2 << 16) | t2; if (hh3 && r3 >= 64u) cmp[r3 - 64u] = (p3 << 16) | t3; }
-            const bool isH1 = lane < H - 64u;
+            const uint64_t hmask1 = H >= 128u ? ~0ull : (1ull << (H - 64u)) - 1ull;   // lanes 0 .. H - 65
             hv = 0u;
-            if (isH1) hv = cmp[lane];
-            carry = chunk_best(hv, isH1, cmid, bestv);
+            if (__builtin_amdgcn_inverse_ballot_w64(hmask1)) hv = cmp[lane];
+            carry = chunk_best(hv, hmask1, cmid, bestv);
             best[65u + lane] = bestv;
             LZ4W_TICK(1)
             q0 = best[ri0]; q1 = best[ri1];

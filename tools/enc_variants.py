@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=16384)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--data", default="json", choices=["json", "text", "random", "zeros"])
+    ap.add_argument("--no-small", action="store_true", help="skip the small inputs (scalar calls: few blocks, windows dealt to workgroups)")
     args = ap.parse_args()
     import torch
     import oracle_api as O
@@ -77,7 +78,7 @@ def main():
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     ctx0 = C.c_void_p()
     assert base.lz4flex_ctx_create(C.byref(ctx0), 0) == 0
-    inputs = small_inputs()
+    inputs = [] if args.no_small else small_inputs()
     models = [wave_model.compress(d) for d in inputs]
 
     for path in args.libs:
