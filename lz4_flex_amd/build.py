@@ -129,6 +129,10 @@ REPLAY_SRC = "lz4_decompress_replay.hip"
 REPLAY_PLAIN_LOADS = "-DLZ4R_PLAIN_LOADS"   # the replay decoder's loads in every lane, waited for by the compiler: slower, always right
 
 
+FUSED_SRC = "lz4_decompress_fused.hip"
+FUSED_PLAIN_LOADS = "-DLZ4F_PLAIN_LOADS"     # the fused decoder's loads under a plain branch, waited for by the compiler: slower, always right
+
+
 def file_isa(src, extra_flags=()):
     """the `hipcc -S` listing (device code) of one source file with the build's flags"""
     out = os.path.join(BDIR, src.rsplit(".", 1)[0] + "_check.s")
@@ -161,6 +165,21 @@ def replay_extra_flags():
     return [REPLAY_PLAIN_LOADS]
 
 
+def fused_isa(extra_flags=()):
+    """the listing of the fused decoder"""
+    return file_isa(FUSED_SRC, extra_flags)
+
+
+def fused_extra_flags():
+    """[] when this toolchain leaves the fused decoder's in-flight registers alone, else [FUSED_PLAIN_LOADS]"""
+    ok, msg, loads, waits = check_async_loads(fused_isa(), "lz4f")
+    if ok and loads >= 8 and waits >= 8:
+        return []
+    print("lz4_flex_amd.build: %s: the hand-scheduled loads of the fused decoder are not safe with this compiler (%s); "
+          "building it with %s" % (FUSED_SRC, msg or "markers missing: %d loads, %d waits" % (loads, waits), FUSED_PLAIN_LOADS), file=sys.stderr)
+    return [FUSED_PLAIN_LOADS]
+
+
 def wave_extra_flags():
     """[] when this toolchain leaves the in-flight registers alone (today's does), else [PLAIN_LOADS] -- decided at build time on
     the ISA that is about to be shipped, so that a compiler update degrades the encoder's speed and not its output"""
@@ -175,7 +194,7 @@ def wave_extra_flags():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    per_file = {WAVE_SRC: wave_extra_flags(), REPLAY_SRC: replay_extra_flags()}
+    per_file = {WAVE_SRC: wave_extra_flags(), REPLAY_SRC: replay_extra_flags(), FUSED_SRC: fused_extra_flags()}
     hipcc = _hipcc()
     os.makedirs(BDIR, exist_ok=True)
     sh = source_hash()

@@ -67,7 +67,7 @@ struct lz4flex_ctx {
     hipStream_t wave_last = nullptr;
     bool wave_used = false;
     int dec_blocks_per_wg = 0;    // split decoder: blocks per workgroup (8/16/32/64), 0 = 64
-    int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 4 = parser / copier split (lz4_decompress_split.hip), 5 / 6 = a wavefront / a pair of wavefronts per block (lz4_decompress_wave.hip), 7 = a workgroup per block (lz4_decompress_pcd.hip; 8: its test geometry), 9 = plan / replay (lz4_decompress_plan.hip + lz4_decompress_replay.hip)
+    int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 4 = parser / copier split (lz4_decompress_split.hip), 5 / 6 = a wavefront / a pair of wavefronts per block (lz4_decompress_wave.hip), 7 = a workgroup per block (lz4_decompress_pcd.hip; 8: its test geometry), 9 = plan / replay (lz4_decompress_plan.hip + lz4_decompress_replay.hip), 12 = parser / emitter / quads (lz4_decompress_fused.hip)
     int comp_sliding = 1;         // throughput encoder: the windows of a block longer than 64 KiB advance by 32 KiB (every window start has history); 0 = by 64 KiB (round 3's bytes, faster)
     int comp_carry_wait = 1;      // tests: 0 = a window of the throughput encoder that has to wait for its predecessor's carry gives up at once (the block then takes the second launch)
     int dec_second_pass = 1;      // tests: 0 leaves the blocks a first-pass decoder marked (status 0x7F000001) instead of decoding them again
@@ -105,6 +105,7 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
     int v = c->dec_variant != 0 ? c->dec_variant
                                 : ((a.n <= PCD_MAX_BLOCKS || big_blocks) ? 7 : (a.n <= DISPATCH_WAVE_PAIR_MAX ? 6 : (a.n <= DISPATCH_WAVE_MAX ? 5 : 4)));
     if (a.out_pos != nullptr && v != 8) v = 7;           // prefix mode (Linked frames): only the workgroup decoder knows it
+    if (v == 12 && a.dict_base != nullptr) v = 4;
     // the workgroup decoder's geometry by batch size (lz4_decompress_pcd.hip GeoMid*: smaller workgroups, more of them per CU); large
     // blocks and chains keep the full workgroup (a chain is one block at a time, a large block wants the long tiles)
     int pcd_geo = v == 8 ? 1 : (v == 10 ? 2 : (v == 11 ? 3 : 0));
@@ -173,6 +174,16 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
         r.only_status = REDO;
         // a chained batch's marked blocks depend on each other: in chain order, not side by side
         return r.chain_done ? launch_decompress_chain_redo(r, s) : launch_decompress(r, c->dec_lanes, s);
+    }
+    if (v == 12) {
+        // parser -> emitter -> quads (lz4_decompress_fused.hip); oversized blocks go to the reference-order kernel
+        constexpr int32_t REDO = 0x7F000001;
+        const hipError_t e = launch_decompress_fused(a, REDO, s);
+        if (e != hipSuccess) return e;
+        if (!c->dec_second_pass) return hipSuccess;
+        DecompressArgs r = a;
+        r.only_status = REDO;
+        return launch_decompress(r, c->dec_lanes, s);
     }
     return launch_decompress_split(a, s, c->dec_blocks_per_wg);
 }
@@ -285,7 +296,7 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
 #ifdef LZ4FLEX_ALL_VARIANTS
     if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v == 1 || v == 3) c->comp_variant = v; }
 #endif
-    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v == 0 || v == 1 || (v >= 4 && v <= 11)) c->dec_variant = v; }
+    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v == 0 || v == 1 || (v >= 4 && v <= 12)) c->dec_variant = v; }
     int prev = 0;
     (void)hipGetDevice(&prev);
     e = hipSetDevice(device);
@@ -378,7 +389,7 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "decompress_variant")) {
-        if (value != 0 && value != 1 && (value < 4 || value > 11)) return -LZ4FLEX_E_INVALID_ARG;
+        if (value != 0 && value != 1 && (value < 4 || value > 12)) return -LZ4FLEX_E_INVALID_ARG;
         c->dec_variant = value;
         return 0;
     }

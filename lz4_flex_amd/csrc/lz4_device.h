@@ -103,6 +103,9 @@ hipError_t launch_decompress_chain_redo(const DecompressArgs& a, hipStream_t s);
 hipError_t launch_decompress_wave(const DecompressArgs& a, int32_t redo_code, hipStream_t s);
 hipError_t launch_decompress_wave_pair(const DecompressArgs& a, int32_t redo_code, hipStream_t s);
 hipError_t launch_decompress_split(const DecompressArgs& a, hipStream_t s, int blocks_per_wg = 0);   // parser / copier wavefronts, no dict/prefix
+// parser -> emitter -> quad wavefronts (lz4_decompress_fused.hip: the split decoder's parser, the replay decoder's copy engine, no dict/prefix);
+// blocks of 512 KiB or more are left with status redo_code for a second pass of launch_decompress
+hipError_t launch_decompress_fused(const DecompressArgs& a, int32_t redo_code, hipStream_t s);
 // one WORKGROUP per block, token chain and copies parallel inside the block (lz4_decompress_pcd.hip: few, large blocks); irregular
 // blocks are left with status redo_code like behind launch_decompress_wave.  test_geometry: tiny tiles / batches (tests only)
 hipError_t launch_decompress_pcd(const DecompressArgs& a, int32_t redo_code, hipStream_t s, int geometry = 0);   // 0 production (1 024 lanes), 1 tests, 2 / 3 medium batches (256 / 512 lanes)

@@ -34,11 +34,12 @@ static inline uint32_t lz4_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
 #define LZ4_ANY(x) __any(x)
 #define lz4_alignbyte(hi, lo, sh) __builtin_amdgcn_alignbyte(hi, lo, sh)
 #endif
-// base + off for a base that is aligned to more than off can reach: an OR on the device (one v_and_or with the masking)
+// base + off for a base that is aligned to more than off can reach (layouts with RING_ALIGNED: every block's ring is 64 B aligned):
+// an OR on the device (one v_and_or with the masking).  Used inside ParserT<L> only.
 #ifdef LZ4FLEX_HOST_SIM
 #define LZ4_ALIGNED_PLUS(base, off) ((base) + (off))
 #else
-#define LZ4_ALIGNED_PLUS(base, off) ((lds_u8*)(uintptr_t)((uint32_t)(uintptr_t)(base) | (uint32_t)(off)))
+#define LZ4_ALIGNED_PLUS(base, off) (L::RING_ALIGNED ? (lds_u8*)(uintptr_t)((uint32_t)(uintptr_t)(base) | (uint32_t)(off)) : (lds_u8*)((base) + (off)))
 #endif
 
 namespace lz4flex_dev {
@@ -55,9 +56,15 @@ constexpr uint32_t TAILB = 48;        // bytes of the block's end staged in LDS
 constexpr uint32_t TAIL_BUF = 80;     // + zero padding: a 24-byte window read at any tail position stays inside
 constexpr uint32_t RING = 64;         // compressed bytes around the parse position, per block (+ 8 mirrored bytes behind it)
 constexpr uint32_t RING_BYTES = 80;
-// LDS layout of one block: output buffer | record queue | head, tail | tail copy | sink | ring (64 B aligned)
-template <uint32_t OUT_CAP_, uint32_t OUT_H_, uint32_t QD_>
+// LDS layout of one block: output buffer | record queue | head, tail | tail copy | sink | ring (64 B aligned) | PAD
+// PAD: one lane per block (parser) and four lanes per block (copiers) address LDS with the block's size as their stride.  LDS has 32
+// banks of 4 bytes: with a stride of 2 496 bytes (624 dwords, 16 mod 32) the parser's 64 lanes hit TWO banks -- every one of its
+// accesses is executed 32 lanes per bank, one after the other -- and the copiers' 16-byte accesses two of eight 16-byte bank groups.
+// 16 bytes of padding (628 dwords: a multiple of 4 that is 4 x odd) spread both over all eight groups; the rings are then only 16-byte
+// aligned (RING_ALIGNED false: the parser adds where it could OR).
+template <uint32_t OUT_CAP_, uint32_t OUT_H_, uint32_t QD_, uint32_t PAD_ = 0u>
 struct Layout {
+    static constexpr bool RING_ALIGNED = PAD_ % 64u == 0u;
     static constexpr uint32_t QD = QD_;             // records per queue (power of two)
     static constexpr uint32_t OUT_H = OUT_H_;       // history kept in LDS after a write-back
     static constexpr uint32_t OUT_CAP = OUT_CAP_;
@@ -67,11 +74,14 @@ struct Layout {
     static constexpr uint32_t TAIL_OFF = CTL_OFF + 16u;
     static constexpr uint32_t SINK_OFF = TAIL_OFF + TAIL_BUF;   // 16 bytes nobody reads: target of the parser's record store when it has nothing to push
     static constexpr uint32_t RING_OFF = (SINK_OFF + 16u + 63u) & ~63u;
-    static constexpr uint32_t BLK_LDS = (RING_OFF + RING_BYTES + 63u) & ~63u;   // a multiple of 64: every block's ring is 64 B aligned
-    static_assert(BLK_LDS % 64 == 0 && RING_OFF % 64 == 0 && OUT_H % 16 == 0 && (QD & (QD - 1u)) == 0 && QD >= 8, "layout");
+    static constexpr uint32_t BLK_LDS = ((RING_OFF + RING_BYTES + 63u) & ~63u) + PAD_;   // without PAD a multiple of 64: every block's ring is 64 B aligned
+    static_assert(BLK_LDS % 16 == 0 && RING_OFF % 64 == 0 && OUT_H % 16 == 0 && (QD & (QD - 1u)) == 0 && QD >= 8, "layout");
 };
-using LayoutBig = Layout<1984, 512, 16>;     // 2 496 B per block: 64 blocks = one workgroup per CU (156 KiB of its 160 KiB of LDS)
-static_assert(LayoutBig::BLK_LDS == 2496 && LayoutBig::FLUSH_AT == 712, "LDS per block");
+#ifndef LZ4S_LDS_PAD
+#define LZ4S_LDS_PAD 16
+#endif
+using LayoutBig = Layout<1984, 512, 16, LZ4S_LDS_PAD>;     // 2 496 + 16 B per block: 64 blocks = one workgroup per CU (157 KiB of its 160 KiB of LDS)
+static_assert(LayoutBig::BLK_LDS == 2496 + LZ4S_LDS_PAD && LayoutBig::FLUSH_AT == 712 && 64u * LayoutBig::BLK_LDS <= 163840u, "LDS per block");
 using LayoutSmall = Layout<1024, 256, 8>;    // 1 408 B per block (host simulation of a short queue; not launched)
 static_assert(LayoutSmall::BLK_LDS == 1408, "LDS per block");
 // the default layout's constants at namespace level (host simulation, tools)

@@ -38,7 +38,8 @@ def _gpu_decode(blk, data, cap, dict_data=None):
 # wavefront per block, -7 = one block per workgroup (parallel-chain decoder, lz4_decompress_pcd.hip), -8 = the same kernel with
 # its small test geometry (2 KiB tiles, 64-byte parts, 128 sequences per batch, 0.5 + 1 KiB window: boundaries everywhere),
 # -9 = the plan / replay decoder (lz4_decompress_plan.hip + lz4_decompress_replay.hip: a copy plan per block, then four lanes per block replay it)
-DECODERS = [16, -408, -432, -464, -5, -6, -7, -8, -9, -10, -11]
+# -12 = the fused decoder (lz4_decompress_fused.hip: parser -> emitter -> quads in one workgroup of 64 blocks)
+DECODERS = [16, -408, -432, -464, -5, -6, -7, -8, -9, -10, -11, -12]
 
 
 def _select_decoder(lib, ctx, lanes):
@@ -48,7 +49,7 @@ def _select_decoder(lib, ctx, lanes):
     elif lanes <= -400:
         assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 4) == 0
         assert lib.lz4flex_set_tuning(ctx, b"decompress_blocks_per_wg", -lanes - 400) == 0
-    elif lanes in (-5, -6, -7, -8, -9, -10, -11):
+    elif lanes in (-5, -6, -7, -8, -9, -10, -11, -12):
         assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", -lanes) == 0
     else:
         raise AssertionError(lanes)

@@ -101,3 +101,40 @@ def test_replay_plain_load_fallback_compiles_without_hand_counted_waits():
     assert not any("lz4r-load" in l or "lz4r-wait" in l for l in lines)
     assert any("global_load_dwordx4" in l for l in lines)
     build.replay_isa()      # (leave the default listing behind)
+
+
+# ---- the fused decoder (lz4_decompress_fused.hip): the replay decoder's loads behind an LDS step queue, tag "lz4f"
+@pytest.fixture(scope="module")
+def fused_isa():
+    from lz4_flex_amd import build
+    return build.fused_isa()
+
+
+def test_fused_async_loads_are_not_touched_before_their_wait(fused_isa):
+    from lz4_flex_amd import build
+    ok, msg, n_loads, n_waits = build.check_async_loads(fused_isa, "lz4f")
+    assert ok, msg
+    assert n_loads >= 8 and n_waits >= 8
+    assert build.fused_extra_flags() == []
+    # no scratch memory at all: the quads keep LOOKAHEAD slots of five registers each alive around the turn
+    assert not any("scratch_" in l for l in fused_isa)
+
+
+def test_the_check_sees_a_touched_fused_register(fused_isa):
+    from lz4_flex_amd import build
+    for i, line in enumerate(fused_isa):
+        if "lz4f-load" in line and "dwordx4" in line:
+            dst = re.search(r"global_load_dwordx4\s+v\[(\d+):(\d+)\]", line)
+            bad = fused_isa[:i + 2] + ["\tv_mov_b32_e32 v0, v%s" % dst.group(1)] + fused_isa[i + 2:]   # (behind the line that restores exec)
+            ok, msg, _l, _w = build.check_async_loads(bad, "lz4f")
+            assert not ok and "not waited for yet" in msg
+            return
+    raise AssertionError("no marked load in the listing")
+
+
+def test_fused_plain_load_fallback_compiles_without_hand_counted_waits():
+    from lz4_flex_amd import build
+    lines = build.fused_isa([build.FUSED_PLAIN_LOADS])
+    assert not any("lz4f-load" in l or "lz4f-wait" in l for l in lines)
+    assert any("global_load_dwordx4" in l for l in lines)
+    build.fused_isa()      # (leave the default listing behind)

@@ -93,6 +93,16 @@ def main():
         print("wave decoder, cycles per window: " + ", ".join("%s=%.0f" % (a_, x / nw) for a_, x in zip(names, v)) +
               "; per window: sequences %.1f, phase-B matches %.1f (easy %.1f), far-LP %.1f, near-LP %.1f; windows %d" %
               (v[9] / nw, v[10] / nw, v[11] / nw, v[12] / nw, v[13] / nw, v[8]), flush=True)
+    if hasattr(lib, "lz4flex_debug_fused_prof"):           # -DLZ4F_PROF variant build
+        lib.lz4flex_debug_fused_prof.argtypes = [C.c_void_p, C.c_int]
+        v = (C.c_ulonglong * 16)()
+        lib.lz4flex_debug_fused_prof(None, 1)
+        dec_once(); torch.cuda.synchronize()
+        lib.lz4flex_debug_fused_prof(v, 0)
+        v = list(v); wg = max((n + 63) // 64, 1)
+        print("fused decoder, per workgroup: parser %.0f cycles / %.0f steps; emitter %.0f cycles / %.0f iterations, per block %.0f placed a piece, %.0f found the "
+              "step queue full, %.0f had nothing to do; quads %.0f cycles / %.0f turns per wavefront, per block %.0f turns with steps" %
+              (v[0] / wg, v[1] / wg, v[5] / wg, v[6] / wg, v[7] / n, v[8] / n, v[9] / n, v[2] / wg / 4, v[3] / wg / 4, v[4] / n), flush=True)
     if hasattr(lib, "lz4flex_debug_phase_split"):          # -DLZ4FLEX_PROFILE_PHASES variant build
         lib.lz4flex_debug_phase_split.argtypes = [C.c_void_p, C.c_int]
         v = (C.c_ulonglong * 16)()
