@@ -1,21 +1,22 @@
-// lz4_decompress_fused.hip -- batched LZ4 block decoder, PARSER -> EMITTER -> QUADS in one workgroup of 64 blocks ("v6").
+// lz4_decompress_fused.hip -- batched LZ4 block decoder, PARSER -> CUTTER -> QUADS in one workgroup of 64 blocks ("v6").
 //
 // Same contract as lz4_decompress_split.hip (reference src/block/decompress.rs:201-449: result bytes, byte count, error variant and
 // OutputTooSmall{expected,actual}, unsafe-flavour check order; blocks without dictionary / prefix), same parser
 // (lz4_split_parser.h: one lane per block, every bounds check of the reference).  What changed is everything behind the parser's
 // queue (lz4_fused_common.h says why):
-//   * EMITTER wavefront, one lane per block: cuts the parser's sequence records into pieces and packs pieces that do not depend on
-//     each other into STEPS of four 4-byte records -- the plan the replay decoder (round 4) executes, made on the fly;
-//   * four QUAD wavefronts, four lanes per block: execute the steps.  Per step and lane: one record from the block's step queue
-//     (a turn of LOOKAHEAD steps is read at once), one exec-masked 16-byte global load for literals and far sources, requested
-//     LOOKAHEAD steps before the step executes (inline assembly with hand-counted waits, lz4_decompress_replay.hip's scheme), one
-//     LDS read for near sources, four ordered 16-byte LDS writes into the block's 1 KiB output ring; complete 64-byte lines of
-//     the output leave the ring every fourth step.  A literal run that may touch the block's last byte, or that is longer than the
-//     parser's window, is a SPECIAL step: the quad copies it through the ring with exact bounds, at the end of the turn.
-// Wavefronts of a workgroup are dealt to the four SIMDs in turn: the parser (wavefront 3) and the emitter (2) have a SIMD each,
+//   * CUTTER wavefront, one lane per block: cuts the parser's sequence records into pieces (<= 64 bytes, never reading what they
+//     write, never crossing the ring's end), one 4-byte word per piece into the block's piece queue;
+//   * four QUAD wavefronts, four lanes per block: per step a quad takes the pieces at the head of its queue that fit four lanes and do
+//     not depend on each other (pack_step: every lane for itself), requests memory sources -- literals, matches further back than
+//     the ring -- with an exec-masked 16-byte global load LOOKAHEAD steps before the step executes (inline assembly with hand-counted
+//     waits, lz4_decompress_replay.hip's scheme), and executes: one LDS read for near sources, four ordered 16-byte LDS writes into
+//     the block's 1 KiB output ring; complete 64-byte lines of the output leave the ring every fourth step.  A literal run that may
+//     touch the block's last byte, or that is longer than the parser's window, is a SPECIAL: the quad stops fetching behind it, copies
+//     it through the ring with exact bounds when its step executes, and goes on.
+// Wavefronts of a workgroup are dealt to the four SIMDs in turn: the parser (wavefront 3) and the cutter (2) have a SIMD each,
 // the quads (0, 1, 4, 5) share two; wavefronts 6 and 7 only exist to make that placement and end at the first barrier.
-// Blocks of 512 KiB or more (compressed or sink) do not fit the records' fields: they are left with status `redo_code` for the
-// reference-order kernel, like the blocks the other fast decoders mark.
+// Blocks of 512 KiB or more (compressed or sink) are left with status `redo_code` for the reference-order kernel, like the blocks
+// the other fast decoders mark.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -73,20 +74,32 @@ struct Quad {
     uint64_t lane_is[G];     // execution masks: lane g of every quad
     uint32_t op;             // output position
     uint32_t F;              // lines below F are in memory (a multiple of 64)
-    uint32_t fe;             // next step the front end fetches
+    uint32_t pi;             // next word of the piece queue the front end takes
+    uint32_t opf;            // output position of the next step the front end packs
+    uint32_t hold;           // a special is in the slots: nothing is fetched behind it until it is served
     uint32_t done;
     uint32_t sp, sp_src, sp_len;     // the special step of this turn (0: none)
 
-    // fetch: the step's four words -> this lane's job; request its bytes, if they come from memory (an instruction whose mask is empty
-    // still counts)
-    __device__ __forceinline__ void front(Slot& s, const u32x4& ww) {
-        const bool rest = step_rests(ww.x);
-        const LaneJob J = decode_lane(ww.x, ww.y, ww.z, ww.w, g);
-        const uint32_t r = rest ? (K_END << KIND_SHIFT) | (ww.x & 3u) : (J.n << N_SHIFT) | (J.kind << KIND_SHIFT) | (J.rel << REL_SHIFT) | J.field;
-        const uint8_t* p = (J.kind == K_FAR ? out_b : in_b) + J.field;
-        const bool need = !rest && (J.kind - 1u) < 2u && J.n != 0u;
-        s.v.x = rest ? ww.y : s.v.x;         // (before the load: nothing touches the slot's registers between the load and its wait)
-        s.v.y = rest ? ww.z : s.v.y;
+    // fetch: the pieces at the head of the queue -> a step -> this lane's job; request its bytes, if they come from memory (an
+    // instruction whose mask is empty still counts).  pt = the queue's tail (a snapshot)
+    __device__ __forceinline__ void front(Slot& s, uint32_t pt) {
+        const lds_u8* pq = blk + Layout::PQ_OFF;
+        const uint32_t w0 = *reinterpret_cast<const lds_vu32*>(pq + 4u * (pi & (PQ - 1u)));
+        const uint32_t w1 = *reinterpret_cast<const lds_vu32*>(pq + 4u * ((pi + 1u) & (PQ - 1u)));
+        const uint32_t w2 = *reinterpret_cast<const lds_vu32*>(pq + 4u * ((pi + 2u) & (PQ - 1u)));
+        const uint32_t w3 = *reinterpret_cast<const lds_vu32*>(pq + 4u * ((pi + 3u) & (PQ - 1u)));
+        const uint32_t have = pt - pi;
+        const uint32_t avail = (hold | done) != 0u ? 0u : (have < 4u ? have : 4u);
+        const LaneJob J = pack_step(w0, w1, w2, w3, avail, opf, g);
+        const bool special = J.special != 0u;
+        pi += J.take;
+        opf += J.total + (special ? w2 : 0u);
+        hold = special ? 1u : hold;
+        const uint32_t r = special ? (K_END << KIND_SHIFT) | J.special : (J.n << N_SHIFT) | (J.kind << KIND_SHIFT) | (J.rel << REL_SHIFT) | (J.src & MASK);
+        const uint8_t* p = (J.kind == K_FAR ? out_b : in_b) + J.src;
+        const bool need = J.n != 0u && (J.kind - 1u) < 2u;
+        s.v.x = special ? w1 : s.v.x;         // (before the load: nothing touches the slot's registers between the load and its wait)
+        s.v.y = special ? w2 : s.v.y;
         slot_load(s.v, p, __builtin_amdgcn_ballot_w64(need));
         s.r = r;
     }
@@ -162,6 +175,7 @@ struct Quad {
             done = 1u;
         }
         sp = 0u;
+        hold = 0u;
     }
 };
 
@@ -186,7 +200,7 @@ __global__ void __launch_bounds__(512) lz4_decompress_fused_kernel(DecompressArg
         Q.out_b = valid ? a.out_base + a.out_off[b] : g_fused_pad;
         Q.out_wr = const_cast<uint8_t*>(Q.out_b) + Q.g16;
         Q.ilen = valid ? a.in_len[b] : 0u;
-        Q.op = 0u; Q.F = 0u; Q.fe = 0u; Q.sp = 0u; Q.sp_src = 0u; Q.sp_len = 0u;
+        Q.op = 0u; Q.F = 0u; Q.pi = 0u; Q.opf = 0u; Q.hold = 0u; Q.sp = 0u; Q.sp_src = 0u; Q.sp_len = 0u;
         Q.done = valid ? 0u : 1u;
         for (uint32_t k = 0; k < G; ++k) {
             Q.lane_is[k] = 0x1111111111111111ull << k;
@@ -207,29 +221,24 @@ __global__ void __launch_bounds__(512) lz4_decompress_fused_kernel(DecompressArg
         uint32_t pq_turns = 0u, pq_ok = 0u;
 #endif
         for (;;) {
-            // a turn: L steps leave the slots, L steps enter them -- if the block's queue holds a whole turn (else the lanes rest)
-            const uint32_t st = *reinterpret_cast<lds_vu32*>(Q.blk + STEP_TAIL);
-            const bool ok = Q.done == 0u && (st - Q.fe) >= L;
-            u32x4 rr[L];
-#pragma unroll
-            for (uint32_t i = 0; i < L; ++i)
-                rr[i] = *reinterpret_cast<lds_vu128*>(Q.blk + Layout::STEPQ_OFF + 16u * ((Q.fe + i) & (QS - 1u)));      // (the quad's four lanes read the same 16 bytes)
+            // a turn: L steps leave the slots, L steps enter them (as far as the block's queue holds pieces)
+            const uint32_t pt = *reinterpret_cast<lds_vu32*>(Q.blk + PIECE_TAIL);
+            const uint32_t pi0 = Q.pi;
 #pragma unroll
             for (uint32_t i = 0; i < L; ++i) {
                 Q.back(sl[i]);
                 if (i % FLUSH_EVERY == FLUSH_EVERY - 1u) Q.flush();
-                Q.front(sl[i], ok ? rr[i] : u32x4{NOP_WORD, NOP_WORD, NOP_WORD, NOP_WORD});
+                Q.front(sl[i], pt);
             }
-            Q.fe += ok ? L : 0u;
 #ifdef LZ4F_PROF
-            pq_turns++; pq_ok += ok;
+            pq_turns++; pq_ok += Q.pi != pi0;
 #endif
-            if (Q.g == 0u) *reinterpret_cast<lds_vu32*>(Q.blk + STEP_HEAD) = Q.fe;
+            if (Q.g == 0u) *reinterpret_cast<lds_vu32*>(Q.blk + PIECE_HEAD) = Q.pi;
             if (__any(Q.sp != 0u)) {
                 if (Q.sp != 0u) Q.serve();
             }
             if (__all(Q.done != 0u)) break;
-            if (!__any(ok)) __builtin_amdgcn_s_sleep(4);          // nothing to do in the whole wavefront: yield issue slots
+            if (!__any(Q.pi != pi0)) __builtin_amdgcn_s_sleep(4);          // nothing fetched in the whole wavefront: yield issue slots
         }
 #ifndef LZ4F_PLAIN_LOADS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // requests still in flight own their registers until they land
@@ -239,11 +248,11 @@ __global__ void __launch_bounds__(512) lz4_decompress_fused_kernel(DecompressArg
         if (lane == 0u) { FP_ADD(2, __builtin_readcyclecounter() - tq0); FP_ADD(3, pq_turns); }
 #endif
     } else if (pw == 2u) {
-        // ---- emitter: lane j owns block first + j
+        // ---- cutter: lane j owns block first + j
         const uint32_t j = lane, b = first + j;
         const bool valid = b < a.n && a.in_len[b < a.n ? b : 0u] <= MAX_FIELD && a.out_cap[b < a.n ? b : 0u] <= MAX_FIELD;
-        Emitter em;
-        em.init(lds + j * BLK_LDS);
+        Cutter cu;
+        cu.init(lds + j * BLK_LDS);
         __syncthreads();
         __builtin_amdgcn_s_setprio(2);
         bool alive = valid;
@@ -251,15 +260,15 @@ __global__ void __launch_bounds__(512) lz4_decompress_fused_kernel(DecompressArg
         const unsigned long long te0 = __builtin_readcyclecounter();
         uint32_t pe_it = 0u, pe_place = 0u, pe_full = 0u, pe_idle = 0u;
         while (__any(alive)) {
-            const uint32_t op0 = em.op, st0 = em.stail, hd0 = em.head;
-            const bool full = alive && (em.stail - em.step_head()) >= QS;
-            alive = em.iterate(alive) && alive;
-            pe_it++; pe_place += em.op != op0; pe_full += full; pe_idle += alive && em.op == op0 && em.stail == st0 && em.head == hd0 && !full;
+            const uint32_t op0 = cu.op, hd0 = cu.head;
+            const bool full = alive && (cu.ptail - cu.piece_head()) > PQ - 3u;
+            alive = cu.iterate(alive) && alive;
+            pe_it++; pe_place += cu.op != op0; pe_full += full; pe_idle += alive && cu.op == op0 && cu.head == hd0 && !full;
         }
         FP_ADD(7, pe_place); FP_ADD(8, pe_full); FP_ADD(9, pe_idle);
         if (lane == 0u) { FP_ADD(5, __builtin_readcyclecounter() - te0); FP_ADD(6, pe_it); }
 #else
-        while (__any(alive)) alive = em.iterate(alive) && alive;
+        while (__any(alive)) alive = cu.iterate(alive) && alive;
 #endif
     } else {
         // ---- parser: lane j owns block first + j (lz4_decompress_split.hip's, with the quads' word width)
@@ -269,7 +278,7 @@ __global__ void __launch_bounds__(512) lz4_decompress_fused_kernel(DecompressArg
         v5::ParserT<Layout> p;
         p.q.blk = lds + j * BLK_LDS;
         p.init_window(valid ? a.in_base + a.in_off[b] : v5::g_pad, valid ? a.in_len[b] : 0u);
-        p.rare_below = 0u;           // short periods are the emitter's business (doubling pieces)
+        p.rare_below = 0u;           // short periods are the cutter's business (doubling pieces)
         p.lit_slack = LANE_B - 1u;
         p.cap = valid ? a.out_cap[b] : 0u;
         p.ip = 0u; p.op = 0u; p.tok_over = 0u; p.qtail = 0u;
