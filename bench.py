@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 BLOCK = 65536
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
-ROUND = 4               # stamped into the traffic figure's provenance
+ROUND = 5               # stamped into the traffic figure's provenance
 
 
 def median(xs):
@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="kernel experiments only: skip the bit-exact check (never for reported numbers)")
     ap.add_argument("--only", choices=["both", "compress", "decompress"], default="both",
                     help="profiling aid: run only one kernel in the timed steps (value then covers that kernel only)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="the default line (config 2, one GPU) also runs configs 3, 4 and 5 for a few steps behind its timed loop and "
+                         "carries their figures under `other_configs`; this switches that off")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         relaunch_ranks(args.gpus)                  # does not return
@@ -155,11 +158,41 @@ def main():
         out = run_sharded_frame(args, env)
     else:
         out = run_linked_frame(args, env)
+    # The driver only runs the default line: the other BASELINE configs ride on it (one GPU, behind the headline's timed loop and its
+    # verification; a few steps each, the same code as `--config K`), so that their figures are driver-observed too
+    if (args.config == 2 and world == 1 and args.only == "both" and not args.blocks and not args.no_cpu_baseline and not args.no_other_configs
+            and not args.no_verify and not args.decompress_variant):
+        out["other_configs"] = other_configs(args, env)
     if rank == 0:
         print(json.dumps(out))
     lib.lz4flex_ctx_destroy(ctx)
     if world > 1:
         dist.destroy_process_group()
+
+
+def other_configs(args, env):
+    """configs 3, 4 (one GPU's 1 GiB share) and 5 through their own run_* functions: 5 timed steps behind 2 warm-up steps each"""
+    import copy
+    res = {}
+    for k, fn in ((3, run_blocks), (4, run_sharded_frame), (5, run_linked_frame)):
+        a2 = copy.copy(args)
+        a2.config, a2.steps, a2.warmup, a2.blocks = k, 5, 2, 0
+        t0 = time.perf_counter()
+        try:
+            env["torch"].cuda.empty_cache()
+            o = fn(a2, env)
+            cb = o.get("cpu_baseline") or {}
+            res["config%d" % k] = {"metric": o["metric"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": a2.steps,
+                                   "ratio": o.get("ratio"), "verified": o.get("verified"), "workload": o["config"]["workload"],
+                                   "cpu_baseline": {kk: cb.get(kk) for kk in ("value", "unit", "cores", "kind", "sample", "error") if kk in cb},
+                                   "roofline_frac": (o.get("roofline") or {}).get("frac"), "wall_s": None}
+            for extra in ("parts_ms", "windows_64k", "many_streams"):
+                if o.get(extra) is not None:
+                    res["config%d" % k][extra] = o[extra]
+        except Exception as e:     # a failing side configuration must not cost the headline line
+            res["config%d" % k] = {"error": repr(e)}
+        res["config%d" % k]["wall_s"] = round(time.perf_counter() - t0, 2)
+    return res
 
 
 def timed(args, env, step):
@@ -267,9 +300,13 @@ def run_blocks(args, env):
         kernels["compress"] = {"kernel": kname, "ms_per_launch": round(t_c * 1e3, 4), "MiB_per_s": round(total / 1048576 / t_c, 1),
                                "roofline": roof(alg_bytes, t_c)}
     if args.only in ("both", "decompress"):
-        dv = args.decompress_variant or (7 if n <= 1024 else (6 if n <= 2304 else (5 if n <= 5120 else 4)))   # capi.cpp launch_decompress_fast's choice by batch size
+        # capi.cpp launch_decompress_fast's choice by batch size: the thresholds are the library's (lz4_device.h DISPATCH_*)
+        th = [lib.lz4flex_get_tuning(ctx, b"dispatch_threshold_%d" % i) for i in range(7)]     # pair of workgroups, pcd 1024 / 512 / 256 lanes, wave pair, wave, full chip
+        assert min(th) > 0 and th == sorted(th), th
+        dv = args.decompress_variant or (7 if n <= th[3] else (6 if n <= th[4] else (5 if n <= th[5] else 4)))
         kernels["decompress"] = {"kernel": {7: "lz4_decompress_pcd_kernel", 8: "lz4_decompress_pcd_kernel", 6: "lz4_decompress_wave_pair_kernel",
-                                            5: "lz4_decompress_wave_kernel", 4: "lz4_decompress_split_kernel", 1: "lz4_decompress_blocks_kernel"}[dv],
+                                            5: "lz4_decompress_wave_kernel", 4: "lz4_decompress_split_kernel", 1: "lz4_decompress_blocks_kernel",
+                                            9: "lz4_replay_kernel", 10: "lz4_decompress_pcd_kernel", 11: "lz4_decompress_pcd_kernel", 12: "lz4_decompress_fused_kernel"}[dv],
                                  "ms_per_launch": round(t_d * 1e3, 4), "MiB_per_s": round(total / 1048576 / t_d, 1),
                                  "roofline": roof(alg_bytes, t_d)}
     attach_traffic(kernels, n, args.compress_mode, args.config)

@@ -21,10 +21,13 @@ for f in sorted(glob.glob("$OUT/${only}_p*/**/*counter_collection.csv", recursiv
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
         if "lz4" not in k: continue
-        agg[re.sub(r"\(.*", "", k)[-80:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        name = re.sub(r"^void\s+", "", re.sub(r"\)\s*\[.*$|\(.*$", "", k)).replace(" ", "")      # whole name, template arguments included: never cut from the left
+        name = re.sub(r"^(?:\w+::)+", "", name)                                             # ... without the namespaces in front of the kernel's own name
+        agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"_how": "rocprofv3 --pmc <two counters> --kernel-trace per pass (tools/prof_insts.sh), bench.py --only $only --steps 3 --warmup 1: "
                "16 384 JSON blocks of 64 KiB per launch; per counter the median over the kernel's launches; SQ_* instruction counters are per wavefront"}
 for k, v in agg.items():
+    if max(len(vals) for vals in v.values()) < 3: continue          # the untimed pass of the OTHER kernel (bench.py --only runs it once to have data)
     out[k] = {c: {"n": len(vals), "median": sorted(vals)[len(vals) // 2]} for c, vals in sorted(v.items())}
     print("== kernel", k)
     for c, d in out[k].items():
