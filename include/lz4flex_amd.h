@@ -245,9 +245,10 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  *   block (lz4_decompress_pcd.hip: few, large blocks; 8 = the same with its small test geometry, 10 / 11 = with 256 / 512 lanes
  *   per block: what 0 picks for 513 ... 1 024 / 257 ... 512 blocks), 5 = one block per wavefront
  *   (lz4_decompress_wave.hip), 6 = the same with a parser and an executor wavefront per block, 4 = parser /
- *   copier split decoder (large batches), 9 = plan / replay (lz4_decompress_plan.hip + lz4_decompress_replay.hip: a parallel
- *   parse per block writes a copy plan, a parse-free copier executes it; an experiment -- slower than 0 on every shape
- *   measured), 1 = decoder whose window lives in HBM/L2 (always used for dictionary / prefix blocks); "decompress_blocks_per_wg" (variant 4: 0 = 64, the default at every batch size; 8/16/32: the older narrow geometries, tests); "decompress_lanes"
+ *   copier split decoder (large batches), 12 = the split decoder's parser feeding a piece cutter and the replay decoder's copy
+ *   engine inside one workgroup (lz4_decompress_fused.hip: level with 4 on JSON, ahead on text, behind on incompressible data and
+ *   runs), 9 = plan / replay (lz4_decompress_plan.hip + lz4_decompress_replay.hip; -DLZ4FLEX_TOOLS builds only since
+ *   round 5: slower than 0 on every shape measured), 1 = decoder whose window lives in HBM/L2 (always used for dictionary / prefix blocks); "decompress_blocks_per_wg" (variant 4: 0 = 64, the default at every batch size; 8/16/32: the older narrow geometries, tests); "decompress_lanes"
  *   (16; 8/32/64 in -DLZ4FLEX_ALL_VARIANTS builds, variant 1); exact encoder: "compress_lanes" (8/16 lanes of a wavefront per
  *   block), "compress_variant" (1 = group encoder + emitter wavefront; 3 = group encoder alone, -DLZ4FLEX_ALL_VARIANTS builds);
  *   "decompress_second_pass" (tests: 0 leaves the blocks that variants 5..8 hand to the reference-order kernel marked with
@@ -256,7 +257,9 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  *   CUs' worth of time instead of one; 0 = never; 2 = every batch of at most 128 blocks: tests); "compress_carry_wait" (tests: 0 = a 64 KiB window of the throughput
  *   encoder that has to wait for the window before it -- few, large blocks: a block's windows run on different workgroups --
  *   gives up at once instead of after a fraction of a second; such a block is encoded again by the launch that follows, to
- *   the same bytes: a time-sliced GPU costs time, never an error). */
+ *   the same bytes: a time-sliced GPU costs time, never an error).
+ * Keys that start with "debug_" inject faults for this library's own tests; they are unsupported and refused
+ * (-LZ4FLEX_E_INVALID_ARG) unless the process runs with LZ4FLEX_TEST_HOOKS=1. */
 int lz4flex_set_tuning(lz4flex_ctx *ctx, const char *key, int value);
 /* the current value of a setting (>= 0), or -LZ4FLEX_E_INVALID_ARG for an unknown key */
 int lz4flex_get_tuning(lz4flex_ctx *ctx, const char *key);

@@ -87,6 +87,19 @@ static constexpr uint32_t PCD_MAX_BLOCKS = DISPATCH_PCD_256;     // up to here t
 static constexpr uint32_t CHAIN_WS_BLOCKS = 65536u;      // blocks per chained decode batch (LZ4FLEX_MEM_CHAINED)
 
 // the decoders for blocks without dictionary / prefix
+// The "done" words of a chained batch are the context's: two chained batches on different streams would clear and poll the same
+// flags -- a launch on another stream than the previous one waits for it first, every launch records the event (ADVICE r3 for the
+// device path, r4 for the host path: ONE helper for both)
+static hipError_t chain_ws_begin(lz4flex_ctx* c, uint32_t n, hipStream_t s) {
+    if (c->chain_used && s != c->chain_last) { const hipError_t w = hipStreamWaitEvent(s, c->chain_evt, 0); if (w != hipSuccess) return w; }
+    // (marked used BEFORE the kernels: a call that fails between here and its record still leaves work of this stream on the words)
+    c->chain_last = s; c->chain_used = true;
+    const hipError_t m = hipMemsetAsync(c->chain_ws, 0, 4ull * n, s);
+    if (m != hipSuccess) return m;
+    return hipEventRecord(c->chain_evt, s);
+}
+static hipError_t chain_ws_end(lz4flex_ctx* c, hipStream_t s) { return hipEventRecord(c->chain_evt, s); }
+
 static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a_, hipStream_t s, bool big_blocks = false) {
     DecompressArgs a = a_;
     // 0: by batch shape.  Up to ~5 000 blocks the wave decoder (a wavefront per block: a block is done in half the time the
@@ -110,6 +123,8 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
     // blocks and chains keep the full workgroup (a chain is one block at a time, a large block wants the long tiles)
     int pcd_geo = v == 8 ? 1 : (v == 10 ? 2 : (v == 11 ? 3 : 0));
     if (c->dec_variant == 0 && v == 7 && !big_blocks && a.out_pos == nullptr && a.n > DISPATCH_PCD_1024) pcd_geo = a.n <= DISPATCH_PCD_512 ? 3 : 2;
+#ifdef LZ4FLEX_TOOLS
+    if (v == 9 && (uint64_t)a.n * plan_slot_words() > 0xFFFFFFFFull) v = 4;     // BlockPlan's word indices are 32-bit: such a batch takes the split decoder
     if (v == 9) {
         // plan / replay: every block is turned into a copy plan (one wavefront per block, everything that is parallel), then the
         // plans are replayed (four lanes per block, the serial rest); blocks without a plan (errors, sinks too small, oversized) go
@@ -146,6 +161,7 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
         r.only_status = REDO;
         return launch_decompress(r, c->dec_lanes, s);
     }
+#endif
     if ((v >= 5 && v <= 8) || v == 10 || v == 11) {
         // one block per wavefront (6: per pair of wavefronts; 7 / 8: per workgroup); blocks it marks (errors, sinks too small) are
         // decoded again in the reference's order
@@ -292,11 +308,14 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
     if (!c) return -LZ4FLEX_E_NOMEM;
     c->device = device;
     if (const char* e = getenv("LZ4FLEX_COMPRESS_MODE")) c->comp_mode = (!strcmp(e, "exact") || !strcmp(e, "1")) ? 1 : 0;
-    if (const char* e = getenv("LZ4FLEX_SLIDING_WINDOW")) c->comp_sliding = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("LZ4FLEX_SLIDING_WINDOW")) {      // "0" or "1", nothing else ("off" used to read as 0 silently: ADVICE r4)
+        if (!strcmp(e, "0") || !strcmp(e, "1")) c->comp_sliding = e[0] - '0';
+        else { g_last_error = "LZ4FLEX_SLIDING_WINDOW must be 0 or 1"; delete c; return -LZ4FLEX_E_INVALID_ARG; }
+    }
 #ifdef LZ4FLEX_ALL_VARIANTS
     if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v == 1 || v == 3) c->comp_variant = v; }
 #endif
-    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v == 0 || v == 1 || (v >= 4 && v <= 12)) c->dec_variant = v; }
+    if (const char* e = getenv("LZ4FLEX_DECOMPRESS_VARIANT")) { const int v = atoi(e); if (v == 0 || v == 1 || (v >= 4 && v <= 12 && v != 9)) c->dec_variant = v; }
     int prev = 0;
     (void)hipGetDevice(&prev);
     e = hipSetDevice(device);
@@ -390,6 +409,9 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
     }
     if (!strcmp(key, "decompress_variant")) {
         if (value != 0 && value != 1 && (value < 4 || value > 12)) return -LZ4FLEX_E_INVALID_ARG;
+#ifndef LZ4FLEX_TOOLS
+        if (value == 9) return -LZ4FLEX_E_INVALID_ARG;          // plan / replay: tools builds only
+#endif
         c->dec_variant = value;
         return 0;
     }
@@ -426,6 +448,13 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         if (value != 8 && value != 16) return -LZ4FLEX_E_INVALID_ARG;
         c->comp_lanes = value;
         return 0;
+    }
+    // Test hooks (fault injection; unsupported, see the header): only in a process that opted in with LZ4FLEX_TEST_HOOKS=1 (tests/conftest.py
+    // does) -- the frame layer and every scalar call of a process share the default context, a hook set there by anybody else would make
+    // unrelated users fail or take the slow redo path
+    if (!strncmp(key, "debug_", 6)) {
+        const char* e = getenv("LZ4FLEX_TEST_HOOKS");
+        if (!e || strcmp(e, "1") != 0) return -LZ4FLEX_E_INVALID_ARG;
     }
     if (!strcmp(key, "debug_chain_giveup")) {
         if (value < 0) return -LZ4FLEX_E_INVALID_ARG;
@@ -675,11 +704,12 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
         bool big = false;                                    // host arrays are visible: blocks beyond 128 KiB compressed are "large"
         for (uint32_t i = 0; i < n; i++) big |= in_len[i] > 131072u;
         if (chained) {
-            HIP_TRY(hipMemsetAsync(c->chain_ws, 0, 4ull * n, s));
+            HIP_TRY(chain_ws_begin(c, n, s));
             a.chain_done = c->chain_ws;
             a.debug_giveup = (uint32_t)c->chain_giveup;
         }
         le = ((c->dec_variant != 1 || chained) && !has_dict) ? launch_decompress_fast(c, a, s, big) : launch_decompress(a, c->dec_lanes, s);
+        if (chained) (void)chain_ws_end(c, s);               // (also behind a failed launch: whatever was enqueued is ordered)
     }
     if (le != hipSuccess) return hip_fail(le, "kernel launch");
     HIP_TRY(hipMemcpyAsync(hp + at_out_len, dd + at_out_len, desc_bytes - at_out_len, hipMemcpyDeviceToHost, s));
@@ -777,17 +807,11 @@ static int run_device_batch(lz4flex_ctx* c, bool compress, const void* in_base, 
         a.dict_len = ext ? ext->dict_len : nullptr;
         a.out_len = out_len; a.status = status; a.detail = detail; a.n = n;
         if (chained && n) {
-            // the "done" words are the context's: two chained batches on different streams would clear and poll the same flags
-            //  -- a launch on another stream than the previous one waits for it first
-            if (c->chain_used && s != c->chain_last) HIP_TRY(hipStreamWaitEvent(s, c->chain_evt, 0));
-            HIP_TRY(hipMemsetAsync(c->chain_ws, 0, 4ull * n, s));
+            HIP_TRY(chain_ws_begin(c, n, s));
             a.chain_done = c->chain_ws;
         }
         le = ((c->dec_variant != 1 || chained) && !a.dict_base) ? launch_decompress_fast(c, a, s, big_hint != 0) : launch_decompress(a, c->dec_lanes, s);
-        if (le == hipSuccess && chained && n) {
-            HIP_TRY(hipEventRecord(c->chain_evt, s));
-            c->chain_last = s; c->chain_used = true;
-        }
+        if (chained && n) (void)chain_ws_end(c, s);
     }
     if (le != hipSuccess) return hip_fail(le, "kernel launch");
     return 0;

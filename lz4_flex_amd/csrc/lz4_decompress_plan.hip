@@ -20,6 +20,10 @@
 //      again, and a second time to WRITE them.
 // A part closes its last step where it ends (a step never holds pieces of two parts): 64-byte parts cost a JSON block 6 %
 // more steps than the host model's serial emission.
+// Round 5: compiled in -DLZ4FLEX_TOOLS builds only (decompress_variant 9 is refused by the product library): the plan kernel lost to the
+// default dispatch on every shape measured; the replay kernel and the record format it feeds stay (tests/test_gpu_replay.py,
+// the fused decoder's copy engine descends from it).
+#ifdef LZ4FLEX_TOOLS
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -472,3 +476,4 @@ extern "C" int lz4flex_debug_plan(const void* in_base, const void* in_off, const
     return (int)lz4flex_dev::launch_plan(a, (hipStream_t)stream);
 }
 extern "C" unsigned lz4flex_debug_plan_slot_words() { return (unsigned)lz4flex_dev::plan_slot_words(); }
+#endif  // LZ4FLEX_TOOLS

@@ -4,6 +4,7 @@ import sys
 
 import pytest
 
+os.environ.setdefault("LZ4FLEX_TEST_HOOKS", "1")      # the library's fault-injection keys ("debug_*") only exist for processes that opt in
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

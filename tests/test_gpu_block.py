@@ -39,7 +39,8 @@ def _gpu_decode(blk, data, cap, dict_data=None):
 # its small test geometry (2 KiB tiles, 64-byte parts, 128 sequences per batch, 0.5 + 1 KiB window: boundaries everywhere),
 # -9 = the plan / replay decoder (lz4_decompress_plan.hip + lz4_decompress_replay.hip: a copy plan per block, then four lanes per block replay it)
 # -12 = the fused decoder (lz4_decompress_fused.hip: parser -> emitter -> quads in one workgroup of 64 blocks)
-DECODERS = [16, -408, -432, -464, -5, -6, -7, -8, -9, -10, -11, -12]
+# (-9, the plan / replay decoder, left the product library in round 5: -DLZ4FLEX_TOOLS builds only)
+DECODERS = [16, -408, -432, -464, -5, -6, -7, -8, -10, -11, -12]
 
 
 def _select_decoder(lib, ctx, lanes):
@@ -49,7 +50,7 @@ def _select_decoder(lib, ctx, lanes):
     elif lanes <= -400:
         assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 4) == 0
         assert lib.lz4flex_set_tuning(ctx, b"decompress_blocks_per_wg", -lanes - 400) == 0
-    elif lanes in (-5, -6, -7, -8, -9, -10, -11, -12):
+    elif lanes in (-5, -6, -7, -8, -10, -11, -12):
         assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", -lanes) == 0
     else:
         raise AssertionError(lanes)

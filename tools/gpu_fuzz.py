@@ -111,7 +111,7 @@ def main():
     rnd = random.Random(args.seed)
     # (decompress_variant, blocks per workgroup of the split decoder | for 7 / 8: 2 = a parser and a copier workgroup per block, in
     # launches of 100 blocks)
-    decoders = [(1, 0), (4, 8), (4, 32), (4, 64), (5, 0), (6, 0), (7, 0), (8, 0), (7, 2), (8, 2), (9, 0), (10, 0), (11, 0)]
+    decoders = [(1, 0), (4, 8), (4, 32), (4, 64), (5, 0), (6, 0), (7, 0), (8, 0), (7, 2), (8, 2), (10, 0), (11, 0), (12, 0)]   # (9, plan / replay: tools builds only since round 5; 12: the fused decoder)
     t_end = time.time() + args.seconds
     rounds = inputs = blocks = 0
     while time.time() < t_end:
