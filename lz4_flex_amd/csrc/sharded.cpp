@@ -64,6 +64,14 @@ const Rccl& rccl() {
     return r;
 }
 
+// LZ4FLEX_FORCE_COLLECTIVES=1: a communicator of ONE rank still goes through every collective (size all-gather, broadcasts, the
+// segment gather / range scatter as a grouped send + receive to itself) instead of taking the shortcuts a single rank allows.  This is
+// how tests/test_gpu_sharded_native.py runs the REAL librccl on a one-GPU box: the only RCCL evidence obtainable without a multi-GPU node.
+bool force_collectives() {
+    const char* e = getenv("LZ4FLEX_FORCE_COLLECTIVES");
+    return e && !strcmp(e, "1");
+}
+
 size_t block_bytes(int code) {
     switch (code) {
         case 4: return 64u << 10;
@@ -117,7 +125,9 @@ int lz4flex_frame_compress_sharded(lz4flex_ctx* ctx, void* nccl_comm, int rank, 
     if (info->block_mode != 0 || info->content_checksum || info->has_content_size || info->legacy_frame) return -LZ4FLEX_E_UNSUPPORTED;
     const size_t bs = block_bytes(info->block_size);
     if (!bs) return -LZ4FLEX_E_INVALID_ARG;                        // an explicit block size (Auto is a property of a stream, not of a shard)
-    if (world > 1 && (!nccl_comm || !rccl().ok)) return -LZ4FLEX_E_UNSUPPORTED;
+    const bool coll = world > 1 || (nccl_comm != nullptr && force_collectives());     // the exchange goes through RCCL
+    const bool self = coll && world == 1;                                             // ... the root's own segment too (send + receive to itself)
+    if (coll && (!nccl_comm || !rccl().ok)) return -LZ4FLEX_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)hip_stream;
     const uint32_t n = (uint32_t)((local_len + bs - 1) / bs);
     const uint64_t stride = (lz4flex_get_maximum_output_size(bs) + 63) / 64 * 64;
@@ -172,7 +182,7 @@ int lz4flex_frame_compress_sharded(lz4flex_ctx* ctx, void* nccl_comm, int rank, 
     if (local_rc) seg_bytes = ~0ull - (uint64_t)(uint32_t)(-local_rc);    // the code travels with the verdict: every rank returns the same one
     // ---- 1) all-gather of the segment sizes, 2) exclusive prefix sum
     std::vector<uint64_t> all((size_t)world, 0);
-    if (world > 1) {
+    if (coll) {
         uint64_t* dsz = sizes.as<uint64_t>();
         TRY_HIP(hipMemcpyAsync(dsz + world, &seg_bytes, 8, hipMemcpyHostToDevice, s));
         TRY_NCCL(rccl().AllGather(dsz + world, dsz, 1, NCCL_U64, nccl_comm, s));
@@ -194,7 +204,7 @@ int lz4flex_frame_compress_sharded(lz4flex_ctx* ctx, void* nccl_comm, int rank, 
     // ---- the root's verdict on its buffer reaches every rank before anybody sends (a root that left alone would leave the
     // senders waiting)
     uint64_t go = (rank != root || (frame && frame_cap >= total)) ? 1 : 0;
-    if (world > 1) {
+    if (coll) {
         uint64_t* dsz = sizes.as<uint64_t>();
         TRY_HIP(hipMemcpyAsync(dsz, &go, 8, hipMemcpyHostToDevice, s));
         TRY_NCCL(rccl().Broadcast(dsz, dsz, 1, NCCL_U64, root, nccl_comm, s));
@@ -207,11 +217,12 @@ int lz4flex_frame_compress_sharded(lz4flex_ctx* ctx, void* nccl_comm, int rank, 
         uint8_t* f = (uint8_t*)frame;
         TRY_HIP(hipMemcpyAsync(f, hdr, (size_t)hl, hipMemcpyHostToDevice, s));
         TRY_HIP(hipMemsetAsync(f + total - 4, 0, 4, s));
-        if (seg_bytes) TRY_HIP(hipMemcpyAsync(f + off[(size_t)rank], seg.p, seg_bytes, hipMemcpyDeviceToDevice, s));
-        if (world > 1) {
+        if (seg_bytes && !self) TRY_HIP(hipMemcpyAsync(f + off[(size_t)rank], seg.p, seg_bytes, hipMemcpyDeviceToDevice, s));
+        if (coll) {
             TRY_NCCL(rccl().GroupStart());
             for (int r = 0; r < world; r++)
-                if (r != rank && all[(size_t)r]) TRY_NCCL(rccl().Recv(f + off[(size_t)r], all[(size_t)r], NCCL_U8, r, nccl_comm, s));
+                if ((r != rank || self) && all[(size_t)r]) TRY_NCCL(rccl().Recv(f + off[(size_t)r], all[(size_t)r], NCCL_U8, r, nccl_comm, s));
+            if (self && seg_bytes) TRY_NCCL(rccl().Send(seg.p, seg_bytes, NCCL_U8, root, nccl_comm, s));
             TRY_NCCL(rccl().GroupEnd());
         }
     } else if (seg_bytes) {
@@ -227,7 +238,9 @@ int lz4flex_frame_decompress_sharded(lz4flex_ctx* ctx, void* nccl_comm, int rank
                                      uint64_t frame_bytes, void* out, uint64_t out_cap, uint64_t* out_len, uint64_t* first_block,
                                      uint64_t* n_blocks, lz4flex_frame_info* info_out, lz4flex_err_detail* detail, void* hip_stream) {
     if (world < 1 || rank < 0 || rank >= world || root < 0 || root >= world) return -LZ4FLEX_E_INVALID_ARG;
-    if (world > 1 && (!nccl_comm || !rccl().ok)) return -LZ4FLEX_E_UNSUPPORTED;
+    const bool coll = world > 1 || (nccl_comm != nullptr && force_collectives());     // (see lz4flex_frame_compress_sharded)
+    const bool self = coll && world == 1;
+    if (coll && (!nccl_comm || !rccl().ok)) return -LZ4FLEX_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)hip_stream;
     // ---- the root validates the header (host: 19 bytes) and walks the block headers on its device
     uint64_t meta[4] = {0, 0, 0, 0};                                 // blocks, BlockSize code, block checksums, error code
@@ -274,7 +287,7 @@ int lz4flex_frame_decompress_sharded(lz4flex_ctx* ctx, void* nccl_comm, int rank
         return 0;
     }();
     if (root_rc && !meta[3]) meta[3] = (uint64_t)(-root_rc);
-    if (world > 1) {
+    if (coll) {
         TRY_HIP(hipMemcpyAsync(d_meta.p, meta, 32, hipMemcpyHostToDevice, s));
         TRY_NCCL(rccl().Broadcast(d_meta.p, d_meta.p, 4, NCCL_U64, root, nccl_comm, s));
         TRY_HIP(hipMemcpyAsync(meta, d_meta.p, 32, hipMemcpyDeviceToHost, s));
@@ -291,7 +304,7 @@ int lz4flex_frame_decompress_sharded(lz4flex_ctx* ctx, void* nccl_comm, int rank
     std::vector<uint32_t> h_word((size_t)nb);
     if (nb) {
         if (rank != root) { TRY_HIP(d_off.alloc(8ull * nb)); TRY_HIP(d_word.alloc(4ull * nb)); }
-        if (world > 1) {
+        if (coll) {
             TRY_NCCL(rccl().Broadcast(d_off.p, d_off.p, nb, NCCL_U64, root, nccl_comm, s));
             TRY_NCCL(rccl().Broadcast(d_word.p, d_word.p, 4 * nb, NCCL_U8, root, nccl_comm, s));
         }
@@ -319,13 +332,15 @@ int lz4flex_frame_decompress_sharded(lz4flex_ctx* ctx, void* nccl_comm, int rank
     const uint8_t* local = nullptr;
     if (rank == root) {
         local = (const uint8_t*)frame + a;
-        if (world > 1) {
+        if (self) { TRY_HIP(recv.alloc(b - a)); if (b > a) local = recv.as<uint8_t>(); }    // (forced: the root's own range travels too)
+        if (coll) {
             TRY_NCCL(rccl().GroupStart());
             for (int r = 0; r < world; r++) {
                 uint64_t ra, rb;
                 range_of(r, &ra, &rb);
-                if (r != rank && rb > ra) TRY_NCCL(rccl().Send((const uint8_t*)frame + ra, rb - ra, NCCL_U8, r, nccl_comm, s));
+                if ((r != rank || self) && rb > ra) TRY_NCCL(rccl().Send((const uint8_t*)frame + ra, rb - ra, NCCL_U8, r, nccl_comm, s));
             }
+            if (self && b > a) TRY_NCCL(rccl().Recv(recv.p, b - a, NCCL_U8, root, nccl_comm, s));
             TRY_NCCL(rccl().GroupEnd());
         }
     } else {

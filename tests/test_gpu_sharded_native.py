@@ -136,3 +136,17 @@ def test_frame_across_ranks_through_the_c_abi(env, world, mode, bs_code, n_block
     assert mock.mock_world_errors(wptr) == 0, "a collective was called with different arguments on different ranks, or a send met a receive of another size"
     for ctx in ctxs:
         lib.lz4flex_ctx_destroy(ctx)
+
+
+def test_real_rccl_with_a_communicator_of_one_rank():
+    """The REAL librccl, bound by csrc/sharded.cpp's dlopen, with the one communicator a one-GPU box can have: a single rank.
+    LZ4FLEX_FORCE_COLLECTIVES=1 makes the entry points go through every collective anyway (size all-gather, verdict and block-table
+    broadcasts, the segment gather and the range scatter as a grouped send + receive to itself), and the frames are checked against
+    the oracle's FrameEncoder / FrameDecoder.  A process of its own: the library resolves its RCCL once, and this file's other
+    tests hand it a mock.  (More than one rank of the real RCCL has never run: no multi-GPU node was available to this build.)"""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_one_rank.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+    out = r.stdout.decode(errors="replace")
+    if "RCCL-ONE-RANK SKIP" in out:
+        pytest.skip(out.strip().splitlines()[-1])
+    assert r.returncode == 0 and "RCCL-ONE-RANK OK" in out, out[-3000:]
