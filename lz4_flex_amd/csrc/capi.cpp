@@ -67,6 +67,7 @@ struct lz4flex_ctx {
     hipStream_t wave_last = nullptr;
     bool wave_used = false;
     int dec_blocks_per_wg = 0;    // split decoder: blocks per workgroup (8/16/32/64), 0 = 64
+    int comp_sub = 0;             // throughput encoder, "compress_subwindows": 0 = by batch size, 1 = never, 2 / 4 = always that many sub-windows per block of <= 64 KiB
     int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 4 = parser / copier split (lz4_decompress_split.hip), 5 / 6 = a wavefront / a pair of wavefronts per block (lz4_decompress_wave.hip), 7 = a workgroup per block (lz4_decompress_pcd.hip; 8: its test geometry), 9 = plan / replay (lz4_decompress_plan.hip + lz4_decompress_replay.hip), 12 = parser / emitter / quads (lz4_decompress_fused.hip)
     int comp_sliding = 1;         // throughput encoder: the windows of a block longer than 64 KiB advance by 32 KiB (every window start has history); 0 = by 64 KiB (round 3's bytes, faster)
     int comp_carry_wait = 1;      // tests: 0 = a window of the throughput encoder that has to wait for its predecessor's carry gives up at once (the block then takes the second launch)
@@ -220,6 +221,10 @@ static int launch_compress_any(lz4flex_ctx* c, const CompressArgs& a, bool big, 
         if (c->wave_used && s != c->wave_last) HIP_TRY(hipStreamWaitEvent(s, c->wave_done, 0));
         CompressArgs aw = a;
         aw.slide = c->comp_sliding != 0 ? 1u : 0u;
+        // sub-windows (lz4_compress_wave.hip Item::sub): batches that leave at least half / three quarters of the persistent workgroups
+        // without a block cut their blocks of <= 64 KiB into 2 / 4 items each
+        aw.sub = c->comp_sub != 0 ? (uint32_t)c->comp_sub
+                                  : (a.n * 4u <= (uint32_t)c->wave_wgs ? 4u : (a.n * 2u <= (uint32_t)c->wave_wgs ? 2u : 1u));
         le = launch_compress_wave(aw, c->wave_ws, c->wave_wgs, s, c->wave_prof, c->comp_carry_wait != 0);
         if (le == hipSuccess) {
             HIP_TRY(hipEventRecord(c->wave_done, s));
@@ -402,6 +407,11 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         c->comp_mode = value;
         return 0;
     }
+    if (!strcmp(key, "compress_subwindows")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4) return -LZ4FLEX_E_INVALID_ARG;
+        c->comp_sub = value;
+        return 0;
+    }
     if (!strcmp(key, "decompress_blocks_per_wg")) {
         if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return -LZ4FLEX_E_INVALID_ARG;
         c->dec_blocks_per_wg = value;
@@ -484,6 +494,8 @@ int lz4flex_get_tuning(lz4flex_ctx* c, const char* key) {
     if (!strcmp(key, "compress_variant")) return c->comp_variant;
     if (!strcmp(key, "compress_carry_wait")) return c->comp_carry_wait;
     if (!strcmp(key, "compress_sliding_window")) return c->comp_sliding;
+    if (!strcmp(key, "compress_subwindows")) return c->comp_sub;
+    if (!strcmp(key, "compress_workgroups")) return c->wave_wgs;         // (what "compress_subwindows" 0 decides by: n * 4 <= this -> 4, n * 2 <= this -> 2)
     if (!strcmp(key, "decompress_pcd_pair")) return c->dec_pcd_pair;
     if (!strcmp(key, "compress_lanes")) return c->comp_lanes;
     if (!strcmp(key, "decompress_variant")) return c->dec_variant;

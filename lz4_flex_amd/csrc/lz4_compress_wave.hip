@@ -73,11 +73,14 @@ constexpr uint32_t HIST = WINDOW / 2u;      // history in front of a block (see 
 // the segments are the fixed ones, clipped (only an anchored last window has skip != 0); with it (skip >= HIST in every window)
 // the eight segments share the parsed part in the same proportions -- clipped, half of the workers would have nothing to do.
 // Starts other than `skip` itself are multiples of 512.
-__device__ __forceinline__ uint32_t seg_start(uint32_t j, uint32_t skip, bool hmode) {
-    if (!hmode) return seg_lo(j) > skip ? seg_lo(j) : skip;
+// send: 0 = the fixed segments; else the eight segments share [skip, send) in the fixed ones' proportions (WINDOW with history or sliding
+// windows; the end of a SUB-WINDOW, see Item::sub)
+__device__ __forceinline__ uint32_t seg_start(uint32_t j, uint32_t skip, uint32_t send) {
+    if (send == 0u) return seg_lo(j) > skip ? seg_lo(j) : skip;
     if (j == 0u) return skip;
-    if (j >= WORKERS) return WINDOW;
-    const uint32_t v = (skip + (WINDOW - skip) * (seg_lo(j) / 512u) / 128u) & ~511u;
+    if (j >= WORKERS) return send;
+    const uint32_t span = send > skip ? send - skip : 0u;
+    const uint32_t v = (skip + span * (seg_lo(j) / 512u) / 128u) & ~511u;
     return v > skip ? v : skip;
 }
 
@@ -988,7 +991,7 @@ __device__ __forceinline__ void put_len_header(g_u8* dst, uint32_t lit, uint32_t
 
 // Place segment w of the current window (after the barrier: every worker's SegMeta is final).
 __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8_t* __restrict__ gin_, uint32_t blk_len_, uint32_t win_idx_, bool last_win_,
-                              uint32_t wl_, uint32_t wbase_, uint32_t wskip_, bool hmode_, const uint8_t* body_, uint8_t* gout_, uint32_t carry_slot_, uint32_t w_, uint32_t lane,
+                              uint32_t wl_, uint32_t wbase_, uint32_t wskip_, uint32_t send_, const uint8_t* body_, uint8_t* gout_, uint32_t carry_slot_, uint32_t w_, uint32_t lane,
                               uint32_t* out_len_, int32_t* status_, uint32_t* gcarry_, uint32_t iter_, uint32_t spins_max_) {
     const g_u8* __restrict__ gin = uni_gptr<const g_u8>(gin_);
     const g_u8* body = uni_gptr<const g_u8>(body_);
@@ -998,7 +1001,8 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
     const uint32_t blk_len = uni(blk_len_), win_idx = uni(win_idx_), wl = uni(wl_), carry_slot = uni(carry_slot_), w = uni(w_);
     const uint32_t wbase = uni(wbase_), wskip = uni(wskip_);       // the window's first byte in the block; its first wskip positions are history
     const uint32_t spins_max = uni(spins_max_);                    // CARRY_SPINS (tests: 1 -- a window gives up at once)
-    const bool last_win = uni((uint32_t)last_win_) != 0u, hmode = uni((uint32_t)hmode_) != 0u;
+    const bool last_win = uni((uint32_t)last_win_) != 0u;
+    const uint32_t send = uni(send_);
     const lds_u32* mp = (const lds_u32*)(lds + L_META);
     lds_u32* cp = (lds_u32*)(lds + L_META) + 5u * WORKERS;          // BlkCarry[2]
     // Where this window's output starts and how many literals the block has pending: from the previous window, which this
@@ -1041,7 +1045,7 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
         }
     }
     auto seg_at = [&](uint32_t j) -> uint32_t {                     // start of segment j, clipped to the parsed part of the window
-        const uint32_t v = seg_start(j, wskip, hmode);
+        const uint32_t v = seg_start(j, wskip, send);
         return v < wl ? v : wl;
     };
     auto seg_len = [&](uint32_t j) -> uint32_t { return seg_at(j + 1u) - seg_at(j); };
@@ -1142,8 +1146,16 @@ __device__ __attribute__((noinline)) void load_window(const uint8_t* __restrict_
 // anchored-last-window mechanism, applied to every window.  All blocks of a launch still encode side by side: the history
 // is INPUT, nothing waits.  Price: every byte is indexed and loaded twice (the indexer, 160 k of a window's 300 k cycles,
 // becomes the longer half).
+// SUB-WINDOWS (round 5; CompressArgs::sub = 2 or 4): a block of at most 64 KiB is ONE window, one workgroup, and a worker's walk over its
+// 8 KiB segment is what the block waits for -- with fewer blocks than workgroups most of the chip idles (160 text blocks: 160 of 512
+// workgroups for 0.23 ms; a scalar compress_into: one).  Such a block is cut into `sub` items of 64 KiB / sub parsed bytes each: item k is
+// the window [0, (k + 1) quarter) of the block with its first k quarters as history -- the anchored-last-window mechanism again --, its
+// eight segments share the parsed quarter, and the items of a block are drawn by different workgroups like the windows of a long
+// block (the carry ring).  Price: item k indexes and loads k + 1 quarters (2.5 x the indexing for sub = 4: free on an idle chip), the
+// segments are shorter (ratio + 0.1 ... 0.3 %), and the bytes depend on `sub` (the scalar model takes it as a parameter).
 struct Item {
     uint32_t blk, win, nwin, len, skip, hist, slide;     // slide: the windows advance by HIST (history in front of the block, or CompressArgs::slide and a long block)
+    uint32_t sub;                                        // 0, or the parsed bytes per sub-window (WINDOW / CompressArgs::sub) of a block cut into sub-windows
     uint64_t in_off;
 };
 // window geometry: window t.win covers [win_base, win_base + win_len) of the item and parses [win_from, that end)
@@ -1151,16 +1163,25 @@ __device__ __forceinline__ uint32_t win_stride(const Item& t) { return t.slide !
 // the LAST window of an item longer than a window is anchored at the item's end and overlaps the window before it, so the tail can
 // match backwards like the reference's (src/block/compress.rs:403-405: the window is the previous 64 KiB; a 66 675-byte block is
 // 65 536 + 1 139 bytes)
-__device__ __forceinline__ uint32_t win_base(const Item& t) { return (t.win + 1u == t.nwin && t.len > WINDOW) ? t.len - WINDOW : t.win * win_stride(t); }
-__device__ __forceinline__ uint32_t win_from(const Item& t) { return t.win == 0u ? t.hist : (t.win - 1u) * win_stride(t) + WINDOW; }
+__device__ __forceinline__ uint32_t win_base(const Item& t) {
+    if (t.sub != 0u) return 0u;
+    return (t.win + 1u == t.nwin && t.len > WINDOW) ? t.len - WINDOW : t.win * win_stride(t);
+}
+__device__ __forceinline__ uint32_t win_from(const Item& t) {
+    if (t.sub != 0u) return t.win * t.sub;
+    return t.win == 0u ? t.hist : (t.win - 1u) * win_stride(t) + WINDOW;
+}
 __device__ __forceinline__ uint32_t win_skip(const Item& t) { return win_from(t) - win_base(t); }
 __device__ __forceinline__ uint32_t win_len(const Item& t) {
+    if (t.sub != 0u) return t.win + 1u == t.nwin ? t.len : (t.win + 1u) * t.sub;     // (t.len <= WINDOW)
     const uint32_t base = win_base(t);
     return t.len > base ? (t.len - base < WINDOW ? t.len - base : WINDOW) : 0u;
 }
+// what the window's eight segments share (seg_start's `send`)
+__device__ __forceinline__ uint32_t win_send(const Item& t) { return t.sub != 0u ? win_len(t) : (t.slide != 0u ? WINDOW : 0u); }
 __device__ __forceinline__ void item_load(const CompressArgs& a, Item& it) {
     // first window of block it.blk (or invalid)
-    it.win = 0u; it.nwin = 0u; it.len = 0u; it.skip = 0u; it.hist = 0u; it.slide = 0u; it.in_off = 0ull;
+    it.win = 0u; it.nwin = 0u; it.len = 0u; it.skip = 0u; it.hist = 0u; it.slide = 0u; it.sub = 0u; it.in_off = 0ull;
     if (it.blk >= a.n) return;
     const uint32_t len = a.in_len[it.blk];
     const uint32_t cap = a.out_cap[it.blk];
@@ -1173,6 +1194,10 @@ __device__ __forceinline__ void item_load(const CompressArgs& a, Item& it) {
     it.slide = (h != 0u || (a.slide != 0u && len > WINDOW)) ? 1u : 0u;
     it.nwin = it.slide != 0u ? (it.len <= WINDOW ? 1u : 1u + (it.len - WINDOW + HIST - 1u) / HIST)
                       : (len == 0u ? 1u : (uint32_t)(((uint64_t)len + WINDOW - 1u) / WINDOW));
+    if ((a.sub == 2u || a.sub == 4u) && h == 0u && len <= WINDOW && len > WINDOW / a.sub) {       // sub-windows: see Item
+        it.sub = WINDOW / a.sub;
+        it.nwin = (len + it.sub - 1u) / it.sub;
+    }
     const uint64_t need = 20ull + (uint64_t)len * 110ull / 100ull;   // get_maximum_output_size, compress.rs:588-590
     if ((uint64_t)cap < need) { it.skip = 1u; it.nwin = 1u; }
 }
@@ -1307,8 +1332,8 @@ __device__ __forceinline__ void wave_body(const CompressArgs& a, uint8_t* __rest
             if (ix.blk < a.n) do_index(ix, (k + 1u) & 1u);
         } else if (!it.skip) {
             const uint32_t base = win_base(it), skip = win_skip(it);
-            uint32_t s0 = seg_start(w, skip, it.slide != 0u);
-            uint32_t s1 = seg_start(w + 1u, skip, it.slide != 0u);
+            uint32_t s0 = seg_start(w, skip, win_send(it));
+            uint32_t s1 = seg_start(w + 1u, skip, win_send(it));
             s0 = s0 < wl ? s0 : wl;
             s1 = s1 < wl ? s1 : wl;
             const uint32_t act_abs = it.len >= 12u ? it.len - 11u : 0u;
@@ -1336,7 +1361,7 @@ __device__ __forceinline__ void wave_body(const CompressArgs& a, uint8_t* __rest
             if (it.skip) {
                 if (threadIdx.x == 0u) { a.out_len[it.blk] = 0u; a.status[it.blk] = LZ4FLEX_DEV_E_OUTPUT_TOO_SMALL; }
             } else {
-                place_segment(lds, a.in_base + it.in_off, it.len, it.win, last_win, wl, win_base(it), win_skip(it), it.slide != 0u, bodies + (size_t)w * BODY_STRIDE,
+                place_segment(lds, a.in_base + it.in_off, it.len, it.win, last_win, wl, win_base(it), win_skip(it), win_send(it), bodies + (size_t)w * BODY_STRIDE,
                               a.out_base + a.out_off[it.blk], k & 1u, w, lane, a.out_len + it.blk, a.status + it.blk,
                               wmode ? carry + CARRY_DWORDS * (size_t)it.blk : nullptr, k + 1u, carry_spins);
             }

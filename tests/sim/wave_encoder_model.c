@@ -40,6 +40,8 @@ typedef struct {
     uint32_t skipd;  /* a position buried this deep in a running match is not evaluated */
     uint32_t hist;   /* 0, or HIST: `in` starts HIST bytes before the block (a Linked frame's previous bytes); they are history only */
     uint32_t slide;  /* 1: windows advance by HIST even without history in front of the block (every window start of a long block sees >= 32 KiB behind it) */
+    uint32_t sub;    /* 2 / 4: a block of at most 64 KiB (and more than 64 KiB / sub, without history) is cut into sub-windows: window k = [0, (k + 1) * 64 KiB / sub)
+                        of the block, parsed from k * 64 KiB / sub on (the kernel's Item::sub: small batches); else 0 / 1 */
 } lz4w_params;
 #define HIST (WINDOW / 2u)
 
@@ -53,15 +55,26 @@ static inline uint32_t ld32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); re
 /* With history in front of the block (hist == HIST; `n` counts it) the windows advance by HIST instead of WINDOW, so every parsed
  * position has 32 to 64 KiB of the stream behind it in its window. */
 static uint32_t g_slide;   /* (set by lz4w_compress from the parameters: hist != 0 or slide) */
+static uint32_t g_subq;    /* (... 0, or the parsed bytes per sub-window) */
 static uint32_t win_count(uint32_t n, uint32_t hist) {
     (void)hist;
+    if (g_subq) return (n + g_subq - 1) / g_subq;
     if (g_slide) return n <= WINDOW ? 1 : 1 + (n - WINDOW + HIST - 1) / HIST;
     return (n + WINDOW - 1) / WINDOW;
 }
 static uint32_t win_base(uint32_t n, uint32_t wi, uint32_t hist) {
+    if (g_subq) return 0;
     return (wi + 1 == win_count(n, hist) && n > WINDOW) ? n - WINDOW : wi * (g_slide ? HIST : WINDOW);
 }
-static uint32_t win_from(uint32_t wi, uint32_t hist) { return wi == 0 ? hist : (wi - 1) * (g_slide ? HIST : WINDOW) + WINDOW; }   /* parsed from here on */
+static uint32_t win_from(uint32_t wi, uint32_t hist) {   /* parsed from here on */
+    if (g_subq) return wi * g_subq;
+    return wi == 0 ? hist : (wi - 1) * (g_slide ? HIST : WINDOW) + WINDOW;
+}
+static uint32_t win_end(uint32_t n, uint32_t wi, uint32_t hist) {   /* the window's end */
+    if (g_subq) return wi + 1 == win_count(n, hist) ? n : (wi + 1) * g_subq;
+    const uint32_t base = win_base(n, wi, hist);
+    return (n - base < WINDOW) ? n : base + WINDOW;
+}
 
 /* index pass: d[p] for every p (0 = no candidate).  The table is cleared at every window start, so a candidate never lies
  * before its position's window; steps of 64 positions are counted from the window's base. */
@@ -70,7 +83,7 @@ void lz4w_index(const uint8_t *in, uint32_t n, uint16_t *d, uint32_t hist) {
     for (uint32_t p = 0; p < n; p++) d[p] = 0;
     for (uint32_t wi = 0; wi < win_count(n, hist); wi++) {
         const uint32_t base = win_base(n, wi, hist), newfrom = win_from(wi, hist);
-        const uint32_t wend = (n - base < WINDOW) ? n : base + WINDOW;
+        const uint32_t wend = win_end(n, wi, hist);
         memset(tab, 0, 2u << HBITS);
         for (uint32_t b = base; b < wend; b += WAVE) {
             uint32_t idx[WAVE];
@@ -138,15 +151,17 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
         static const uint32_t lo8[9] = {0, 16, 33, 50, 67, 82, 98, 113, 128};
         uint32_t s0 = wbase + 512u * (P->nseg == 8 ? lo8[wj] : (128u * wj) / P->nseg);
         uint32_t s1 = wbase + 512u * (P->nseg == 8 ? lo8[wj + 1] : (128u * (wj + 1)) / P->nseg);
-        if (g_slide) {
-            /* with history (or sliding windows) the segments share the PARSED part of the window in the same proportions (clipped, half of the
+        if (g_slide || g_subq) {
+            /* with history (or sliding windows, or sub-windows) the segments share the PARSED part of the window in the same proportions (clipped, half of the
              * kernel's workers would idle); starts other than the first are multiples of 512 */
             const uint32_t skip = newfrom - wbase;
+            const uint32_t send = g_subq ? win_end(n, sj / P->nseg, hist) - wbase : WINDOW;      /* what the segments share ends here */
+            const uint32_t span = send > skip ? send - skip : 0;
             const uint32_t g0 = (s0 - wbase) / 512u, g1 = (s1 - wbase) / 512u;
-            uint32_t r0 = (skip + (WINDOW - skip) * g0 / 128u) & ~511u, r1 = (skip + (WINDOW - skip) * g1 / 128u) & ~511u;
+            uint32_t r0 = (skip + span * g0 / 128u) & ~511u, r1 = (skip + span * g1 / 128u) & ~511u;
             if (wj == 0 || r0 < skip) r0 = skip;
             if (r1 < skip) r1 = skip;
-            if (wj + 1 == P->nseg) r1 = WINDOW;
+            if (wj + 1 == P->nseg) r1 = send;
             s0 = wbase + r0; s1 = wbase + r1;
         }
         if (s0 < newfrom) s0 = newfrom;
@@ -239,6 +254,7 @@ size_t lz4w_compress(const uint8_t *in, uint32_t n, uint8_t *out, const lz4w_par
     uint16_t *d = (uint16_t *)calloc((size_t)n + WAVE, 2);
     lz4w_seq *seqs = (lz4w_seq *)malloc(sizeof(lz4w_seq) * ((size_t)n / 4 + 2));
     g_slide = (P->hist != 0 || P->slide != 0);
+    g_subq = ((P->sub == 2 || P->sub == 4) && P->hist == 0 && n <= WINDOW && n > WINDOW / P->sub) ? WINDOW / P->sub : 0;
     if (n) lz4w_index(in, n, d, P->hist);
     const size_t ns = n ? lz4w_parse(in, n, d, P, seqs) : 0;
     size_t o = 0;

@@ -25,6 +25,12 @@ def blk():
     return block
 
 
+def SUB(n_blocks):
+    """the sub-windows the library's default gives the blocks (of <= 64 KiB) of a batch of n_blocks (lz4_compress_wave.hip Item::sub)"""
+    from lz4_flex_amd import _lib
+    return W.auto_sub(n_blocks, _lib.load().lz4flex_get_tuning(None, b"compress_workgroups"))
+
+
 def cases():
     rnd = random.Random(99)
     out = [b"", b"a", b"abcd" * 3, bytes(11), bytes(12), bytes(13), bytes(64), bytes(65), bytes(4096), bytes(100000)]
@@ -104,7 +110,7 @@ def test_wave_encoder_device_batch_many_blocks(blk):
     for k in range(0, len(blocks), 1):
         got = bytes(h_out[int(out_off[k]):int(out_off[k]) + int(h_len[k])])
         if k % 10 == 0 or len(blocks[k]) > 65536:
-            assert got == W.compress(blocks[k]), (k, len(blocks[k]))
+            assert got == W.compress(blocks[k], sub=SUB(len(blocks))), (k, len(blocks[k]))
         assert O.decompress(got, len(blocks[k])) == ("ok", blocks[k]), k
     # GPU decoder on the GPU encoder's output
     d_back = torch.zeros_like(d_in)
@@ -180,7 +186,7 @@ def _window_mode_batch(blk, L):
                 assert bytes(outb[out_off[k]:out_off[k] + cap[k]]) == b"\xEE" * cap[k]
                 continue
             got = bytes(outb[out_off[k]:out_off[k] + int(ol[k])])
-            assert got == W.compress(b), (k, len(b))
+            assert got == W.compress(b, sub=SUB(len(blocks))), (k, len(b))
             assert O.decompress(got, len(b)) == ("ok", b), k
 
 
@@ -259,7 +265,7 @@ def _history_batch(blk, L, sizes, seed):
         with_h = hist[k] >= W.HIST and n > 0
         used += with_h
         if k % step == 0 or n > 65536:
-            want = W.compress(stream[o - W.HIST:o + n], hist=W.HIST) if with_h else W.compress(b)
+            want = W.compress(stream[o - W.HIST:o + n], hist=W.HIST) if with_h else W.compress(b, sub=SUB(len(sizes)))
             assert got == want, (k, o, n, hist[k])
         assert O.decompress(got, n, dict_data=stream[max(0, o - 65536):o] if with_h else None) == ("ok", b), (k, o, n)
     assert used >= len(sizes) // 3
@@ -295,3 +301,49 @@ def test_history_must_lie_inside_the_input(blk):
     out = np.zeros(O.max_out(65536) + 64, dtype=np.uint8)
     with pytest.raises(block.DeviceError):
         blk.compress_batch(src, [1000], [65536], out, [0], [O.max_out(65536)], flags=[40000 << 8])
+
+
+@pytest.mark.parametrize("carry_wait", [1, 0])
+@pytest.mark.parametrize("setting,n_blocks", [(0, 1), (0, 100), (0, 200), (0, 300), (1, 40), (2, 40), (4, 40), (4, 700)])
+def test_wave_encoder_subwindows(blk, setting, n_blocks, carry_wait):
+    """small batches (round 5): a block of at most 64 KiB is cut into 2 or 4 sub-windows that different workgroups encode side by side, the
+    output position travelling between them like between the windows of a long block.  "compress_subwindows" 0 (by batch size: 1 block and
+    100 blocks -> 4, 200 -> 2, 300 -> 1 with 512 workgroups), 1 / 2 / 4 forced (700 blocks: more blocks than workgroups, a workgroup walks
+    its blocks' sub-windows itself).  Ragged lengths around every quarter, text / JSON / noise / runs; every block == the scalar model with
+    that many sub-windows, decodes with the oracle and with liblz4; carry_wait 0: every waiting sub-window gives up, the second launch
+    encodes the block again to the same bytes"""
+    from lz4_flex_amd import _lib as L
+    lib = L.load()
+    rnd = random.Random(1000 * setting + n_blocks)
+    j, t = O.fixture_plain("compression_66k_JSON"), O.fixture_plain("compression_65k")
+    noise = bytes(rnd.getrandbits(8) for _ in range(70000))
+    lens = [65536, 65536, 65535, 49152, 49153, 32768, 32769, 32767, 16384, 16385, 16383, 40000, 20000, 1000, 12, 0, 65536, 60001, 33000, 70000, 65537]
+    blocks = []
+    for k in range(n_blocks):
+        src = (j, t, j, noise, bytes(70000), j)[k % 6]
+        n = lens[k % len(lens)] if k % 5 else 65536
+        ph = rnd.randrange(len(src))
+        blocks.append((src * 3)[ph:ph + n])
+    sub = setting if setting else SUB(n_blocks)
+    assert lib.lz4flex_set_tuning(None, b"compress_subwindows", setting) == 0
+    assert lib.lz4flex_set_tuning(None, b"compress_carry_wait", carry_wait) == 0
+    try:
+        src_buf = np.frombuffer(b"".join(blocks) + b"\0", dtype=np.uint8).copy()
+        in_len = [len(b) for b in blocks]
+        in_off = [int(x) for x in np.concatenate([[0], np.cumsum(in_len)[:-1]])]
+        cap = [O.max_out(n) for n in in_len]
+        out_off = [int(x) for x in np.concatenate([[0], np.cumsum(cap)[:-1]])]
+        for rep in range(2):
+            outb = np.full(sum(cap) + 64, 0xEE, dtype=np.uint8)
+            ol, st = blk.compress_batch(src_buf, in_off, in_len, outb, out_off, cap)
+            assert not st.any()
+            for k, b in enumerate(blocks):
+                got = bytes(outb[out_off[k]:out_off[k] + int(ol[k])])
+                if k < 64 or k % 9 == 0:
+                    assert got == W.compress(b, sub=sub), (k, len(b), sub)
+                assert O.decompress(got, len(b)) == ("ok", b), k
+                if b and k % 4 == 0:
+                    assert O.c_decompress(got, len(b)) == b, k
+    finally:
+        assert lib.lz4flex_set_tuning(None, b"compress_subwindows", 0) == 0
+        assert lib.lz4flex_set_tuning(None, b"compress_carry_wait", 1) == 0

@@ -11,7 +11,7 @@ NSEG, CAP, SKIPD = 8, 1024, 64    # the kernel's constants (lz4_compress_wave.hi
 
 
 class Params(C.Structure):
-    _fields_ = [("nseg", C.c_uint32), ("cap", C.c_uint32), ("skipd", C.c_uint32), ("hist", C.c_uint32), ("slide", C.c_uint32)]
+    _fields_ = [("nseg", C.c_uint32), ("cap", C.c_uint32), ("skipd", C.c_uint32), ("hist", C.c_uint32), ("slide", C.c_uint32), ("sub", C.c_uint32)]
 
 
 _m = None
@@ -32,15 +32,23 @@ def lib():
 HIST = 32768                      # lz4_compress_wave.hip: HIST
 
 
-def compress(data, nseg=NSEG, cap=CAP, skipd=SKIPD, hist=0, slide=None):
-    """slide: None = the library's default; hist: 0, or HIST -- `data` starts with HIST bytes of history (the stream in front of the block: a Linked frame), which are
+def auto_sub(n_blocks, workgroups):
+    """what the library's default ("compress_subwindows" 0) picks for a batch of n_blocks with `workgroups` persistent workgroups
+    (lz4flex_get_tuning "compress_workgroups")"""
+    return 4 if n_blocks * 4 <= workgroups else (2 if n_blocks * 2 <= workgroups else 1)
+
+
+def compress(data, nseg=NSEG, cap=CAP, skipd=SKIPD, hist=0, slide=None, sub=None):
+    """sub: 1, or 2 / 4 = sub-windows (what the library does to the blocks of small batches: auto_sub); slide: None = the library's default; hist: 0, or HIST -- `data` starts with HIST bytes of history (the stream in front of the block: a Linked frame), which are
     not emitted; the result is the block alone and needs them as its dictionary"""
     data = bytes(data)
     assert hist == 0 or (hist == HIST and len(data) > hist)
     out = C.create_string_buffer(20 + len(data) * 110 // 100 + 16)
     if slide is None:           # the library's default ("compress_sliding_window" 1): the windows of a block longer than 64 KiB advance by 32 KiB
         slide = 1 if len(data) - hist > 65536 else 0
-    p = Params(nseg, cap, skipd, hist, slide)
+    if sub is None:             # the library's default for a block that travels alone (a scalar call: auto_sub(1, ...) = 4); a block of a batch: auto_sub(n, workgroups)
+        sub = 4
+    p = Params(nseg, cap, skipd, hist, slide, sub)
     ns = C.c_uint32(0)
     n = lib().lz4w_compress(data, len(data), out, C.byref(p), C.byref(ns))
     return out.raw[:n]
