@@ -517,6 +517,12 @@ def run_linked_frame(args, env):
             dep = {"error": repr(e)}
         finally:
             block.set_compress_mode(args.compress_mode)
+    many = None
+    if rank == 0:
+        try:
+            many = many_linked_streams(args, env, plain)
+        except Exception as e:
+            many = {"error": repr(e)}
     base = {"note": "--no-cpu-baseline"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -541,8 +547,95 @@ def run_linked_frame(args, env):
         "roofline": dict(roof(alg, elapsed / args.steps), kernel=("lz4_compress_chain_kernel" if exact else "lz4_compress_wave_kernel") + " + lz4_decompress_pcd_kernel (chained batch)"),
         "verified": "NOT VERIFIED" if args.no_verify else "frame round trip bit-exact; " + oracle_checked,
         "dependency_carrying_frame": dep,
+        "many_streams": many,
         "cpu_baseline": base,
     }
+
+
+def many_linked_streams(args, env, plain, n=256, size=4 << 20):
+    """config 5 in the shape that has parallelism in it: n independent streams, a Linked frame of 64 KiB blocks each, device-resident
+    (lz4flex_frame_compress_many / lz4flex_frame_decompress_many: all blocks of all streams in one encoder launch; one chained decode
+    launch, n chains side by side).  Wall clock around the calls (they return when the work is done), median of 5 after 2 warm-ups;
+    every frame is then decoded by the oracle's FrameDecoder."""
+    torch, dev = env["torch"], env["dev"]
+    from lz4_flex_amd import _lib, frame as F, workloads
+    lib = _lib.load()
+    fi = F.FrameInfo(block_size=F.BlockSize.Max64KB, block_mode=F.BlockMode.Linked)
+    src = workloads.json_tiles(plain, n * size, device=dev)
+    cap = int(lib.lz4flex_frame_compress_bound(size, fi._c()))
+    frames = torch.zeros(n * cap, dtype=torch.uint8, device=dev)
+    back = torch.zeros(n * size, dtype=torch.uint8, device=dev)
+    in_off, f_off = [i * size for i in range(n)], [i * cap for i in range(n)]
+    tc, td, flen = [], [], None
+    for it in range(7):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        flen, st = F.compress_frames_device(src, in_off, [size] * n, fi, frames, f_off, [cap] * n)
+        t1 = time.perf_counter()
+        assert st == [0] * n
+        olen, st = F.decompress_frames_device(frames, f_off, flen, back, in_off, [size] * n)
+        t2 = time.perf_counter()
+        assert st == [0] * n and olen == [size] * n
+        if it >= 2:
+            tc.append(t1 - t0); td.append(t2 - t1)
+    tc.sort(); td.sort()
+    c_ms, d_ms = tc[len(tc) // 2] * 1e3, td[len(td) // 2] * 1e3
+    checked = None
+    if not args.no_verify:
+        assert torch.equal(back, src)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_api as O
+        host = src.cpu().numpy()
+        fh = frames.cpu().numpy()
+        for i in range(n):
+            f = fh[f_off[i]:f_off[i] + flen[i]].tobytes()
+            rc, b, used = O.frame_decompress(f, size)
+            assert rc == 0 and used == len(f) and b == host[i * size:(i + 1) * size].tobytes(), "stream %d: the oracle's FrameDecoder does not return it" % i
+        checked = "round trip bit-exact on the device; each of the %d frames decoded by the oracle's FrameDecoder == its stream" % n
+    out = {"what": "%d streams x %d MiB, one Linked frame of 64 KiB blocks each, device-resident, compress_mode %s" % (n, size >> 20, args.compress_mode),
+           "compress_ms": round(c_ms, 3), "decompress_ms": round(d_ms, 3),
+           "round_trip_MiB_per_s": round(n * size / 1048576 / ((c_ms + d_ms) / 1e3), 1),
+           "round_trip_GiB_per_s": round(n * size / (1 << 30) / ((c_ms + d_ms) / 1e3), 2),
+           "ratio": round(sum(flen) / (n * size), 5), "verified": checked or "NOT VERIFIED"}
+    if not args.no_cpu_baseline and not args.no_verify:
+        out["cpu_every_thread_a_frame"] = cpu_many_frames(host[:size].tobytes())
+    return out
+
+
+def cpu_many_frames(data):
+    """the reference's answer to many Linked streams: a thread per stream (oracle FrameEncoder + FrameDecoder, every hardware thread)"""
+    import threading
+    O = _oracle_fresh()
+    hw, _phys = host_topology()
+    o = O.lib()
+    fi = O.frame_info(block_mode=1, block_size=4)
+    cap = len(data) + len(data) // 100 + (len(data) // 65536 + 2) * 16 + 64
+
+    def one_pass(reps):
+        out = C.create_string_buffer(cap)
+        back = C.create_string_buffer(len(data))
+        used = C.c_size_t(0)
+        d = O.ErrDetail()
+        for _ in range(reps):
+            n = o.lz4o_frame_compress(data, len(data), None, 0, C.byref(fi), out, cap, C.byref(d))
+            m = o.lz4o_frame_decompress(out, n, back, len(data), C.byref(used), C.byref(d))
+            assert n > 0 and m == len(data)
+    best, reps = 0.0, 1
+    for attempt in range(6):
+        th = [threading.Thread(target=one_pass, args=(reps,)) for _ in range(hw)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        if dt >= 0.3:
+            best = max(best, hw * reps * len(data) / 1048576 / dt)
+            if attempt >= 3:
+                break
+        else:
+            reps = max(reps + 1, int(reps * 0.4 / max(dt, 1e-3)))
+    return {"threads": hw, "round_trip_MiB_per_s": round(best, 1), "sample": "one 4 MiB stream per thread, oracle FrameEncoder + FrameDecoder, passes of >= 0.3 s"}
 
 
 # --------------------------------------------------------------------------------------- CPU baseline

@@ -219,6 +219,13 @@ typedef struct lz4flex_decompress_ext {
     const uint64_t *dict_off;
     const uint32_t *dict_len;
     const uint32_t *out_pos;   /* nullable */
+    /* nullable; LZ4FLEX_MEM_DEVICE | LZ4FLEX_MEM_CHAINED batches only: the batch holds SEVERAL chains (N Linked frames decoded side
+     * by side, lz4flex_frame_decompress_many).  Block i's predecessor in its chain is block chain_prev[i] -- an index BELOW i -- or
+     * 0xFFFFFFFF for the first block of a chain; the blocks of one chain share an out_off, different chains have regions of their
+     * own.  Order the blocks level by level (every chain's block k before any chain's block k + 1) and all chains advance together. */
+    const uint32_t *chain_prev;
+    uint32_t n_chains;         /* with chain_prev: how many chains the batch holds (a hint for the kernel geometry: few chains get a
+                                * large workgroup per block, many chains small ones); 0 = unknown */
 } lz4flex_decompress_ext;
 int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
                                 uint32_t n, void *out_base, const uint64_t *out_off, const uint32_t *out_cap,
@@ -354,6 +361,32 @@ int lz4flex_copy_batch_device(const void *src_base, const uint64_t *src_off, con
  * result words travel to the host; the frame stays where it is. */
 int lz4flex_frame_walk_device(const void *frame, uint64_t frame_len, uint32_t header_len, int block_checksums, uint32_t block_size,
                               uint32_t max_blocks, uint64_t *payload_off, uint32_t *len_word, uint32_t *info, void *hip_stream);
+
+/* ---- many frames at once (BASELINE configs[4] in the shape that has parallelism in it: N streams, a frame each) ------------------
+ * What N FrameEncoders / FrameDecoders do, one per stream (src/frame/compress.rs:261-371, src/frame/decompress.rs:189-342), as ONE
+ * batch: the blocks of all streams are encoded by one launch; on the way back the BlockInfo words of all frames are walked on the
+ * device (a thread per frame) and all blocks are decoded by one launch -- for BlockMode::Linked frames a chained batch of N chains
+ * that advance together (src/frame/decompress.rs:195-222: a Linked frame is a dependency chain; one stream is serial, N streams are
+ * N-fold parallel).  Stream i is in_base[in_off[i] .. + in_len[i]) and its result goes to out_base[out_off[i] .. + out_cap[i]);
+ * out_len[i] = bytes written, status[i] = 0 or the negative code lz4flex_frame_compress / lz4flex_frame_decompress would have
+ * returned for that stream alone (detail: nullable, n entries).  in_off / in_len / out_off / out_cap / out_len / status / detail
+ * are HOST arrays; in_base / out_base are DEVICE memory (LZ4FLEX_MEM_DEVICE: work on hip_stream) or HOST memory (LZ4FLEX_MEM_HOST:
+ * staged through the context's scratch; hip_stream ignored).  The calls return after the work has completed.
+ * compress_many: info NULL = FrameInfo::default(); BlockSize::Auto is resolved per stream from its length (frame/header.rs:57-67);
+ * has_content_size: every frame's header carries ITS stream's length (info->content_size is not read).  compress_mode fast: the
+ * frames hold this library's own parse (a Linked frame's blocks reach into the 32 KiB in front of them); exact: the reference's
+ * bytes (Linked: lz4flex_compress_chains, a chain per stream).  out_cap[i] >= lz4flex_frame_compress_bound(in_len[i], info) always fits.
+ * decompress_many: out_cap[i] should be the stream's size or little more (a frame's block table is sized from it).  The batch takes
+ * frames whose blocks all fill the block size but the last; anything else (skippable frames, flush() boundaries,
+ * checksum mismatches, corrupt blocks, buffers too small, legacy frames) is decoded by lz4flex_frame_decompress, stream by stream,
+ * which also names the error -- same results, one stream's speed.  A stream's FIRST frame is decoded; bytes behind it are not read
+ * (FrameDecoder::read returns 0 at the end of a frame, tests/tests.rs:633-647). */
+int lz4flex_frame_compress_many(lz4flex_ctx *ctx, const void *in_base, const uint64_t *in_off, const uint64_t *in_len, uint32_t n,
+                                const lz4flex_frame_info *info, void *out_base, const uint64_t *out_off, const uint64_t *out_cap,
+                                uint64_t *out_len, int32_t *status, int mem_kind, void *hip_stream);
+int lz4flex_frame_decompress_many(lz4flex_ctx *ctx, const void *in_base, const uint64_t *in_off, const uint64_t *in_len, uint32_t n,
+                                  void *out_base, const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len, int32_t *status,
+                                  lz4flex_err_detail *detail, int mem_kind, void *hip_stream);
 
 /* ---- the frame across the GPUs of one node (one process per GPU, an RCCL communicator; BASELINE configs[3]) ----------------
  * FrameEncoder / FrameDecoder for BlockMode::Independent frames whose blocks are spread over `world` ranks: the per-block

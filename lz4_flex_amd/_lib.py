@@ -33,7 +33,8 @@ class ChainBlock(C.Structure):
 
 
 class DecompressExt(C.Structure):
-    _fields_ = [("dict_base", C.c_void_p), ("dict_off", C.c_void_p), ("dict_len", C.c_void_p), ("out_pos", C.c_void_p)]
+    _fields_ = [("dict_base", C.c_void_p), ("dict_off", C.c_void_p), ("dict_len", C.c_void_p), ("out_pos", C.c_void_p),
+                ("chain_prev", C.c_void_p), ("n_chains", C.c_uint32)]
 
 
 WRITE_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
@@ -93,6 +94,8 @@ SIGNATURES = {
     "lz4flex_frame_assemble_device": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _U32, _I32, _VP, _VP, _VP, _VP]),
     "lz4flex_copy_batch_device": (_I32, [_VP, _VP, _VP, _VP, _VP, _U32, _VP]),
     "lz4flex_frame_walk_device": (_I32, [_VP, _U64, _U32, _I32, _U32, _U32, _VP, _VP, _VP, _VP]),
+    "lz4flex_frame_compress_many": (_I32, [_VP, _VP, _VP, _VP, _U32, C.POINTER(FrameInfoC), _VP, _VP, _VP, _VP, _VP, _I32, _VP]),
+    "lz4flex_frame_decompress_many": (_I32, [_VP, _VP, _VP, _VP, _U32, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _VP]),
     "lz4flex_frame_segment_bound": (_U64, [_U64, C.POINTER(FrameInfoC)]),
     "lz4flex_frame_compress_sharded": (_I32, [_VP, _VP, _I32, _I32, _I32, _VP, _U64, _U64, C.POINTER(FrameInfoC), _VP, _U64,
                                                C.POINTER(_U64), _VP]),

@@ -81,6 +81,10 @@ struct lz4flex_ctx {
     hipStream_t plan_last = nullptr;
     bool plan_used = false;
     int chain_giveup = 0;         // tests: block chain_giveup - 1 of the next chained decode batches gives up without an error (the ordered second pass decodes it and everything behind it)
+    // many frames at once (frame_many.cpp): device scratch of the calls that run to completion before they return (compressed staging,
+    // descriptor arrays, staged host buffers).  Grow-only, a hipMalloc when a larger job arrives; freed with the context.
+    void* many_ws[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t many_cap[4] = {0, 0, 0, 0};
     int fail_next_batch = 0;      // tests: the next N batch calls on this context fail before they launch anything (what an allocation failure looks like to the caller)
 };
 
@@ -118,12 +122,17 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
     // with 512 lanes per block, from 513 on with 256 (more workgroups per CU; pcd_geo below): 512 / 1 024 JSON blocks 0.23 / 0.38 ms.
     int v = c->dec_variant != 0 ? c->dec_variant
                                 : ((a.n <= PCD_MAX_BLOCKS || big_blocks) ? 7 : (a.n <= DISPATCH_WAVE_PAIR_MAX ? 6 : (a.n <= DISPATCH_WAVE_MAX ? 5 : 4)));
+    const int geo_req = v == 10 ? 2 : (v == 11 ? 3 : 0);  // (an explicit geometry holds for prefix / chained batches too)
     if (a.out_pos != nullptr && v != 8) v = 7;           // prefix mode (Linked frames): only the workgroup decoder knows it
     if (v == 12 && a.dict_base != nullptr) v = 4;
     // the workgroup decoder's geometry by batch size (lz4_decompress_pcd.hip GeoMid*: smaller workgroups, more of them per CU); large
     // blocks and chains keep the full workgroup (a chain is one block at a time, a large block wants the long tiles)
-    int pcd_geo = v == 8 ? 1 : (v == 10 ? 2 : (v == 11 ? 3 : 0));
+    int pcd_geo = v == 8 ? 1 : geo_req;
     if (c->dec_variant == 0 && v == 7 && !big_blocks && a.out_pos == nullptr && a.n > DISPATCH_PCD_1024) pcd_geo = a.n <= DISPATCH_PCD_512 ? 3 : 2;
+    // several chains side by side (chain_prev): one block per chain is runnable at a time, so the CHAINS are what fills the chip --
+    // tools/many_probe.py, 1 GiB of Linked JSON frames of 64 KiB blocks, 1 024 / 256 lanes per block: 256 chains 8.3 / 16.8 ms,
+    // 1 024 chains 8.3 / 6.1, 4 096 chains 9.0 / 6.7, 64 chains 20.5 / 63
+    if (c->dec_variant == 0 && v == 7 && a.chain_prev != nullptr && a.n_chains > DISPATCH_PCD_1024) pcd_geo = a.n_chains <= DISPATCH_PCD_512 ? 3 : 2;
 #ifdef LZ4FLEX_TOOLS
     if (v == 9 && (uint64_t)a.n * plan_slot_words() > 0xFFFFFFFFull) v = 4;     // BlockPlan's word indices are 32-bit: such a batch takes the split decoder
     if (v == 9) {
@@ -364,6 +373,7 @@ void lz4flex_ctx_destroy(lz4flex_ctx* c) {
     if (c->pcd_ws) (void)hipFree(c->pcd_ws);
     if (c->pcd_done) (void)hipEventDestroy(c->pcd_done);
     if (c->wave_prof) (void)hipFree(c->wave_prof);
+    for (void* p : c->many_ws) if (p) (void)hipFree(p);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_pay) (void)hipHostFree(c->h_pay);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -544,6 +554,8 @@ struct lz4flex_decompress_ext_ {
     const uint64_t* dict_off;
     const uint32_t* dict_len;
     const uint32_t* out_pos;
+    const uint32_t* chain_prev;
+    uint32_t n_chains;
 };
 
 // A host batch of a few small blocks (the scalar calls above all: compress_into / decompress_into are 1-block batches): ONE transfer up
@@ -623,6 +635,7 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
                           uint64_t* detail, const lz4flex_decompress_ext_* ext, bool chained = false) {
     if (n == 0) return 0;
     if (chained && (n > CHAIN_WS_BLOCKS || !ext || !ext->out_pos || ext->dict_base)) return -LZ4FLEX_E_INVALID_ARG;
+    if (ext && ext->chain_prev) return -LZ4FLEX_E_INVALID_ARG;      // several chains in one batch: DEVICE batches only (a host batch stages ONE output region)
     int prev = 0;
     (void)hipGetDevice(&prev);
     HIP_TRY(hipSetDevice(c->device));
@@ -799,6 +812,7 @@ static int run_device_batch(lz4flex_ctx* c, bool compress, const void* in_base, 
                             const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len, int32_t* status,
                             uint64_t* detail, const lz4flex_decompress_ext_* ext, void* hip_stream, int big_hint, bool chained = false) {
     if (chained && (compress || n > CHAIN_WS_BLOCKS || !ext || !ext->out_pos || ext->dict_base)) return -LZ4FLEX_E_INVALID_ARG;
+    if (!chained && ext && ext->chain_prev) return -LZ4FLEX_E_INVALID_ARG;
     hipStream_t s = (hipStream_t)hip_stream;   // DEVICE batches run on the caller's stream (NULL = HIP's null stream)
     hipError_t le;
     if (compress) {
@@ -821,6 +835,9 @@ static int run_device_batch(lz4flex_ctx* c, bool compress, const void* in_base, 
         if (chained && n) {
             HIP_TRY(chain_ws_begin(c, n, s));
             a.chain_done = c->chain_ws;
+            a.chain_prev = ext->chain_prev;
+            a.n_chains = ext->n_chains;
+            a.debug_giveup = (uint32_t)c->chain_giveup;
         }
         le = ((c->dec_variant != 1 || chained) && !a.dict_base) ? launch_decompress_fast(c, a, s, big_hint != 0) : launch_decompress(a, c->dec_lanes, s);
         if (chained && n) (void)chain_ws_end(c, s);
@@ -838,6 +855,27 @@ static int default_ctx(lz4flex_ctx** out) {
     *out = g_default_ctx;
     return 0;
 }
+
+// frame_many.cpp's view of a context (lz4_device.h): the context or the calling thread's default one; its device; grow-only scratch
+namespace lz4flex_dev {
+int ctx_resolve(lz4flex_ctx** ctx) { return *ctx ? 0 : default_ctx(ctx); }
+int ctx_device(lz4flex_ctx* c) { return c->device; }
+hipStream_t ctx_stream(lz4flex_ctx* c) { return c->stream; }
+int ctx_comp_mode(lz4flex_ctx* c) { return c->comp_mode; }
+int ctx_scratch(lz4flex_ctx* c, int slot, size_t bytes, void** out) {
+    if (slot < 0 || slot >= 4) return -LZ4FLEX_E_INVALID_ARG;
+    if (bytes > c->many_cap[slot]) {
+        if (c->many_ws[slot]) (void)hipFree(c->many_ws[slot]);
+        c->many_ws[slot] = nullptr; c->many_cap[slot] = 0;
+        const size_t want = bytes + bytes / 8 + 4096;
+        const hipError_t e = hipMalloc(&c->many_ws[slot], want);
+        if (e != hipSuccess) { (void)hip_fail(e, "scratch"); return e == hipErrorOutOfMemory ? -LZ4FLEX_E_NOMEM : -LZ4FLEX_E_HIP; }
+        c->many_cap[slot] = want;
+    }
+    *out = c->many_ws[slot];
+    return 0;
+}
+}  // namespace lz4flex_dev
 
 extern "C" {
 
@@ -867,7 +905,7 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx* ctx, const void* in_base, const uin
     if (n && (!in_off || !in_len || !out_off || !out_cap || !out_len || !status)) return -LZ4FLEX_E_INVALID_ARG;
     if (ctx->fail_next_batch > 0) { ctx->fail_next_batch--; g_last_error = "debug_fail_next_batch"; return -LZ4FLEX_E_HIP; }
     lz4flex_decompress_ext_ e{};
-    if (ext) { e.dict_base = ext->dict_base; e.dict_off = ext->dict_off; e.dict_len = ext->dict_len; e.out_pos = ext->out_pos; }
+    if (ext) { e.dict_base = ext->dict_base; e.dict_off = ext->dict_off; e.dict_len = ext->dict_len; e.out_pos = ext->out_pos; e.chain_prev = ext->chain_prev; e.n_chains = ext->n_chains; }
     const bool chained = (mem_kind & LZ4FLEX_MEM_CHAINED) != 0;
     if ((mem_kind & 0xFF) == LZ4FLEX_MEM_HOST)
         return run_host_batch(ctx, false, (const uint8_t*)in_base, in_off, in_len, nullptr, n, (uint8_t*)out_base, out_off,

@@ -647,7 +647,8 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
     // prefix mode (Linked frames): the sink already holds OP0 bytes that matches may refer to; in a chained batch they are being
     // written by the earlier blocks of the batch
     const uint32_t OP0 = a.out_pos != nullptr ? a.out_pos[b] : 0u;
-    const uint32_t* const prev_flag = (a.chain_done != nullptr && b != 0u) ? a.chain_done + (b - 1u) : nullptr;
+    const uint32_t prev_b = a.chain_prev != nullptr ? a.chain_prev[b] : b - 1u;        // (block 0: 0xFFFFFFFF either way)
+    const uint32_t* const prev_flag = (a.chain_done != nullptr && prev_b < b) ? a.chain_done + prev_b : nullptr;
     bool prev_ok = prev_flag == nullptr;      // the bytes before OP0 are final
     uint32_t cbase = 0u;       // the tile's first byte: a true token position
     uint32_t OP = OP0;         // output position: everything before it is written back

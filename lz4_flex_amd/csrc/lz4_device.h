@@ -10,6 +10,8 @@
 #define LZ4FLEX_DEV_E_OFFSET_ZERO 4
 #define LZ4FLEX_DEV_E_OFFSET_OUT_OF_BOUNDS 5
 
+struct lz4flex_ctx;
+
 namespace lz4flex_dev {
 
 // All pointers are device pointers.
@@ -33,6 +35,10 @@ struct DecompressArgs {
     // one output region and block i's prefix [.., out_pos[i]) is what blocks 0..i-1 of this batch write (Linked frames,
     // src/frame/decompress.rs:195-222,280-306).  chain_done[i] becomes 1 (done, and every block before it) or 2 (given up).
     uint32_t* chain_done;
+    // with chain_done: nullable; n words.  Set => the batch holds SEVERAL chains (N Linked frames side by side): block i's predecessor
+    // is block chain_prev[i] (< i), 0xFFFFFFFF = the first block of its chain (nothing of the batch lies before it).  Null: i - 1.
+    const uint32_t* chain_prev;
+    uint32_t n_chains;         // with chain_prev: the number of chains (0 = unknown); picks the workgroup size (capi.cpp)
     // lz4_decompress_pcd_kernel: nullable.  Set (n <= PCD_PAIR_MAX_BLOCKS, the first 64 n bytes zero before the launch) => every block
     // gets TWO workgroups: one parses its tiles and hands the token lists over through this workspace, the other copies
     // (lz4_decompress_pcd.hip "roles"); decompress_pcd_pair_ws_bytes() bytes
@@ -135,7 +141,31 @@ hipError_t launch_frame_assemble(const uint8_t* src_base, const uint64_t* src_of
                                  uint64_t* seg_off, uint64_t* pay_off, uint32_t* pay_len, uint32_t* sums, hipStream_t s);
 hipError_t launch_frame_walk(const uint8_t* f, uint64_t n, uint32_t hdr, uint32_t tail, uint32_t block_size, uint32_t max_blocks, uint64_t* off,
                              uint32_t* len, uint32_t* info, hipStream_t s);
+// many frames at once (frame_many.cpp).  ManyStream: one stream to encode -- its blocks are [first, first + count) of the block arrays,
+// its frame goes to out_base[out_off .. + out_cap); hdr = FrameInfo::write's bytes; flags bit 0 block checksums, bit 1 content checksum.
+struct ManyStream { uint64_t out_off, out_cap; uint32_t first, count, hdr_len, flags; uint8_t hdr[24]; };
+// ManyFrame: one frame to decode -- base[off .. + len), header of hdr_len bytes, table slots [slot, slot + slot_cap); skip: not walked
+struct ManyFrame { uint64_t off, len; uint32_t hdr_len, block_size, flags, slot, slot_cap, skip; };
+// verdict[s]: 0 written, 1 a block failed to compress, 2 the frame does not fit; frame_len[s] = bytes written.  dst_off (n_blocks) is
+// scratch, pay_off / pay_len / sums (n_blocks) with block_checksums only, content_sum (n_streams) with content checksums only.
+hipError_t launch_frame_many_assemble(const ManyStream* st, uint32_t n_streams, const uint8_t* src_base, const uint64_t* src_off, const uint32_t* in_len,
+                                      const uint8_t* comp_base, const uint64_t* comp_off, const uint32_t* comp_len, const int32_t* comp_st, uint32_t n_blocks,
+                                      int block_checksums, const uint32_t* content_sum, uint8_t* out_base, uint64_t* dst_off, uint64_t* pay_off,
+                                      uint32_t* pay_len, uint32_t* sums, uint64_t* frame_len, int32_t* verdict, hipStream_t s);
+hipError_t launch_frame_many_heads(const uint8_t* base, const uint64_t* off, const uint64_t* len, uint32_t n, uint8_t* heads, hipStream_t s);
+hipError_t launch_frame_many_walk(const uint8_t* base, const ManyFrame* fr, uint32_t n, uint64_t* pay_off, uint32_t* word, uint32_t* info, hipStream_t s);
+hipError_t launch_frame_sums_check(const uint8_t* base, const uint64_t* pay_off, const uint32_t* pay_len, const uint32_t* sums, uint32_t n, uint32_t* bad,
+                                   hipStream_t s);
 hipError_t launch_copy_batch(const uint8_t* src_base, const uint64_t* src_off, const uint32_t* len, uint8_t* dst_base, const uint64_t* dst_off,
                              uint32_t n, hipStream_t s);
+
+
+// capi.cpp, for frame_many.cpp: *ctx = the calling thread's default context if null; the context's device / own stream / compress_mode;
+// grow-only device scratch in 4 slots (valid until the next ctx_scratch of the same slot; the caller runs to completion before it returns)
+int ctx_resolve(struct ::lz4flex_ctx** ctx);
+int ctx_device(struct ::lz4flex_ctx* c);
+hipStream_t ctx_stream(struct ::lz4flex_ctx* c);
+int ctx_comp_mode(struct ::lz4flex_ctx* c);
+int ctx_scratch(struct ::lz4flex_ctx* c, int slot, size_t bytes, void** out);
 
 }  // namespace lz4flex_dev

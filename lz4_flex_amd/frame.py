@@ -370,3 +370,104 @@ def decompress_frame(data, max_size):
     if r < 0:
         raise _frame_error(int(-r), d)
     return out[:r], int(consumed.value)         # (the whole object when the frame filled it: no copy)
+
+
+# ---- many frames at once (include/lz4flex_amd.h "many frames at once": N streams, a frame each, one batch) ---------------------
+def _u64(values):
+    return (C.c_uint64 * max(len(values), 1))(*values)
+
+
+def compress_frames(streams, frame_info=None):
+    """N host buffers -> N frames (what a FrameEncoder per stream would write), all blocks of all streams in one batch.
+    Returns a list of bytes; raises the first stream's error if one failed."""
+    lib = L.load()
+    fi = (frame_info or FrameInfo())._c()
+    bufs = [_as_bytes(s) for s in streams]
+    n = len(bufs)
+    if n == 0:
+        return []
+    src = b"".join(bufs)
+    in_len = [len(b) for b in bufs]
+    in_off, at = [], 0
+    for v in in_len:
+        in_off.append(at); at += v
+    caps = [int(lib.lz4flex_frame_compress_bound(v, C.byref(fi))) for v in in_len]
+    out_off, at = [], 0
+    for v in caps:
+        out_off.append(at); at += v
+    out = _new_bytes(None, max(at, 1))
+    out_len = (C.c_uint64 * n)()
+    status = (C.c_int32 * n)()
+    r = lib.lz4flex_frame_compress_many(None, src, _u64(in_off), _u64(in_len), n, C.byref(fi), out, _u64(out_off), _u64(caps), out_len, status,
+                                        L.MEM_HOST, None)
+    if r != 0:
+        raise DeviceError("lz4flex error %d: %s" % (-r, L.last_error()))
+    for i in range(n):
+        if status[i] != 0:
+            raise _frame_error(int(-status[i]), L.ErrDetail())
+    return [out[out_off[i]:out_off[i] + int(out_len[i])] for i in range(n)]
+
+
+def decompress_frames(frames, max_sizes, return_errors=False):
+    """N frames (host bytes) -> N byte strings, all blocks of all frames in one batch (Linked frames: N chains side by side).
+    max_sizes: an int or one per frame.  return_errors: failed streams come back as exception objects instead of raising."""
+    lib = L.load()
+    bufs = [_as_bytes(f) for f in frames]
+    n = len(bufs)
+    if n == 0:
+        return []
+    caps = [int(max_sizes)] * n if isinstance(max_sizes, int) else [int(v) for v in max_sizes]
+    src = b"".join(bufs) or b"\0"
+    in_len = [len(b) for b in bufs]
+    in_off, at = [], 0
+    for v in in_len:
+        in_off.append(at); at += v
+    out_off, at = [], 0
+    for v in caps:
+        out_off.append(at); at += v
+    out = _new_bytes(None, max(at, 1))
+    out_len = (C.c_uint64 * n)()
+    status = (C.c_int32 * n)()
+    detail = (L.ErrDetail * n)()
+    r = lib.lz4flex_frame_decompress_many(None, src, _u64(in_off), _u64(in_len), n, out, _u64(out_off), _u64(caps), out_len, status, detail,
+                                          L.MEM_HOST, None)
+    if r != 0:
+        raise DeviceError("lz4flex error %d: %s" % (-r, L.last_error()))
+    res = []
+    for i in range(n):
+        if status[i] != 0:
+            err = _frame_error(int(-status[i]), detail[i])
+            if not return_errors:
+                raise err
+            res.append(err)
+        else:
+            res.append(out[out_off[i]:out_off[i] + int(out_len[i])])
+    return res
+
+
+def compress_frames_device(src, in_off, in_len, frame_info, dst, out_off, out_cap, stream=None):
+    """device-resident streams: src / dst are torch uint8 tensors on the GPU, offsets and lengths plain Python sequences.
+    Returns (out_len list, status list); the call has completed when it returns."""
+    lib = L.load()
+    fi = (frame_info or FrameInfo())._c()
+    n = len(in_off)
+    out_len = (C.c_uint64 * max(n, 1))()
+    status = (C.c_int32 * max(n, 1))()
+    r = lib.lz4flex_frame_compress_many(None, C.c_void_p(src.data_ptr()), _u64(in_off), _u64(in_len), n, C.byref(fi), C.c_void_p(dst.data_ptr()),
+                                        _u64(out_off), _u64(out_cap), out_len, status, L.MEM_DEVICE, C.c_void_p(stream) if stream else None)
+    if r != 0:
+        raise DeviceError("lz4flex error %d: %s" % (-r, L.last_error()))
+    return list(out_len[:n]), list(status[:n])
+
+
+def decompress_frames_device(src, in_off, in_len, dst, out_off, out_cap, stream=None):
+    """device-resident frames -> device-resident streams; returns (out_len list, status list)"""
+    lib = L.load()
+    n = len(in_off)
+    out_len = (C.c_uint64 * max(n, 1))()
+    status = (C.c_int32 * max(n, 1))()
+    r = lib.lz4flex_frame_decompress_many(None, C.c_void_p(src.data_ptr()), _u64(in_off), _u64(in_len), n, C.c_void_p(dst.data_ptr()),
+                                          _u64(out_off), _u64(out_cap), out_len, status, None, L.MEM_DEVICE, C.c_void_p(stream) if stream else None)
+    if r != 0:
+        raise DeviceError("lz4flex error %d: %s" % (-r, L.last_error()))
+    return list(out_len[:n]), list(status[:n])
