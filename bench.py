@@ -186,7 +186,7 @@ def other_configs(args, env):
                                    "ratio": o.get("ratio"), "verified": o.get("verified"), "workload": o["config"]["workload"],
                                    "cpu_baseline": {kk: cb.get(kk) for kk in ("value", "unit", "cores", "kind", "sample", "error") if kk in cb},
                                    "roofline_frac": (o.get("roofline") or {}).get("frac"), "wall_s": None}
-            for extra in ("parts_ms", "windows_64k", "many_streams"):
+            for extra in ("parts_ms", "windows_64k", "windows_32k", "many_streams"):
                 if o.get(extra) is not None:
                     res["config%d" % k][extra] = o[extra]
         except Exception as e:     # a failing side configuration must not cost the headline line
@@ -416,31 +416,37 @@ def run_sharded_frame(args, env):
         del h_frame, back, want
     frame_bytes = int(state["frame"].numel()) if rank == 0 else 0
     alg = total + frame_bytes
-    # The timed figure is the library's default: the 64 KiB windows of a 4 MiB block advance by 32 KiB, so every window start has history
-    # (the reference's continuously sliding window; ratio below the reference's).  The same steps with windows that advance by 64 KiB
-    # ("compress_sliding_window" 0: round 3's bytes, every byte indexed once) are timed beside it, outside the reported value.
-    windows_64k = None
+    # The timed figure is the library's default: the 64 KiB windows of a 4 MiB block advance by 48 KiB, so every window start has 16 KiB of
+    # history (the reference's window slides continuously; ratio just below the reference's).  The same steps with windows that advance
+    # by 64 KiB ("compress_sliding_window" 0: round 3's bytes, every byte indexed once) and by 32 KiB (1: round 4's default, every byte
+    # indexed twice) are timed beside it, outside the reported value.
+    windows_64k = windows_32k = None
     if world == 1 and not args.no_verify and args.compress_mode != "exact":
         from lz4_flex_amd import _lib as L
         lib = L.load()
-        try:
-            assert lib.lz4flex_set_tuning(None, b"compress_sliding_window", 0) == 0
-            for _ in range(2):
-                step(None)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            k = max(3, min(args.steps, 5))
-            for _ in range(k):
-                step(None)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / k
-            assert torch.equal(state["out"], workloads.log_stream(lo * bs, (hi - lo) * bs, device=dev))
-            windows_64k = {"what": "the same step with compress_sliding_window = 0 (windows advance by 64 KiB)", "value": round((total / 1048576) / dt, 1),
-                           "ms_per_step": round(dt * 1e3, 3), "ratio": round(int(state["frame"].numel()) / total, 5)}
-        except Exception as e:
-            windows_64k = {"error": repr(e)}
-        finally:
-            lib.lz4flex_set_tuning(None, b"compress_sliding_window", 1)
+        default = lib.lz4flex_get_tuning(None, b"compress_sliding_window")
+
+        def with_setting(value, what):
+            try:
+                assert lib.lz4flex_set_tuning(None, b"compress_sliding_window", value) == 0
+                for _ in range(2):
+                    step(None)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                k = max(3, min(args.steps, 5))
+                for _ in range(k):
+                    step(None)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / k
+                assert torch.equal(state["out"], workloads.log_stream(lo * bs, (hi - lo) * bs, device=dev))
+                return {"what": what, "value": round((total / 1048576) / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+                        "ratio": round(int(state["frame"].numel()) / total, 5)}
+            except Exception as e:
+                return {"error": repr(e)}
+            finally:
+                lib.lz4flex_set_tuning(None, b"compress_sliding_window", default)
+        windows_64k = with_setting(0, "the same step with compress_sliding_window = 0 (windows advance by 64 KiB)")
+        windows_32k = with_setting(1, "the same step with compress_sliding_window = 1 (windows advance by 32 KiB: round 4's default)")
     out = {
         "metric": "MiB/s frame compress + decompress, BlockIndependent Max4MB, synthetic log stream, 1 GiB per GPU, frame gathered on rank 0",
         "value": round((total / 1048576) / (elapsed / args.steps), 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps,
@@ -453,6 +459,7 @@ def run_sharded_frame(args, env):
         "ratio": round(frame_bytes / total, 5) if frame_bytes else None,
         "parts_ms": {k: round(v / args.steps * 1e3, 3) for k, v in t_parts.items()},
         "windows_64k": windows_64k,
+        "windows_32k": windows_32k,
         "roofline": dict(roof(alg, elapsed / args.steps), kernel="whole step (lz4_compress_wave_kernel + frame assembly + lz4_decompress_pcd_kernel)"),
         "verified": "NOT VERIFIED" if args.no_verify else "every rank's decoded block range equals the stream bytes it owns" +
                     ("; " + oracle_checked if oracle_checked else ""),

@@ -242,11 +242,11 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  *   reference's and still one launch per batch of blocks; in mode 1 it holds the reference's bytes (one dependency chain,
  *   milliseconds per block).
  *   Environment: LZ4FLEX_COMPRESS_MODE=exact|fast.
- * "compress_sliding_window" (throughput encoder): 1 (default) = the 64 KiB windows of a block LONGER than 64 KiB advance by
- *   32 KiB, so every window start has 32 ... 64 KiB of the block behind it -- the reference's window slides continuously
- *   (src/block/compress.rs:403-405); 4 MiB log blocks 0.3027 -> 0.2928 (the reference: 0.2947) at the price of indexing
- *   every byte twice; 0 = windows advance by 64 KiB (faster, round 3's bytes).  Blocks of <= 64 KiB are one window either way.
- *   Environment: LZ4FLEX_SLIDING_WINDOW=0|1.
+ * "compress_sliding_window" (throughput encoder): how far the 64 KiB windows of a block LONGER than 64 KiB advance.  2 (default
+ *   since round 5) = by 48 KiB, so every window start has 16 ... 64 KiB of the block behind it -- the reference's window slides
+ *   continuously (src/block/compress.rs:403-405); 4 MiB log blocks: ratio 0.2940 (the reference: 0.2947) for a third more indexing;
+ *   1 = by 32 KiB (round 4's default: 0.2929, every byte indexed twice); 0 = by 64 KiB (0.3027, fastest, round 3's bytes).
+ *   Blocks of <= 64 KiB are one window either way.  Environment: LZ4FLEX_SLIDING_WINDOW=0|1|2.
  * "compress_subwindows" (throughput encoder): 0 (default) = by batch size -- a batch that leaves most of the encoder's persistent
  *   workgroups ("compress_workgroups", read-only: two per CU) without a block cuts every block of at most 64 KiB into 4 (n * 4 <=
  *   workgroups) or 2 (n * 2 <= workgroups) sub-windows that different workgroups encode side by side: a scalar compress_into and

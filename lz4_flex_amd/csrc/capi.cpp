@@ -69,7 +69,7 @@ struct lz4flex_ctx {
     int dec_blocks_per_wg = 0;    // split decoder: blocks per workgroup (8/16/32/64), 0 = 64
     int comp_sub = 0;             // throughput encoder, "compress_subwindows": 0 = by batch size, 1 = never, 2 / 4 = always that many sub-windows per block of <= 64 KiB
     int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 4 = parser / copier split (lz4_decompress_split.hip), 5 / 6 = a wavefront / a pair of wavefronts per block (lz4_decompress_wave.hip), 7 = a workgroup per block (lz4_decompress_pcd.hip; 8: its test geometry), 9 = plan / replay (lz4_decompress_plan.hip + lz4_decompress_replay.hip), 12 = parser / emitter / quads (lz4_decompress_fused.hip)
-    int comp_sliding = 1;         // throughput encoder: the windows of a block longer than 64 KiB advance by 32 KiB (every window start has history); 0 = by 64 KiB (round 3's bytes, faster)
+    int comp_sliding = 2;         // throughput encoder: the windows of a block longer than 64 KiB advance by 48 KiB (2: every window start has 16 KiB of history) or 32 KiB (1: round 4's bytes); 0 = by 64 KiB (round 3's bytes, fastest)
     int comp_carry_wait = 1;      // tests: 0 = a window of the throughput encoder that has to wait for its predecessor's carry gives up at once (the block then takes the second launch)
     int dec_second_pass = 1;      // tests: 0 leaves the blocks a first-pass decoder marked (status 0x7F000001) instead of decoding them again
     // plan / replay decoder (lz4_decompress_plan.hip, lz4_decompress_replay.hip): the copy plans of a batch, plan_slot_words() words per
@@ -229,7 +229,7 @@ static int launch_compress_any(lz4flex_ctx* c, const CompressArgs& a, bool big, 
         if (!c->wave_ws || !c->wave_done) { g_last_error = "context without encoder workspace"; return -LZ4FLEX_E_INVALID_ARG; }
         if (c->wave_used && s != c->wave_last) HIP_TRY(hipStreamWaitEvent(s, c->wave_done, 0));
         CompressArgs aw = a;
-        aw.slide = c->comp_sliding != 0 ? 1u : 0u;
+        aw.slide = c->comp_sliding == 2 ? 49152u : (c->comp_sliding == 1 ? 32768u : 0u);
         // sub-windows (lz4_compress_wave.hip Item::sub): batches that leave at least half / three quarters of the persistent workgroups
         // without a block cut their blocks of <= 64 KiB into 2 / 4 items each
         aw.sub = c->comp_sub != 0 ? (uint32_t)c->comp_sub
@@ -322,9 +322,9 @@ int lz4flex_ctx_create(lz4flex_ctx** out, int device) {
     if (!c) return -LZ4FLEX_E_NOMEM;
     c->device = device;
     if (const char* e = getenv("LZ4FLEX_COMPRESS_MODE")) c->comp_mode = (!strcmp(e, "exact") || !strcmp(e, "1")) ? 1 : 0;
-    if (const char* e = getenv("LZ4FLEX_SLIDING_WINDOW")) {      // "0" or "1", nothing else ("off" used to read as 0 silently: ADVICE r4)
-        if (!strcmp(e, "0") || !strcmp(e, "1")) c->comp_sliding = e[0] - '0';
-        else { g_last_error = "LZ4FLEX_SLIDING_WINDOW must be 0 or 1"; delete c; return -LZ4FLEX_E_INVALID_ARG; }
+    if (const char* e = getenv("LZ4FLEX_SLIDING_WINDOW")) {      // "0", "1" or "2", nothing else ("off" used to read as 0 silently: ADVICE r4)
+        if (!strcmp(e, "0") || !strcmp(e, "1") || !strcmp(e, "2")) c->comp_sliding = e[0] - '0';
+        else { g_last_error = "LZ4FLEX_SLIDING_WINDOW must be 0, 1 or 2"; delete c; return -LZ4FLEX_E_INVALID_ARG; }
     }
 #ifdef LZ4FLEX_ALL_VARIANTS
     if (const char* e = getenv("LZ4FLEX_COMPRESS_VARIANT")) { const int v = atoi(e); if (v == 1 || v == 3) c->comp_variant = v; }
@@ -451,7 +451,7 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "compress_sliding_window")) {
-        if (value != 0 && value != 1) return -LZ4FLEX_E_INVALID_ARG;
+        if (value < 0 || value > 2) return -LZ4FLEX_E_INVALID_ARG;
         c->comp_sliding = value;
         return 0;
     }

@@ -1154,12 +1154,12 @@ __device__ __attribute__((noinline)) void load_window(const uint8_t* __restrict_
 // block (the carry ring).  Price: item k indexes and loads k + 1 quarters (2.5 x the indexing for sub = 4: free on an idle chip), the
 // segments are shorter (ratio + 0.1 ... 0.3 %), and the bytes depend on `sub` (the scalar model takes it as a parameter).
 struct Item {
-    uint32_t blk, win, nwin, len, skip, hist, slide;     // slide: the windows advance by HIST (history in front of the block, or CompressArgs::slide and a long block)
+    uint32_t blk, win, nwin, len, skip, hist, slide;     // slide: 0, or the bytes the windows advance by (HIST with history in front of the block; CompressArgs::slide for a long block)
     uint32_t sub;                                        // 0, or the parsed bytes per sub-window (WINDOW / CompressArgs::sub) of a block cut into sub-windows
     uint64_t in_off;
 };
 // window geometry: window t.win covers [win_base, win_base + win_len) of the item and parses [win_from, that end)
-__device__ __forceinline__ uint32_t win_stride(const Item& t) { return t.slide != 0u ? HIST : WINDOW; }
+__device__ __forceinline__ uint32_t win_stride(const Item& t) { return t.slide != 0u ? t.slide : WINDOW; }
 // the LAST window of an item longer than a window is anchored at the item's end and overlaps the window before it, so the tail can
 // match backwards like the reference's (src/block/compress.rs:403-405: the window is the previous 64 KiB; a 66 675-byte block is
 // 65 536 + 1 139 bytes)
@@ -1191,8 +1191,10 @@ __device__ __forceinline__ void item_load(const CompressArgs& a, Item& it) {
     it.in_off = a.in_off[it.blk] - h;
     // (sliding windows without history: every window start of a block longer than a window sees >= 32 KiB behind it, like the
     // reference's continuously sliding window, src/block/compress.rs:403-405 -- 4 MiB log blocks 0.3027 -> 0.2928, the reference 0.2947)
-    it.slide = (h != 0u || (a.slide != 0u && len > WINDOW)) ? 1u : 0u;
-    it.nwin = it.slide != 0u ? (it.len <= WINDOW ? 1u : 1u + (it.len - WINDOW + HIST - 1u) / HIST)
+    // Round 5: the stride of a long block is a parameter -- by 48 KiB (16 KiB of history at every window start) 0.2940, still below the
+    // reference, with a third more indexing instead of twice as much.
+    it.slide = h != 0u ? HIST : ((a.slide != 0u && len > WINDOW) ? a.slide : 0u);
+    it.nwin = it.slide != 0u ? (it.len <= WINDOW ? 1u : 1u + (it.len - WINDOW + it.slide - 1u) / it.slide)
                       : (len == 0u ? 1u : (uint32_t)(((uint64_t)len + WINDOW - 1u) / WINDOW));
     if ((a.sub == 2u || a.sub == 4u) && h == 0u && len <= WINDOW && len > WINDOW / a.sub) {       // sub-windows: see Item
         it.sub = WINDOW / a.sub;

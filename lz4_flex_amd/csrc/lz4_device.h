@@ -70,7 +70,7 @@ struct CompressArgs {
     uint32_t* out_len;
     int32_t* status;
     uint32_t n;
-    uint32_t slide;            // throughput encoder: 1 = the windows of a block longer than 64 KiB advance by 32 KiB (lz4_compress_wave.hip Item)
+    uint32_t slide;            // throughput encoder: 0, or the bytes the windows of a block longer than 64 KiB advance by (32 768 or 49 152; lz4_compress_wave.hip Item)
     uint32_t sub;              // throughput encoder: 2 / 4 = blocks of at most 64 KiB are cut into that many sub-windows (small batches: lz4_compress_wave.hip Item::sub); else one window
 };
 

@@ -39,7 +39,7 @@ typedef struct {
     uint32_t cap;    /* longest match a head counts */
     uint32_t skipd;  /* a position buried this deep in a running match is not evaluated */
     uint32_t hist;   /* 0, or HIST: `in` starts HIST bytes before the block (a Linked frame's previous bytes); they are history only */
-    uint32_t slide;  /* 1: windows advance by HIST even without history in front of the block (every window start of a long block sees >= 32 KiB behind it) */
+    uint32_t slide;  /* windows of a block without history in front of it advance by: 0 = 64 KiB, 1 = 32 KiB (HIST: every window start of a long block sees >= 32 KiB behind it), 2 = 48 KiB (>= 16 KiB) */
     uint32_t sub;    /* 2 / 4: a block of at most 64 KiB (and more than 64 KiB / sub, without history) is cut into sub-windows: window k = [0, (k + 1) * 64 KiB / sub)
                         of the block, parsed from k * 64 KiB / sub on (the kernel's Item::sub: small batches); else 0 / 1 */
 } lz4w_params;
@@ -54,21 +54,21 @@ static inline uint32_t ld32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); re
  * the tail, and the reference's ratio pin for its JSON fixture (tests/tests.rs:168-170) fails. */
 /* With history in front of the block (hist == HIST; `n` counts it) the windows advance by HIST instead of WINDOW, so every parsed
  * position has 32 to 64 KiB of the stream behind it in its window. */
-static uint32_t g_slide;   /* (set by lz4w_compress from the parameters: hist != 0 or slide) */
+static uint32_t g_slide;   /* (set by lz4w_compress from the parameters: 0, or the bytes the windows advance by -- HIST with hist != 0, else by `slide`) */
 static uint32_t g_subq;    /* (... 0, or the parsed bytes per sub-window) */
 static uint32_t win_count(uint32_t n, uint32_t hist) {
     (void)hist;
     if (g_subq) return (n + g_subq - 1) / g_subq;
-    if (g_slide) return n <= WINDOW ? 1 : 1 + (n - WINDOW + HIST - 1) / HIST;
+    if (g_slide) return n <= WINDOW ? 1 : 1 + (n - WINDOW + g_slide - 1) / g_slide;
     return (n + WINDOW - 1) / WINDOW;
 }
 static uint32_t win_base(uint32_t n, uint32_t wi, uint32_t hist) {
     if (g_subq) return 0;
-    return (wi + 1 == win_count(n, hist) && n > WINDOW) ? n - WINDOW : wi * (g_slide ? HIST : WINDOW);
+    return (wi + 1 == win_count(n, hist) && n > WINDOW) ? n - WINDOW : wi * (g_slide ? g_slide : WINDOW);
 }
 static uint32_t win_from(uint32_t wi, uint32_t hist) {   /* parsed from here on */
     if (g_subq) return wi * g_subq;
-    return wi == 0 ? hist : (wi - 1) * (g_slide ? HIST : WINDOW) + WINDOW;
+    return wi == 0 ? hist : (wi - 1) * (g_slide ? g_slide : WINDOW) + WINDOW;
 }
 static uint32_t win_end(uint32_t n, uint32_t wi, uint32_t hist) {   /* the window's end */
     if (g_subq) return wi + 1 == win_count(n, hist) ? n : (wi + 1) * g_subq;
@@ -253,7 +253,7 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
 size_t lz4w_compress(const uint8_t *in, uint32_t n, uint8_t *out, const lz4w_params *P, uint32_t *n_seq) {
     uint16_t *d = (uint16_t *)calloc((size_t)n + WAVE, 2);
     lz4w_seq *seqs = (lz4w_seq *)malloc(sizeof(lz4w_seq) * ((size_t)n / 4 + 2));
-    g_slide = (P->hist != 0 || P->slide != 0);
+    g_slide = P->hist != 0 ? HIST : (P->slide == 2 ? 49152u : (P->slide == 1 ? HIST : 0u));
     g_subq = ((P->sub == 2 || P->sub == 4) && P->hist == 0 && n <= WINDOW && n > WINDOW / P->sub) ? WINDOW / P->sub : 0;
     if (n) lz4w_index(in, n, d, P->hist);
     const size_t ns = n ? lz4w_parse(in, n, d, P, seqs) : 0;

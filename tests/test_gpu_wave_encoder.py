@@ -204,13 +204,13 @@ def test_wave_encoder_heads_at_a_window_end(blk):
     from lz4_flex_amd import _lib as L
     lib = L.load()
     try:
-        for slide in (0, 1):          # windows advancing by 64 KiB (where the fuzzer found it), and by 32 KiB (the default for long blocks)
+        for slide in (0, 1, 2):       # windows advancing by 64 KiB (where the fuzzer found it), by 32 KiB and by 48 KiB (the default for long blocks)
             assert lib.lz4flex_set_tuning(None, b"compress_sliding_window", slide) == 0
             c = blk.compress(d)
             assert O.decompress(c, len(d)) == ("ok", d)
             assert c == W.compress(d, slide=slide)
     finally:
-        assert lib.lz4flex_set_tuning(None, b"compress_sliding_window", 1) == 0
+        assert lib.lz4flex_set_tuning(None, b"compress_sliding_window", W.SLIDE_DEFAULT) == 0
 
 
 def test_wave_encoder_sliding_windows_off(blk):
@@ -227,7 +227,27 @@ def test_wave_encoder_sliding_windows_off(blk):
             assert O.decompress(c, n) == ("ok", d)
             assert c == W.compress(d, slide=0), n
     finally:
-        assert lib.lz4flex_set_tuning(None, b"compress_sliding_window", 1) == 0
+        assert lib.lz4flex_set_tuning(None, b"compress_sliding_window", W.SLIDE_DEFAULT) == 0
+
+
+def test_wave_encoder_window_strides(blk):
+    """"compress_sliding_window" 1 / 2: the windows of a long block advance by 32 / 48 KiB; blocks of every length class == model with
+    that setting, decoded by the oracle (0: the test above)"""
+    from lz4_flex_amd import _lib as L
+    lib = L.load()
+    j = O.fixture_plain("compression_66k_JSON")
+    t = O.fixture_plain("compression_65k")
+    try:
+        for slide in (1, 2):
+            assert lib.lz4flex_set_tuning(None, b"compress_sliding_window", slide) == 0
+            for n in (65537, 66675, 98304, 114688, 114689, 131072 + 77, 163840, 300000, 1048576 + 5, 4 << 20):
+                for src in (j, t):
+                    d = (src * (n // len(src) + 2))[:n]
+                    c = blk.compress(d)
+                    assert O.decompress(c, n) == ("ok", d)
+                    assert c == W.compress(d, slide=slide), (slide, n)
+    finally:
+        assert lib.lz4flex_set_tuning(None, b"compress_sliding_window", W.SLIDE_DEFAULT) == 0
 
 
 def _history_batch(blk, L, sizes, seed):

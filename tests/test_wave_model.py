@@ -88,7 +88,7 @@ def test_model_on_the_window_end_fixture():
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "golden", "fuzz_window_end_heads.zlib"), "rb") as f:
         d = zlib.decompress(f.read())
-    for slide, size in ((0, 41631), (1, 40898)):      # windows that advance by 64 KiB (where the fuzzer found it) / by 32 KiB (the default for long blocks)
+    for slide, size in ((0, 41631), (1, 40898), (2, 41108)):      # windows that advance by 64 KiB (where the fuzzer found it) / by 32 KiB / by 48 KiB (the default for long blocks)
         c = W.compress(d, slide=slide)
         assert O.decompress(c, len(d)) == ("ok", d)
         assert O.c_decompress(c, len(d)) == d

@@ -32,6 +32,9 @@ def lib():
 HIST = 32768                      # lz4_compress_wave.hip: HIST
 
 
+SLIDE_DEFAULT = 2        # "compress_sliding_window": 0 = windows advance by 64 KiB, 1 = by 32 KiB, 2 = by 48 KiB (the default since round 5)
+
+
 def auto_sub(n_blocks, workgroups):
     """what the library's default ("compress_subwindows" 0) picks for a batch of n_blocks with `workgroups` persistent workgroups
     (lz4flex_get_tuning "compress_workgroups")"""
@@ -44,8 +47,8 @@ def compress(data, nseg=NSEG, cap=CAP, skipd=SKIPD, hist=0, slide=None, sub=None
     data = bytes(data)
     assert hist == 0 or (hist == HIST and len(data) > hist)
     out = C.create_string_buffer(20 + len(data) * 110 // 100 + 16)
-    if slide is None:           # the library's default ("compress_sliding_window" 1): the windows of a block longer than 64 KiB advance by 32 KiB
-        slide = 1 if len(data) - hist > 65536 else 0
+    if slide is None:           # the library's default ("compress_sliding_window" 2): the windows of a block longer than 64 KiB advance by 48 KiB (1: by 32 KiB)
+        slide = SLIDE_DEFAULT if len(data) - hist > 65536 else 0
     if sub is None:             # the library's default for a block that travels alone (a scalar call: auto_sub(1, ...) = 4); a block of a batch: auto_sub(n, workgroups)
         sub = 4
     p = Params(nseg, cap, skipd, hist, slide, sub)
