@@ -273,7 +273,10 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  * Keys that start with "debug_" inject faults for this library's own tests; they are unsupported and refused
  * (-LZ4FLEX_E_INVALID_ARG) unless the process runs with LZ4FLEX_TEST_HOOKS=1. */
 int lz4flex_set_tuning(lz4flex_ctx *ctx, const char *key, int value);
-/* the current value of a setting (>= 0), or -LZ4FLEX_E_INVALID_ARG for an unknown key */
+/* the current value of a setting (>= 0), or -LZ4FLEX_E_INVALID_ARG for an unknown key.  Two read-only lists need no device and no
+ * context: "dispatch_threshold_<i>" (the batch sizes at which the default decoder dispatch changes kernel or geometry, ascending) and
+ * "decoder_config_<i>" (every decoder configuration this build can be pinned to: variant * 1000 + "decompress_lanes" (variant 1) /
+ * "decompress_blocks_per_wg" (variant 4) / 0); both end where the key is refused */
 int lz4flex_get_tuning(lz4flex_ctx *ctx, const char *key);
 
 /* ---- frame (src/frame/) ------------------------------------------------------------------ */

@@ -499,6 +499,19 @@ int lz4flex_get_tuning(lz4flex_ctx* c, const char* key) {
         if (i < 0 || i >= (int)(sizeof t / sizeof t[0]) || (key[19] < '0' || key[19] > '9')) return -LZ4FLEX_E_INVALID_ARG;
         return (int)t[i];
     }
+    // every decoder configuration this build can be pinned to, as variant * 1000 + parameter ("decompress_lanes" for variant 1,
+    // "decompress_blocks_per_wg" for variant 4, else 0); the list ends where the key is refused.  ONE list: tests/test_gpu_block.py's
+    // decoder matrix and tools/gpu_fuzz.py are generated from it (a decoder added here is tested there), no device needed.
+    if (!strncmp(key, "decoder_config_", 15)) {
+        const int t[] = {1016, 4008, 4032, 4064, 5000, 6000, 7000, 8000, 10000, 11000, 12000,
+#ifdef LZ4FLEX_TOOLS
+                         9000,
+#endif
+        };
+        const int i = atoi(key + 15);
+        if (i < 0 || i >= (int)(sizeof t / sizeof t[0]) || (key[15] < '0' || key[15] > '9')) return -LZ4FLEX_E_INVALID_ARG;
+        return t[i];
+    }
     if (!c) { const int rc = default_ctx(&c); if (rc) return rc; }
     if (!strcmp(key, "compress_mode")) return c->comp_mode;
     if (!strcmp(key, "compress_variant")) return c->comp_variant;

@@ -234,12 +234,20 @@ __global__ void __launch_bounds__(256) lz4_decompress_blocks_kernel(DecompressAr
 // of such a batch cannot be decoded side by side -- block k + 1 would read block k's last 64 KiB while block k is being written
 // again (status 0, wrong bytes) -- so ONE wavefront decodes them one after the other, in chain order.  Slow, and only
 // ever busy when a first-pass block gave up for a non-error reason (a time-sliced or oversubscribed GPU) or the frame is corrupt.
+// Several chains in one batch (DecompressArgs::chain_prev: N Linked frames side by side) are independent of each other: the grid then
+// holds several wavefronts, and the chain whose first block is r belongs to wavefront r mod gridDim.x -- every chain is still decoded by
+// ONE wavefront in index order, different chains side by side (the serial second pass).
 __global__ void __launch_bounds__(64) lz4_decompress_chain_redo_kernel(DecompressArgs a) {
     constexpr int G = 16;
     const uint32_t lane = threadIdx.x;
     for (uint32_t b0 = 0u; b0 < a.n; b0 += 64u) {
         const uint32_t bi = b0 + lane;
-        const bool marked = bi < a.n && a.status[bi] == a.only_status;
+        bool marked = bi < a.n && a.status[bi] == a.only_status;
+        if (marked && a.chain_prev != nullptr && gridDim.x > 1u) {
+            uint32_t r = bi;                                            // the chain's first block: follow the predecessors (indices fall)
+            for (uint32_t p = a.chain_prev[r]; p < r; p = a.chain_prev[r]) r = p;
+            marked = r % gridDim.x == blockIdx.x;
+        }
         uint64_t m = __builtin_amdgcn_ballot_w64(marked);
         while (m != 0ull) {
             const uint32_t b = b0 + (uint32_t)__builtin_ctzll(m);
@@ -267,7 +275,8 @@ __global__ void __launch_bounds__(64) lz4_decompress_chain_redo_kernel(Decompres
 hipError_t launch_decompress_chain_redo(const DecompressArgs& a, hipStream_t s) {
     if (a.n == 0u) return hipSuccess;
     if (a.dict_base != nullptr || a.only_status == 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(lz4_decompress_chain_redo_kernel, dim3(1), dim3(64), 0, s, a);
+    const uint32_t grid = a.chain_prev != nullptr ? (a.n_chains > 1u ? (a.n_chains < 1024u ? a.n_chains : 1024u) : 64u) : 1u;
+    hipLaunchKernelGGL(lz4_decompress_chain_redo_kernel, dim3(grid), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

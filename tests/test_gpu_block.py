@@ -40,7 +40,27 @@ def _gpu_decode(blk, data, cap, dict_data=None):
 # -9 = the plan / replay decoder (lz4_decompress_plan.hip + lz4_decompress_replay.hip: a copy plan per block, then four lanes per block replay it)
 # -12 = the fused decoder (lz4_decompress_fused.hip: parser -> emitter -> quads in one workgroup of 64 blocks)
 # (-9, the plan / replay decoder, left the product library in round 5: -DLZ4FLEX_TOOLS builds only)
-DECODERS = [16, -408, -432, -464, -5, -6, -7, -8, -10, -11, -12]
+def _decoders_of_the_library():
+    """the decoder matrix comes from the library (lz4flex_get_tuning "decoder_config_<i>": variant * 1000 + parameter; no device needed),
+    so a decoder the library can be pinned to cannot go untested; encoded as above"""
+    from lz4_flex_amd import _lib
+    try:
+        lib = _lib.load()
+    except ImportError:                                   # (collection on a box without the built library: the GPU tests cannot run there anyway)
+        return [16, -408, -432, -464, -5, -6, -7, -8, -10, -11, -12]
+    out, i = [], 0
+    while True:
+        v = lib.lz4flex_get_tuning(None, b"decoder_config_%d" % i)
+        if v < 0:
+            break
+        variant, par = divmod(v, 1000)
+        out.append(par if variant == 1 else (-400 - par if variant == 4 else -variant))
+        i += 1
+    return out
+
+
+DECODERS = _decoders_of_the_library()
+assert set(DECODERS) >= {16, -408, -432, -464, -5, -6, -7, -8, -10, -11, -12}, DECODERS
 
 
 def _select_decoder(lib, ctx, lanes):
@@ -50,7 +70,7 @@ def _select_decoder(lib, ctx, lanes):
     elif lanes <= -400:
         assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 4) == 0
         assert lib.lz4flex_set_tuning(ctx, b"decompress_blocks_per_wg", -lanes - 400) == 0
-    elif lanes in (-5, -6, -7, -8, -10, -11, -12):
+    elif lanes <= -5:
         assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", -lanes) == 0
     else:
         raise AssertionError(lanes)

@@ -111,7 +111,16 @@ def main():
     rnd = random.Random(args.seed)
     # (decompress_variant, blocks per workgroup of the split decoder | for 7 / 8: 2 = a parser and a copier workgroup per block, in
     # launches of 100 blocks)
-    decoders = [(1, 0), (4, 8), (4, 32), (4, 64), (5, 0), (6, 0), (7, 0), (8, 0), (7, 2), (8, 2), (10, 0), (11, 0), (12, 0)]   # (9, plan / replay: tools builds only since round 5; 12: the fused decoder)
+    # every decoder configuration the library names (lz4flex_get_tuning "decoder_config_<i>": the same list the test matrix is made of),
+    # plus the workgroup decoder with two workgroups per block: (variant, blocks per workgroup or pair mode)
+    decoders, i = [], 0
+    while True:
+        v = lib.lz4flex_get_tuning(None, b"decoder_config_%d" % i)
+        if v < 0:
+            break
+        decoders.append((v // 1000, v % 1000 if v // 1000 == 4 else 0))
+        i += 1
+    decoders += [(7, 2), (8, 2)]
     t_end = time.time() + args.seconds
     rounds = inputs = blocks = 0
     while time.time() < t_end:
