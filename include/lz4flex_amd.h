@@ -249,9 +249,9 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  *   Blocks of <= 64 KiB are one window either way.  Environment: LZ4FLEX_SLIDING_WINDOW=0|1|2.
  * "compress_subwindows" (throughput encoder): 0 (default) = by batch size -- a batch that leaves most of the encoder's persistent
  *   workgroups ("compress_workgroups", read-only: two per CU) without a block cuts every block of at most 64 KiB into 4 (n * 4 <=
- *   workgroups) or 2 (n * 2 <= workgroups) sub-windows that different workgroups encode side by side: a scalar compress_into and
- *   small batches take about half the time, at a ratio a few tenths of a percent higher; the BYTES of a block therefore depend on
- *   the size of the batch it travels in (always a valid block); 1 = never, 2 / 4 = always.
+ *   workgroups), 3 or 2 sub-windows that different workgroups encode side by side: a scalar compress_into and small batches take
+ *   about half the time, at a ratio a few tenths of a percent higher; the BYTES of a block therefore depend on the size of the batch
+ *   it travels in (always a valid block); 1 = never, 2 / 3 / 4 = always.
  * Kernel selection, for measurements only (every choice produces the same bytes / lengths / error variants):
  * "decompress_variant": 0 = by batch size (default), 7 = one block per WORKGROUP, token chain and copies parallel inside the
  *   block (lz4_decompress_pcd.hip: few, large blocks; 8 = the same with its small test geometry, 10 / 11 = with 256 / 512 lanes

@@ -231,9 +231,9 @@ static int launch_compress_any(lz4flex_ctx* c, const CompressArgs& a, bool big, 
         CompressArgs aw = a;
         aw.slide = c->comp_sliding == 2 ? 49152u : (c->comp_sliding == 1 ? 32768u : 0u);
         // sub-windows (lz4_compress_wave.hip Item::sub): batches that leave at least half / three quarters of the persistent workgroups
-        // without a block cut their blocks of <= 64 KiB into 2 / 4 items each
+        // without a block cut their blocks of <= 64 KiB into 2 / 3 / 4 items each
         aw.sub = c->comp_sub != 0 ? (uint32_t)c->comp_sub
-                                  : (a.n * 4u <= (uint32_t)c->wave_wgs ? 4u : (a.n * 2u <= (uint32_t)c->wave_wgs ? 2u : 1u));
+                                  : (a.n * 4u <= (uint32_t)c->wave_wgs ? 4u : (a.n * 3u <= (uint32_t)c->wave_wgs ? 3u : (a.n * 2u <= (uint32_t)c->wave_wgs ? 2u : 1u)));
         le = launch_compress_wave(aw, c->wave_ws, c->wave_wgs, s, c->wave_prof, c->comp_carry_wait != 0);
         if (le == hipSuccess) {
             HIP_TRY(hipEventRecord(c->wave_done, s));
@@ -418,7 +418,7 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "compress_subwindows")) {
-        if (value != 0 && value != 1 && value != 2 && value != 4) return -LZ4FLEX_E_INVALID_ARG;
+        if (value < 0 || value > 4) return -LZ4FLEX_E_INVALID_ARG;
         c->comp_sub = value;
         return 0;
     }
@@ -518,7 +518,7 @@ int lz4flex_get_tuning(lz4flex_ctx* c, const char* key) {
     if (!strcmp(key, "compress_carry_wait")) return c->comp_carry_wait;
     if (!strcmp(key, "compress_sliding_window")) return c->comp_sliding;
     if (!strcmp(key, "compress_subwindows")) return c->comp_sub;
-    if (!strcmp(key, "compress_workgroups")) return c->wave_wgs;         // (what "compress_subwindows" 0 decides by: n * 4 <= this -> 4, n * 2 <= this -> 2)
+    if (!strcmp(key, "compress_workgroups")) return c->wave_wgs;         // (what "compress_subwindows" 0 decides by: n * 4 <= this -> 4, n * 3 <= this -> 3, n * 2 <= this -> 2)
     if (!strcmp(key, "decompress_pcd_pair")) return c->dec_pcd_pair;
     if (!strcmp(key, "compress_lanes")) return c->comp_lanes;
     if (!strcmp(key, "decompress_variant")) return c->dec_variant;

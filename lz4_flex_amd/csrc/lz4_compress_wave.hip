@@ -1146,7 +1146,7 @@ __device__ __attribute__((noinline)) void load_window(const uint8_t* __restrict_
 // anchored-last-window mechanism, applied to every window.  All blocks of a launch still encode side by side: the history
 // is INPUT, nothing waits.  Price: every byte is indexed and loaded twice (the indexer, 160 k of a window's 300 k cycles,
 // becomes the longer half).
-// SUB-WINDOWS (round 5; CompressArgs::sub = 2 or 4): a block of at most 64 KiB is ONE window, one workgroup, and a worker's walk over its
+// SUB-WINDOWS (round 5; CompressArgs::sub = 2, 3 or 4): a block of at most 64 KiB is ONE window, one workgroup, and a worker's walk over its
 // 8 KiB segment is what the block waits for -- with fewer blocks than workgroups most of the chip idles (160 text blocks: 160 of 512
 // workgroups for 0.23 ms; a scalar compress_into: one).  Such a block is cut into `sub` items of 64 KiB / sub parsed bytes each: item k is
 // the window [0, (k + 1) quarter) of the block with its first k quarters as history -- the anchored-last-window mechanism again --, its
@@ -1155,7 +1155,7 @@ __device__ __attribute__((noinline)) void load_window(const uint8_t* __restrict_
 // segments are shorter (ratio + 0.1 ... 0.3 %), and the bytes depend on `sub` (the scalar model takes it as a parameter).
 struct Item {
     uint32_t blk, win, nwin, len, skip, hist, slide;     // slide: 0, or the bytes the windows advance by (HIST with history in front of the block; CompressArgs::slide for a long block)
-    uint32_t sub;                                        // 0, or the parsed bytes per sub-window (WINDOW / CompressArgs::sub) of a block cut into sub-windows
+    uint32_t sub;                                        // 0, or the parsed bytes per sub-window (WINDOW / CompressArgs::sub, rounded up to 512) of a block cut into sub-windows
     uint64_t in_off;
 };
 // window geometry: window t.win covers [win_base, win_base + win_len) of the item and parses [win_from, that end)
@@ -1196,9 +1196,9 @@ __device__ __forceinline__ void item_load(const CompressArgs& a, Item& it) {
     it.slide = h != 0u ? HIST : ((a.slide != 0u && len > WINDOW) ? a.slide : 0u);
     it.nwin = it.slide != 0u ? (it.len <= WINDOW ? 1u : 1u + (it.len - WINDOW + it.slide - 1u) / it.slide)
                       : (len == 0u ? 1u : (uint32_t)(((uint64_t)len + WINDOW - 1u) / WINDOW));
-    if ((a.sub == 2u || a.sub == 4u) && h == 0u && len <= WINDOW && len > WINDOW / a.sub) {       // sub-windows: see Item
-        it.sub = WINDOW / a.sub;
-        it.nwin = (len + it.sub - 1u) / it.sub;
+    if (a.sub >= 2u && a.sub <= 4u && h == 0u && len <= WINDOW) {                                  // sub-windows: see Item
+        const uint32_t q = ((WINDOW + a.sub - 1u) / a.sub + 511u) & ~511u;                             // 32 768, 22 016 (three: 43 groups of 512), 16 384
+        if (len > q) { it.sub = q; it.nwin = (len + q - 1u) / q; }
     }
     const uint64_t need = 20ull + (uint64_t)len * 110ull / 100ull;   // get_maximum_output_size, compress.rs:588-590
     if ((uint64_t)cap < need) { it.skip = 1u; it.nwin = 1u; }

@@ -40,7 +40,7 @@ typedef struct {
     uint32_t skipd;  /* a position buried this deep in a running match is not evaluated */
     uint32_t hist;   /* 0, or HIST: `in` starts HIST bytes before the block (a Linked frame's previous bytes); they are history only */
     uint32_t slide;  /* windows of a block without history in front of it advance by: 0 = 64 KiB, 1 = 32 KiB (HIST: every window start of a long block sees >= 32 KiB behind it), 2 = 48 KiB (>= 16 KiB) */
-    uint32_t sub;    /* 2 / 4: a block of at most 64 KiB (and more than 64 KiB / sub, without history) is cut into sub-windows: window k = [0, (k + 1) * 64 KiB / sub)
+    uint32_t sub;    /* 2 / 3 / 4: a block of at most 64 KiB (and more than 64 KiB / sub, without history) is cut into sub-windows: window k = [0, (k + 1) * 64 KiB / sub)
                         of the block, parsed from k * 64 KiB / sub on (the kernel's Item::sub: small batches); else 0 / 1 */
 } lz4w_params;
 #define HIST (WINDOW / 2u)
@@ -254,7 +254,11 @@ size_t lz4w_compress(const uint8_t *in, uint32_t n, uint8_t *out, const lz4w_par
     uint16_t *d = (uint16_t *)calloc((size_t)n + WAVE, 2);
     lz4w_seq *seqs = (lz4w_seq *)malloc(sizeof(lz4w_seq) * ((size_t)n / 4 + 2));
     g_slide = P->hist != 0 ? HIST : (P->slide == 2 ? 49152u : (P->slide == 1 ? HIST : 0u));
-    g_subq = ((P->sub == 2 || P->sub == 4) && P->hist == 0 && n <= WINDOW && n > WINDOW / P->sub) ? WINDOW / P->sub : 0;
+    g_subq = 0;
+    if (P->sub >= 2 && P->sub <= 4 && P->hist == 0 && n <= WINDOW) {
+        const uint32_t q = ((WINDOW + P->sub - 1) / P->sub + 511u) & ~511u;   /* 32 768, 22 016, 16 384 */
+        if (n > q) g_subq = q;
+    }
     if (n) lz4w_index(in, n, d, P->hist);
     const size_t ns = n ? lz4w_parse(in, n, d, P, seqs) : 0;
     size_t o = 0;

@@ -324,11 +324,11 @@ def test_history_must_lie_inside_the_input(blk):
 
 
 @pytest.mark.parametrize("carry_wait", [1, 0])
-@pytest.mark.parametrize("setting,n_blocks", [(0, 1), (0, 100), (0, 200), (0, 300), (1, 40), (2, 40), (4, 40), (4, 700)])
+@pytest.mark.parametrize("setting,n_blocks", [(0, 1), (0, 100), (0, 160), (0, 200), (0, 300), (1, 40), (2, 40), (3, 40), (4, 40), (4, 700), (3, 600)])
 def test_wave_encoder_subwindows(blk, setting, n_blocks, carry_wait):
     """small batches (round 5): a block of at most 64 KiB is cut into 2 or 4 sub-windows that different workgroups encode side by side, the
     output position travelling between them like between the windows of a long block.  "compress_subwindows" 0 (by batch size: 1 block and
-    100 blocks -> 4, 200 -> 2, 300 -> 1 with 512 workgroups), 1 / 2 / 4 forced (700 blocks: more blocks than workgroups, a workgroup walks
+    100 blocks -> 4, 160 -> 3, 200 -> 2, 300 -> 1 with 512 workgroups), 1 / 2 / 3 / 4 forced (700 blocks: more blocks than workgroups, a workgroup walks
     its blocks' sub-windows itself).  Ragged lengths around every quarter, text / JSON / noise / runs; every block == the scalar model with
     that many sub-windows, decodes with the oracle and with liblz4; carry_wait 0: every waiting sub-window gives up, the second launch
     encodes the block again to the same bytes"""
@@ -337,7 +337,7 @@ def test_wave_encoder_subwindows(blk, setting, n_blocks, carry_wait):
     rnd = random.Random(1000 * setting + n_blocks)
     j, t = O.fixture_plain("compression_66k_JSON"), O.fixture_plain("compression_65k")
     noise = bytes(rnd.getrandbits(8) for _ in range(70000))
-    lens = [65536, 65536, 65535, 49152, 49153, 32768, 32769, 32767, 16384, 16385, 16383, 40000, 20000, 1000, 12, 0, 65536, 60001, 33000, 70000, 65537]
+    lens = [65536, 65536, 65535, 49152, 49153, 32768, 32769, 32767, 16384, 16385, 16383, 40000, 20000, 1000, 12, 0, 65536, 60001, 33000, 70000, 65537, 22016, 22017, 44032, 44033]
     blocks = []
     for k in range(n_blocks):
         src = (j, t, j, noise, bytes(70000), j)[k % 6]

@@ -111,3 +111,21 @@ def test_history_in_front_of_a_block():
     rc, ref = O.frame_compress(stream, block_size=4, block_mode=1)
     assert rc == 0
     assert with_h < alone and with_h < len(ref) - 50, (with_h, alone, len(ref))
+
+
+def test_sub_windows_of_the_model():
+    """sub = 2 / 3 / 4 (what the library does to the blocks of small batches): lengths around every boundary of every setting; valid
+    blocks for the reference's decoder and for liblz4; blocks too short for a second sub-window are the one-window bytes"""
+    j, t = O.fixture_plain("compression_66k_JSON"), O.fixture_plain("compression_65k")
+    for sub, q in ((2, 32768), (3, 22016), (4, 16384)):
+        for n in (q - 1, q, q + 1, 2 * q, 2 * q + 1, min(3 * q + 1, 65536), 65535, 65536, 12, 0):
+            for src in (j, t):
+                d = (src * 2)[7:7 + n]
+                c = W.compress(d, sub=sub)
+                assert O.decompress(c, len(d)) == ("ok", d), (sub, n)
+                if d:
+                    assert O.c_decompress(c, len(d)) == d
+                if n <= q:
+                    assert c == W.compress(d, sub=1)
+    d = (j * 2)[:65537]
+    assert W.compress(d, sub=3) == W.compress(d, sub=1)          # longer than a window: windows, not sub-windows

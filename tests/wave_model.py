@@ -38,7 +38,7 @@ SLIDE_DEFAULT = 2        # "compress_sliding_window": 0 = windows advance by 64 
 def auto_sub(n_blocks, workgroups):
     """what the library's default ("compress_subwindows" 0) picks for a batch of n_blocks with `workgroups` persistent workgroups
     (lz4flex_get_tuning "compress_workgroups")"""
-    return 4 if n_blocks * 4 <= workgroups else (2 if n_blocks * 2 <= workgroups else 1)
+    return 4 if n_blocks * 4 <= workgroups else (3 if n_blocks * 3 <= workgroups else (2 if n_blocks * 2 <= workgroups else 1))
 
 
 def compress(data, nseg=NSEG, cap=CAP, skipd=SKIPD, hist=0, slide=None, sub=None):

@@ -96,14 +96,92 @@ def frames(args):
     print("gpu_fuzz --frames: seed %d, %d frames written (random options, chunking, both modes), each decoded by the oracle and by both front ends; %d oracle-written frames decoded" % (args.seed, n, n // 2))
 
 
+def many(args):
+    """lz4flex_frame_{compress,decompress}_many: batches of random streams x random frame options x both compress modes.  Every frame
+    written is decoded by the oracle's FrameDecoder (exact mode: equals the oracle's FrameEncoder); the frames of a batch -- this
+    library's, the oracle's, some with a flush boundary, some cut or with a flipped bit -- go back through decompress_frames and
+    every stream must come out as lz4flex_frame_decompress returns it alone (bytes, or the same error class)."""
+    import io
+    import oracle_api as O
+    from lz4_flex_amd import block, frame as F
+    rnd = random.Random(args.seed)
+    t_end = time.time() + args.seconds
+    sizes = {0: F.BlockSize.Auto, 4: F.BlockSize.Max64KB, 5: F.BlockSize.Max256KB, 6: F.BlockSize.Max1MB, 7: F.BlockSize.Max4MB}
+    batches = written = read = 0
+    while time.time() < t_end:
+        streams = [make_input(rnd) for _ in range(rnd.randint(1, 40))]
+        bs = rnd.choice([0, 4, 4, 4, 5, 6, 7])
+        linked, bc, cc, cs = rnd.random() < 0.6, rnd.random() < 0.25, rnd.random() < 0.25, rnd.random() < 0.25
+        fi = F.FrameInfo(block_size=sizes[bs], block_mode=F.BlockMode.Linked if linked else F.BlockMode.Independent,
+                         block_checksums=bc, content_checksum=cc, content_size=0 if cs else None)
+        frames_in = []
+        for mode in ("fast", "exact"):
+            block.set_compress_mode(mode)
+            try:
+                frs = F.compress_frames(streams, fi)
+            finally:
+                block.set_compress_mode("fast")
+            for d, fr in zip(streams, frs):
+                rc, back, used = O.frame_decompress(fr, len(d))
+                assert rc == 0 and back == d and used == len(fr), ("many: the oracle's FrameDecoder does not return the stream", mode, bs, linked, bc, cc, cs, len(d))
+                if mode == "exact":
+                    want = O.frame_compress(d, block_mode=1 if linked else 0, block_size=bs, block_checksums=int(bc), content_checksum=int(cc),
+                                            content_size=len(d) if cs else None)[1]
+                    assert fr == want, ("many, exact mode: frame != the oracle's FrameEncoder", bs, linked, bc, cc, cs, len(d))
+                written += 1
+            frames_in.append(frs)
+        # the way back: a mix of frames per stream
+        mix, caps = [], []
+        for i, d in enumerate(streams):
+            k = rnd.random()
+            if k < 0.3:
+                fr = frames_in[0][i]
+            elif k < 0.5:
+                fr = frames_in[1][i]
+            elif k < 0.7:
+                fr = O.frame_compress(d, block_mode=rnd.randint(0, 1), block_size=rnd.choice([4, 5, 6, 7]), block_checksums=rnd.randint(0, 1),
+                                      content_checksum=rnd.randint(0, 1))[1]
+            elif k < 0.8 and len(d) > 2:
+                sink = io.BytesIO()
+                enc = F.FrameEncoder(sink, F.FrameInfo(block_size=F.BlockSize.Max64KB, block_mode=F.BlockMode.Linked))
+                cut = rnd.randint(1, len(d) - 1)
+                enc.write(d[:cut]); enc.flush(); enc.write(d[cut:]); enc.finish()
+                fr = sink.getvalue()
+            elif k < 0.9:
+                fr = bytearray(frames_in[0][i])
+                fr[rnd.randrange(len(fr))] ^= 1 << rnd.randrange(8)
+                fr = bytes(fr)
+            else:
+                fr = frames_in[1][i][:rnd.randint(0, len(frames_in[1][i]))]
+            mix.append(fr)
+            caps.append(len(d) + rnd.choice([0, 0, 0, 1, 70000]))
+        got = F.decompress_frames(mix, caps, return_errors=True)
+        for i, (fr, cap) in enumerate(zip(mix, caps)):
+            try:
+                alone = F.decompress_frame(fr, cap)[0]
+            except Exception as e:
+                alone = e
+            if isinstance(alone, Exception):
+                assert type(got[i]) is type(alone), ("many: error class", i, repr(got[i])[:80], repr(alone)[:80])
+            else:
+                assert got[i] == alone, ("many: bytes", i, len(fr), cap)
+            read += 1
+        batches += 1
+    print("gpu_fuzz --many: seed %d, %d batches, %d frames written by compress_frames (random options, both modes) and decoded by the oracle, "
+          "%d frames (ours, the oracle's, flushed, corrupted, cut) through decompress_frames == lz4flex_frame_decompress alone" % (args.seed, batches, written, read))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--frames", action="store_true")
+    ap.add_argument("--many", action="store_true")
     args = ap.parse_args()
     if args.frames:
         return frames(args)
+    if args.many:
+        return many(args)
     import oracle_api as O
     import wave_model as W
     from lz4_flex_amd import _lib as L, block
