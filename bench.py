@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="kernel experiments only: skip the bit-exact check (never for reported numbers)")
     ap.add_argument("--only", choices=["both", "compress", "decompress"], default="both",
                     help="profiling aid: run only one kernel in the timed steps (value then covers that kernel only)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="the default line measures roofline.traffic of the dominant kernel in this run (two rocprofv3 --pmc passes of a "
+                         "short compress-only child run, ~30 s); this switches that off (the figure then comes from profiles/traffic.json)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="the default line (config 2, one GPU) also runs configs 3, 4 and 5 for a few steps behind its timed loop and "
                          "carries their figures under `other_configs`; this switches that off")
@@ -163,11 +166,62 @@ def main():
     if (args.config == 2 and world == 1 and args.only == "both" and not args.blocks and not args.no_cpu_baseline and not args.no_other_configs
             and not args.no_verify and not args.decompress_variant):
         out["other_configs"] = other_configs(args, env)
+        if not args.no_live_traffic:
+            live_traffic(out, args)
     if rank == 0:
         print(json.dumps(out))
     lib.lz4flex_ctx_destroy(ctx)
     if world > 1:
         dist.destroy_process_group()
+
+
+def live_traffic(out, args):
+    """roofline.traffic of the dominant kernel (the encoder) measured in THIS run, as MI355X_MICROARCH.md prescribes: rocprofv3 --pmc
+    FETCH_SIZE and --pmc WRITE_SIZE in separate passes (only --kernel-trace beside the counter), each over a short compress-only child
+    run of this script on the same workload; median over the kernel's launches; FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at
+    64 B), units KiB.  Any failure leaves the figure from profiles/traffic.json in place (traffic_source says which it is)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return
+    kname = out["roofline"].get("kernel", "lz4_compress_wave_kernel")
+    med = {}
+    tmp = tempfile.mkdtemp(prefix="lz4flex_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--only", "compress", "--no-cpu-baseline", "--no-other-configs",
+                   "--no-live-traffic", "--compress-mode", args.compress_mode]
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
+            vals = []
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if kname in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                            vals.append(float(r["Counter_Value"]))
+            if len(vals) < 2:
+                return
+            vals.sort()
+            med[counter] = (vals[len(vals) // 2], len(vals))
+        hbm = int(med["FETCH_SIZE"][0] * 2048 + med["WRITE_SIZE"][0] * 1024)
+        src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (--kernel-trace only beside the counter) over a "
+               "compress-only child run (1 + 3 launches each); medians %.0f / %.0f KiB over %d / %d launches; FETCH_SIZE x 2 (gfx950), KiB -> bytes"
+               % (med["FETCH_SIZE"][0], med["WRITE_SIZE"][0], med["FETCH_SIZE"][1], med["WRITE_SIZE"][1]))
+        for r in (out["roofline"], out.get("kernels", {}).get("compress", {}).get("roofline")):
+            if r:
+                if r.get("traffic") is not None:
+                    r["traffic_profiles_file"] = r["traffic"]
+                r["traffic"] = hbm
+                r["traffic_source"] = src
+    except Exception as e:
+        out["roofline"]["live_traffic_error"] = repr(e)[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def other_configs(args, env):
