@@ -21,7 +21,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
-#include <numeric>
+#include <new>
 #include <vector>
 
 #include "../../include/lz4flex_amd.h"
@@ -34,6 +34,7 @@ using namespace lz4flex_dev;
 constexpr uint32_t UNCOMPRESSED_BIT = 0x80000000u;
 constexpr uint64_t WINDOW_SIZE = 65536, FAST_HISTORY = 32768;
 constexpr uint32_t CHAIN_MAX = 65536u;                   // blocks per chained decode batch (LZ4FLEX_MEM_CHAINED)
+constexpr uint64_t MAX_SLOTS = 1ull << 26;               // block-table entries per decompress_many call (12 bytes each on the host and on the device)
 constexpr uint64_t STREAM_MAX = 0x7FFF0000ull - (8u << 20);   // longer streams take the one-shot path (table reposition near 2 GiB, frame/compress.rs:266-271)
 
 size_t block_bytes(int code) {                           // BlockSize::get_size, frame/header.rs:68-77
@@ -275,7 +276,7 @@ int decompress_many_device(lz4flex_ctx* c, const uint8_t* in, const uint64_t* in
         // (a header that does not parse, a legacy frame, an output a chained batch cannot address: the streaming decoder's business)
         if (hl < 0 || fi[i].legacy_frame || bs == 0 || (fi[i].block_mode == 1 && out_cap[i] > 0xFFFFFFFFull - 2 * bs)) { again[i] = 1; continue; }
         const uint64_t cap_blocks = out_cap[i] / bs + 2;
-        if (slots + cap_blocks > 0x7FFFFFFFull) { again[i] = 1; continue; }
+        if (slots + cap_blocks > MAX_SLOTS) { again[i] = 1; continue; }             // (a table of that size is not worth building: out_cap far beyond the data)
         hdr_len[i] = (uint32_t)hl;
         m.hdr_len = (uint32_t)hl; m.block_size = (uint32_t)bs;
         m.flags = (fi[i].block_checksums ? 1u : 0u) | (fi[i].content_checksum ? 2u : 0u);
@@ -460,6 +461,7 @@ int lz4flex_frame_compress_many(lz4flex_ctx* ctx, const void* in_base, const uin
     lz4flex_frame_info def{};
     if (!info) info = &def;                                                             // FrameInfo::default(), frame/header.rs:151-163
     if (info->legacy_frame) return -LZ4FLEX_E_INVALID_ARG;
+    try {
     if (mem_kind == LZ4FLEX_MEM_DEVICE)
         return compress_many_device(ctx, (const uint8_t*)in_base, in_off, in_len, n, info, (uint8_t*)out_base, out_off, out_cap, out_len, status,
                                     (hipStream_t)hip_stream);
@@ -479,6 +481,7 @@ int lz4flex_frame_compress_many(lz4flex_ctx* ctx, const void* in_base, const uin
         if (status[i] == 0 && out_len[i]) TRY_HIP(hipMemcpyAsync((uint8_t*)out_base + out_off[i], (const uint8_t*)d_out + s_out[i], (size_t)out_len[i], hipMemcpyDeviceToHost, s));
     TRY_HIP(hipStreamSynchronize(s));
     return 0;
+    } catch (const std::bad_alloc&) { return -LZ4FLEX_E_NOMEM; }      // (host tables and staging are std::vectors: nothing escapes the C ABI)
 }
 
 int lz4flex_frame_decompress_many(lz4flex_ctx* ctx, const void* in_base, const uint64_t* in_off, const uint64_t* in_len, uint32_t n,
@@ -487,6 +490,7 @@ int lz4flex_frame_decompress_many(lz4flex_ctx* ctx, const void* in_base, const u
     if (n == 0) return 0;
     if (!in_off || !in_len || !out_off || !out_cap || !out_len || !status || !in_base) return -LZ4FLEX_E_INVALID_ARG;
     TRY_RC(ctx_resolve(&ctx));
+    try {
     if (mem_kind == LZ4FLEX_MEM_DEVICE)
         return decompress_many_device(ctx, (const uint8_t*)in_base, in_off, in_len, n, (uint8_t*)out_base, out_off, out_cap, out_len, status, detail,
                                       (hipStream_t)hip_stream);
@@ -505,6 +509,7 @@ int lz4flex_frame_decompress_many(lz4flex_ctx* ctx, const void* in_base, const u
         if (status[i] == 0 && out_len[i]) TRY_HIP(hipMemcpyAsync((uint8_t*)out_base + out_off[i], (const uint8_t*)d_out + s_out[i], (size_t)out_len[i], hipMemcpyDeviceToHost, s));
     TRY_HIP(hipStreamSynchronize(s));
     return 0;
+    } catch (const std::bad_alloc&) { return -LZ4FLEX_E_NOMEM; }
 }
 
 }  // extern "C"
