@@ -106,3 +106,41 @@ def test_dispatch_thresholds_are_readable_without_a_device():
         ts.append(v)
     assert len(ts) >= 5 and ts == sorted(ts) and ts[-1] == 16384
     assert lib.lz4flex_get_tuning(None, b"dispatch_threshold_x") < 0
+
+
+def test_decoder_configurations_are_listed_without_a_device():
+    """lz4flex_get_tuning "decoder_config_<i>": every decoder configuration the build can be pinned to (variant * 1000 + parameter); the
+    GPU decoder matrix (tests/test_gpu_block.py DECODERS) and tools/gpu_fuzz.py are generated from it"""
+    from lz4_flex_amd import _lib
+    lib = _lib.load()
+    cs = []
+    for i in range(64):
+        v = lib.lz4flex_get_tuning(None, b"decoder_config_%d" % i)
+        if v < 0:
+            break
+        cs.append(v)
+    assert {1016, 4064, 5000, 6000, 7000, 8000, 10000, 11000, 12000} <= set(cs) and len(cs) == len(set(cs))
+    assert 9000 not in cs                    # the plan / replay decoder left the product library (tools builds only)
+    assert lib.lz4flex_get_tuning(None, b"decoder_config_") < 0
+
+
+def test_many_frames_entry_points_check_their_arguments_without_a_device():
+    """lz4flex_frame_{compress,decompress}_many: nothing to do is success, missing arrays are refused before any device is touched;
+    with no device the calls fail loudly (there is no CPU path)"""
+    import ctypes as C
+    from lz4_flex_amd import _lib, frame
+    lib = _lib.load()
+    z = (C.c_uint64 * 1)(0)
+    st = (C.c_int32 * 1)(0)
+    buf = C.create_string_buffer(64)
+    assert lib.lz4flex_frame_compress_many(None, buf, z, z, 0, None, buf, z, z, z, st, _lib.MEM_HOST, None) == 0
+    assert lib.lz4flex_frame_decompress_many(None, buf, z, z, 0, buf, z, z, z, st, None, _lib.MEM_HOST, None) == 0
+    assert lib.lz4flex_frame_compress_many(None, buf, None, z, 1, None, buf, z, z, z, st, _lib.MEM_HOST, None) == -_lib.E_INVALID_ARG
+    assert lib.lz4flex_frame_decompress_many(None, buf, z, z, 1, buf, z, z, z, None, None, _lib.MEM_HOST, None) == -_lib.E_INVALID_ARG
+    assert frame.compress_frames([]) == [] and frame.decompress_frames([], 10) == []
+    if lib.lz4flex_device_count() == 0:
+        cap = (C.c_uint64 * 1)(64)
+        assert lib.lz4flex_frame_compress_many(None, buf, z, z, 1, None, buf, z, cap, z, st, _lib.MEM_HOST, None) == -_lib.E_NO_DEVICE
+        from lz4_flex_amd import block
+        with pytest.raises(block.DeviceError):
+            frame.compress_frames([b"no gpu, no codec"])
