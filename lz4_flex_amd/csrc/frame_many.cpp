@@ -267,7 +267,6 @@ int decompress_many_device(lz4flex_ctx* c, const uint8_t* in, const uint64_t* in
     Desc W;
     const size_t a_fr = W.take(sizeof(ManyFrame) * (size_t)n);
     uint64_t slots = 0;
-    std::vector<uint32_t> hdr_len(n, 0);
     for (uint32_t i = 0; i < n; i++) {
         ManyFrame& m = W.host<ManyFrame>(a_fr)[i];
         m.off = in_off[i]; m.len = in_len[i]; m.skip = 1;
@@ -277,7 +276,6 @@ int decompress_many_device(lz4flex_ctx* c, const uint8_t* in, const uint64_t* in
         if (hl < 0 || fi[i].legacy_frame || bs == 0 || (fi[i].block_mode == 1 && out_cap[i] > 0xFFFFFFFFull - 2 * bs)) { again[i] = 1; continue; }
         const uint64_t cap_blocks = out_cap[i] / bs + 2;
         if (slots + cap_blocks > MAX_SLOTS) { again[i] = 1; continue; }             // (a table of that size is not worth building: out_cap far beyond the data)
-        hdr_len[i] = (uint32_t)hl;
         m.hdr_len = (uint32_t)hl; m.block_size = (uint32_t)bs;
         m.flags = (fi[i].block_checksums ? 1u : 0u) | (fi[i].content_checksum ? 2u : 0u);
         m.slot = (uint32_t)slots; m.slot_cap = (uint32_t)cap_blocks; m.skip = 0;
