@@ -124,7 +124,7 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
                                 : ((a.n <= PCD_MAX_BLOCKS || big_blocks) ? 7 : (a.n <= DISPATCH_WAVE_PAIR_MAX ? 6 : (a.n <= DISPATCH_WAVE_MAX ? 5 : 4)));
     const int geo_req = v == 10 ? 2 : (v == 11 ? 3 : 0);  // (an explicit geometry holds for prefix / chained batches too)
     if (a.out_pos != nullptr && v != 8) v = 7;           // prefix mode (Linked frames): only the workgroup decoder knows it
-    if (v == 12 && a.dict_base != nullptr) v = 4;
+    if ((v == 12 || v == 13) && a.dict_base != nullptr) v = 4;
     // the workgroup decoder's geometry by batch size (lz4_decompress_pcd.hip GeoMid*: smaller workgroups, more of them per CU); large
     // blocks and chains keep the full workgroup (a chain is one block at a time, a large block wants the long tiles)
     int pcd_geo = v == 8 ? 1 : geo_req;
@@ -200,6 +200,16 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
         r.only_status = REDO;
         // a chained batch's marked blocks depend on each other: in chain order, not side by side
         return r.chain_done ? launch_decompress_chain_redo(r, s) : launch_decompress(r, c->dec_lanes, s);
+    }
+    if (v == 13) {
+        // a wavefront per block, a lane per sequence (lz4_decompress_seq.hip); irregular blocks go to the reference-order kernel
+        constexpr int32_t REDO = 0x7F000001;
+        const hipError_t e = launch_decompress_seq(a, REDO, s);
+        if (e != hipSuccess) return e;
+        if (!c->dec_second_pass) return hipSuccess;
+        DecompressArgs r = a;
+        r.only_status = REDO;
+        return launch_decompress(r, c->dec_lanes, s);
     }
     if (v == 12) {
         // parser -> emitter -> quads (lz4_decompress_fused.hip); oversized blocks go to the reference-order kernel
@@ -428,7 +438,7 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "decompress_variant")) {
-        if (value != 0 && value != 1 && (value < 4 || value > 12)) return -LZ4FLEX_E_INVALID_ARG;
+        if (value != 0 && value != 1 && (value < 4 || value > 13)) return -LZ4FLEX_E_INVALID_ARG;
 #ifndef LZ4FLEX_TOOLS
         if (value == 9) return -LZ4FLEX_E_INVALID_ARG;          // plan / replay: tools builds only
 #endif
@@ -503,7 +513,7 @@ int lz4flex_get_tuning(lz4flex_ctx* c, const char* key) {
     // "decompress_blocks_per_wg" for variant 4, else 0); the list ends where the key is refused.  ONE list: tests/test_gpu_block.py's
     // decoder matrix and tools/gpu_fuzz.py are generated from it (a decoder added here is tested there), no device needed.
     if (!strncmp(key, "decoder_config_", 15)) {
-        const int t[] = {1016, 4008, 4032, 4064, 5000, 6000, 7000, 8000, 10000, 11000, 12000,
+        const int t[] = {1016, 4008, 4032, 4064, 5000, 6000, 7000, 8000, 10000, 11000, 12000, 13000,
 #ifdef LZ4FLEX_TOOLS
                          9000,
 #endif

@@ -109,6 +109,9 @@ hipError_t launch_decompress_chain_redo(const DecompressArgs& a, hipStream_t s);
 // launch_decompress (only_status = redo_code), which decodes them in the reference's check order
 hipError_t launch_decompress_wave(const DecompressArgs& a, int32_t redo_code, hipStream_t s);
 hipError_t launch_decompress_wave_pair(const DecompressArgs& a, int32_t redo_code, hipStream_t s);
+// one block per wavefront, one LANE PER SEQUENCE (lz4_decompress_seq.hip, round 6): speculative part walks give the token positions,
+// 64 sequences at a time are placed by a prefix sum and copied by their lanes; irregular blocks are left with status redo_code
+hipError_t launch_decompress_seq(const DecompressArgs& a, int32_t redo_code, hipStream_t s);
 hipError_t launch_decompress_split(const DecompressArgs& a, hipStream_t s, int blocks_per_wg = 0);   // parser / copier wavefronts, no dict/prefix
 // parser -> emitter -> quad wavefronts (lz4_decompress_fused.hip: the split decoder's parser, the replay decoder's copy engine, no dict/prefix);
 // blocks of 512 KiB or more are left with status redo_code for a second pass of launch_decompress

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=16384)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--data", default="json")
+    ap.add_argument("--variant", default="4", help="decompress_variant(s) to run with every library, comma separated (4 = split decoder with 64 blocks per workgroup, 13 = sequence decoder)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -78,13 +79,14 @@ def main():
     t_ooff, t_cap = torch.from_numpy(a_ooff.astype(np.int64)).to(dev), torch.from_numpy(a_cap.astype(np.int32)).to(dev)
     na = len(cases)
 
-    for path in args.libs:
+    for path, variant in [(q, int(v)) for q in args.libs for v in args.variant.split(",")]:
         lib = bind(path)
         ctx = C.c_void_p()
         assert lib.lz4flex_ctx_create(C.byref(ctx), 0) == 0
-        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 4) == 0
-        assert lib.lz4flex_set_tuning(ctx, b"decompress_blocks_per_wg", 64) == 0
-        tag = "%s [%s]" % (os.path.basename(os.path.dirname(path)), lib.lz4flex_build_id().decode())
+        assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", variant) == 0
+        if variant == 4:
+            assert lib.lz4flex_set_tuning(ctx, b"decompress_blocks_per_wg", 64) == 0
+        tag = "%s [%s] v%d" % (os.path.basename(os.path.dirname(path)), lib.lz4flex_build_id().decode(), variant)
         # (1) adversarial batch
         t_out = torch.full((out_bytes,), 0xA5, dtype=torch.uint8, device=dev)
         t_ol = torch.zeros(na, dtype=torch.int32, device=dev)
@@ -119,6 +121,19 @@ def main():
                                                 L.MEM_DEVICE, stream) == 0, lib.lz4flex_last_error()
         dec_once(); dec_once(); torch.cuda.synchronize()
         ok = int((bst != 0).sum().item()) == 0 and torch.equal(back, src)
+        if not ok:
+            neq = (back != src).view(n, B).any(dim=1).nonzero().flatten()
+            print("    bench: %d blocks with a status, %d blocks with wrong bytes, first %s" % (int((bst != 0).sum().item()), neq.numel(), neq[:8].tolist()), flush=True)
+            if neq.numel():
+                b0 = int(neq[0]); d = (back.view(n, B)[b0] != src.view(n, B)[b0]).nonzero().flatten()
+                print("    block %d: %d wrong bytes, first at %s, last at %d; got %s want %s" % (b0, d.numel(), d[:8].tolist(), int(d[-1]),
+                      bytes(back.view(n, B)[b0][int(d[0]) - 8:int(d[0]) + 24].tolist()), bytes(src.view(n, B)[b0][int(d[0]) - 8:int(d[0]) + 24].tolist())), flush=True)
+        if variant >= 5:      # how many blocks did the first pass leave to the reference-order kernel?
+            assert lib.lz4flex_set_tuning(ctx, b"decompress_second_pass", 0) == 0
+            dec_once(); torch.cuda.synchronize()
+            print("    first pass left %d of %d bench blocks to the second pass" % (int((bst != 0).sum().item()), n), flush=True)
+            assert lib.lz4flex_set_tuning(ctx, b"decompress_second_pass", 1) == 0
+            dec_once(); torch.cuda.synchronize()
         if hasattr(lib, "lz4flex_debug_phase_split"):
             lib.lz4flex_debug_phase_split.argtypes = [C.c_void_p, C.c_int]
             v = (C.c_ulonglong * 16)()
