@@ -50,23 +50,47 @@ using pcd::X_ERR;
 constexpr uint32_t PB = 60u;                 // bytes per part
 constexpr uint32_t NPART = 64u;              // parts per tile = lanes
 constexpr uint32_t PT = PB * NPART;          // 3 840 compressed bytes per tile
-constexpr uint32_t TPAD = 16u;               // bytes in front of the tile (a hop reads the byte before its token)
-constexpr uint32_t TMARGIN = 240u;           // bytes behind the tile staged with it (a lane's literals + offset: <= 2 + 64 + 3 + 8)
+constexpr uint32_t TPAD = 16u;               // bytes in front of the tile (a lane reads the 16 bytes that END with its literals)
+constexpr uint32_t TMARGIN = 240u;           // bytes behind the tile staged with it
 constexpr uint32_t TILE_LDS = TPAD + PT + TMARGIN;
 constexpr uint32_t POSCAP = PT / 3u + 8u;    // sequences per tile: a sequence with a match is at least 3 bytes
 constexpr uint32_t POS_LDS = (2u * POSCAP + 15u) & ~15u;
 constexpr uint32_t LITMAX = 64u;             // literal run a lane copies itself
 constexpr uint32_t FARMAX = 64u;             // match from the written-back output a lane copies itself
-static_assert(TILE_LDS % 16u == 0u && PT % 16u == 0u, "geometry");
+constexpr uint32_t WALK_LITMAX = 200u;       // literal run a hop steps over without the generic walker (its end stays inside the staged bytes)
+// LDS: [token list | tile | window | 16]  (the tile is not first: a lane may read up to 16 bytes in front of it)
+constexpr uint32_t LDS_POS = 0u, LDS_TILE = POS_LDS, LDS_WIN = POS_LDS + TILE_LDS;
+static_assert(TILE_LDS % 16u == 0u && PT % 16u == 0u && POS_LDS % 16u == 0u, "geometry");
+static_assert(PT - 1u + 4u + 15u + WALK_LITMAX + 4u < PT + TMARGIN, "a hop's length byte lies inside the staged bytes");
+static_assert(PT + 1u + LITMAX + 16u <= PT + TMARGIN && PT + 1u + LITMAX + 8u <= PT + TMARGIN, "a lane's literals and offset lie inside the staged bytes");
 
-template <uint32_t R_>
+template <uint32_t R_, uint32_t KEEP_>
 struct Geo {
-    static constexpr uint32_t R = R_;                    // window bytes
-    static constexpr uint32_t KEEP = R_ / 2u;            // history a slide keeps
-    static constexpr uint32_t BUDGET = R_ - KEEP - 64u;  // output bytes of one chunk / one cooperative piece
-    static constexpr uint32_t LDS = TILE_LDS + POS_LDS + R_ + 16u;   // (+ 16: a lane's 16-byte source read may end behind the window)
+    static constexpr uint32_t R = R_;                              // window bytes
+    static constexpr uint32_t KEEP = KEEP_;                        // history a slide keeps
+    static constexpr uint32_t BUDGET = (R_ - KEEP_ - 64u) / 2u;    // output bytes of one chunk (two chunks are in flight) / of one cooperative piece
+    static constexpr uint32_t LDS = POS_LDS + TILE_LDS + R_ + 16u; // (+ 16: a lane's 16-byte source read may end behind the window)
 };
 
+#ifdef LZ4S_PROF      // tools: cycles of every wavefront per phase -> g_sq_prof[0..15], event counts in [16..31]
+__device__ unsigned long long g_sq_prof[32];
+struct Prof { uint64_t c[32]; uint64_t t; };
+#define SQ_PROF_ARG , Prof& P
+#define SQ_PROF_PASS , P
+#define SQ_TICK(i) { const uint64_t t_ = __builtin_readcyclecounter(); P.c[i] += t_ - P.t; P.t = t_; }
+#define SQ_COUNT(i, n) { P.c[i] += (uint64_t)(n); }
+#else
+#define SQ_PROF_ARG
+#define SQ_PROF_PASS
+#define SQ_TICK(i)
+#define SQ_COUNT(i, n)
+#endif
+
+// Behind a region only some lanes execute: an (empty) instruction of its own.  Without it the compiler lets the region end in the
+// block where uniform paths (an early return, a loop's exit) meet as well, and then takes every value merged there -- the
+// function's result, the loop's state -- for divergent: masks and counters move to vector registers, uniform branches become
+// exec-mask loops (the first build of this file ran its whole main loop that way).
+#define SQ_JOIN() asm volatile("; join")
 #define LZ4S_DPP(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xf, false))
 __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
     v += LZ4S_DPP(v, 0x111, 0xf);     // row_shr:1
@@ -80,110 +104,102 @@ __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+__device__ __forceinline__ bool lanes(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }      // this lane's bit of a wave-uniform mask
 __device__ __forceinline__ uint32_t ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
+__device__ __forceinline__ uint64_t low_mask(uint32_t n) { return n >= 64u ? ~0ull : (1ull << n) - 1ull; }
 __device__ __forceinline__ uint32_t bperm(uint32_t lane_src, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lane_src * 4u), (int)v); }
 
-__device__ __forceinline__ u32x4 lds_rd16(const lds_u8* p) { u32x4 v; __builtin_memcpy(&v, (const void*)p, 16); return v; }
-__device__ __forceinline__ void lds_wr16(lds_u8* p, const u32x4& v) { __builtin_memcpy((void*)p, &v, 16); }
+// LDS by byte address (the dynamic segment starts at 0)
+__device__ __forceinline__ lds_u8* L8(uint32_t a) { return (lds_u8*)(uintptr_t)a; }
+__device__ __forceinline__ u32x4 lds_rd16(uint32_t a) { u32x4 v; __builtin_memcpy(&v, (const void*)L8(a), 16); return v; }
+__device__ __forceinline__ void lds_wr16(uint32_t a, const u32x4& v) { __builtin_memcpy((void*)L8(a), &v, 16); }
+__device__ __forceinline__ void lds_wr8(uint32_t a, uint32_t lo, uint32_t hi) { const u32x2 v = {lo, hi}; __builtin_memcpy((void*)L8(a), &v, 8); }
+__device__ __forceinline__ void lds_wr4(uint32_t a, uint32_t v) { __builtin_memcpy((void*)L8(a), &v, 4); }
+__device__ __forceinline__ void lds_wr2(uint32_t a, uint32_t v) { const uint16_t t = (uint16_t)v; __builtin_memcpy((void*)L8(a), &t, 2); }
+__device__ __forceinline__ void lds_wr1(uint32_t a, uint32_t v) { *L8(a) = (uint8_t)v; }
 // the four bytes at LDS address a (any alignment) out of two aligned dwords
-__device__ __forceinline__ uint32_t lds_rd4u(const lds_u8* base, uint32_t a) {
-    const lds_u32* q = (const lds_u32*)(base + (a & ~3u));
+__device__ __forceinline__ uint32_t lds_rd4u(uint32_t a) {
+    const lds_u32* q = (const lds_u32*)(uintptr_t)(a & ~3u);
     const uint32_t d0 = q[0], d1 = q[1];
     return __builtin_amdgcn_alignbyte(d1, d0, a & 3u);
 }
 
 // n (1..16) bytes of v to LDS, exactly (lz4_decompress_wave.hip write_exact16)
-__device__ __forceinline__ void write_exact16(lds_u8* dst, const u32x4& v, uint32_t n) {
-    if (n >= 16u) { __builtin_memcpy((void*)dst, &v, 16); return; }
+__device__ __forceinline__ void write_exact16(uint32_t dst, const u32x4& v, uint32_t n) {
+    if (n >= 16u) { lds_wr16(dst, v); return; }
     const bool n8 = (n & 8u) != 0u, n4 = (n & 4u) != 0u, n2 = (n & 2u) != 0u;
     const uint32_t w4 = n8 ? v.z : v.x;                               // the dword at byte offset (n & 8)
     const uint32_t wq = n8 ? (n4 ? v.w : v.z) : (n4 ? v.y : v.x);     // the dword at byte offset (n & 12)
-    if (n8) { const uint64_t t = (uint64_t)v.x | ((uint64_t)v.y << 32); __builtin_memcpy((void*)dst, &t, 8); }
-    if (n4) __builtin_memcpy((void*)(dst + (n & 8u)), &w4, 4);
-    if (n2) { const uint16_t t = (uint16_t)wq; __builtin_memcpy((void*)(dst + (n & 12u)), &t, 2); }
-    if (n & 1u) dst[n & 14u] = (uint8_t)(wq >> (n2 ? 16 : 0));
+    if (n8) lds_wr8(dst, v.x, v.y);
+    if (n4) lds_wr4(dst + (n & 8u), w4);
+    if (n2) lds_wr2(dst + (n & 12u), wq);
+    if (n & 1u) lds_wr1(dst + (n & 14u), wq >> (n2 ? 16 : 0));
 }
 
 // the compressed bytes for the generic sequence walker (lz4_pcd_common.h parse_seq): the staged tile from LDS, else memory
 struct Reader {
-    const lds_u8* tile;      // LDS copy of [t0 - TPAD, t0 + PT + TMARGIN)
     const g_u8* g;
     uint32_t t0;
     __device__ __forceinline__ uint32_t operator()(uint32_t pos) const {
         const uint32_t r = pos - t0;
-        return r < PT + TMARGIN ? (uint32_t)tile[TPAD + r] : (uint32_t)g[pos];
+        return r < PT + TMARGIN ? (uint32_t)*L8(LDS_TILE + TPAD + r) : (uint32_t)g[pos];
     }
     __device__ __forceinline__ uint32_t u32(uint32_t pos) const { return (*this)(pos) | ((*this)(pos + 1u) << 8) | ((*this)(pos + 2u) << 16) | ((*this)(pos + 3u) << 24); }
 };
+// where the sequence at position p ends (the next token; ilen: the block ends there), exactly, byte by byte -- the walk's rare path, kept
+// out of its loop.  X_ERR: this chain cannot be a real one.
+__device__ __noinline__ uint32_t slow_next(const g_u8* g, uint32_t t0, uint32_t ilen, uint32_t p) {
+    Reader rd;
+    rd.g = g; rd.t0 = t0;
+    pcd::Seq q;
+    const uint32_t nx = pcd::parse_seq<Reader, false>(rd, ilen, p, q);
+    return nx == X_END ? ilen : nx;
+}
 
-struct Part {
+struct Part {           // positions relative to the tile's first byte t0
     uint64_t marks;      // token positions of the standing walk, relative to the part's first byte
     uint32_t from;       // where the standing walk began (X_ERR: none)
-    uint32_t exit;       // where its chain leaves the part: a position >= the part's end (>= ilen: the block ends or fails there), or X_ERR
+    uint32_t exit;       // where its chain leaves the part: a position >= the part's end (>= ilen - t0: the block ends or fails there), or X_ERR
 };
 
-// the generic walker's verdict as an exit position
-__device__ __forceinline__ uint32_t as_pos(uint32_t nx, uint32_t ilen) { return nx == X_END ? ilen : nx; }
-
-// One walk of a part from p.  FIRST: every position is marked.  Else: until the walk lands on a position the standing walk marked
-// (its marks stand from there, and its exit) or leaves the part.
+// One walk of a part from r (decompress.rs:244-258, 366-391: positions only).  FIRST: every position is marked.  Else: until the walk
+// lands on a position the standing walk marked (its marks stand from there, and its exit) or leaves the part.  A hop is two LDS
+// round trips at most: token + first length byte, and the match length byte of a 15-nibble.
 template <bool FIRST>
-__device__ __forceinline__ void walk_part(const Reader& rd, uint32_t ilen, uint32_t p, uint32_t part0, uint32_t part_end, Part& s) {
-    const uint32_t entry = p;
+__device__ __forceinline__ void walk_part(const g_u8* g, uint32_t t0, uint32_t ilen, uint32_t r, uint32_t p0, uint32_t pend, Part& s) {
+    const uint32_t entry = r;
+    const uint32_t tb = LDS_TILE + TPAD;
     uint64_t m2 = 0ull;
     uint32_t exit_ = X_ERR;
     bool merged = false;
-    uint32_t prev = p;
-    bool pm15 = false;                    // the previous sequence's match nibble was 15 and its length byte has not been looked at
-    const lds_u8* tb = rd.tile + TPAD - rd.t0;     // tb + position (wraps; only ever indexed with positions of the staged range)
     for (;;) {
-        if (p >= part_end) { exit_ = p; break; }
-        const uint64_t bit = 1ull << (p - part0);
-        if (!FIRST && (s.marks & bit) != 0ull) { merged = true; break; }
-        // the bytes p - 1 .. p + 2 in one round trip
-        const uint32_t w = lds_rd4u(tb, p - 1u);
-        const uint32_t pb = w & 0xFFu, t = (w >> 8) & 0xFFu, e1 = (w >> 16) & 0xFFu;
-        if (pm15 && pb == 255u) {         // the previous match length goes on: that sequence again, byte by byte
-            pcd::Seq q;
-            const uint32_t nx = pcd::parse_seq<Reader, false>(rd, ilen, prev, q);
-            if (nx == X_ERR) break;
-            p = as_pos(nx, ilen);
-            pm15 = false;
-            continue;
-        }
-        const uint32_t L = t >> 4, M = t & 15u;
-        uint32_t nx;
-        bool m15 = M == 15u;
-        if (L == 15u && e1 == 255u) {     // more than one literal length byte
-            pcd::Seq q;
-            nx = pcd::parse_seq<Reader, false>(rd, ilen, p, q);
-            if (nx == X_ERR) break;
-            nx = as_pos(nx, ilen);
-            m15 = false;
-        } else {
-            const uint32_t lit = L == 15u ? 15u + e1 : L;
-            nx = p + (L == 15u ? 2u : 1u) + lit + 2u + (m15 ? 1u : 0u);
-        }
-        // a 15-nibble's length byte is checked by the next hop -- unless there is none: the walk leaves the part or meets the standing walk
-        if (m15 && nx < ilen) {
-            const bool leaving = nx >= part_end;
-            const bool meeting = !FIRST && !leaving && ((s.marks >> (nx - part0)) & 1ull) != 0ull;
-            if (leaving || meeting) {
-                if (rd(nx - 1u) == 255u) {
-                    pcd::Seq q;
-                    nx = pcd::parse_seq<Reader, false>(rd, ilen, p, q);
-                    if (nx == X_ERR) break;
-                    nx = as_pos(nx, ilen);
-                }
-                m15 = false;
+        bool slow = false;
+        uint64_t bit = 0ull;
+        for (;;) {
+            if (r >= pend) { exit_ = r; break; }
+            bit = 1ull << (r - p0);
+            if (!FIRST && (s.marks & bit) != 0ull) { merged = true; break; }
+            const uint32_t w = lds_rd4u(tb + r);
+            const uint32_t L = (w >> 4) & 15u, M = w & 15u, e1 = (w >> 8) & 0xFFu;
+            const bool l15 = L == 15u;
+            uint32_t nx = r + (l15 ? 15u + e1 + 4u : L + 3u);
+            slow = l15 && e1 > WALK_LITMAX - 15u;
+            if (M == 15u && !slow) {
+                const uint32_t e2 = *L8(tb + nx);
+                nx += 1u;
+                slow = e2 == 255u;
             }
+            if (slow) break;
+            m2 |= bit;
+            r = nx;
         }
+        if (!slow) break;
+        const uint32_t nx = slow_next(g, t0, ilen, t0 + r);     // (r < pend: a position of the block)
+        if (nx == X_ERR) break;
         m2 |= bit;
-        prev = p;
-        pm15 = m15;
-        p = nx;
+        r = nx - t0;
     }
-    if (merged) { s.marks = m2 | (s.marks & ~((1ull << (p - part0)) - 1ull)); s.from = entry; }
+    if (merged) { s.marks = m2 | (s.marks & ~((1ull << (r - p0)) - 1ull)); s.from = entry; }
     else { s.marks = m2; s.from = entry; s.exit = exit_; }
 }
 
@@ -191,46 +207,56 @@ template <class G>
 struct Dec {
     const g_u8* in;
     g_u8* out;
-    lds_u8* tile;
-    lds_u16* pos;
-    lds_u8* win;
     uint32_t ilen, cap, lane;
     uint32_t OP;         // bytes produced
     uint32_t W0;         // the window holds [W0, OP), W0 a multiple of 16
-    uint32_t F;          // bytes written back, a multiple of 16 (W0 <= F unless nothing slid yet)
+    uint32_t F;          // bytes written back, a multiple of 16 (W0 <= F)
 
-    // ring -> output, whole 16-byte units
-    __device__ __forceinline__ void write_back() {
-        const uint32_t lim = OP & ~15u;
-        for (uint32_t q = F + 16u * lane; q < lim; q += 1024u) {
-            const u32x4 v = lds_rd16(win + (q - W0));
-            __builtin_memcpy((void*)(out + q), &v, 16);
+    // window -> output, whole 16-byte units of [F, op)
+    __device__ __forceinline__ void write_back(uint32_t op) {
+        const uint32_t lim = op & ~15u;
+        for (uint32_t q0 = F; q0 < lim; q0 += 1024u) {         // (uniform trip counts, the lanes' share inside: a loop that lanes leave at different
+            const uint32_t q = q0 + 16u * lane;                 //  times makes the compiler take every value merged behind it for divergent)
+            if (q < lim) {
+                const u32x4 v = lds_rd16(LDS_WIN + (q - W0));
+                __builtin_memcpy((void*)(out + q), &v, 16);
+            }
+            SQ_JOIN();
         }
         F = lim;
     }
-    // make room for `need` (<= BUDGET) more bytes: write back, move the last KEEP bytes to the window's start
-    __device__ __forceinline__ void ensure(uint32_t need) {
-        if (OP - W0 + need <= G::R) return;
-        write_back();
-        const uint32_t nw = (OP - G::KEEP) & ~15u;          // (OP - W0 > KEEP here: need <= BUDGET)
-        const uint32_t S = nw - W0, n = OP - nw;
-        for (uint32_t i = 16u * lane; i < n; i += 1024u) {   // a lower iteration never writes what a higher one reads (S >= 0); within one, reads precede writes
-            const u32x4 v = lds_rd16(win + S + i);
-            lds_wr16(win + i, v);
+    // make room for `need` (<= 2 BUDGET) more bytes behind op: write back, move the last KEEP bytes to the window's start
+    __device__ __forceinline__ void ensure(uint32_t op, uint32_t need) {
+        if (op - W0 + need <= G::R) return;
+        write_back(op);
+        const uint32_t nw = (op - G::KEEP) & ~15u;           // (op - W0 > KEEP here: need <= R - KEEP - 64)
+        const uint32_t S = nw - W0, n = op - nw;
+        for (uint32_t i0 = 0u; i0 < n; i0 += 1024u) {        // a lower iteration never writes what a higher one reads (S >= 0); within one, reads precede writes
+            const uint32_t i = i0 + 16u * lane;
+            if (i < n) {
+                const u32x4 v = lds_rd16(LDS_WIN + S + i);
+                lds_wr16(LDS_WIN + i, v);
+            }
+            SQ_JOIN();
         }
         W0 = nw;
     }
     __device__ __forceinline__ void finish() {
-        write_back();
-        if (F + lane < OP) out[F + lane] = win[F + lane - W0];
+        write_back(OP);
+        if (F + lane < OP) out[F + lane] = *L8(LDS_WIN + F + lane - W0);
+        SQ_JOIN();
         F = OP;
     }
     // literals of any length from the compressed stream, whole wavefront, <= BUDGET bytes per piece
     __device__ __forceinline__ void coop_literals(uint32_t src, uint32_t n) {
         for (uint32_t c = 0u; c < n; c += G::BUDGET) {
             const uint32_t m = n - c < G::BUDGET ? n - c : G::BUDGET;
-            ensure(m);
-            for (uint32_t i = lane; i < m; i += 64u) win[OP - W0 + i] = in[src + c + i];
+            ensure(OP, m);
+            for (uint32_t i0 = 0u; i0 < m; i0 += 64u) {
+                const uint32_t i = i0 + lane;
+                if (i < m) *L8(LDS_WIN + OP - W0 + i) = in[src + c + i];
+                SQ_JOIN();
+            }
             OP += m;
         }
     }
@@ -241,7 +267,7 @@ struct Dec {
         const float rcp = offset < 64u ? 1.0f / (float)offset : 0.0f;
         for (uint32_t c = 0u; c < n; c += G::BUDGET) {
             const uint32_t m = n - c < G::BUDGET ? n - c : G::BUDGET;
-            ensure(m);
+            ensure(OP, m);
             const uint32_t d = OP, src = d - offset;
             for (uint32_t s0 = 0u; s0 < m; s0 += 64u) {
                 const uint32_t i = s0 + lane;
@@ -255,9 +281,10 @@ struct Dec {
                         si = r;
                     }
                     const uint32_t ps = src + si;
-                    const uint8_t byte = ps >= W0 ? win[ps - W0] : out[ps];
-                    win[d - W0 + i] = byte;
+                    const uint8_t byte = ps >= W0 ? *L8(LDS_WIN + ps - W0) : out[ps];
+                    *L8(LDS_WIN + d - W0 + i) = byte;
                 }
+                SQ_JOIN();
             }
             OP += m;
         }
@@ -265,13 +292,13 @@ struct Dec {
     // One sequence of any shape at `ip`, by the whole wavefront, with the reference's checks (decompress.rs:334-443; any violation ->
     // false: the reference-order kernel decodes the block again and names the error).  done: the block ended here.
     __device__ bool exact_seq(uint32_t ip, bool& done) {
-        const uint32_t t = in[ip];
+        const uint32_t t = uni(in[ip]);
         ip += 1u;
         uint32_t lit = t >> 4;
         if (lit == 15u) {
             for (;;) {
                 if (ip >= ilen) return false;
-                const uint32_t b = in[ip];
+                const uint32_t b = uni(in[ip]);
                 ip += 1u;
                 lit += b;
                 if (lit > 0x7FFFFFFFu) return false;      // (a 32-bit sum must not wrap: the reference counts in usize)
@@ -283,14 +310,14 @@ struct Dec {
         ip += lit;
         if (ip >= ilen) { done = true; return true; }
         if (ilen - ip < 2u) return false;
-        const uint32_t offset = (uint32_t)in[ip] | ((uint32_t)in[ip + 1u] << 8);
+        const uint32_t offset = uni((uint32_t)in[ip] | ((uint32_t)in[ip + 1u] << 8));
         ip += 2u;
         if (offset == 0u) return false;
         uint32_t ml = 4u + (t & 15u);
         if (ml == 19u) {
             for (;;) {
                 if (ip >= ilen) return false;
-                const uint32_t b = in[ip];
+                const uint32_t b = uni(in[ip]);
                 ip += 1u;
                 ml += b;
                 if (ml > 0x7FFFFFFFu) return false;
@@ -304,140 +331,207 @@ struct Dec {
     }
 };
 
-// The chunks of one tile: sequences [0, n_tile) of the token list (positions relative to t0).  false: the block is irregular.
+// A chunk: up to 64 consecutive sequences of the tile's token list, lane = sequence, placed but not yet copied
+struct Chunk {
+    uint32_t lit, ml, dst, src, lsr;    // per lane: lengths, output position of the literals, source position of the match, literals' position relative to t0
+    u32x4 f0, f1, f2, f3;               // a far match's source bytes (requested at set-up, used a chunk later)
+    uint64_t act, haslit, near, far;    // lanes: in the chunk; with literals; match from the window; match from the written-back output
+    uint32_t nact, T, tp0;              // sequences, output bytes; nact == 0: the sequence at tp0 (relative to t0) is executed alone by the wavefront
+    bool last;                          // the block's last sequence is the chunk's last
+};
+
+// Set-up of the chunk that starts at sequence sidx with `op` bytes in front of it -- of which the last `pending` are still being
+// produced by the chunk before (room for both is made here: a slide never moves a placed chunk).  false: the block is irregular.
 template <class G>
-__device__ __forceinline__ bool run_chunks(Dec<G>& D, uint32_t t0, uint32_t n_tile, bool& done) {
-    const uint32_t lane = D.lane, ilen = D.ilen;
-    const lds_u8* tb = D.tile + TPAD;            // tb + tile-relative position
+__device__ __forceinline__ bool setup_chunk(Dec<G>& D, uint32_t t0, uint32_t n_tile, uint32_t sidx, uint32_t op, uint32_t pending, Chunk& C) {
+    const uint32_t lane = D.lane;
+    const uint32_t ilr = D.ilen - t0;                          // the block's end, relative to t0
+    const uint32_t tb = LDS_TILE + TPAD;
+    const uint32_t nrem = n_tile - sidx;
+    const uint32_t idx = sidx + (lane < nrem ? lane : nrem - 1u);
+    const uint32_t tpr = (uint32_t)*(const lds_u16*)(uintptr_t)(LDS_POS + 2u * idx);
+    // ---- token, lengths, offset (decompress.rs:249-258, 284, 373-391) ----------------------------------------------------
+    const uint32_t w = lds_rd4u(tb + tpr);
+    const uint32_t L = (w >> 4) & 15u, M = w & 15u, e1 = (w >> 8) & 0xFFu;
+    const bool l15 = L == 15u;
+    const uint32_t lit = l15 ? 15u + e1 : L;
+    const uint32_t lsr = tpr + (l15 ? 2u : 1u);
+    const uint64_t biglit = ballot(lit > LITMAX);              // (covers a length byte of 255) not a lane's work: exact_seq
+    const uint32_t lend = lit > LITMAX ? 0u : lsr + lit;
+    const uint32_t w1 = lds_rd4u(tb + lend);
+    const uint32_t off = w1 & 0xFFFFu, e2 = (w1 >> 16) & 0xFFu;
+    const bool m15 = M == 15u;
+    const uint32_t mlx = 4u + M + (m15 ? e2 : 0u);
+    const uint32_t nxt = lend + (m15 ? 3u : 2u);               // the next token
+    const uint64_t lastm = ballot(lend >= ilr);                // the block's last sequence: literals only (:366-368) -- or an error
+    const uint64_t errm = ballot(lend > ilr) |                                                           // :346-348
+                          (~lastm & (ballot(lend + 2u > ilr) | ballot(nxt >= ilr) | ballot(off == 0u))); // :373-375, :439-443, :168-173
+    const uint64_t bigm = biglit | (~lastm & (ballot(m15 && e2 == 255u) | ballot(off < mlx)));           // more length bytes; a match that reads its own output
+    const uint32_t ml = lanes(lastm) ? 0u : mlx;
+    // ---- the chunk: up to the first sequence that is not a lane's work, and at most BUDGET bytes ------------------------------
+    uint32_t nact = nrem < 64u ? nrem : 64u;
+    {
+        const uint64_t bm = bigm & low_mask(nact);
+        if (bm != 0ull) nact = ctz64(bm);
+    }
+    const uint32_t u = lanes(low_mask(nact)) ? lit + ml : 0u;
+    const uint32_t incl = wave_incl_add(u);
+    {
+        const uint64_t over = ballot(incl > G::BUDGET) & low_mask(nact);
+        if (over != 0ull) nact = ctz64(over);
+    }
+    uint32_t T = nact != 0u ? rdlane(incl, nact - 1u) : 0u;
+    C.tp0 = rdlane(tpr, 0u);
+    if (nact != 0u) {
+        if ((errm & low_mask(nact)) != 0ull) return false;
+        if (T > D.cap - op) return false;                      // OutputTooSmall (:349-356, :403-408): named by the reference-order kernel
+        D.write_back(op - pending);                            // (every chunk: a source that leaves the window has to be in memory)
+        D.ensure(op - pending, pending + T);
+    }
+    const uint32_t dst = op + incl - u, dm = dst + lit;
+    const uint32_t src = dm - off;
+    uint64_t am = low_mask(nact);
+    const uint64_t hasm = ~lastm;
+    if ((ballot(off > dm) & hasm & am) != 0ull) return false;  // OffsetOutOfBounds (:286-289, :398-402)
+    // a source in front of the window comes from the written-back output: all of it has to be there, and short enough for a lane.
+    // "The window" is what the NEXT chunk's set-up will have left of it when this chunk is copied: a slide keeps KEEP bytes in front
+    // of the chunk that is pending then -- this one
+    const uint32_t near_lo = op > G::KEEP && op - G::KEEP > D.W0 ? op - G::KEEP : D.W0;
+    const uint64_t farm = ballot(src < near_lo) & hasm;
+    {
+        const uint64_t fbig = farm & am & (ballot(src + ml > D.F) | ballot(ml > FARMAX));
+        if (fbig != 0ull) { nact = ctz64(fbig); am = low_mask(nact); T = nact != 0u ? rdlane(incl, nact - 1u) : 0u; }
+    }
+    C.lit = lit; C.ml = ml; C.dst = dst; C.src = src; C.lsr = lsr;
+    C.nact = nact; C.T = T;
+    C.act = am;
+    C.haslit = ballot(lit != 0u) & am;
+    C.far = farm & am;
+    C.near = hasm & am & ~farm;
+    C.last = nact != 0u && ((lastm >> (nact - 1u)) & 1ull) != 0ull;
+    // ---- far sources: requested now, used a chunk later --------------------------------------------------------------------------
+    C.f0 = u32x4{0u, 0u, 0u, 0u}; C.f1 = C.f0; C.f2 = C.f0; C.f3 = C.f0;
+    if (lanes(C.far)) {
+        __builtin_memcpy(&C.f0, (const void*)(D.out + src), 16);
+        if (ml > 16u) __builtin_memcpy(&C.f1, (const void*)(D.out + src + ml - 16u), 16);
+        if (ml > 32u) __builtin_memcpy(&C.f2, (const void*)(D.out + src + 16u), 16);
+        if (ml > 48u) __builtin_memcpy(&C.f3, (const void*)(D.out + src + 32u), 16);
+    }
+    SQ_JOIN();
+    return true;
+}
+
+// What a lane needs to copy its n bytes (1 <= n) from LDS address s to LDS address d: the addresses of the LAST 16 bytes on both sides
+// and the lanes of every size class.  Two 16-byte reads -- the first and the last 16 bytes, the latter possibly beginning in front of
+// s -- and two overlapping writes of the size class; more than 32 bytes: the pieces between them.  Source and destination do not
+// overlap.  Computed once per chunk; the rounds only AND the classes with their ready lanes.
+struct CopyPlan {
+    uint32_t s, d, s2, d2, n;
+    uint64_t c16, c8, c4, c2, c1, gt32;       // n >= 16; 8..15; 4..7; 2..3; 1; n > 32
+};
+template <bool SMALL>
+__device__ __forceinline__ CopyPlan plan_copy(uint32_t s, uint32_t d, uint32_t n) {
+    CopyPlan P;
+    P.s = s; P.d = d; P.n = n; P.s2 = s + n - 16u; P.d2 = d + n - 16u;
+    const uint64_t ge16 = ballot(n >= 16u), ge8 = ballot(n >= 8u);
+    P.c16 = ge16; P.c8 = ge8 & ~ge16; P.gt32 = ballot(n > 32u);
+    if (SMALL) {
+        const uint64_t ge4 = ballot(n >= 4u), ge2 = ballot(n >= 2u);
+        P.c4 = ge4 & ~ge8; P.c2 = ge2 & ~ge4; P.c1 = ~ge2;
+    } else { P.c4 = ~ge8; P.c2 = 0ull; P.c1 = 0ull; }
+    return P;
+}
+template <bool SMALL>
+__device__ __forceinline__ void lane_copy(const CopyPlan& P, uint64_t m) {
+    u32x4 r1, r2;
+    if (lanes(m)) { r1 = lds_rd16(P.s); r2 = lds_rd16(P.s2); }
+    if (lanes(m & P.c16)) { lds_wr16(P.d, r1); lds_wr16(P.d2, r2); }
+    if (lanes(m & P.c8)) { lds_wr8(P.d, r1.x, r1.y); lds_wr8(P.d2 + 8u, r2.z, r2.w); }
+    if (lanes(m & P.c4)) { lds_wr4(P.d, r1.x); lds_wr4(P.d2 + 12u, r2.w); }
+    if (SMALL) {
+        if (lanes(m & P.c2)) { lds_wr2(P.d, r1.x); lds_wr2(P.d2 + 14u, r2.w >> 16); }
+        if (lanes(m & P.c1)) lds_wr1(P.d, r1.x);
+    }
+    SQ_JOIN();
+    uint64_t more = m & P.gt32;
+    for (uint32_t p = 16u; more != 0ull; p += 16u) {
+        if (lanes(more)) { const u32x4 r = lds_rd16(P.s + p); lds_wr16(P.d + p, r); }
+        SQ_JOIN();
+        more &= ballot(p + 32u < P.n);                        // the next piece, at p + 16, begins in front of the last one's start: p + 16 < n - 16
+    }
+}
+
+// The copies of a placed chunk (decompress.rs:276-280, 314-325, 357-361, 410-437).
+template <class G>
+__device__ __forceinline__ void exec_chunk(Dec<G>& D, const Chunk& C SQ_PROF_ARG) {
+    const uint32_t wb = LDS_WIN - D.W0;                        // window address of output position 0
+    const uint32_t wl = wb + C.dst, wm = wl + C.lit;
+    // ---- literals: 16 bytes per access, exact length ---------------------------------------------------------------------------
+    if (C.haslit != 0ull) { const CopyPlan L = plan_copy<true>(LDS_TILE + TPAD + C.lsr, wl, C.lit); lane_copy<true>(L, C.haslit); }
+    SQ_TICK(6)
+    // ---- far matches: the bytes requested at set-up -------------------------------------------------------------------------------
+    if (C.far != 0ull) {
+        if (lanes(C.far)) {
+            if (C.ml <= 16u) write_exact16(wm, C.f0, C.ml);
+            else {
+                lds_wr16(wm, C.f0);
+                if (C.ml > 32u) lds_wr16(wm + 16u, C.f2);
+                if (C.ml > 48u) lds_wr16(wm + 32u, C.f3);
+                lds_wr16(wm + C.ml - 16u, C.f1);
+            }
+        }
+        SQ_JOIN();
+    }
+    SQ_TICK(7) SQ_COUNT(17, 1) SQ_COUNT(20, C.nact) SQ_COUNT(23, __builtin_popcountll(C.far)) SQ_COUNT(24, __builtin_popcountll(C.near))
+    // ---- matches inside the window, in rounds: ready = every sequence that starts before the source's end is done ----------------
+    uint64_t todo = C.near;
+    const CopyPlan M = plan_copy<false>(wb + C.src, wm, C.ml);
+    const uint32_t s1 = C.src + C.ml;
+    while (todo != 0ull) {
+        const uint32_t dp = ctz64(todo);                      // every lane below dp is done: all bytes in front of its sequence are final
+        const uint32_t S = rdlane(C.dst, dp);
+        const uint64_t rm = todo & (ballot(s1 <= S) | (1ull << dp));
+        lane_copy<false>(M, rm);
+        todo &= ~rm;
+        SQ_COUNT(18, 1)
+    }
+    SQ_TICK(8)
+}
+
+// The chunks of one tile: sequences [0, n_tile) of the token list.  Two chunks are in flight: the next one is set up (token decode,
+// placement, checks, room in the window, requests for far sources) before the current one is copied.  false: the block is irregular.
+template <class G>
+__device__ __forceinline__ bool run_chunks(Dec<G>& D, uint32_t t0, uint32_t n_tile, bool& done SQ_PROF_ARG) {
     uint32_t sidx = 0u;
-    while (sidx < n_tile) {
-        const uint32_t idx = sidx + lane;
-        bool act = idx < n_tile;
-        const uint32_t tpr = act ? (uint32_t)D.pos[idx] : 0u;
-        // ---- token, lengths, offset (decompress.rs:249-258, 284, 373-391) ----------------------------------------------------
-        const uint32_t w = lds_rd4u(tb, tpr);
-        const uint32_t t = w & 0xFFu, e1 = (w >> 8) & 0xFFu;
-        const uint32_t L = t >> 4, M = t & 15u;
-        const uint32_t lit = L == 15u ? 15u + e1 : L;
-        const uint32_t lsr = tpr + (L == 15u ? 2u : 1u);          // literals, relative to t0
-        bool big = (L == 15u && e1 == 255u) || lit > LITMAX;      // not a lane's work: exact_seq
-        const uint32_t lend = big ? 0u : lsr + lit;
-        const uint32_t w1 = lds_rd4u(tb, lend);
-        const uint32_t off = w1 & 0xFFFFu, e2 = (w1 >> 16) & 0xFFu;
-        const uint32_t mlx = 4u + M + (M == 15u ? e2 : 0u);
-        big |= (M == 15u && e2 == 255u);
-        const uint32_t nxt = lend + 2u + (M == 15u ? 1u : 0u);    // the next token, relative to t0
-        const bool last = t0 + lend >= ilen;                      // the block's last sequence: literals only (:366-368) -- or an error
-        const bool has_m = !last;
-        bool err = t0 + lend > ilen;                              // :346-348
-        err |= has_m && (t0 + lend + 2u > ilen || t0 + nxt >= ilen || off == 0u);      // :373-375, :439-443, :168-173
-        big |= has_m && off < mlx;                                // a match that reads its own output: the periodic form
-        const uint32_t ml = has_m ? mlx : 0u;
-        // ---- the chunk: up to the first sequence that is not a lane's work, and at most BUDGET bytes ------------------------------
-        const uint64_t bigm = ballot(act && big);
-        uint32_t nact = n_tile - sidx < 64u ? n_tile - sidx : 64u;
-        if (bigm != 0ull) { const uint32_t k = ctz64(bigm); nact = k < nact ? k : nact; }
-        act = lane < nact;
-        const uint32_t u = act ? lit + ml : 0u;
-        const uint32_t incl = wave_incl_add(u);
-        {
-            const uint64_t over = ballot(act && incl > G::BUDGET);
-            if (over != 0ull) { const uint32_t k = ctz64(over); nact = k < nact ? k : nact; act = lane < nact; }
-        }
-        uint32_t T = nact != 0u ? rdlane(incl, nact - 1u) : 0u;
-        if (nact != 0u) {
-            if (ballot(act && err) != 0ull) return false;
-            if (T > D.cap - D.OP) return false;                    // OutputTooSmall (:349-356, :403-408): named by the reference-order kernel
-            D.ensure(T);
-        }
-        const uint32_t dst = D.OP + incl - u, dm = dst + lit;
-        const uint32_t src = dm - off;
-        if (ballot(act && has_m && off > dm) != 0ull) return false;    // OffsetOutOfBounds (:286-289, :398-402)
-        // a source in front of the window comes from the written-back output: all of it has to be there, and short enough for a lane
-        const bool farl = act && has_m && src < D.W0;
-        {
-            const uint64_t fbig = ballot(farl && (src + ml > D.F || ml > FARMAX));
-            if (fbig != 0ull) { const uint32_t k = ctz64(fbig); nact = k < nact ? k : nact; act = lane < nact; T = nact != 0u ? rdlane(incl, nact - 1u) : 0u; }
-        }
-        if (nact == 0u) {                                         // the first sequence alone, by the whole wavefront
-            const uint32_t tp0 = t0 + rdlane(tpr, 0u);
-            if (!D.exact_seq(tp0, done)) return false;
+    Chunk C;
+    if (!setup_chunk<G>(D, t0, n_tile, 0u, D.OP, 0u, C)) return false;
+    SQ_TICK(4)
+    for (;;) {
+        if (C.nact == 0u) {                                    // the sequence alone, by the whole wavefront
+            if (!D.exact_seq(t0 + C.tp0, done)) return false;
             sidx += 1u;
+            SQ_TICK(9) SQ_COUNT(19, 1)
             if (done) return sidx == n_tile;
+            if (sidx >= n_tile) return true;
+            if (!setup_chunk<G>(D, t0, n_tile, sidx, D.OP, 0u, C)) return false;
+            SQ_TICK(4)
             continue;
         }
-        const bool is_far = farl && act;
-        const bool is_near = act && has_m && !is_far;
-        // ---- far sources: requested now, used behind the literals ------------------------------------------------------------------
-        u32x4 f0 = {0u, 0u, 0u, 0u}, f1 = f0, f2 = f0, f3 = f0;
-        if (is_far) {
-            __builtin_memcpy(&f0, (const void*)(D.out + src), 16);
-            if (ml > 16u) __builtin_memcpy(&f1, (const void*)(D.out + src + ml - 16u), 16);
-            if (ml > 32u) __builtin_memcpy(&f2, (const void*)(D.out + src + 16u), 16);
-            if (ml > 48u) __builtin_memcpy(&f3, (const void*)(D.out + src + 32u), 16);
-        }
-        // ---- literals (decompress.rs:276-280, :357-361): 16 bytes per access, exact length ----------------------------------------
-        lds_u8* wl = D.win + (dst - D.W0);
-        const bool lp = act && lit != 0u;
-        if (ballot(lp) != 0ull) {
-            const lds_u8* la = tb + lsr;
-            if (lp) {
-                const u32x4 r1 = lds_rd16(la);
-                if (lit <= 16u) write_exact16(wl, r1, lit);
-                else {
-                    const u32x4 r2 = lds_rd16(la + lit - 16u);
-                    lds_wr16(wl, r1);
-                    lds_wr16(wl + lit - 16u, r2);
-                }
-            }
-            if (ballot(lp && lit > 32u) != 0ull) {
-                for (uint32_t p = 16u; p < LITMAX - 16u; p += 16u)
-                    if (lp && p + 16u < lit) { const u32x4 r = lds_rd16(la + p); lds_wr16(wl + p, r); }
-            }
-        }
-        // ---- far matches ----------------------------------------------------------------------------------------------------------------
-        lds_u8* wm = D.win + (dm - D.W0);
-        if (is_far) {
-            if (ml <= 16u) write_exact16(wm, f0, ml);
-            else {
-                lds_wr16(wm, f0);
-                if (ml > 32u) lds_wr16(wm + 16u, f2);
-                if (ml > 48u) lds_wr16(wm + 32u, f3);
-                lds_wr16(wm + ml - 16u, f1);
-            }
-        }
-        // ---- matches inside the window, in rounds: ready = every sequence that starts before the source's end is done ----------------
-        uint64_t todo = ballot(is_near);
-        const lds_u8* sa = D.win + (src - D.W0);
-        const uint32_t s1 = src + ml;
-        while (todo != 0ull) {
-            const uint32_t dp = ctz64(todo);                      // every lane below dp is done: all bytes in front of its sequence are final
-            const uint32_t S = rdlane(dst, dp);
-            const bool ready = is_near && ((todo >> lane) & 1ull) != 0ull && (s1 <= S || lane == dp);
-            if (ready) {
-                const u32x4 r1 = lds_rd16(sa);
-                if (ml <= 16u) write_exact16(wm, r1, ml);
-                else {
-                    const u32x4 r2 = lds_rd16(sa + ml - 16u);
-                    lds_wr16(wm, r1);
-                    lds_wr16(wm + ml - 16u, r2);
-                }
-            }
-            const uint64_t rm = ballot(ready);
-            if (ballot(ready && ml > 32u) != 0ull) {
-                for (uint32_t p = 16u; ; p += 16u) {
-                    const bool more = ready && p + 16u < ml;
-                    if (ballot(more) == 0ull) break;
-                    if (more) { const u32x4 r = lds_rd16(sa + p); lds_wr16(wm + p, r); }
-                }
-            }
-            todo &= ~rm;
-        }
-        D.OP += T;
-        sidx += nact;
-        if (ballot(act && last) != 0ull) { done = true; return sidx == n_tile; }
+        const uint32_t nsidx = sidx + C.nact, nop = D.OP + C.T;
+        const bool have_next = nsidx < n_tile && !C.last;
+        Chunk N;
+        N.nact = 0u; N.T = 0u; N.tp0 = 0u; N.last = false; N.act = 0ull; N.haslit = 0ull; N.near = 0ull; N.far = 0ull;
+        N.lit = 0u; N.ml = 0u; N.dst = 0u; N.src = 0u; N.lsr = 0u;
+        N.f0 = u32x4{0u, 0u, 0u, 0u}; N.f1 = N.f0; N.f2 = N.f0; N.f3 = N.f0;
+        if (have_next) { if (!setup_chunk<G>(D, t0, n_tile, nsidx, nop, C.T, N)) return false; }
+        SQ_TICK(4)
+        exec_chunk<G>(D, C SQ_PROF_PASS);
+        D.OP = nop;
+        sidx = nsidx;
+        if (C.last) { done = true; return sidx == n_tile; }
+        if (!have_next) return true;
+        C = N;
     }
-    return true;
 }
 
 template <class G>
@@ -446,12 +540,11 @@ __global__ void __launch_bounds__(64) lz4_decompress_seq_kernel(DecompressArgs a
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (b >= a.n) return;
+    // (every LDS access below goes by byte address from 0: the dynamic segment is the kernel's only LDS)
+    if ((uint32_t)(uintptr_t)(lds_u8*)seq_lds != 0u) { if (lane == 0u) { a.status[b] = redo_code; a.out_len[b] = 0u; } return; }
     Dec<G> D;
     D.in = (const g_u8*)(a.in_base + a.in_off[b]);
     D.out = (g_u8*)(a.out_base + a.out_off[b]);
-    D.tile = (lds_u8*)seq_lds;
-    D.pos = (lds_u16*)((lds_u8*)seq_lds + TILE_LDS);
-    D.win = (lds_u8*)seq_lds + TILE_LDS + POS_LDS;
     D.ilen = a.in_len[b];
     D.cap = a.out_cap[b];
     D.lane = lane;
@@ -459,37 +552,54 @@ __global__ void __launch_bounds__(64) lz4_decompress_seq_kernel(DecompressArgs a
     const uint32_t ilen = D.ilen;
     bool ok = ilen != 0u, done = false;          // (an empty block: decompress.rs:207-209, the reference-order kernel reports it)
     uint32_t entry = 0u;
-    if (lane < 4u) ((lds_u32*)D.tile)[lane] = 0u;     // the bytes in front of the first tile
-    while (ok && !done) {
+#ifdef LZ4S_PROF
+    Prof P;
+    for (int i = 0; i < 32; ++i) P.c[i] = 0ull;
+    P.t = __builtin_readcyclecounter();
+#endif
+    if (lane < 4u) lds_wr4(LDS_TILE + 4u * lane, 0u);     // the bytes in front of the first tile
+    for (;;) {
+        // (loop-carried scalars, said to be uniform: a value merged behind a loop that lanes leave at different times -- the walks -- is
+        // divergent to the compiler, and everything computed from it lands in vector registers)
+        entry = uni(entry); D.OP = uni(D.OP); D.W0 = uni(D.W0); D.F = uni(D.F);
+        if (uni((ok && !done) ? 1u : 0u) == 0u) break;
         const uint32_t t0 = entry & ~15u;
+        SQ_TICK(15)
         // ---- stage the tile: [t0, t0 + PT + TMARGIN), zeros behind the block --------------------------------------------------------
-        __builtin_amdgcn_s_barrier();                      // (one wavefront: orders the LDS accesses of the previous tile)
-        for (uint32_t o = 16u * lane; o < PT + TMARGIN; o += 1024u) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            const uint32_t g = t0 + o;
-            if (g + 16u <= ilen) __builtin_memcpy(&v, (const void*)(D.in + g), 16);
-            else if (g < ilen) {
-                uint32_t wv[4] = {0u, 0u, 0u, 0u};
-                for (uint32_t k = 0u; k < 16u; ++k) if (g + k < ilen) wv[k >> 2] |= (uint32_t)D.in[g + k] << (8u * (k & 3u));
-                v = u32x4{wv[0], wv[1], wv[2], wv[3]};
+        for (uint32_t o0 = 0u; o0 < PT + TMARGIN; o0 += 1024u) {
+            const uint32_t o = o0 + 16u * lane;
+            if (o < PT + TMARGIN) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                const uint32_t g = t0 + o;
+                if (g + 16u <= ilen) __builtin_memcpy(&v, (const void*)(D.in + g), 16);
+                else if (g < ilen) {
+                    uint32_t wv[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (uint32_t k = 0u; k < 16u; ++k) if (g + k < ilen) wv[k >> 2] |= (uint32_t)D.in[g + k] << (8u * (k & 3u));
+                    v = u32x4{wv[0], wv[1], wv[2], wv[3]};
+                }
+                lds_wr16(LDS_TILE + TPAD + o, v);
             }
-            lds_wr16(D.tile + TPAD + o, v);
+            SQ_JOIN();
         }
-        __builtin_amdgcn_s_barrier();
-        Reader rd;
-        rd.tile = D.tile; rd.g = D.in; rd.t0 = t0;
-        // ---- 1. first walks: lane 0 from the tile's entry, the others from their part's first byte ---------------------------------
-        const uint32_t part0 = t0 + PB * lane;
-        const uint32_t part_end = part0 + PB < ilen ? part0 + PB : ilen;
-        const bool has_part = part0 < ilen;
+        SQ_TICK(0) SQ_COUNT(16, 1)
+        // ---- 1. first walks: lane 0 from the tile's entry, the others from their part's first byte (positions relative to t0) --------
+        const uint32_t ilr = ilen - t0;
+        const uint32_t p0 = PB * lane;
+        const uint32_t pend = p0 + PB < ilr ? p0 + PB : ilr;
+        const uint32_t entry_r = entry - t0;
         Part s;
         s.marks = 0ull; s.from = X_ERR; s.exit = X_ERR;
-        if (has_part) walk_part<true>(rd, ilen, lane == 0u ? entry : part0, part0, part_end, s);
+        if (p0 < ilr) walk_part<true>(D.in, t0, ilen, lane == 0u ? entry_r : p0, p0, pend, s);
+        SQ_JOIN();
+        SQ_TICK(1)
         // ---- 2. / 3. which parts does the true chain visit, and where does it enter them?  (lz4_decompress_plan.hip) ----------------
-        uint32_t my_entry = X_ERR, tile_exit = X_ERR;
+        uint32_t my_entry = X_ERR;
+        uint64_t path = 1ull;
+        bool settled = false;
         for (uint32_t round = 0u; round < NPART + 2u; ++round) {
-            const bool inside = s.exit != X_ERR && s.exit < t0 + PT && s.exit < ilen;
-            const uint32_t nxt = inside ? ((s.exit - t0) * 2185u) >> 17 : 64u;          // / 60, exact below 4 096
+            const bool inside = s.exit != X_ERR && s.exit < PT && s.exit < ilr;
+            const uint32_t nxt = inside ? (s.exit * 2185u) >> 17 : 64u;          // / 60, exact below 4 096
             uint64_t reach = 1ull << lane;
             uint32_t jump = nxt;
 #pragma unroll
@@ -498,49 +608,58 @@ __global__ void __launch_bounds__(64) lz4_decompress_seq_kernel(DecompressArgs a
                 const uint32_t rlo = bperm(sl, (uint32_t)reach), rhi = bperm(sl, (uint32_t)(reach >> 32)), j2 = bperm(sl, jump);
                 if (jump < 64u) { reach |= ((uint64_t)rhi << 32) | rlo; jump = j2; }
             }
-            const uint64_t path = ((uint64_t)rdlane((uint32_t)(reach >> 32), 0u) << 32) | rdlane((uint32_t)reach, 0u);
-            const bool on_path = ((path >> lane) & 1ull) != 0ull;
+            path = ((uint64_t)rdlane((uint32_t)(reach >> 32), 0u) << 32) | rdlane((uint32_t)reach, 0u);
             const uint64_t before = path & ((1ull << lane) - 1ull);
             const uint32_t pred = before != 0ull ? 63u - (uint32_t)__builtin_clzll(before) : lane;
             const uint32_t pulled = bperm(pred, s.exit);
-            my_entry = lane == 0u ? entry : (on_path && before != 0ull ? pulled : X_ERR);
-            const uint32_t lastp = 63u - (uint32_t)__builtin_clzll(path);
-            tile_exit = rdlane(s.exit, lastp);
-            const bool need = my_entry != X_ERR && s.from != my_entry;
-            if (ballot(need) == 0ull) break;
-            if (need) walk_part<false>(rd, ilen, my_entry, part0, part_end, s);
-            tile_exit = X_ERR;                                       // (not final: the next pass says)
+            my_entry = lane == 0u ? entry_r : (lanes(path) && before != 0ull ? pulled : X_ERR);
+            const uint64_t needm = ballot(my_entry != X_ERR && s.from != my_entry);
+            if (needm == 0ull) { settled = true; break; }
+            if (lanes(needm)) walk_part<false>(D.in, t0, ilen, my_entry, p0, pend, s);
+            SQ_JOIN();
+            SQ_COUNT(21, 1)
         }
+        // (the compiler folds the loop's uniform exit into the divergent re-walk branch and then takes everything behind it for
+        // divergent: say what is uniform)
+        settled = uni(settled ? 1u : 0u) != 0u;
+        path = ((uint64_t)uni((uint32_t)(path >> 32)) << 32) | uni((uint32_t)path);
+        // the last part on the path says where the chain leaves the tile
+        const uint32_t tile_exit = settled ? rdlane(s.exit, 63u - (uint32_t)__builtin_clzll(path)) : X_ERR;
+        SQ_TICK(2)
         if (tile_exit == X_ERR) { ok = false; break; }
         // ---- 4. the token list ---------------------------------------------------------------------------------------------------------
-        const bool live = my_entry != X_ERR;
-        uint64_t m = live ? s.marks : 0ull;
+        uint64_t m = my_entry != X_ERR ? s.marks : 0ull;
         const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
         const uint32_t cincl = wave_incl_add(cnt);
         const uint32_t n_tile = rdlane(cincl, 63u);
         if (n_tile > POSCAP || n_tile == 0u) { ok = false; break; }
         {
-            uint32_t at = cincl - cnt;
-            const uint32_t rel0 = PB * lane;
+            uint32_t at = LDS_POS + 2u * (cincl - cnt);
             while (ballot(m != 0ull) != 0ull) {
                 if (m != 0ull) {
-                    D.pos[at] = (uint16_t)(rel0 + ctz64(m));
-                    at += 1u;
+                    lds_wr2(at, p0 + ctz64(m));
+                    at += 2u;
                     m &= m - 1ull;
                 }
+                SQ_JOIN();
             }
         }
-        __builtin_amdgcn_s_barrier();
+        SQ_TICK(3)
         // ---- 5. the chunks ----------------------------------------------------------------------------------------------------------------
         bool tdone = false;
-        if (!run_chunks<G>(D, t0, n_tile, tdone)) { ok = false; break; }
+        if (!run_chunks<G>(D, t0, n_tile, tdone SQ_PROF_PASS)) { ok = false; break; }
         if (tdone) { done = true; break; }
-        if (tile_exit >= ilen) { ok = false; break; }       // the chain ran out without a last sequence
-        entry = tile_exit;
+        if (tile_exit >= ilr) { ok = false; break; }        // the chain ran out without a last sequence
+        entry = t0 + tile_exit;
         // (a long literal run or match length run jumps over tiles: the next tile starts where the chain goes on)
     }
     if (ok && done) {
+        SQ_TICK(15)
         D.finish();
+        SQ_TICK(10)
+#ifdef LZ4S_PROF
+        if (lane == 0u) for (int i = 0; i < 32; ++i) if (P.c[i] != 0ull) atomicAdd(&g_sq_prof[i], (unsigned long long)P.c[i]);
+#endif
         if (lane == 0u) {
             a.status[b] = 0;
             a.out_len[b] = D.OP;
@@ -559,7 +678,7 @@ __global__ void __launch_bounds__(64) lz4_decompress_seq_kernel(DecompressArgs a
 hipError_t launch_decompress_seq(const DecompressArgs& a, int32_t redo_code, hipStream_t s) {
     if (a.n == 0u) return hipSuccess;
     if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;
-    typedef sq::Geo<8192u> G;
+    typedef sq::Geo<8192u, 4096u> G;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)sq::lz4_decompress_seq_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
@@ -570,3 +689,16 @@ hipError_t launch_decompress_seq(const DecompressArgs& a, int32_t redo_code, hip
 }
 
 }  // namespace lz4flex_dev
+
+#ifdef LZ4S_PROF
+extern "C" int lz4flex_debug_seq_prof(unsigned long long* vals, int reset) {
+    if (reset) {
+        unsigned long long z[32] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(lz4flex_dev::sq::g_sq_prof), z, sizeof z);
+        return 0;
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(vals, HIP_SYMBOL(lz4flex_dev::sq::g_sq_prof), 256);
+    return 0;
+}
+#endif

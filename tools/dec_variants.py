@@ -148,6 +148,18 @@ def main():
                   "group-steps piece %d idle %d blocked %d" %
                   (v[0] / pw, v[1] / pw, v[0] / max(v[1], 1), v[2], 100.0 * v[3] / max(v[2], 1), 100.0 * v[4] / max(v[2], 1), 100.0 * v[5] / max(v[2], 1), v[6],
                    v[8] / pw, v[9] / pw, v[10] / pw, v[14] / pw, v[11], v[12], v[13]), flush=True)
+        if variant == 13 and hasattr(lib, "lz4flex_debug_seq_prof"):
+            lib.lz4flex_debug_seq_prof.argtypes = [C.c_void_p, C.c_int]
+            v = (C.c_ulonglong * 32)()
+            lib.lz4flex_debug_seq_prof(None, 1)
+            dec_once(); torch.cuda.synchronize()
+            lib.lz4flex_debug_seq_prof(v, 0)
+            v = [x / n for x in v]
+            names = ["stage", "walk1", "resolve+rewalk", "poslist", "chunk setup", "ensure", "far req + literals", "far write", "rounds", "exact_seq", "finish"]
+            tot = sum(v[:16])
+            print("  seq prof, cycles per block: total %.0f | " % tot + " | ".join("%s %.0f" % (nm, v[i]) for i, nm in enumerate(names)) + " | other %.0f" % v[15], flush=True)
+            print("  seq prof, per block: tiles %.2f chunks %.1f rounds %.1f (%.2f per chunk) exact %.2f sequences %.0f resolve passes %.2f far lanes %.0f near lanes %.0f" %
+                  (v[16], v[17], v[18], v[18] / max(v[17], 1e-9), v[19], v[20], v[21], v[23], v[24]), flush=True)
         ts = []
         for _ in range(args.reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
