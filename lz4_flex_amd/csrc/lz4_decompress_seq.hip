@@ -28,7 +28,7 @@
 //     written back 16 bytes per lane.  Sequences that do not fit a lane (literal runs > 64, matches > 273 bytes or overlapping
 //     their source, far matches > 64, anything with more than one length byte) are executed ALONE by the whole wavefront
 //     (exact_seq: decompress.rs:334-443 for one sequence of any shape) and cut the chunk in front of them.
-// LDS per wavefront: tile 4 096 + token list 2 576 + window 8 192 = 14 864 bytes: 11 wavefronts per CU.
+// LDS per wavefront: token list 2 560 + tile 4 080 + window 8 192 + 16 = 14 848 bytes: 11 wavefronts per CU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -47,20 +47,30 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 using pcd::X_END;
 using pcd::X_ERR;
 
-constexpr uint32_t PB = 60u;                 // bytes per part
+#ifndef LZ4S_PB
+#define LZ4S_PB 60
+#endif
+#ifndef LZ4S_R
+#define LZ4S_R 3584
+#endif
+#ifndef LZ4S_KEEP
+#define LZ4S_KEEP 1280
+#endif
+constexpr uint32_t PB = LZ4S_PB;             // bytes per part (an odd number of dwords: lane k reading part k hits its own bank)
 constexpr uint32_t NPART = 64u;              // parts per tile = lanes
 constexpr uint32_t PT = PB * NPART;          // 3 840 compressed bytes per tile
 constexpr uint32_t TPAD = 16u;               // bytes in front of the tile (a lane reads the 16 bytes that END with its literals)
-constexpr uint32_t TMARGIN = 240u;           // bytes behind the tile staged with it
+constexpr uint32_t TMARGIN = 224u;           // bytes behind the tile staged with it
 constexpr uint32_t TILE_LDS = TPAD + PT + TMARGIN;
-constexpr uint32_t POSCAP = PT / 3u + 8u;    // sequences per tile: a sequence with a match is at least 3 bytes
+constexpr uint32_t POSCAP = PT / 3u;         // sequences per tile: a sequence with a match is at least 3 bytes
 constexpr uint32_t POS_LDS = (2u * POSCAP + 15u) & ~15u;
 constexpr uint32_t LITMAX = 64u;             // literal run a lane copies itself
 constexpr uint32_t FARMAX = 64u;             // match from the written-back output a lane copies itself
+constexpr uint32_t BIGRUN = 1024u;           // literal runs / matches from here on go memory to memory (exact_seq)
 constexpr uint32_t WALK_LITMAX = 200u;       // literal run a hop steps over without the generic walker (its end stays inside the staged bytes)
-// LDS: [token list | tile | window | 16]  (the tile is not first: a lane may read up to 16 bytes in front of it)
-constexpr uint32_t LDS_POS = 0u, LDS_TILE = POS_LDS, LDS_WIN = POS_LDS + TILE_LDS;
-static_assert(TILE_LDS % 16u == 0u && PT % 16u == 0u && POS_LDS % 16u == 0u, "geometry");
+// LDS: [token list | tile | window | scratch 16]  (the tile is not first: a lane may read up to 16 bytes in front of it)
+constexpr uint32_t LDS_POS = 0u, LDS_TILE = LDS_POS + POS_LDS, LDS_WIN = LDS_TILE + TILE_LDS;
+static_assert(TILE_LDS % 16u == 0u && PT % 16u == 0u && POS_LDS % 16u == 0u && PB % 4u == 0u && (PB / 4u) % 2u == 1u && PB <= 64u, "geometry");
 static_assert(PT - 1u + 4u + 15u + WALK_LITMAX + 4u < PT + TMARGIN, "a hop's length byte lies inside the staged bytes");
 static_assert(PT + 1u + LITMAX + 16u <= PT + TMARGIN && PT + 1u + LITMAX + 8u <= PT + TMARGIN, "a lane's literals and offset lie inside the staged bytes");
 
@@ -69,7 +79,9 @@ struct Geo {
     static constexpr uint32_t R = R_;                              // window bytes
     static constexpr uint32_t KEEP = KEEP_;                        // history a slide keeps
     static constexpr uint32_t BUDGET = (R_ - KEEP_ - 64u) / 2u;    // output bytes of one chunk (two chunks are in flight) / of one cooperative piece
-    static constexpr uint32_t LDS = POS_LDS + TILE_LDS + R_ + 16u; // (+ 16: a lane's 16-byte source read may end behind the window)
+    static constexpr uint32_t SCRATCH = LDS_WIN + R_;              // 16 bytes behind the window: where a lane's 16-byte source read may end, and where the
+    static constexpr uint32_t LDS = LDS_WIN + R_ + 16u;            // later rounds' writes of the wrong size class go (29 x 512 bytes: 11 wavefronts per CU)
+    static_assert(R_ >= 1024u + 1040u + 16u, "the window holds a long run's extended period");
 };
 
 #ifdef LZ4S_PROF      // tools: cycles of every wavefront per phase -> g_sq_prof[0..15], event counts in [16..31]
@@ -247,8 +259,97 @@ struct Dec {
         SQ_JOIN();
         F = OP;
     }
+    // ---- runs of BIGRUN bytes or more go memory to memory, 16 bytes per lane, and the window is read back behind them ----------------
+    // everything produced so far, the last odd bytes too
+    __device__ __forceinline__ void flush_all() {
+        write_back(OP);
+        if (F + lane < OP) out[F + lane] = *L8(LDS_WIN + F + lane - W0);
+        SQ_JOIN();
+    }
+    // the window = the last KEEP bytes of the output, from memory (this wavefront's own stores: one CU, one L1 -- coherent in program order)
+    __device__ __forceinline__ void reload_window() {
+        W0 = OP > G::KEEP ? (OP - G::KEEP) & ~15u : 0u;
+        const uint32_t n = OP - W0;
+        for (uint32_t i0 = 0u; i0 < n; i0 += 1024u) {
+            const uint32_t i = i0 + 16u * lane;
+            if (i < n) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (W0 + i + 16u <= OP) __builtin_memcpy(&v, (const void*)(out + W0 + i), 16);
+                else {
+                    uint32_t wv[4] = {0u, 0u, 0u, 0u};
+                    for (uint32_t k = 0u; k < 16u; ++k) if (W0 + i + k < OP) wv[k >> 2] |= (uint32_t)out[W0 + i + k] << (8u * (k & 3u));
+                    v = u32x4{wv[0], wv[1], wv[2], wv[3]};
+                }
+                lds_wr16(LDS_WIN + i, v);
+            }
+            SQ_JOIN();
+        }
+        F = OP & ~15u;
+    }
+    // n bytes from memory at `from` to the output at OP, 1 KiB per step in order (a step's source may be an earlier step's destination)
+    __device__ __forceinline__ void mem_copy(const g_u8* from, uint32_t n) {
+        for (uint32_t i0 = 0u; i0 < n; i0 += 1024u) {
+            const uint32_t i = i0 + 16u * lane;
+            if (i + 16u <= n) {
+                u32x4 v;
+                __builtin_memcpy(&v, (const void*)(from + i), 16);
+                __builtin_memcpy((void*)(out + OP + i), &v, 16);
+            } else if (i < n) {
+                for (uint32_t k = i; k < n; ++k) out[OP + k] = from[k];
+            }
+            SQ_JOIN();
+        }
+    }
+    __device__ __forceinline__ uint32_t mod_small(uint32_t i, uint32_t m, float rcp) {      // i mod m, i < 2^22, rcp = 1 / m
+        const uint32_t q = (uint32_t)((float)i * rcp);
+        uint32_t r = i - q * m;                                    // q is off by at most one either way
+        r = (int32_t)r < 0 ? r + m : r;
+        return r >= m ? r - m : r;
+    }
+    __device__ void big_literals(uint32_t src, uint32_t n) {
+        flush_all();
+        mem_copy(in + src, n);
+        OP += n;
+        reload_window();
+    }
+    // a long match.  offset >= 1024: a step's source lies in front of the step: memory to memory.  Else the periodic form
+    // out[d + i] = out[d - offset + i mod offset] (decompress.rs:57-82, decompress_safe.rs:301-318; offset 1 = a run of one byte, :311-313):
+    // the period, repeated to 1 KiB + 16 + offset bytes in the (flushed) window's place, is what every step stores a kibibyte of
+    __device__ void big_match(uint32_t offset, uint32_t n) {
+        flush_all();
+        if (offset >= 1024u) {
+            mem_copy(out + OP - offset, n);
+        } else {
+            const float rcp = 1.0f / (float)offset;
+            const uint32_t el = offset + 1040u;
+            for (uint32_t k0 = 0u; k0 < el; k0 += 64u) {
+                const uint32_t k = k0 + lane;
+                if (k < el) *L8(LDS_WIN + k) = out[OP - offset + mod_small(k, offset, rcp)];
+                SQ_JOIN();
+            }
+            uint32_t ph = 0u;                                      // i0 mod offset
+            const uint32_t adv = mod_small(1024u, offset, rcp);
+            for (uint32_t i0 = 0u; i0 < n; i0 += 1024u) {
+                const uint32_t i = i0 + 16u * lane;
+                if (i < n) {
+                    const u32x4 v = lds_rd16(LDS_WIN + ph + 16u * lane);
+                    if (i + 16u <= n) __builtin_memcpy((void*)(out + OP + i), &v, 16);
+                    else {
+                        const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+                        for (uint32_t k = 0u; i + k < n; ++k) out[OP + i + k] = (uint8_t)(wv[k >> 2] >> (8u * (k & 3u)));
+                    }
+                }
+                SQ_JOIN();
+                ph += adv;
+                ph = ph >= offset ? ph - offset : ph;
+            }
+        }
+        OP += n;
+        reload_window();
+    }
     // literals of any length from the compressed stream, whole wavefront, <= BUDGET bytes per piece
     __device__ __forceinline__ void coop_literals(uint32_t src, uint32_t n) {
+        if (n >= BIGRUN) { big_literals(src, n); return; }
         for (uint32_t c = 0u; c < n; c += G::BUDGET) {
             const uint32_t m = n - c < G::BUDGET ? n - c : G::BUDGET;
             ensure(OP, m);
@@ -264,6 +365,7 @@ struct Dec {
     // from the output written back earlier.  offset < 64: the periodic form out[d + i] = out[d - offset + i mod offset]
     // (decompress.rs:57-82, decompress_safe.rs:301-318), which only reads bytes in front of the match.
     __device__ __forceinline__ void coop_match(uint32_t offset, uint32_t n) {
+        if (n >= BIGRUN) { big_match(offset, n); return; }
         const float rcp = offset < 64u ? 1.0f / (float)offset : 0.0f;
         for (uint32_t c = 0u; c < n; c += G::BUDGET) {
             const uint32_t m = n - c < G::BUDGET ? n - c : G::BUDGET;
@@ -487,14 +589,59 @@ __device__ __forceinline__ void exec_chunk(Dec<G>& D, const Chunk& C SQ_PROF_ARG
     uint64_t todo = C.near;
     const CopyPlan M = plan_copy<false>(wb + C.src, wm, C.ml);
     const uint32_t s1 = C.src + C.ml;
-    while (todo != 0ull) {
+    if (todo != 0ull) {
+        // the first round: most of the chunk's matches (every source in front of the chunk)
         const uint32_t dp = ctz64(todo);                      // every lane below dp is done: all bytes in front of its sequence are final
         const uint32_t S = rdlane(C.dst, dp);
         const uint64_t rm = todo & (ballot(s1 <= S) | (1ull << dp));
         lane_copy<false>(M, rm);
         todo &= ~rm;
         SQ_COUNT(18, 1)
+#ifdef LZ4S_EXP_NOROUNDS      // timing experiments only (wrong bytes): the first round alone
+        todo = 0ull;
+#endif
     }
+#ifdef LZ4S_CHEAP_ROUNDS       // (measured: fewer vector and scalar instructions, more LDS instructions -- and the LDS pipe is the busier unit: 2.40 vs 2.31 ms)
+    if (todo != 0ull) {
+        // the later rounds have a few ready lanes each and cost their instructions: no size classes -- every ready lane does the six
+        // writes of all three, those of the classes it is not in to a scratch slot
+        const uint32_t dA = lanes(M.c16) ? M.d : G::SCRATCH, dA2 = lanes(M.c16) ? M.d2 : G::SCRATCH;
+        const uint32_t dB = lanes(M.c8) ? M.d : G::SCRATCH, dB2 = lanes(M.c8) ? M.d2 + 8u : G::SCRATCH;
+        const uint32_t dC = lanes(M.c4) ? M.d : G::SCRATCH, dC2 = lanes(M.c4) ? M.d2 + 12u : G::SCRATCH;
+        do {
+            const uint32_t dp = ctz64(todo);
+            const uint32_t S = rdlane(C.dst, dp);
+            const uint64_t rm = todo & (ballot(s1 <= S) | (1ull << dp));
+            if (lanes(rm)) {
+                const u32x4 r1 = lds_rd16(M.s), r2 = lds_rd16(M.s2);
+                lds_wr16(dA, r1); lds_wr16(dA2, r2);
+                lds_wr8(dB, r1.x, r1.y); lds_wr8(dB2, r2.z, r2.w);
+                lds_wr4(dC, r1.x); lds_wr4(dC2, r2.w);
+            }
+            SQ_JOIN();
+            uint64_t more = rm & M.gt32;
+            for (uint32_t p = 16u; more != 0ull; p += 16u) {
+                if (lanes(more)) { const u32x4 r = lds_rd16(M.s + p); lds_wr16(M.d + p, r); }
+                SQ_JOIN();
+                more &= ballot(p + 32u < M.n);
+            }
+            todo &= ~rm;
+            SQ_COUNT(18, 1)
+        } while (todo != 0ull);
+    }
+#else
+    while (todo != 0ull) {
+        const uint32_t dp = ctz64(todo);
+        const uint32_t S = rdlane(C.dst, dp);
+        const uint64_t rm = todo & (ballot(s1 <= S) | (1ull << dp));
+        lane_copy<false>(M, rm);
+        todo &= ~rm;
+        SQ_COUNT(18, 1)
+#ifdef LZ4S_EXP_NOROUNDS      // timing experiments only (wrong bytes): the first round alone
+        todo = 0ull;
+#endif
+    }
+#endif
     SQ_TICK(8)
 }
 
@@ -525,7 +672,9 @@ __device__ __forceinline__ bool run_chunks(Dec<G>& D, uint32_t t0, uint32_t n_ti
         N.f0 = u32x4{0u, 0u, 0u, 0u}; N.f1 = N.f0; N.f2 = N.f0; N.f3 = N.f0;
         if (have_next) { if (!setup_chunk<G>(D, t0, n_tile, nsidx, nop, C.T, N)) return false; }
         SQ_TICK(4)
+#ifndef LZ4S_EXP_NOEXEC         // timing experiments only (wrong bytes): chunks are placed, nothing is copied
         exec_chunk<G>(D, C SQ_PROF_PASS);
+#endif
         D.OP = nop;
         sidx = nsidx;
         if (C.last) { done = true; return sidx == n_tile; }
@@ -597,22 +746,40 @@ __global__ void __launch_bounds__(64) lz4_decompress_seq_kernel(DecompressArgs a
         uint32_t my_entry = X_ERR;
         uint64_t path = 1ull;
         bool settled = false;
+        const uint32_t nparts = ilr < PT ? (ilr + PB - 1u) / PB : NPART;       // parts that hold bytes of the block
         for (uint32_t round = 0u; round < NPART + 2u; ++round) {
             const bool inside = s.exit != X_ERR && s.exit < PT && s.exit < ilr;
-            const uint32_t nxt = inside ? (s.exit * 2185u) >> 17 : 64u;          // / 60, exact below 4 096
-            uint64_t reach = 1ull << lane;
-            uint32_t jump = nxt;
+            const uint32_t nxt = inside ? s.exit / PB : 64u;
+            // the usual tile: every part's chain leaves into the NEXT part (no sequence is longer than a part) -- the path is all parts and
+            // a part's entry is its left neighbour's exit, one DPP move; else the general form, pointer jumping over the exits
+            const uint64_t chain_ok = ballot(nxt == lane + 1u || (lane + 1u >= nparts && nxt == 64u)) | ~low_mask(nparts);
+            if (chain_ok == ~0ull) {
+                path = low_mask(nparts);
+                const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)X_ERR, (int)s.exit, 0x138, 0xf, 0xf, false);   // wave_shr:1
+                my_entry = lane == 0u ? entry_r : (lane < nparts ? left : X_ERR);
+            } else {
+                uint64_t reach = 1ull << lane;
+                uint32_t jump = nxt;
 #pragma unroll
-            for (uint32_t i = 0u; i < 6u; ++i) {
-                const uint32_t sl = jump < 64u ? jump : lane;
-                const uint32_t rlo = bperm(sl, (uint32_t)reach), rhi = bperm(sl, (uint32_t)(reach >> 32)), j2 = bperm(sl, jump);
-                if (jump < 64u) { reach |= ((uint64_t)rhi << 32) | rlo; jump = j2; }
+                for (uint32_t i = 0u; i < 6u; ++i) {
+                    const uint32_t sl = jump < 64u ? jump : lane;
+                    const uint32_t rlo = bperm(sl, (uint32_t)reach), rhi = bperm(sl, (uint32_t)(reach >> 32)), j2 = bperm(sl, jump);
+                    if (jump < 64u) { reach |= ((uint64_t)rhi << 32) | rlo; jump = j2; }
+                }
+                path = ((uint64_t)rdlane((uint32_t)(reach >> 32), 0u) << 32) | rdlane((uint32_t)reach, 0u);
+                const uint64_t before = path & ((1ull << lane) - 1ull);
+                const uint32_t pred = before != 0ull ? 63u - (uint32_t)__builtin_clzll(before) : lane;
+                const uint32_t pulled = bperm(pred, s.exit);
+                my_entry = lane == 0u ? entry_r : (lanes(path) && before != 0ull ? pulled : X_ERR);
             }
-            path = ((uint64_t)rdlane((uint32_t)(reach >> 32), 0u) << 32) | rdlane((uint32_t)reach, 0u);
-            const uint64_t before = path & ((1ull << lane) - 1ull);
-            const uint32_t pred = before != 0ull ? 63u - (uint32_t)__builtin_clzll(before) : lane;
-            const uint32_t pulled = bperm(pred, s.exit);
-            my_entry = lane == 0u ? entry_r : (lanes(path) && before != 0ull ? pulled : X_ERR);
+            SQ_JOIN();
+            path = ((uint64_t)uni((uint32_t)(path >> 32)) << 32) | uni((uint32_t)path);
+            // an entry the standing walk passed through needs no walk: its marks stand from there
+            if (my_entry != X_ERR && s.from != my_entry && my_entry - p0 < 64u && ((s.marks >> (my_entry - p0)) & 1ull) != 0ull) {
+                s.marks &= ~((1ull << (my_entry - p0)) - 1ull);
+                s.from = my_entry;
+            }
+            SQ_JOIN();
             const uint64_t needm = ballot(my_entry != X_ERR && s.from != my_entry);
             if (needm == 0ull) { settled = true; break; }
             if (lanes(needm)) walk_part<false>(D.in, t0, ilen, my_entry, p0, pend, s);
@@ -647,6 +814,11 @@ __global__ void __launch_bounds__(64) lz4_decompress_seq_kernel(DecompressArgs a
         SQ_TICK(3)
         // ---- 5. the chunks ----------------------------------------------------------------------------------------------------------------
         bool tdone = false;
+#ifdef LZ4S_EXP_NOCHUNKS       // timing experiments only (no output): the walks and the token list alone
+        if (tile_exit >= ilr) { done = true; break; }
+        entry = t0 + tile_exit;
+        continue;
+#endif
         if (!run_chunks<G>(D, t0, n_tile, tdone SQ_PROF_PASS)) { ok = false; break; }
         if (tdone) { done = true; break; }
         if (tile_exit >= ilr) { ok = false; break; }        // the chain ran out without a last sequence
@@ -678,7 +850,7 @@ __global__ void __launch_bounds__(64) lz4_decompress_seq_kernel(DecompressArgs a
 hipError_t launch_decompress_seq(const DecompressArgs& a, int32_t redo_code, hipStream_t s) {
     if (a.n == 0u) return hipSuccess;
     if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;
-    typedef sq::Geo<8192u, 4096u> G;
+    typedef sq::Geo<LZ4S_R, LZ4S_KEEP> G;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)sq::lz4_decompress_seq_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
