@@ -355,11 +355,11 @@ def run_blocks(args, env):
                                "roofline": roof(alg_bytes, t_c)}
     if args.only in ("both", "decompress"):
         # capi.cpp launch_decompress_fast's choice by batch size: the thresholds are the library's (lz4_device.h DISPATCH_*)
-        th = [lib.lz4flex_get_tuning(ctx, b"dispatch_threshold_%d" % i) for i in range(7)]     # pair of workgroups, pcd 1024 / 512 / 256 lanes, wave pair, wave, full chip
+        th = [lib.lz4flex_get_tuning(ctx, b"dispatch_threshold_%d" % i) for i in range(6)]     # pair of workgroups, pcd 1024 / 512 / 256 lanes, a wavefront per block, full chip
         assert min(th) > 0 and th == sorted(th), th
-        dv = args.decompress_variant or (7 if n <= th[3] else (6 if n <= th[4] else (5 if n <= th[5] else 4)))
-        kernels["decompress"] = {"kernel": {7: "lz4_decompress_pcd_kernel", 8: "lz4_decompress_pcd_kernel", 6: "lz4_decompress_wave_pair_kernel",
-                                            5: "lz4_decompress_wave_kernel", 4: "lz4_decompress_split_kernel", 1: "lz4_decompress_blocks_kernel",
+        dv = args.decompress_variant or (7 if n <= th[3] else (13 if n <= th[4] else 4))
+        kernels["decompress"] = {"kernel": {7: "lz4_decompress_pcd_kernel", 8: "lz4_decompress_pcd_kernel", 13: "lz4_decompress_seq_kernel",
+                                            4: "lz4_decompress_split_kernel", 1: "lz4_decompress_blocks_kernel",
                                             9: "lz4_replay_kernel", 10: "lz4_decompress_pcd_kernel", 11: "lz4_decompress_pcd_kernel", 12: "lz4_decompress_fused_kernel"}[dv],
                                  "ms_per_launch": round(t_d * 1e3, 4), "MiB_per_s": round(total / 1048576 / t_d, 1),
                                  "roofline": roof(alg_bytes, t_d)}

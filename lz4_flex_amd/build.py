@@ -166,8 +166,8 @@ def replay_extra_flags():
 
 
 def fused_isa(extra_flags=()):
-    """the listing of the fused decoder"""
-    return file_isa(FUSED_SRC, extra_flags)
+    """the listing of the fused decoder (a -DLZ4FLEX_TOOLS kernel since round 6: the product library does not hold it)"""
+    return file_isa(FUSED_SRC, ["-DLZ4FLEX_TOOLS"] + list(extra_flags))
 
 
 def fused_extra_flags():
@@ -194,7 +194,7 @@ def wave_extra_flags():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    per_file = {WAVE_SRC: wave_extra_flags(), REPLAY_SRC: replay_extra_flags(), FUSED_SRC: fused_extra_flags()}
+    per_file = {WAVE_SRC: wave_extra_flags(), REPLAY_SRC: replay_extra_flags()}      # (the fused decoder is compiled in tools builds only: build_variant(..., ["-DLZ4FLEX_TOOLS"] + fused_extra_flags()))
     hipcc = _hipcc()
     os.makedirs(BDIR, exist_ok=True)
     sh = source_hash()

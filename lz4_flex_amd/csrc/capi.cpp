@@ -68,7 +68,7 @@ struct lz4flex_ctx {
     bool wave_used = false;
     int dec_blocks_per_wg = 0;    // split decoder: blocks per workgroup (8/16/32/64), 0 = 64
     int comp_sub = 0;             // throughput encoder, "compress_subwindows": 0 = by batch size, 1 = never, 2 / 4 = always that many sub-windows per block of <= 64 KiB
-    int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 4 = parser / copier split (lz4_decompress_split.hip), 5 / 6 = a wavefront / a pair of wavefronts per block (lz4_decompress_wave.hip), 7 = a workgroup per block (lz4_decompress_pcd.hip; 8: its test geometry), 9 = plan / replay (lz4_decompress_plan.hip + lz4_decompress_replay.hip), 12 = parser / emitter / quads (lz4_decompress_fused.hip)
+    int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 4 = parser / copier split (lz4_decompress_split.hip), 7 = a workgroup per block (lz4_decompress_pcd.hip; 8: its test geometry; 10 / 11: 256 / 512 lanes), 13 = a wavefront per block, a lane per sequence (lz4_decompress_seq.hip); tools builds: 9 = plan / replay, 12 = parser / emitter / quads
     int comp_sliding = 2;         // throughput encoder: the windows of a block longer than 64 KiB advance by 48 KiB (2: every window start has 16 KiB of history) or 32 KiB (1: round 4's bytes); 0 = by 64 KiB (round 3's bytes, fastest)
     int comp_carry_wait = 1;      // tests: 0 = a window of the throughput encoder that has to wait for its predecessor's carry gives up at once (the block then takes the second launch)
     int dec_second_pass = 1;      // tests: 0 leaves the blocks a first-pass decoder marked (status 0x7F000001) instead of decoding them again
@@ -107,21 +107,16 @@ static hipError_t chain_ws_end(lz4flex_ctx* c, hipStream_t s) { return hipEventR
 
 static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a_, hipStream_t s, bool big_blocks = false) {
     DecompressArgs a = a_;
-    // 0: by batch shape.  Up to ~5 000 blocks the wave decoder (a wavefront per block: a block is done in half the time the
-    // split decoder's serial chain needs, and blocks larger than 64 KiB stay tolerable); larger batches have enough blocks
-    // to fill the chip with one chain per lane, which costs half the instructions per byte.  tools/wave_bench.py --dec, JSON
-    // tiles, ms for 1 024 / 4 096 / 6 144 / 8 192 / 16 384 / 32 768 blocks: wave 0.74 / 1.01 / 1.64 / 1.95 / 3.8 / 7.3, split
-    // 1.31 / 1.31 / 1.52 / 1.55 / 1.79 / 3.86 (round 1's pipelined decoder 2.43 / 2.54 / 2.62 / 2.59 / 2.9 / 4.15: deleted).
-    // up to 2 304 blocks (nine pairs of wavefronts per CU) the wave decoder runs with a parser and an executor wavefront per
-    // block: 256 / 1 024 / 2 048 blocks 0.45 / 0.52 / 0.65 ms against 0.73 / 0.75 / 0.82 with one wavefront
-    // up to PCD_MAX_BLOCKS blocks, or blocks known to be large: a whole workgroup per block, token chain and copies parallel INSIDE
-    // the block (lz4_decompress_pcd.hip) -- the only decoder here whose time for a block is not the length of the block's chain.
-    // tools/dec_shapes.py, JSON tiles (its worst case: the deepest dependency chains), 256 / 512 / 1 024 / 2 304 blocks: 0.15 / 0.28 /
-    // 0.52 / 1.13 ms against 0.45 / 0.49 / 0.52 / 0.71 (pair of wavefronts per block); 1 024 text / log blocks 0.81 / 0.42 against
-    // 1.02 / 0.58; 256 x 4 MiB log blocks: 4.9 ms against 28.8; one 16 MiB block: 14.6 ms against 113.  Round 4: from 257 blocks on
-    // with 512 lanes per block, from 513 on with 256 (more workgroups per CU; pcd_geo below): 512 / 1 024 JSON blocks 0.23 / 0.38 ms.
-    int v = c->dec_variant != 0 ? c->dec_variant
-                                : ((a.n <= PCD_MAX_BLOCKS || big_blocks) ? 7 : (a.n <= DISPATCH_WAVE_PAIR_MAX ? 6 : (a.n <= DISPATCH_WAVE_MAX ? 5 : 4)));
+    // 0: by batch shape (lz4_device.h DISPATCH_*; tools/dec_shapes.py measures every decoder on every shape, profiles/r06_decoder_shapes.txt):
+    //   * up to DISPATCH_PCD_256 blocks, or blocks known to be large: a whole WORKGROUP per block, token chain and copies parallel INSIDE the
+    //     block (lz4_decompress_pcd.hip) -- the decoder whose time for a block is not the length of the block's chain: 256 / 512 JSON blocks
+    //     0.14 / 0.23 ms, 256 x 4 MiB log blocks 4.7 ms, one 16 MiB block 14.6 ms;
+    //   * up to DISPATCH_SEQ_MAX blocks: a WAVEFRONT per block, a lane per sequence (lz4_decompress_seq.hip, round 6: it replaced the wave
+    //     decoder and its two-wavefront form, 0.74 / 1.01 ms for 1 024 / 4 096 JSON blocks): 768 / 2 304 / 4 096 / 8 192 / 12 288 JSON blocks
+    //     0.32 / 0.41 / 0.53 / 1.00 / 1.44 ms, 4 096 text / log / incompressible blocks 0.88 / 0.49 / 0.30 ms;
+    //   * larger batches: a LANE per block parses, four lanes copy (lz4_decompress_split.hip): 1.63 - 1.67 ms for any batch of 5 121 ...
+    //     16 384 JSON blocks -- the chain of one block.
+    int v = c->dec_variant != 0 ? c->dec_variant : ((a.n <= PCD_MAX_BLOCKS || big_blocks) ? 7 : (a.n <= DISPATCH_SEQ_MAX ? 13 : 4));
     const int geo_req = v == 10 ? 2 : (v == 11 ? 3 : 0);  // (an explicit geometry holds for prefix / chained batches too)
     if (a.out_pos != nullptr && v != 8) v = 7;           // prefix mode (Linked frames): only the workgroup decoder knows it
     if ((v == 12 || v == 13) && a.dict_base != nullptr) v = 4;
@@ -172,9 +167,8 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
         return launch_decompress(r, c->dec_lanes, s);
     }
 #endif
-    if ((v >= 5 && v <= 8) || v == 10 || v == 11) {
-        // one block per wavefront (6: per pair of wavefronts; 7 / 8: per workgroup); blocks it marks (errors, sinks too small) are
-        // decoded again in the reference's order
+    if (v == 7 || v == 8 || v == 10 || v == 11) {
+        // one block per workgroup; blocks it marks (errors, sinks too small) are decoded again in the reference's order
         constexpr int32_t REDO = 0x7F000001;
         bool pair = false;
         if (v >= 7 && v <= 8 && (c->dec_pcd_pair == 2 || (c->dec_pcd_pair == 1 && big_blocks)) && c->pcd_ws && a.n <= PCD_PAIR_MAX_BLOCKS) {
@@ -187,7 +181,7 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
             a.pair_ws = c->pcd_ws;
             pair = true;
         }
-        hipError_t e = v >= 7 ? launch_decompress_pcd(a, REDO, s, pcd_geo) : (v == 6 ? launch_decompress_wave_pair(a, REDO, s) : launch_decompress_wave(a, REDO, s));
+        hipError_t e = launch_decompress_pcd(a, REDO, s, pcd_geo);
         if (e != hipSuccess) return e;
         if (pair) {
             e = hipEventRecord(c->pcd_done, s);
@@ -211,6 +205,7 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
         r.only_status = REDO;
         return launch_decompress(r, c->dec_lanes, s);
     }
+#ifdef LZ4FLEX_TOOLS
     if (v == 12) {
         // parser -> emitter -> quads (lz4_decompress_fused.hip); oversized blocks go to the reference-order kernel
         constexpr int32_t REDO = 0x7F000001;
@@ -221,6 +216,7 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
         r.only_status = REDO;
         return launch_decompress(r, c->dec_lanes, s);
     }
+#endif
     return launch_decompress_split(a, s, c->dec_blocks_per_wg);
 }
 
@@ -439,8 +435,9 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
     }
     if (!strcmp(key, "decompress_variant")) {
         if (value != 0 && value != 1 && (value < 4 || value > 13)) return -LZ4FLEX_E_INVALID_ARG;
+        if (value == 5 || value == 6) return -LZ4FLEX_E_INVALID_ARG;      // the wave decoder and its two-wavefront form: replaced by 13 in round 6
 #ifndef LZ4FLEX_TOOLS
-        if (value == 9) return -LZ4FLEX_E_INVALID_ARG;          // plan / replay: tools builds only
+        if (value == 9 || value == 12) return -LZ4FLEX_E_INVALID_ARG;     // plan / replay, parser / emitter / quads: tools builds only
 #endif
         c->dec_variant = value;
         return 0;
@@ -504,7 +501,7 @@ int lz4flex_get_tuning(lz4flex_ctx* c, const char* key) {
     // the batch sizes at which the default decoder dispatch changes kernel or geometry (lz4_device.h), in ascending order; the
     // list ends where the key is refused.  tests/test_gpu_block.py builds its size matrix from it.
     if (!strncmp(key, "dispatch_threshold_", 19)) {
-        const uint32_t t[] = {PCD_PAIR_MAX_BLOCKS, DISPATCH_PCD_1024, DISPATCH_PCD_512, DISPATCH_PCD_256, DISPATCH_WAVE_PAIR_MAX, DISPATCH_WAVE_MAX, DISPATCH_SPLIT_FULL};
+        const uint32_t t[] = {PCD_PAIR_MAX_BLOCKS, DISPATCH_PCD_1024, DISPATCH_PCD_512, DISPATCH_PCD_256, DISPATCH_SEQ_MAX, DISPATCH_SPLIT_FULL};
         const int i = atoi(key + 19);
         if (i < 0 || i >= (int)(sizeof t / sizeof t[0]) || (key[19] < '0' || key[19] > '9')) return -LZ4FLEX_E_INVALID_ARG;
         return (int)t[i];
@@ -513,9 +510,9 @@ int lz4flex_get_tuning(lz4flex_ctx* c, const char* key) {
     // "decompress_blocks_per_wg" for variant 4, else 0); the list ends where the key is refused.  ONE list: tests/test_gpu_block.py's
     // decoder matrix and tools/gpu_fuzz.py are generated from it (a decoder added here is tested there), no device needed.
     if (!strncmp(key, "decoder_config_", 15)) {
-        const int t[] = {1016, 4008, 4032, 4064, 5000, 6000, 7000, 8000, 10000, 11000, 12000, 13000,
+        const int t[] = {1016, 4008, 4032, 4064, 7000, 8000, 10000, 11000, 13000,
 #ifdef LZ4FLEX_TOOLS
-                         9000,
+                         9000, 12000,
 #endif
         };
         const int i = atoi(key + 15);

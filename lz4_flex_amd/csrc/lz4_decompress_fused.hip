@@ -17,6 +17,9 @@
 // the quads (0, 1, 4, 5) share two; wavefronts 6 and 7 only exist to make that placement and end at the first barrier.
 // Blocks of 512 KiB or more (compressed or sink) are left with status `redo_code` for the reference-order kernel, like the blocks
 // the other fast decoders mark.
+// Round 6: compiled in -DLZ4FLEX_TOOLS builds only (decompress_variant 12 is refused by the product library): level with the split decoder on JSON,
+// behind it on incompressible data and runs -- an experiment, and the product ships none by default.
+#ifdef LZ4FLEX_TOOLS
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -357,3 +360,5 @@ extern "C" int lz4flex_debug_fused_prof(unsigned long long* vals, int reset) {
     return 0;
 }
 #endif
+
+#endif  // LZ4FLEX_TOOLS

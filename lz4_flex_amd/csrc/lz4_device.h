@@ -53,9 +53,13 @@ constexpr uint32_t PCD_PAIR_MAX_BLOCKS = 128u;
 // batches of 5 121 ... 16 383 blocks because one geometry was never run on real data).
 constexpr uint32_t DISPATCH_PCD_1024 = 256u;         // <= : a workgroup of 1 024 lanes per block (one per CU); also for large blocks and chains at any count
 constexpr uint32_t DISPATCH_PCD_512 = 512u;          // <= : 512 lanes per block (two per CU)
-constexpr uint32_t DISPATCH_PCD_256 = 1024u;         // <= : 256 lanes per block (four per CU; 1 280 blocks already run in two rounds)
-constexpr uint32_t DISPATCH_WAVE_PAIR_MAX = 2304u;   // <= : a pair of wavefronts per block
-constexpr uint32_t DISPATCH_WAVE_MAX = 5120u;        // <= : a wavefront per block; above: the split decoder
+constexpr uint32_t DISPATCH_PCD_256 = 640u;          // <= : 256 lanes per block (four per CU)
+// round 6: above, a wavefront per block and a lane per sequence (lz4_decompress_seq.hip) -- its time grows with the batch (16 wavefronts per
+// CU: 4 096 blocks are one round), the split decoder's is one block's chain whatever the batch: JSON tiles 768 / 4 096 / 8 192 / 12 288 /
+// 14 336 / 16 384 blocks 0.32 / 0.53 / 1.00 / 1.44 / 1.63 / 1.82 ms against 0.35 (256 lanes per block) / 1.01 / 1.63 / 1.64 / 1.65 / 1.67;
+// text and log tiles are ahead at every size (16 384 blocks: 2.76 against 3.53, 1.57 against 2.25 ms) -- the threshold is the JSON one
+// (profiles/r06_decoder_shapes.txt)
+constexpr uint32_t DISPATCH_SEQ_MAX = 14336u;        // <= : a wavefront per block, a lane per sequence; above: the split decoder
 constexpr uint32_t DISPATCH_SPLIT_FULL = 64u * 256u;  // (not a change of kernel: from here on every CU holds a workgroup of the split decoder; the tests want this size too)
 size_t decompress_pcd_pair_ws_bytes();
 
@@ -105,19 +109,16 @@ hipError_t launch_plan(const PlanArgs& a, hipStream_t s);
 hipError_t launch_decompress(const DecompressArgs& a, int lanes_per_block, hipStream_t s);
 // the second pass of a CHAINED batch: the blocks whose status equals a.only_status, one after the other in chain order (one wavefront)
 hipError_t launch_decompress_chain_redo(const DecompressArgs& a, hipStream_t s);
-// one block per wavefront (lz4_decompress_wave.hip); irregular blocks are left with status redo_code for a second pass of
-// launch_decompress (only_status = redo_code), which decodes them in the reference's check order
-hipError_t launch_decompress_wave(const DecompressArgs& a, int32_t redo_code, hipStream_t s);
-hipError_t launch_decompress_wave_pair(const DecompressArgs& a, int32_t redo_code, hipStream_t s);
 // one block per wavefront, one LANE PER SEQUENCE (lz4_decompress_seq.hip, round 6): speculative part walks give the token positions,
-// 64 sequences at a time are placed by a prefix sum and copied by their lanes; irregular blocks are left with status redo_code
+// 64 sequences at a time are placed by a prefix sum and copied by their lanes; irregular blocks are left with status redo_code for a
+// second pass of launch_decompress (only_status = redo_code), which decodes them in the reference's check order
 hipError_t launch_decompress_seq(const DecompressArgs& a, int32_t redo_code, hipStream_t s);
 hipError_t launch_decompress_split(const DecompressArgs& a, hipStream_t s, int blocks_per_wg = 0);   // parser / copier wavefronts, no dict/prefix
 // parser -> emitter -> quad wavefronts (lz4_decompress_fused.hip: the split decoder's parser, the replay decoder's copy engine, no dict/prefix);
-// blocks of 512 KiB or more are left with status redo_code for a second pass of launch_decompress
+// blocks of 512 KiB or more are left with status redo_code for a second pass of launch_decompress.  -DLZ4FLEX_TOOLS builds only (round 6)
 hipError_t launch_decompress_fused(const DecompressArgs& a, int32_t redo_code, hipStream_t s);
 // one WORKGROUP per block, token chain and copies parallel inside the block (lz4_decompress_pcd.hip: few, large blocks); irregular
-// blocks are left with status redo_code like behind launch_decompress_wave.  test_geometry: tiny tiles / batches (tests only)
+// blocks are left with status redo_code like behind launch_decompress_seq.  test_geometry: tiny tiles / batches (tests only)
 hipError_t launch_decompress_pcd(const DecompressArgs& a, int32_t redo_code, hipStream_t s, int geometry = 0);   // 0 production (1 024 lanes), 1 tests, 2 / 3 medium batches (256 / 512 lanes)
 hipError_t launch_compress(const CompressArgs& a, int variant, hipStream_t s);
 // throughput ("wave") encoder, lz4_compress_wave.hip: persistent workgroups, `workspace` holds

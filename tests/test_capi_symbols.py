@@ -119,8 +119,11 @@ def test_decoder_configurations_are_listed_without_a_device():
         if v < 0:
             break
         cs.append(v)
-    assert {1016, 4064, 5000, 6000, 7000, 8000, 10000, 11000, 12000} <= set(cs) and len(cs) == len(set(cs))
-    assert 9000 not in cs                    # the plan / replay decoder left the product library (tools builds only)
+    assert {1016, 4064, 7000, 8000, 10000, 11000, 13000} <= set(cs) and len(cs) == len(set(cs))
+    assert not ({9000, 12000} & set(cs))     # the plan / replay and the fused decoder left the product library (tools builds only)
+    assert not ({5000, 6000} & set(cs))      # the wave decoder and its two-wavefront form: replaced by the sequence decoder (13) in round 6
+    for gone in (5, 6, 9, 12):
+        assert lib.lz4flex_set_tuning(None, b"decompress_variant", gone) < 0
     assert lib.lz4flex_get_tuning(None, b"decoder_config_") < 0
 
 

@@ -34,12 +34,12 @@ def _gpu_decode(blk, data, cap, dict_data=None):
 # every decoder kernel behind lz4flex_decompress_batch: lanes > 0 = lz4_decompress.hip (variant 1; the default build keeps the
 # 16-lane group width, 8 / 32 / 64 exist with -DLZ4FLEX_ALL_VARIANTS only),
 # -408 / -432 / -464 = parser / copier split decoder with 8 / 32 / 64 blocks per workgroup (8 copier lanes x 4 bytes per block;
-# 64: 4 lanes x 16 bytes), -5 = one block per wavefront (wave decoder), -6 = the wave decoder with a parser and an executor
-# wavefront per block, -7 = one block per workgroup (parallel-chain decoder, lz4_decompress_pcd.hip), -8 = the same kernel with
+# 64: 4 lanes x 16 bytes), -7 = one block per workgroup (parallel-chain decoder, lz4_decompress_pcd.hip), -8 = the same kernel with
 # its small test geometry (2 KiB tiles, 64-byte parts, 128 sequences per batch, 0.5 + 1 KiB window: boundaries everywhere),
 # -9 = the plan / replay decoder (lz4_decompress_plan.hip + lz4_decompress_replay.hip: a copy plan per block, then four lanes per block replay it)
 # -12 = the fused decoder (lz4_decompress_fused.hip: parser -> emitter -> quads in one workgroup of 64 blocks)
-# (-9, the plan / replay decoder, left the product library in round 5: -DLZ4FLEX_TOOLS builds only)
+# -13 = one block per wavefront, one lane per sequence (lz4_decompress_seq.hip, round 6; it replaced -5 / -6, the wave decoder and its two-wavefront form)
+# (-9, the plan / replay decoder, left the product library in round 5, -12 in round 6: -DLZ4FLEX_TOOLS builds only)
 def _decoders_of_the_library():
     """the decoder matrix comes from the library (lz4flex_get_tuning "decoder_config_<i>": variant * 1000 + parameter; no device needed),
     so a decoder the library can be pinned to cannot go untested; encoded as above"""
@@ -47,7 +47,7 @@ def _decoders_of_the_library():
     try:
         lib = _lib.load()
     except ImportError:                                   # (collection on a box without the built library: the GPU tests cannot run there anyway)
-        return [16, -408, -432, -464, -5, -6, -7, -8, -10, -11, -12]
+        return [16, -408, -432, -464, -7, -8, -10, -11, -13]
     out, i = [], 0
     while True:
         v = lib.lz4flex_get_tuning(None, b"decoder_config_%d" % i)
@@ -60,7 +60,7 @@ def _decoders_of_the_library():
 
 
 DECODERS = _decoders_of_the_library()
-assert set(DECODERS) >= {16, -408, -432, -464, -5, -6, -7, -8, -10, -11, -12}, DECODERS
+assert set(DECODERS) >= {16, -408, -432, -464, -7, -8, -10, -11, -13}, DECODERS
 
 
 def _select_decoder(lib, ctx, lanes):
@@ -70,7 +70,7 @@ def _select_decoder(lib, ctx, lanes):
     elif lanes <= -400:
         assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 4) == 0
         assert lib.lz4flex_set_tuning(ctx, b"decompress_blocks_per_wg", -lanes - 400) == 0
-    elif lanes <= -5:
+    elif lanes <= -7:
         assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", -lanes) == 0
     else:
         raise AssertionError(lanes)

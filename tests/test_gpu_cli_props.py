@@ -102,13 +102,15 @@ def test_tuning_reads_back():
     ctx = C.c_void_p()
     assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
     try:
-        for key, vals in ((b"compress_mode", (1, 0)), (b"decompress_variant", (4, 5, 6, 1, 0)), (b"decompress_blocks_per_wg", (32, 64, 0)),
+        for key, vals in ((b"compress_mode", (1, 0)), (b"decompress_variant", (4, 13, 7, 1, 0)), (b"decompress_blocks_per_wg", (32, 64, 0)),
                           (b"decompress_lanes", (16,)), (b"compress_lanes", (16, 8)), (b"compress_variant", (1,))):
             for v in vals:
                 assert lib.lz4flex_set_tuning(ctx, key, v) == 0, (key, v)
                 assert lib.lz4flex_get_tuning(ctx, key) == v, (key, v)
         assert lib.lz4flex_get_tuning(ctx, b"no_such_key") == -_lib.E_INVALID_ARG
         assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", 3) == -_lib.E_INVALID_ARG     # round 1's pipelined decoder is gone
+        for gone in (5, 6, 9, 12):                                                              # the wave decoder (round 6: replaced by 13); tools-only kernels
+            assert lib.lz4flex_set_tuning(ctx, b"decompress_variant", gone) == -_lib.E_INVALID_ARG
         assert lib.lz4flex_set_tuning(ctx, b"decompress_lanes", 8) == -_lib.E_INVALID_ARG       # variant builds only
         assert lib.lz4flex_set_tuning(ctx, b"compress_variant", 3) == -_lib.E_INVALID_ARG
         assert lib.lz4flex_get_tuning(ctx, b"decompress_variant") == 0

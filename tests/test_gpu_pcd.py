@@ -216,7 +216,7 @@ def test_device_batch_of_4mib_blocks_round_trip(env):
     assert O.decompress(first, bs) == ("ok", h)
 
 
-@pytest.mark.parametrize("variant,bpw", [(4, 8), (4, 16), (4, 32), (4, 64), (5, 0), (6, 0), (7, 0)])
+@pytest.mark.parametrize("variant,bpw", [(4, 8), (4, 16), (4, 32), (4, 64), (13, 0), (7, 0)])
 def test_every_decoder_geometry_on_2304_benchmark_blocks(env, variant, bpw):
     """2 304 JSON tiles (configs[1]'s data) written by the throughput encoder, decoded on the device by every kernel and every
     blocks-per-workgroup geometry of the split decoder.  Regression: with 8 / 16 blocks per workgroup the split parser's spare
