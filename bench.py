@@ -188,36 +188,45 @@ def live_traffic(out, args):
     rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rp):
         return
-    kname = out["roofline"].get("kernel", "lz4_compress_wave_kernel")
-    med = {}
     tmp = tempfile.mkdtemp(prefix="lz4flex_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = [rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
-                   os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--only", "compress", "--no-cpu-baseline", "--no-other-configs",
-                   "--no-live-traffic", "--compress-mode", args.compress_mode]
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
-            vals = []
-            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-                with open(f) as fh:
-                    for r in csv.DictReader(fh):
-                        if kname in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
-                            vals.append(float(r["Counter_Value"]))
-            if len(vals) < 2:
-                return
-            vals.sort()
-            med[counter] = (vals[len(vals) // 2], len(vals))
-        hbm = int(med["FETCH_SIZE"][0] * 2048 + med["WRITE_SIZE"][0] * 1024)
-        src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (--kernel-trace only beside the counter) over a "
-               "compress-only child run (1 + 3 launches each); medians %.0f / %.0f KiB over %d / %d launches; FETCH_SIZE x 2 (gfx950), KiB -> bytes"
-               % (med["FETCH_SIZE"][0], med["WRITE_SIZE"][0], med["FETCH_SIZE"][1], med["WRITE_SIZE"][1]))
-        for r in (out["roofline"], out.get("kernels", {}).get("compress", {}).get("roofline")):
-            if r:
-                if r.get("traffic") is not None:
-                    r["traffic_profiles_file"] = r["traffic"]
-                r["traffic"] = hbm
-                r["traffic_source"] = src
+        for which in ("compress", "decompress"):
+            kname = out.get("kernels", {}).get(which, {}).get("kernel")
+            if not kname:
+                continue
+            med = {}
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(tmp, which + "_" + counter)
+                cmd = [rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                       os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--only", which, "--no-cpu-baseline", "--no-other-configs",
+                       "--no-live-traffic", "--compress-mode", args.compress_mode]
+                subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
+                vals = []
+                for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                    with open(f) as fh:
+                        for r in csv.DictReader(fh):
+                            if kname in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                                vals.append(float(r["Counter_Value"]))
+                if len(vals) < 3:          # (fewer: the other kernel's single untimed pass, or nothing)
+                    med = None
+                    break
+                vals.sort()
+                med[counter] = (vals[len(vals) // 2], len(vals))
+            if not med:
+                continue
+            hbm = int(med["FETCH_SIZE"][0] * 2048 + med["WRITE_SIZE"][0] * 1024)
+            src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (--kernel-trace only beside the counter) over a "
+                   "%s-only child run (1 + 3 launches each); medians %.0f / %.0f KiB over %d / %d launches; FETCH_SIZE x 2 (gfx950), KiB -> bytes"
+                   % (which, med["FETCH_SIZE"][0], med["WRITE_SIZE"][0], med["FETCH_SIZE"][1], med["WRITE_SIZE"][1]))
+            targets = [out.get("kernels", {}).get(which, {}).get("roofline")]
+            if out["roofline"].get("kernel") == kname:
+                targets.append(out["roofline"])
+            for r in targets:
+                if r:
+                    if r.get("traffic") is not None:
+                        r["traffic_profiles_file"] = r["traffic"]
+                    r["traffic"] = hbm
+                    r["traffic_source"] = src
     except Exception as e:
         out["roofline"]["live_traffic_error"] = repr(e)[:200]
     finally:
@@ -238,14 +247,28 @@ def other_configs(args, env):
             cb = o.get("cpu_baseline") or {}
             res["config%d" % k] = {"metric": o["metric"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": a2.steps,
                                    "ratio": o.get("ratio"), "verified": o.get("verified"), "workload": o["config"]["workload"],
-                                   "cpu_baseline": {kk: cb.get(kk) for kk in ("value", "unit", "cores", "kind", "sample", "error") if kk in cb},
+                                   "cpu_baseline": {kk: cb.get(kk) for kk in ("value", "unit", "cores", "kind", "sample", "error", "by_threads") if kk in cb},
                                    "roofline_frac": (o.get("roofline") or {}).get("frac"), "wall_s": None}
-            for extra in ("parts_ms", "windows_64k", "windows_32k", "many_streams"):
+            for extra in ("parts_ms", "windows_64k", "windows_32k", "many_streams", "kernels"):
                 if o.get(extra) is not None:
                     res["config%d" % k][extra] = o[extra]
         except Exception as e:     # a failing side configuration must not cost the headline line
             res["config%d" % k] = {"error": repr(e)}
         res["config%d" % k]["wall_s"] = round(time.perf_counter() - t0, 2)
+    # medium batches (round 6): the block codec on fewer blocks than the headline's 16 384 -- the sizes at which the default dispatch takes the
+    # sequence decoder (a wavefront per block, a lane per sequence).  Same code as --config 2 / 3 --blocks N: round trip verified on the device
+    res["medium_batches"] = {}
+    for cfg, nb in ((2, 4096), (2, 8192), (3, 4096)):
+        a2 = copy.copy(args)
+        a2.config, a2.steps, a2.warmup, a2.blocks, a2.no_cpu_baseline = cfg, 5, 2, nb, True
+        key = "%s_%d_blocks" % ("json" if cfg == 2 else "text", nb)
+        try:
+            env["torch"].cuda.empty_cache()
+            o = run_blocks(a2, env)
+            res["medium_batches"][key] = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "ratio": o.get("ratio"),
+                                          "verified": o.get("verified"), "kernels": o.get("kernels")}
+        except Exception as e:
+            res["medium_batches"][key] = {"error": repr(e)}
     return res
 
 

@@ -75,6 +75,10 @@ const char *lz4flex_version(void);
 /* hash of the sources (csrc/ + include/ + compiler flags) this binary was built from; lz4_flex_amd/build.py
  * recomputes it from the tree, so a stale library is detectable */
 const char *lz4flex_build_id(void);
+/* The round of this header: 6.  Changes a caller built against an earlier header has to know: round 5 appended chain_prev / n_chains to
+ * lz4flex_decompress_ext (read only for LZ4FLEX_MEM_DEVICE | LZ4FLEX_MEM_CHAINED batches; a struct of the four older members is fine for
+ * every other call); round 6 removed "decompress_variant" 5 / 6 (the wave decoder; 13 took its place) and moved 12 to tools builds. */
+int lz4flex_abi_version(void);
 /* last HIP error string seen by this thread (diagnostics) */
 const char *lz4flex_last_error(void);
 
@@ -251,19 +255,24 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx *ctx, const void *in_base, const uin
  *   workgroups ("compress_workgroups", read-only: two per CU) without a block cuts every block of at most 64 KiB into 4 (n * 4 <=
  *   workgroups), 3 or 2 sub-windows that different workgroups encode side by side: a scalar compress_into and small batches take
  *   about half the time, at a ratio a few tenths of a percent higher; the BYTES of a block therefore depend on the size of the batch
- *   it travels in (always a valid block); 1 = never, 2 / 3 / 4 = always.
+ *   it travels in (always a valid block) and on the device's CU count; 1 = never, 2 / 3 / 4 = always.
+ * "compress_deterministic": 1 = the bytes of a block are a function of the block and of the settings above alone -- never of the batch
+ *   it travels in or of the device ("compress_subwindows" is taken as 1; small batches and the scalar compress_into then cost about twice
+ *   the time).  What a caller sets that stores, hashes, deduplicates or golden-files compressed blocks (src/block/compress.rs:599-601
+ *   is a pure function of its input; "compress_mode" 1 is the one that also gives the REFERENCE's bytes).  0 (default).
  * Kernel selection, for measurements only (every choice produces the same bytes / lengths / error variants):
  * "decompress_variant": 0 = by batch size (default), 7 = one block per WORKGROUP, token chain and copies parallel inside the
  *   block (lz4_decompress_pcd.hip: few, large blocks; 8 = the same with its small test geometry, 10 / 11 = with 256 / 512 lanes
- *   per block: what 0 picks for 513 ... 1 024 / 257 ... 512 blocks), 5 = one block per wavefront
- *   (lz4_decompress_wave.hip), 6 = the same with a parser and an executor wavefront per block, 4 = parser /
- *   copier split decoder (large batches), 12 = the split decoder's parser feeding a piece cutter and the replay decoder's copy
- *   engine inside one workgroup (lz4_decompress_fused.hip: level with 4 on JSON, ahead on text, behind on incompressible data and
- *   runs), 9 = plan / replay (lz4_decompress_plan.hip + lz4_decompress_replay.hip; -DLZ4FLEX_TOOLS builds only since
- *   round 5: slower than 0 on every shape measured), 1 = decoder whose window lives in HBM/L2 (always used for dictionary / prefix blocks); "decompress_blocks_per_wg" (variant 4: 0 = 64, the default at every batch size; 8/16/32: the older narrow geometries, tests); "decompress_lanes"
+ *   per block: what 0 picks for 513 ... 640 / 257 ... 512 blocks), 13 = one block per WAVEFRONT, one lane per sequence
+ *   (lz4_decompress_seq.hip, round 6: what 0 picks for 641 ... 14 336 blocks; it replaced 5 / 6, the wave decoder and its
+ *   two-wavefront form, which are gone), 4 = parser / copier split decoder (larger batches), 12 = the split decoder's parser feeding
+ *   a piece cutter and the replay decoder's copy engine inside one workgroup (lz4_decompress_fused.hip: level with 4 on JSON, ahead on
+ *   text, behind on incompressible data and runs; -DLZ4FLEX_TOOLS builds only since round 6), 9 = plan / replay
+ *   (lz4_decompress_plan.hip + lz4_decompress_replay.hip; -DLZ4FLEX_TOOLS builds only since round 5: slower than 0 on every shape
+ *   measured), 1 = decoder whose window lives in HBM/L2 (always used for dictionary / prefix blocks); "decompress_blocks_per_wg" (variant 4: 0 = 64, the default at every batch size; 8/16/32: the older narrow geometries, tests); "decompress_lanes"
  *   (16; 8/32/64 in -DLZ4FLEX_ALL_VARIANTS builds, variant 1); exact encoder: "compress_lanes" (8/16 lanes of a wavefront per
  *   block), "compress_variant" (1 = group encoder + emitter wavefront; 3 = group encoder alone, -DLZ4FLEX_ALL_VARIANTS builds);
- *   "decompress_second_pass" (tests: 0 leaves the blocks that variants 5..8 hand to the reference-order kernel marked with
+ *   "decompress_second_pass" (tests: 0 leaves the blocks that variants 7 ... 13 hand to the reference-order kernel marked with
  *   status 0x7F000001 instead of decoding them again); "decompress_pcd_pair" (variants 7 / 8: 1 = batches of at most 128 LARGE
  *   blocks get a parser and a copier workgroup per block -- parse and copy of a block overlap, a single huge block uses two
  *   CUs' worth of time instead of one; 0 = never; 2 = every batch of at most 128 blocks: tests); "compress_carry_wait" (tests: 0 = a 64 KiB window of the throughput
@@ -374,7 +383,9 @@ int lz4flex_frame_walk_device(const void *frame, uint64_t frame_len, uint32_t he
  * out_len[i] = bytes written, status[i] = 0 or the negative code lz4flex_frame_compress / lz4flex_frame_decompress would have
  * returned for that stream alone (detail: nullable, n entries).  in_off / in_len / out_off / out_cap / out_len / status / detail
  * are HOST arrays; in_base / out_base are DEVICE memory (LZ4FLEX_MEM_DEVICE: work on hip_stream) or HOST memory (LZ4FLEX_MEM_HOST:
- * staged through the context's scratch; hip_stream ignored).  The calls return after the work has completed.
+ * staged through the context's scratch; hip_stream ignored).  The calls BLOCK: they return after the work has completed (they synchronise
+ * hip_stream), and they may allocate: the context's scratch grows with the largest job seen (hipMalloc / hipFree, a device-wide
+ * synchronisation, whenever a larger one arrives).  The scratch lives on the CONTEXT's device whatever the calling thread's current one is.
  * compress_many: info NULL = FrameInfo::default(); BlockSize::Auto is resolved per stream from its length (frame/header.rs:57-67);
  * has_content_size: every frame's header carries ITS stream's length (info->content_size is not read).  compress_mode fast: the
  * frames hold this library's own parse (a Linked frame's blocks reach into the 32 KiB in front of them); exact: the reference's

@@ -49,6 +49,7 @@ SIGNATURES = {
     "lz4flex_version": (C.c_char_p, []),
     "lz4flex_last_error": (C.c_char_p, []),
     "lz4flex_build_id": (C.c_char_p, []),
+    "lz4flex_abi_version": (C.c_int, []),
     "lz4flex_get_maximum_output_size": (_SZ, [_SZ]),
     "lz4flex_compress_into": (_I64, [_VP, _SZ, _VP, _SZ]),
     "lz4flex_compress_into_with_dict": (_I64, [_VP, _SZ, _VP, _SZ, _VP, _SZ]),

@@ -67,6 +67,7 @@ struct lz4flex_ctx {
     hipStream_t wave_last = nullptr;
     bool wave_used = false;
     int dec_blocks_per_wg = 0;    // split decoder: blocks per workgroup (8/16/32/64), 0 = 64
+    int comp_det = 0;             // "compress_deterministic": 1 = a block's bytes depend on the block and the settings alone (no sub-windows by batch size)
     int comp_sub = 0;             // throughput encoder, "compress_subwindows": 0 = by batch size, 1 = never, 2 / 4 = always that many sub-windows per block of <= 64 KiB
     int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 4 = parser / copier split (lz4_decompress_split.hip), 7 = a workgroup per block (lz4_decompress_pcd.hip; 8: its test geometry; 10 / 11: 256 / 512 lanes), 13 = a wavefront per block, a lane per sequence (lz4_decompress_seq.hip); tools builds: 9 = plan / replay, 12 = parser / emitter / quads
     int comp_sliding = 2;         // throughput encoder: the windows of a block longer than 64 KiB advance by 48 KiB (2: every window start has 16 KiB of history) or 32 KiB (1: round 4's bytes); 0 = by 64 KiB (round 3's bytes, fastest)
@@ -238,7 +239,7 @@ static int launch_compress_any(lz4flex_ctx* c, const CompressArgs& a, bool big, 
         aw.slide = c->comp_sliding == 2 ? 49152u : (c->comp_sliding == 1 ? 32768u : 0u);
         // sub-windows (lz4_compress_wave.hip Item::sub): batches that leave at least half / three quarters of the persistent workgroups
         // without a block cut their blocks of <= 64 KiB into 2 / 3 / 4 items each
-        aw.sub = c->comp_sub != 0 ? (uint32_t)c->comp_sub
+        aw.sub = c->comp_det ? 1u : c->comp_sub != 0 ? (uint32_t)c->comp_sub
                                   : (a.n * 4u <= (uint32_t)c->wave_wgs ? 4u : (a.n * 3u <= (uint32_t)c->wave_wgs ? 3u : (a.n * 2u <= (uint32_t)c->wave_wgs ? 2u : 1u)));
         le = launch_compress_wave(aw, c->wave_ws, c->wave_wgs, s, c->wave_prof, c->comp_carry_wait != 0);
         if (le == hipSuccess) {
@@ -428,6 +429,11 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         c->comp_sub = value;
         return 0;
     }
+    if (!strcmp(key, "compress_deterministic")) {
+        if (value != 0 && value != 1) return -LZ4FLEX_E_INVALID_ARG;
+        c->comp_det = value;
+        return 0;
+    }
     if (!strcmp(key, "decompress_blocks_per_wg")) {
         if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return -LZ4FLEX_E_INVALID_ARG;
         c->dec_blocks_per_wg = value;
@@ -525,6 +531,7 @@ int lz4flex_get_tuning(lz4flex_ctx* c, const char* key) {
     if (!strcmp(key, "compress_carry_wait")) return c->comp_carry_wait;
     if (!strcmp(key, "compress_sliding_window")) return c->comp_sliding;
     if (!strcmp(key, "compress_subwindows")) return c->comp_sub;
+    if (!strcmp(key, "compress_deterministic")) return c->comp_det;
     if (!strcmp(key, "compress_workgroups")) return c->wave_wgs;         // (what "compress_subwindows" 0 decides by: n * 4 <= this -> 4, n * 3 <= this -> 3, n * 2 <= this -> 2)
     if (!strcmp(key, "decompress_pcd_pair")) return c->dec_pcd_pair;
     if (!strcmp(key, "compress_lanes")) return c->comp_lanes;
@@ -534,6 +541,8 @@ int lz4flex_get_tuning(lz4flex_ctx* c, const char* key) {
     if (!strcmp(key, "decompress_lanes")) return c->dec_lanes;
     return -LZ4FLEX_E_INVALID_ARG;
 }
+
+int lz4flex_abi_version(void) { return 6; }
 
 size_t lz4flex_get_maximum_output_size(size_t input_len) {
     return 16 + 4 + (size_t)((uint64_t)input_len * 110 / 100);
@@ -925,8 +934,13 @@ int lz4flex_decompress_batch_ex(lz4flex_ctx* ctx, const void* in_base, const uin
     if (n && (!in_off || !in_len || !out_off || !out_cap || !out_len || !status)) return -LZ4FLEX_E_INVALID_ARG;
     if (ctx->fail_next_batch > 0) { ctx->fail_next_batch--; g_last_error = "debug_fail_next_batch"; return -LZ4FLEX_E_HIP; }
     lz4flex_decompress_ext_ e{};
-    if (ext) { e.dict_base = ext->dict_base; e.dict_off = ext->dict_off; e.dict_len = ext->dict_len; e.out_pos = ext->out_pos; e.chain_prev = ext->chain_prev; e.n_chains = ext->n_chains; }
     const bool chained = (mem_kind & LZ4FLEX_MEM_CHAINED) != 0;
+    if (ext) {
+        e.dict_base = ext->dict_base; e.dict_off = ext->dict_off; e.dict_len = ext->dict_len; e.out_pos = ext->out_pos;
+        // chain_prev / n_chains (round 5) lie behind the four members every earlier caller knows: they are only looked at in the one
+        // batch shape that uses them -- a caller built against the round-4 header hands over a 32-byte struct (lz4flex_abi_version)
+        if (chained && (mem_kind & 0xFF) == LZ4FLEX_MEM_DEVICE) { e.chain_prev = ext->chain_prev; e.n_chains = ext->n_chains; }
+    }
     if ((mem_kind & 0xFF) == LZ4FLEX_MEM_HOST)
         return run_host_batch(ctx, false, (const uint8_t*)in_base, in_off, in_len, nullptr, n, (uint8_t*)out_base, out_off,
                               out_cap, out_len, status, detail, ext ? &e : nullptr, chained);

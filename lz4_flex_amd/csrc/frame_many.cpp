@@ -103,7 +103,9 @@ int compress_one(const uint8_t* d_in, uint64_t len, const lz4flex_frame_info* in
 }
 int decompress_one(const uint8_t* d_in, uint64_t len, uint8_t* d_out, uint64_t cap, uint64_t* out_len, int32_t* status,
                    lz4flex_err_detail* detail, hipStream_t s) {
-    std::vector<uint8_t> in((size_t)len), out((size_t)cap);
+    // (an "unbounded" out_cap must not become a host allocation of that size: LZ4 expands at most 255 x)
+    const uint64_t most = len > (1ull << 40) ? cap : std::min<uint64_t>(cap, 255ull * len + 64u);
+    std::vector<uint8_t> in((size_t)len), out((size_t)most);
     if (len) TRY_HIP(hipMemcpyAsync(in.data(), d_in, (size_t)len, hipMemcpyDeviceToHost, s));
     TRY_HIP(hipStreamSynchronize(s));
     static uint8_t none = 0;
@@ -460,11 +462,12 @@ int lz4flex_frame_compress_many(lz4flex_ctx* ctx, const void* in_base, const uin
     if (!info) info = &def;                                                             // FrameInfo::default(), frame/header.rs:151-163
     if (info->legacy_frame) return -LZ4FLEX_E_INVALID_ARG;
     try {
+    if (mem_kind != LZ4FLEX_MEM_HOST && mem_kind != LZ4FLEX_MEM_DEVICE) return -LZ4FLEX_E_INVALID_ARG;
+    // (the DEVICE path too: the call's scratch is allocated on -- and cached with -- the context's device, whatever the thread's current one is)
+    DeviceGuard guard(ctx_device(ctx));
     if (mem_kind == LZ4FLEX_MEM_DEVICE)
         return compress_many_device(ctx, (const uint8_t*)in_base, in_off, in_len, n, info, (uint8_t*)out_base, out_off, out_cap, out_len, status,
                                     (hipStream_t)hip_stream);
-    if (mem_kind != LZ4FLEX_MEM_HOST) return -LZ4FLEX_E_INVALID_ARG;
-    DeviceGuard guard(ctx_device(ctx));
     hipStream_t s = ctx_stream(ctx);
     std::vector<uint64_t> s_in, s_out, cap(n);
     for (uint32_t i = 0; i < n; i++) cap[i] = std::min<uint64_t>(out_cap[i], lz4flex_frame_compress_bound((size_t)in_len[i], info));
@@ -480,6 +483,7 @@ int lz4flex_frame_compress_many(lz4flex_ctx* ctx, const void* in_base, const uin
     TRY_HIP(hipStreamSynchronize(s));
     return 0;
     } catch (const std::bad_alloc&) { return -LZ4FLEX_E_NOMEM; }      // (host tables and staging are std::vectors: nothing escapes the C ABI)
+      catch (...) { return -LZ4FLEX_E_NOMEM; }                         // (std::length_error of an absurd size)
 }
 
 int lz4flex_frame_decompress_many(lz4flex_ctx* ctx, const void* in_base, const uint64_t* in_off, const uint64_t* in_len, uint32_t n,
@@ -489,11 +493,11 @@ int lz4flex_frame_decompress_many(lz4flex_ctx* ctx, const void* in_base, const u
     if (!in_off || !in_len || !out_off || !out_cap || !out_len || !status || !in_base) return -LZ4FLEX_E_INVALID_ARG;
     TRY_RC(ctx_resolve(&ctx));
     try {
+    if (mem_kind != LZ4FLEX_MEM_HOST && mem_kind != LZ4FLEX_MEM_DEVICE) return -LZ4FLEX_E_INVALID_ARG;
+    DeviceGuard guard(ctx_device(ctx));
     if (mem_kind == LZ4FLEX_MEM_DEVICE)
         return decompress_many_device(ctx, (const uint8_t*)in_base, in_off, in_len, n, (uint8_t*)out_base, out_off, out_cap, out_len, status, detail,
                                       (hipStream_t)hip_stream);
-    if (mem_kind != LZ4FLEX_MEM_HOST) return -LZ4FLEX_E_INVALID_ARG;
-    DeviceGuard guard(ctx_device(ctx));
     hipStream_t s = ctx_stream(ctx);
     std::vector<uint64_t> s_in, s_out;
     const uint64_t in_bytes = staged(in_len, n, s_in), out_bytes = staged(out_cap, n, s_out);
@@ -508,6 +512,7 @@ int lz4flex_frame_decompress_many(lz4flex_ctx* ctx, const void* in_base, const u
     TRY_HIP(hipStreamSynchronize(s));
     return 0;
     } catch (const std::bad_alloc&) { return -LZ4FLEX_E_NOMEM; }
+      catch (...) { return -LZ4FLEX_E_NOMEM; }
 }
 
 }  // extern "C"

@@ -237,17 +237,23 @@ __global__ void __launch_bounds__(256) lz4_decompress_blocks_kernel(DecompressAr
 // Several chains in one batch (DecompressArgs::chain_prev: N Linked frames side by side) are independent of each other: the grid then
 // holds several wavefronts, and the chain whose first block is r belongs to wavefront r mod gridDim.x -- every chain is still decoded by
 // ONE wavefront in index order, different chains side by side (the serial second pass).
+// The first block of every marked block's chain, once (a thread per block follows the predecessors: indices fall), into the batch's
+// "done" words -- free behind the first pass.  Round 5 had every wavefront of the second pass walk every marked block's chain
+// (O(wavefronts x marked x depth) dependent loads).
+__global__ void lz4_decompress_chain_roots_kernel(DecompressArgs a) {
+    const uint32_t bi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bi >= a.n || a.status[bi] != a.only_status) return;
+    uint32_t r = bi;
+    for (uint32_t p = a.chain_prev[r]; p < r; p = a.chain_prev[r]) r = p;
+    a.chain_done[bi] = r;
+}
 __global__ void __launch_bounds__(64) lz4_decompress_chain_redo_kernel(DecompressArgs a) {
     constexpr int G = 16;
     const uint32_t lane = threadIdx.x;
     for (uint32_t b0 = 0u; b0 < a.n; b0 += 64u) {
         const uint32_t bi = b0 + lane;
         bool marked = bi < a.n && a.status[bi] == a.only_status;
-        if (marked && a.chain_prev != nullptr && gridDim.x > 1u) {
-            uint32_t r = bi;                                            // the chain's first block: follow the predecessors (indices fall)
-            for (uint32_t p = a.chain_prev[r]; p < r; p = a.chain_prev[r]) r = p;
-            marked = r % gridDim.x == blockIdx.x;
-        }
+        if (marked && a.chain_prev != nullptr && gridDim.x > 1u) marked = a.chain_done[bi] % gridDim.x == blockIdx.x;    // (its chain's first block: lz4_decompress_chain_roots_kernel)
         uint64_t m = __builtin_amdgcn_ballot_w64(marked);
         while (m != 0ull) {
             const uint32_t b = b0 + (uint32_t)__builtin_ctzll(m);
@@ -275,7 +281,8 @@ __global__ void __launch_bounds__(64) lz4_decompress_chain_redo_kernel(Decompres
 hipError_t launch_decompress_chain_redo(const DecompressArgs& a, hipStream_t s) {
     if (a.n == 0u) return hipSuccess;
     if (a.dict_base != nullptr || a.only_status == 0) return hipErrorInvalidValue;
-    const uint32_t grid = a.chain_prev != nullptr ? (a.n_chains > 1u ? (a.n_chains < 1024u ? a.n_chains : 1024u) : 64u) : 1u;
+    const uint32_t grid = a.chain_prev != nullptr && a.chain_done != nullptr ? (a.n_chains > 1u ? (a.n_chains < 1024u ? a.n_chains : 1024u) : 64u) : 1u;
+    if (grid > 1u) hipLaunchKernelGGL(lz4_decompress_chain_roots_kernel, dim3((a.n + 255u) / 256u), dim3(256), 0, s, a);
     hipLaunchKernelGGL(lz4_decompress_chain_redo_kernel, dim3(grid), dim3(64), 0, s, a);
     return hipGetLastError();
 }

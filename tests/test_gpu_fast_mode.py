@@ -200,3 +200,40 @@ def test_property_roundtrip_default_mode(mods):   # tests/tests.rs:591-623 propt
             _foreign_frame_decoders_return(f, data)
             assert frame.FrameDecoder.new(io.BytesIO(f)).read_to_end() == data
     prop()
+
+
+def test_compress_deterministic_makes_bytes_a_function_of_the_block(mods):
+    """src/block/compress.rs:599-601 is a pure function of its input.  The default throughput encoder is not: small batches cut their blocks
+    into sub-windows ("compress_subwindows" 0), so the same block compresses to different bytes alone, among 160 and among 600 blocks.
+    "compress_deterministic" 1 is what a caller that hashes / dedupes compressed blocks sets: the same bytes in every batch -- the scalar
+    model's bytes without sub-windows -- and every result decodes (oracle) to the block."""
+    import ctypes as C
+    from lz4_flex_amd import _lib
+    blk = mods[0]
+    lib = _lib.load()
+    plain = O.fixture_plain("compression_66k_JSON")
+    tile = (plain * 3)[1234:1234 + 65536]
+    other = (O.fixture_plain("compression_65k") * 3)[77:77 + 65536]
+    ctx = C.c_void_p()
+    assert lib.lz4flex_ctx_create(C.byref(ctx), -1) == 0
+    try:
+        assert lib.lz4flex_set_tuning(ctx, b"compress_mode", 0) == 0
+        got = {}
+        for det in (0, 1):
+            assert lib.lz4flex_set_tuning(ctx, b"compress_deterministic", det) == 0
+            assert lib.lz4flex_get_tuning(ctx, b"compress_deterministic") == det
+            for n in (1, 160, 600):
+                where = n // 2                                             # the block under test sits in the middle of the batch
+                src = np.frombuffer(other * where + tile + other * (n - 1 - where), dtype=np.uint8)
+                cap = O.max_out(65536)
+                outb = np.zeros(n * cap, dtype=np.uint8)
+                ol, st = blk.compress_batch(src, [65536 * i for i in range(n)], [65536] * n, outb, [cap * i for i in range(n)], [cap] * n, ctx=ctx)
+                assert not st.any()
+                b = bytes(outb[cap * where:cap * where + int(ol[where])])
+                assert O.decompress(b, 65536) == ("ok", tile)
+                got[(det, n)] = b
+        assert got[(1, 1)] == got[(1, 160)] == got[(1, 600)] == W.compress(tile, sub=1)
+        assert len({got[(0, 1)], got[(0, 160)], got[(0, 600)]}) > 1       # (the default really does depend on the batch: else this test shows nothing)
+        assert lib.lz4flex_set_tuning(ctx, b"compress_deterministic", 2) < 0
+    finally:
+        lib.lz4flex_ctx_destroy(ctx)
