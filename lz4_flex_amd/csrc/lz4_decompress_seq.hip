@@ -524,8 +524,8 @@ __device__ __forceinline__ bool setup_chunk(Dec<G>& D, uint32_t t0, uint32_t n_t
 }
 
 // What a lane needs to copy its n bytes (1 <= n) from LDS address s to LDS address d: the addresses of the LAST 16 bytes on both sides
-// and the lanes of every size class.  Two 16-byte reads -- the first and the last 16 bytes, the latter possibly beginning in front of
-// s -- and two overlapping writes of the size class; more than 32 bytes: the pieces between them.  Source and destination do not
+// and the lanes of every size class.  One 16-byte read (16 bytes and more: a second one, of the LAST 16 bytes) and two overlapping
+// writes of the size class; more than 32 bytes: the pieces between them.  Source and destination do not
 // overlap.  Computed once per chunk; the rounds only AND the classes with their ready lanes.
 struct CopyPlan {
     uint32_t s, d, s2, d2, n;
@@ -545,13 +545,21 @@ __device__ __forceinline__ CopyPlan plan_copy(uint32_t s, uint32_t d, uint32_t n
 }
 template <bool SMALL>
 __device__ __forceinline__ void lane_copy(const CopyPlan& P, uint64_t m) {
-    u32x4 r1, r2;
-    if (lanes(m)) { r1 = lds_rd16(P.s); r2 = lds_rd16(P.s2); }
-    if (lanes(m & P.c16)) { lds_wr16(P.d, r1); lds_wr16(P.d2, r2); }
-    if (lanes(m & P.c8)) { lds_wr8(P.d, r1.x, r1.y); lds_wr8(P.d2 + 8u, r2.z, r2.w); }
-    if (lanes(m & P.c4)) { lds_wr4(P.d, r1.x); lds_wr4(P.d2 + 12u, r2.w); }
+    u32x4 r1;
+    if (lanes(m)) r1 = lds_rd16(P.s);
+    // 16 bytes and more: the last 16 bytes are a second read; less: they are bytes of the first (an LDS instruction costs the CU's one LDS
+    // pipe whatever the number of lanes, a handful of vector instructions costs one of four SIMDs)
+    if (lanes(m & P.c16)) { const u32x4 r2 = lds_rd16(P.s2); lds_wr16(P.d, r1); lds_wr16(P.d2, r2); }
+    if (lanes(m & P.c8)) {                                   // n = 8 .. 15: bytes [n - 8, n) of r1
+        const uint32_t k = P.n - 8u;
+        const bool lo4 = k < 4u;
+        const uint32_t a = lo4 ? r1.x : r1.y, b = lo4 ? r1.y : r1.z, c = lo4 ? r1.z : r1.w;
+        lds_wr8(P.d, r1.x, r1.y);
+        lds_wr8(P.d2 + 8u, __builtin_amdgcn_alignbyte(b, a, k & 3u), __builtin_amdgcn_alignbyte(c, b, k & 3u));
+    }
+    if (lanes(m & P.c4)) { lds_wr4(P.d, r1.x); lds_wr4(P.d2 + 12u, __builtin_amdgcn_alignbyte(r1.y, r1.x, P.n & 3u)); }     // n = 4 .. 7: bytes [n - 4, n)
     if (SMALL) {
-        if (lanes(m & P.c2)) { lds_wr2(P.d, r1.x); lds_wr2(P.d2 + 14u, r2.w >> 16); }
+        if (lanes(m & P.c2)) { lds_wr2(P.d, r1.x); lds_wr2(P.d2 + 14u, r1.x >> (8u * (P.n - 2u))); }                          // n = 2, 3
         if (lanes(m & P.c1)) lds_wr1(P.d, r1.x);
     }
     SQ_JOIN();
@@ -601,35 +609,6 @@ __device__ __forceinline__ void exec_chunk(Dec<G>& D, const Chunk& C SQ_PROF_ARG
         todo = 0ull;
 #endif
     }
-#ifdef LZ4S_CHEAP_ROUNDS       // (measured: fewer vector and scalar instructions, more LDS instructions -- and the LDS pipe is the busier unit: 2.40 vs 2.31 ms)
-    if (todo != 0ull) {
-        // the later rounds have a few ready lanes each and cost their instructions: no size classes -- every ready lane does the six
-        // writes of all three, those of the classes it is not in to a scratch slot
-        const uint32_t dA = lanes(M.c16) ? M.d : G::SCRATCH, dA2 = lanes(M.c16) ? M.d2 : G::SCRATCH;
-        const uint32_t dB = lanes(M.c8) ? M.d : G::SCRATCH, dB2 = lanes(M.c8) ? M.d2 + 8u : G::SCRATCH;
-        const uint32_t dC = lanes(M.c4) ? M.d : G::SCRATCH, dC2 = lanes(M.c4) ? M.d2 + 12u : G::SCRATCH;
-        do {
-            const uint32_t dp = ctz64(todo);
-            const uint32_t S = rdlane(C.dst, dp);
-            const uint64_t rm = todo & (ballot(s1 <= S) | (1ull << dp));
-            if (lanes(rm)) {
-                const u32x4 r1 = lds_rd16(M.s), r2 = lds_rd16(M.s2);
-                lds_wr16(dA, r1); lds_wr16(dA2, r2);
-                lds_wr8(dB, r1.x, r1.y); lds_wr8(dB2, r2.z, r2.w);
-                lds_wr4(dC, r1.x); lds_wr4(dC2, r2.w);
-            }
-            SQ_JOIN();
-            uint64_t more = rm & M.gt32;
-            for (uint32_t p = 16u; more != 0ull; p += 16u) {
-                if (lanes(more)) { const u32x4 r = lds_rd16(M.s + p); lds_wr16(M.d + p, r); }
-                SQ_JOIN();
-                more &= ballot(p + 32u < M.n);
-            }
-            todo &= ~rm;
-            SQ_COUNT(18, 1)
-        } while (todo != 0ull);
-    }
-#else
     while (todo != 0ull) {
         const uint32_t dp = ctz64(todo);
         const uint32_t S = rdlane(C.dst, dp);
@@ -641,7 +620,6 @@ __device__ __forceinline__ void exec_chunk(Dec<G>& D, const Chunk& C SQ_PROF_ARG
         todo = 0ull;
 #endif
     }
-#endif
     SQ_TICK(8)
 }
 
