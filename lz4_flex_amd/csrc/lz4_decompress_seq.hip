@@ -3,32 +3,33 @@
 // What it replaces: lz4_flex::block::decompress_into / decompress_internal (src/block/decompress.rs:201-449) for many independent
 // blocks.  Output bytes are the reference's; an irregular block (every error of src/block/mod.rs:82-98, a sink too small, an offset
 // behind the output) is NOT diagnosed here: it is marked and the reference-order decoder of lz4_decompress.hip decodes it again and
-// reports the exact error variant and detail (the scheme of lz4_decompress_wave.hip / lz4_decompress_pcd.hip).
+// reports the exact error variant and detail (the scheme of lz4_decompress_pcd.hip).
 //
 // Round 6.  Every other batch decoder in this tree walks a block's token chain with ONE lane and copies its pieces with one
 // group of four lanes: the kernel's time is one block's chain (3 380 sequences x ~630 dependent wave-instructions).
 // Here nothing is done a sequence at a time:
 //   * WALK (the reference's `ip` chain, decompress.rs:244-332, positions only).  The compressed stream is consumed in tiles of
 //     3 840 bytes staged in LDS; a tile is cut into 64 parts of 60 bytes (15 dwords: lane k reading part k hits its own bank) and
-//     lane k walks part k's chain from an ASSUMED entry, one LDS round trip per hop (token + first length byte; the match length
-//     byte of a 15-nibble lies right before the next token and is checked by the next hop), marking token positions in a 64-bit
-//     register mask.  A chain started at a wrong byte falls into step with the true chain after a few sequences; the exits are
-//     followed from the tile's true entry by pointer jumping (ds_bpermute), parts whose entry was wrong walk again until they
-//     meet their first walk's marks (the parallel-chain parse of lz4_decompress_pcd.hip / lz4_decompress_plan.hip, masks only).
+//     lane k walks part k's chain from an ASSUMED entry, two LDS round trips per hop at most (token + first length byte; the match
+//     length byte of a 15-nibble), marking token positions in a 64-bit register mask.  A chain started at a wrong byte falls into
+//     step with the true chain after a few sequences; the exits are followed from the tile's true entry (every part leaving into
+//     the next one: a DPP move; else pointer jumping with ds_bpermute), parts whose entry was wrong walk again until they meet
+//     their first walk's marks (the parallel-chain parse of lz4_decompress_pcd.hip / lz4_decompress_plan.hip, masks only).
 //     The set bits of the live parts, compacted into a u16 list in LDS, are the tile's sequences in order.
 //   * CHUNKS of 64 consecutive sequences, lane = sequence: token, lengths and offset from two aligned dword-pair reads of the
 //     tile (decompress.rs:249-258, 284, 373-391), a DPP prefix sum of literal + match lengths places all 64 in the output at
 //     once, every reference check that needs the position (offset <= position :286-289 / :398-402, capacity :346-356) is one
 //     ballot.  Literals (<= 64 bytes) are copied by their lane, 16 bytes per access, exact length.  Matches: a source older than
-//     the LDS window comes from the written-back output (loads issued before the literal copies, used behind them); a source in
+//     the LDS window comes from the written-back output (loads issued at set-up, a chunk ahead of their use); a source in
 //     the window copies in ROUNDS -- a lane is ready when every sequence that starts before its source's end is done (the done
 //     PREFIX: one v_readlane + one compare per round), all ready lanes copy at once.  A round costs its instructions whatever
 //     the number of ready lanes; JSON tiles need ~12 rounds per chunk, text ~5 (tools/chunk_study.py).
-//   * the output lives in a linear LDS WINDOW (8 KiB) that slides by copying its upper half down; what leaves it has been
+//   * the output lives in a linear LDS WINDOW (3.5 KiB) that slides by copying its last 1 280 bytes down; what leaves it has been
 //     written back 16 bytes per lane.  Sequences that do not fit a lane (literal runs > 64, matches > 273 bytes or overlapping
 //     their source, far matches > 64, anything with more than one length byte) are executed ALONE by the whole wavefront
 //     (exact_seq: decompress.rs:334-443 for one sequence of any shape) and cut the chunk in front of them.
-// LDS per wavefront: token list 2 560 + tile 4 080 + window 8 192 + 16 = 14 848 bytes: 11 wavefronts per CU.
+// LDS per wavefront: token list 2 560 + tile 4 080 + window 3 584 + 16 = 10 240 bytes: 16 wavefronts per CU (4 096 blocks are one round of
+// wavefronts; 8 KiB windows -- 11 per CU, a fifth of the far matches -- were a quarter slower: DESIGN.md 5.2, profiles/r06_seq_decoder.txt).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -829,11 +830,7 @@ hipError_t launch_decompress_seq(const DecompressArgs& a, int32_t redo_code, hip
     if (a.n == 0u) return hipSuccess;
     if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;
     typedef sq::Geo<LZ4S_R, LZ4S_KEEP> G;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)sq::lz4_decompress_seq_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-        attr_done = true;
-    }
+    static_assert(G::LDS <= 65536u, "the default limit of dynamic LDS: no function attribute to set per device");
     hipLaunchKernelGGL(sq::lz4_decompress_seq_kernel<G>, dim3(a.n), dim3(64), G::LDS, s, a, redo_code);
     return hipGetLastError();
 }
