@@ -67,6 +67,7 @@ constexpr uint32_t POSCAP = PT / 3u;         // sequences per tile: a sequence w
 constexpr uint32_t POS_LDS = (2u * POSCAP + 15u) & ~15u;
 constexpr uint32_t LITMAX = 64u;             // literal run a lane copies itself
 constexpr uint32_t FARMAX = 64u;             // match from the written-back output a lane copies itself
+constexpr uint32_t POS_LIMIT = 0xFFFF0000u;   // positions in either stream stay below this: `pos + a KiB` never wraps (a block beyond it is the reference-order kernel's)
 constexpr uint32_t BIGRUN = 1024u;           // literal runs / matches from here on go memory to memory (exact_seq)
 constexpr uint32_t WALK_LITMAX = 200u;       // literal run a hop steps over without the generic walker (its end stays inside the staged bytes)
 // LDS: [token list | tile | window | scratch 16]  (the tile is not first: a lane may read up to 16 bytes in front of it)
@@ -408,7 +409,7 @@ struct Dec {
                 if (b != 255u) break;
             }
         }
-        if (lit > ilen - ip || lit > cap - OP) return false;
+        if (lit > ilen - ip || lit > cap - OP || OP + lit > POS_LIMIT) return false;
         coop_literals(ip, lit);
         ip += lit;
         if (ip >= ilen) { done = true; return true; }
@@ -427,7 +428,7 @@ struct Dec {
                 if (b != 255u) break;
             }
         }
-        if (offset > OP || ml > cap - OP) return false;
+        if (offset > OP || ml > cap - OP || OP + ml > POS_LIMIT) return false;
         coop_match(offset, ml);
         if (ip >= ilen) return false;              // a match is always followed by another token (decompress.rs:439-443)
         return true;
@@ -487,7 +488,7 @@ __device__ __forceinline__ bool setup_chunk(Dec<G>& D, uint32_t t0, uint32_t n_t
     C.tp0 = rdlane(tpr, 0u);
     if (nact != 0u) {
         if ((errm & low_mask(nact)) != 0ull) return false;
-        if (T > D.cap - op) return false;                      // OutputTooSmall (:349-356, :403-408): named by the reference-order kernel
+        if (T > D.cap - op || op + T > POS_LIMIT) return false;    // OutputTooSmall (:349-356, :403-408): named by the reference-order kernel
         D.write_back(op - pending);                            // (every chunk: a source that leaves the window has to be in memory)
         D.ensure(op - pending, pending + T);
     }
@@ -678,7 +679,7 @@ __global__ void __launch_bounds__(64) lz4_decompress_seq_kernel(DecompressArgs a
     D.lane = lane;
     D.OP = 0u; D.W0 = 0u; D.F = 0u;
     const uint32_t ilen = D.ilen;
-    bool ok = ilen != 0u, done = false;          // (an empty block: decompress.rs:207-209, the reference-order kernel reports it)
+    bool ok = ilen != 0u && ilen <= POS_LIMIT, done = false;     // (an empty block: decompress.rs:207-209, the reference-order kernel reports it)
     uint32_t entry = 0u;
 #ifdef LZ4S_PROF
     Prof P;
