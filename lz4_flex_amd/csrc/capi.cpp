@@ -783,12 +783,20 @@ static int run_host_batch(lz4flex_ctx* c, bool compress, const uint8_t* in_base,
         // every successful block owns [out_off, out_off+len); failed blocks must leave the caller's bytes alone
         // ... and the one-shot copy covers the whole span, so the blocks must TILE it: with gaps between the callers' slots (a
         // padded stride) it would overwrite host bytes that belong to nobody with whatever the device arena holds
+        // (round 6: the block that ENDS the span may be short -- a frame's last block, lz4flex_frame_decompress decoding straight into the
+        // caller's buffer -- the transfer then stops at its last byte)
         bool all_ok = true;
-        uint64_t cap_sum = 0;
-        for (uint32_t i = 0; i < n; i++) { all_ok &= (r_st[i] == 0 && r_len[i] == out_cap[i]); cap_sum += out_cap[i]; }
-        all_ok &= cap_sum == (uint64_t)out_bytes;
+        uint64_t cap_sum = 0, short_tail = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            cap_sum += out_cap[i];
+            if (r_st[i] != 0) { all_ok = false; break; }
+            if (r_len[i] == out_cap[i]) continue;
+            if (out_off[i] + out_cap[i] == hb.out_span.hi && short_tail == 0 && r_len[i] < out_cap[i]) short_tail = out_cap[i] - r_len[i];
+            else { all_ok = false; break; }
+        }
+        all_ok = all_ok && cap_sum == (uint64_t)out_bytes;
         if (all_ok) {
-            HIP_TRY(hipMemcpyAsync(out_base + hb.out_span.lo, d + a_out, out_bytes, hipMemcpyDeviceToHost, s));
+            if (out_bytes > short_tail) HIP_TRY(hipMemcpyAsync(out_base + hb.out_span.lo, d + a_out, out_bytes - (size_t)short_tail, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             return 0;
         }

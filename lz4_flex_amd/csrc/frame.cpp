@@ -143,6 +143,7 @@ struct lz4flex_frame_encoder {
     uint64_t src_stream_offset = 0;   // mirrors the reference field that decides the table state (N3)
     XxHash32 content_hasher{0};
     bool is_frame_open = false, data_to_frame_written = false;
+    bool final_write = false;       // lz4flex_frame_compress: the write in progress is the stream's last (finish follows)
     int sticky_err = 0;
     // Linked mode (frame/compress.rs:62-93): the reference's src ring (prefix + ext_dict) expressed in
     // stream coordinates; the dependent blocks of a batch run as ONE chain on the GPU.
@@ -332,9 +333,13 @@ struct lz4flex_frame_encoder {
         return (int64_t)total;
     }
 
-    // write_block (frame/compress.rs:261-371) for `nblk` staged blocks in one launch; the last may be partial
-    int write_blocks(size_t nblk) {
+    // write_block (frame/compress.rs:261-371) for `nblk` blocks in one launch; the last may be partial.  The blocks are the staged bytes, or
+    // (round 6) `avail` bytes at `direct` in the CALLER's buffer: a write of a whole batch, and the one-shot call's remainder, are compressed
+    // where they lie -- staging them cost a host copy of every byte (12 instead of 24 GiB/s through host buffers)
+    int write_blocks(size_t nblk, const uint8_t* direct = nullptr, size_t avail = 0) {
         if (nblk == 0) return 0;
+        const uint8_t* const base = direct ? direct : src.data();
+        const size_t have = direct ? avail : src_len;
         const size_t mbs = block_size_bytes(fi.block_size);
         const size_t stride = (lz4flex_get_maximum_output_size(mbs) + 63) / 64 * 64;
         if (dst.size() < stride * nblk) dst.resize(stride * nblk);
@@ -343,7 +348,7 @@ struct lz4flex_frame_encoder {
         uint64_t so = src_stream_offset;
         size_t consumed = 0;
         for (size_t i = 0; i < nblk; i++) {
-            const size_t len = std::min(mbs, src_len - i * mbs);
+            const size_t len = std::min(mbs, have - i * mbs);
             // reposition near 2 GiB (frame/compress.rs:266-271): the table collapses to "all zero, offset 0"
             if (so + mbs + WINDOW_SIZE >= (uint64_t)(0xFFFFFFFFu / 2)) so = 0;
             in_off[i] = i * mbs; in_len[i] = (uint32_t)len;
@@ -352,15 +357,16 @@ struct lz4flex_frame_encoder {
             so += len;
             consumed += len;
         }
-        int rc = lz4flex_compress_batch(nullptr, src.data(), in_off.data(), in_len.data(), flags.data(), (uint32_t)nblk,
+        int rc = lz4flex_compress_batch(nullptr, base, in_off.data(), in_len.data(), flags.data(), (uint32_t)nblk,
                                         dst.data(), out_off.data(), out_cap.data(), out_len.data(), status.data(),
                                         LZ4FLEX_MEM_HOST, nullptr);
         if (rc) return rc;
         for (size_t i = 0; i < nblk; i++) {
             if (status[i] != 0) return -LZ4FLEX_FE_COMPRESSION;
-            if ((rc = emit_block(src.data() + in_off[i], in_len[i], dst.data() + out_off[i], out_len[i]))) return rc;
+            if ((rc = emit_block(base + in_off[i], in_len[i], dst.data() + out_off[i], out_len[i]))) return rc;
         }
         src_stream_offset = so;
+        if (direct) return 0;
         // keep an unconsumed tail (never happens: callers pass every staged byte or whole blocks)
         if (consumed < src_len) memmove(src.data(), src.data() + consumed, src_len - consumed);
         src_len -= consumed;
@@ -379,6 +385,15 @@ struct lz4flex_frame_encoder {
             if (src_len == cap) {   // staging full: make space by writing the staged blocks
                 if ((rc = write_blocks(batch_blocks))) return sticky_err = rc;
                 continue;
+            }
+            if (src_len == 0 && len >= cap) {   // a whole batch lies in the caller's buffer: no staging
+                if ((rc = write_blocks(batch_blocks, buf, cap))) return sticky_err = rc;
+                buf += cap; len -= cap;
+                continue;
+            }
+            if (final_write && src_len == 0) {  // the one-shot call's remainder: whatever is left is the frame's end, a partial last block included
+                if ((rc = write_blocks((len + mbs - 1) / mbs, buf, len))) return sticky_err = rc;
+                return (int64_t)total;
             }
             const size_t n = std::min(cap - src_len, len);
             if (src.size() < src_len + n) src.resize(std::min(cap, std::max(src.size() * 2, src_len + n)));   // grows with the data
@@ -515,9 +530,16 @@ struct lz4flex_frame_decoder {
     }
 
     // Independent frames: gather blocks up to the batch size, decode them in one launch.
-    void read_blocks_independent() {
+    // Round 6, `direct`: the reader asked for at least a block's worth of bytes (lz4flex_frame_decompress: for all of them) -- the blocks
+    // are decoded STRAIGHT INTO ITS BUFFER, slot i at i * block size, and the number of bytes delivered is returned (0: nothing went that
+    // way, the ready list says what there is).  Staging them and copying them out was a host copy of every decoded byte: 12 instead of
+    // ~ 20 GiB/s through host buffers.  A slot that is not full (a flush() boundary, the frame's last block) is closed up by moving what
+    // follows it; a block that decodes to nothing -- after which read() returns 0 once, frame/decompress.rs:344-349 -- and everything
+    // behind it goes to the staging buffer as before.
+    size_t read_blocks_independent(uint8_t* direct = nullptr, size_t direct_len = 0) {
         const size_t mbs = block_size_bytes(fi.block_size);
-        const size_t max_blocks = blocks_per_launch(batch_bytes, mbs, batch_auto);
+        size_t max_blocks = blocks_per_launch(batch_bytes, mbs, batch_auto);
+        if (direct) max_blocks = std::min(max_blocks, direct_len / mbs);
         comp.clear(); in_off.clear(); in_len.clear(); out_off.clear(); out_cap.clear();
         ready.clear(); ready_idx = 0; ready_pos = 0;
         ready_linked = false;
@@ -551,38 +573,55 @@ struct lz4flex_frame_decoder {
             // An LZ4 block expands by less than 255x (one length byte adds at most 255 output bytes), so min(block size,
             // 255 len + 64) is as good a sink as the reference's block-size buffer and a frame of tiny blocks cannot make the
             // read-ahead reserve (and the device arena mirror) gigabytes.
-            const size_t cap_i = std::min<size_t>(mbs, 255u * len + 64u);
+            const size_t cap_i = direct ? mbs : std::min<size_t>(mbs, 255u * len + 64u);
             if (!raw) { in_off.push_back(at); in_len.push_back((uint32_t)len); out_off.push_back(out_need); out_cap.push_back((uint32_t)cap_i); out_need += cap_i; }
-            else { s.idx = at; out_need += len; }
+            else { s.idx = at; out_need += direct ? mbs : len; }
             slots.push_back(s);
         }
-        if (out.size() < out_need) out.resize(out_need);
+        if (!direct && out.size() < out_need) out.resize(out_need);
+        uint8_t* const sink = direct ? direct : out.data();
         const size_t nb = in_off.size();
         out_len.assign(nb, 0); status.assign(nb, 0); detail.assign(2 * nb, 0);
         if (nb) {
-            const int rc = lz4flex_decompress_batch(nullptr, comp.data(), in_off.data(), in_len.data(), (uint32_t)nb, out.data(),
+            const int rc = lz4flex_decompress_batch(nullptr, comp.data(), in_off.data(), in_len.data(), (uint32_t)nb, sink,
                                                     out_off.data(), out_cap.data(), out_len.data(), status.data(),
                                                     detail.data(), LZ4FLEX_MEM_HOST, nullptr);
-            if (rc) { fail(rc); pending_zero = false; return; }
+            if (rc) { fail(rc); pending_zero = false; return 0; }
         }
+        size_t delivered = 0;          // direct: bytes closed up at the front of the reader's buffer
+        bool staged = !direct;         // direct: a block decoded to nothing -- from there on the pieces wait in `out`
+        size_t staged_at = 0;
         for (const Slot& s : slots) {
             size_t plen;
-            if (s.raw) { memcpy(out.data() + s.out_at, comp.data() + s.idx, s.raw_len); plen = s.raw_len; }
+            if (s.raw) { memcpy(sink + s.out_at, comp.data() + s.idx, s.raw_len); plen = s.raw_len; }
             else {
                 if (status[s.idx] != 0) {
                     lz4flex_err_detail d{}; d.expected = detail[2 * s.idx]; d.actual = detail[2 * s.idx + 1]; d.inner = status[s.idx];
                     fail(-LZ4FLEX_FE_DECOMPRESSION, &d);
                     pending_zero = false;
-                    return;   // pieces before this one were queued; the error surfaces after them
+                    return delivered;   // pieces before this one were delivered / queued; the error surfaces after them
                 }
                 plen = out_len[s.idx];
             }
-            ready.push_back({s.out_at, plen});
             content_len += plen;
-            if (fi.content_checksum) content_hasher.write(out.data() + s.out_at, plen);
+            if (fi.content_checksum) content_hasher.write(sink + s.out_at, plen);
+            if (direct && !staged && plen == 0) {
+                staged = true;
+                if (out.size() < out_need) out.resize(out_need);
+            }
+            if (!direct) ready.push_back({s.out_at, plen});
+            else if (!staged) {
+                if (s.out_at != delivered && plen) memmove(direct + delivered, direct + s.out_at, plen);
+                delivered += plen;
+            } else {
+                if (plen) memcpy(out.data() + staged_at, direct + s.out_at, plen);
+                ready.push_back({staged_at, plen});
+                staged_at += plen;
+            }
         }
-        if (pending_err) { pending_zero = false; return; }
+        if (pending_err) { pending_zero = false; return delivered; }
         if (saw_end && !pending_zero) end_mark();
+        return delivered;
     }
 
     // Linked frames (frame/decompress.rs:195-222,280-306: the reference decodes block after block into one window, a block's
@@ -753,9 +792,14 @@ struct lz4flex_frame_decoder {
                 if (rc == 1) return 0;
                 if (rc < 0) { if (d) *d = hd; return rc; }
             }
-            if (fi.block_mode == 1) read_block_linked(); else read_blocks_independent();
+            if (fi.block_mode == 1) read_block_linked();
+            else if (len >= block_size_bytes(fi.block_size) && len >= DIRECT_MIN) {
+                const size_t n = read_blocks_independent(buf, len);
+                if (n) return (int64_t)n;
+            } else read_blocks_independent();
         }
     }
+    static constexpr size_t DIRECT_MIN = 1u << 20;    // a reader with less room than this gets its bytes from the staging buffer (small reads: one launch per read would cost more than the copy)
 };
 
 extern "C" {
@@ -848,6 +892,7 @@ int64_t lz4flex_frame_compress(const uint8_t* in, size_t in_len, const lz4flex_f
     FlatW fw{out, 0, out_cap, false};
     lz4flex_frame_encoder* e = lz4flex_frame_encoder_new(info, flat_write, &fw);
     if (!e) return -LZ4FLEX_E_NOMEM;
+    e->final_write = true;                     // (whole blocks AND the remainder are compressed where they lie: no staging copy)
     int64_t rc = e->write(in, in_len);
     if (rc >= 0) rc = e->try_finish(detail);
     lz4flex_frame_encoder_free(e);
