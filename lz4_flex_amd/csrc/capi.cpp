@@ -389,16 +389,16 @@ void lz4flex_ctx_destroy(lz4flex_ctx* c) {
 
 #ifdef LZ4FLEX_TOOLS
 // variant builds for tools/ only (-DLZ4FLEX_TOOLS; not in the public header, not in the product library): enable != 0 starts /
-// resets the wave encoder's per-role cycle counters of this context, vals (nullable) receives the 16 sums accumulated so far
+// resets the wave encoder's per-role cycle counters of this context, vals (nullable) receives the 32 sums accumulated so far
 int lz4flex_debug_wave_prof(lz4flex_ctx* c, int enable, unsigned long long* vals) {
     if (!c) return -LZ4FLEX_E_INVALID_ARG;
     if (vals && c->wave_prof) {
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(vals, c->wave_prof, 128, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(vals, c->wave_prof, 256, hipMemcpyDeviceToHost));
     }
     if (enable) {
-        if (!c->wave_prof) HIP_TRY(hipMalloc((void**)&c->wave_prof, 128));
-        HIP_TRY(hipMemset(c->wave_prof, 0, 128));
+        if (!c->wave_prof) HIP_TRY(hipMalloc((void**)&c->wave_prof, 256));
+        HIP_TRY(hipMemset(c->wave_prof, 0, 256));
     } else if (c->wave_prof) {
         (void)hipFree(c->wave_prof);
         c->wave_prof = nullptr;

@@ -47,15 +47,20 @@ typedef __attribute__((address_space(1))) int32_t g_i32;
 
 constexpr uint32_t WINDOW = 65536u;
 #ifndef LZ4W_WORKERS
-#define LZ4W_WORKERS 8
+#define LZ4W_WORKERS 11
 #endif
 constexpr uint32_t WORKERS = LZ4W_WORKERS;   // worker wavefronts = segments per window
 constexpr uint32_t GROUPS = WINDOW / 512u;   // segment boundaries are multiples of 512 (one cand[] group)
-// segment w of a full window = [seg_lo(w), seg_lo(w + 1)); a shorter window clips them.  Eight workers do not get equal
-// shares: a later segment sees more of the window, finds more candidates and costs more per position (JSON tiles, cycles per
-// window with 16 groups each: 241 226 224 232 253 252 252 263 k -- the window waits for the slowest), so the segments are
-// 16 17 17 17 15 16 15 15 groups long (the scalar model has the same table)
+// segment w of a full window = [seg_lo(w), seg_lo(w + 1)); a shorter window clips them.  The workers do not get equal shares: a
+// later segment sees more of the window, finds more candidates and costs more per position, and the three workers that share their
+// SIMD with the indexer get more done (JSON tiles, matching cycles per window with 11 / 12 groups each: 174 173 156 169 190 177 186
+// 189 202 213 209 k -- the window waits for the slowest), so the segments are 12 13 13 13 12 11 12 12 10 10 10 groups long (the
+// scalar model has the same table; eight workers, rounds 2 - 5: 16 17 17 17 15 16 15 15)
 __host__ __device__ constexpr uint32_t seg_lo(uint32_t w) {
+    if (WORKERS == 11u) {
+        constexpr uint32_t lo[12] = {0u, 12u, 25u, 38u, 51u, 63u, 74u, 86u, 98u, 108u, 118u, 128u};
+        return 512u * lo[w < 11u ? w : 11u];
+    }
     if (WORKERS == 8u) {
         constexpr uint32_t lo[9] = {0u, 16u, 33u, 50u, 67u, 82u, 98u, 113u, 128u};
         return 512u * lo[w < 8u ? w : 8u];
@@ -94,8 +99,17 @@ constexpr uint32_t NEARP = 20u;           // ... and are followed within this ma
 constexpr uint32_t LONGN = 8u;            // ... when the superstep holds at least this many of them
 constexpr uint32_t HBITS = 12u;
 constexpr uint32_t THREADS = 64u * (WORKERS + 1u);
-constexpr uint32_t STG_BYTES = 448u;      // per worker: encoded sequences waiting for a 16 B-per-lane flush
-constexpr uint32_t FLUSH_AT = 160u;       // a staging round adds at most 16 x 18 = 288 bytes on the lane-parallel path
+#ifndef LZ4W_STG
+#define LZ4W_STG 360
+#endif
+#ifndef LZ4W_RING_SLOTS
+#define LZ4W_RING_SLOTS 1
+#endif
+constexpr uint32_t STG_BYTES = LZ4W_STG;  // per worker: encoded sequences waiting for a 16 B-per-lane flush
+constexpr uint32_t TMP_OFF = STG_BYTES - 256u;   // match_segment's second scratch array lies inside the staging buffer, above what encode_seqs leaves there
+constexpr uint32_t FLUSH_AT = TMP_OFF - 32u;     // a staging round adds at most STG_BYTES - FLUSH_AT = 288 bytes on the lane-parallel path
+constexpr uint32_t RING_SLOTS = LZ4W_RING_SLOTS; // chunk slots of the indexer (one wavefront, LDS operations in order: one would do)
+static_assert(STG_BYTES >= 272u + 16u && FLUSH_AT >= 32u && STG_BYTES - FLUSH_AT >= 18u, "emit_generic's 256-byte pieces and one ordinary sequence fit");
 constexpr uint32_t WORKER_LDS = STG_BYTES + 256u;   // + the compaction buffer of a superstep: 64 heads x 4 B
 constexpr uint32_t CHUNK = 1024u;         // the indexer streams the next window in 1 KiB chunks (16 steps)
 constexpr uint32_t CHUNK_SLOT = CHUNK + 16u;      // + the first bytes of the next chunk (positions 1021..1023 hash across the end)
@@ -105,7 +119,7 @@ constexpr uint32_t L_WIN = 0u;                              // the window + 64 B
 constexpr uint32_t L_TAB = WINDOW + 64u;                    // the indexer's table, 4096 x u16
 constexpr uint32_t L_STG = L_TAB + (2u << HBITS);
 constexpr uint32_t L_RING = L_STG + WORKERS * WORKER_LDS;   // two chunk slots of the indexer
-constexpr uint32_t L_META = L_RING + 2u * CHUNK_SLOT;
+constexpr uint32_t L_META = L_RING + RING_SLOTS * CHUNK_SLOT;
 constexpr uint32_t LDS_BYTES = L_META + 256u;
 static_assert(LDS_BYTES <= 81920u, "two workgroups per CU");
 static_assert(WORKERS >= 1u && WORKERS <= 15u && seg_lo(WORKERS) == WINDOW, "segments tile the window");
@@ -283,7 +297,7 @@ __device__ __attribute__((noinline)) void index_window(const uint8_t* __restrict
         // registers, 16 steps.  Issue order per chunk: [wait], 2 loads, 4 cand[] stores.
 #define LZ4W_ONE_CHUNK(N, CC, J)                                                                    \
         {                                                                                           \
-            lds_u8* sl = lds + L_RING + ((J) & 1u) * CHUNK_SLOT;                                    \
+            lds_u8* sl = lds + L_RING + ((J) & (RING_SLOTS - 1u)) * CHUNK_SLOT;                                    \
             chunk_wait<N>(q[J]);                                                                    \
             __builtin_memcpy((void*)(sl + 16u * lane), &q[J].main, 16);                             \
             __builtin_memcpy((void*)(sl + CHUNK), &q[J].extra, 4);   /* every lane writes the same dword */ \
@@ -310,7 +324,7 @@ __device__ __attribute__((noinline)) void index_window(const uint8_t* __restrict
         // the <= 3 chunks left are already requested (q[0..2]): drain everything, then index them
         chunk_wait<0>(q[0]); chunk_wait<0>(q[1]); chunk_wait<0>(q[2]); chunk_wait<0>(q[3]);
         for (uint32_t j = 0; c < n_main; ++c, ++j) {
-            lds_u8* sl = lds + L_RING + (j & 1u) * CHUNK_SLOT;
+            lds_u8* sl = lds + L_RING + (j & (RING_SLOTS - 1u)) * CHUNK_SLOT;
             const ChunkRegs r = j == 0u ? q[0] : (j == 1u ? q[1] : q[2]);
             __builtin_memcpy((void*)(sl + 16u * lane), &r.main, 16);
             __builtin_memcpy((void*)(sl + CHUNK), &r.extra, 4);
@@ -550,8 +564,8 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
     lds_u8* const win = lds + L_WIN;
     lds_u8* const stg = lds + L_STG + w * WORKER_LDS;
     lds_u32* const cmp = (lds_u32*)(stg + STG_BYTES);             // compaction buffer: 64 x 4 B
-    lds_u32* const tmp = (lds_u32*)(stg + 192u);                  // second one: the staging buffer holds < FLUSH_AT bytes between calls of encode_seqs
-    static_assert(FLUSH_AT <= 192u && 192u + 256u <= STG_BYTES, "scratch inside the staging buffer");
+    lds_u32* const tmp = (lds_u32*)(stg + TMP_OFF);                 // second one: the staging buffer holds < FLUSH_AT bytes between calls of encode_seqs
+    static_assert(FLUSH_AT <= TMP_OFF && TMP_OFF + 256u <= STG_BYTES && (RING_SLOTS == 1u || RING_SLOTS == 2u), "scratch inside the staging buffer");
     EncState st;
     st.fill = 0u; st.body_len = 0u; st.has = 0u; st.first_lit = 0u; st.first_ml = 0u; st.last_end = s0;
     uint32_t cursor = s0, carry = 0u, dlast = 0u;
@@ -778,7 +792,7 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
             // rank r -- which starts one word below tmp | cmp (contiguous; LDS operations of a wavefront execute in order: a
             // chunk's heads are read before its results overwrite them); the positions gather from it
             lds_u32* const best = tmp - 1;
-            static_assert(192u + 256u == STG_BYTES && FLUSH_AT <= 188u, "tmp and cmp are contiguous, the word below them is free");
+            static_assert(TMP_OFF + 256u == STG_BYTES && FLUSH_AT + 4u <= TMP_OFF, "tmp and cmp are contiguous, the word below them is free");
             best[0] = carry;
             if (hh0 && r0 < 64u) cmp[r0] = (p0 << 16) | t0;
             if (hh1 && r1 < 64u) cmp[r1] = (p1 << 16) | t1;
@@ -1376,8 +1390,8 @@ __device__ __forceinline__ void wave_body(const CompressArgs& a, uint8_t* __rest
             if (prof && lane == 0u)
                 for (uint32_t i = 0; i < 7u; ++i)
                     if (t_acc[i] != 0ull) atomicAdd(prof + i, (unsigned long long)t_acc[i]);
-#ifdef LZ4W_PROF_WORKERS    // tools: matching cycles per worker -> prof[8 + w] (the segment table above comes from these)
-            if (prof && lane == 0u && w < 8u) atomicAdd(prof + 8u + w, (unsigned long long)t_acc[2]);
+#ifdef LZ4W_PROF_WORKERS    // tools: matching cycles per worker -> prof[16 + w] (the segment table above comes from these)
+            if (prof && lane == 0u && w < WORKERS) atomicAdd(prof + 16u + w, (unsigned long long)t_acc[2]);
 #endif
             break;
         }

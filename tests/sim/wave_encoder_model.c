@@ -146,11 +146,15 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
         const uint32_t wbase = win_base(n, sj / P->nseg, hist);    /* candidates must lie in the segment's 64 KiB window */
         const uint32_t newfrom = win_from(sj / P->nseg, hist);     /* the window's positions before this are history */
         const uint32_t wj = sj % P->nseg;
-        /* eight segments are 16 17 17 17 15 16 15 15 groups of 512 long (later segments cost more per position: the kernel's
-         * workers finish together), any other count tiles the window evenly */
+        /* eleven segments (the kernel's workers since round 6) are 12 13 13 13 12 11 12 12 10 10 10 groups of 512 long, eight
+         * (rounds 2 - 5) 16 17 17 17 15 16 15 15 (later segments cost more per position: the kernel's workers finish together),
+         * any other count tiles the window evenly */
         static const uint32_t lo8[9] = {0, 16, 33, 50, 67, 82, 98, 113, 128};
-        uint32_t s0 = wbase + 512u * (P->nseg == 8 ? lo8[wj] : (128u * wj) / P->nseg);
-        uint32_t s1 = wbase + 512u * (P->nseg == 8 ? lo8[wj + 1] : (128u * (wj + 1)) / P->nseg);
+        static const uint32_t lo11[12] = {0, 12, 25, 38, 51, 63, 74, 86, 98, 108, 118, 128};
+        const uint32_t g_lo = P->nseg == 11 ? lo11[wj] : (P->nseg == 8 ? lo8[wj] : (128u * wj) / P->nseg);
+        const uint32_t g_hi = P->nseg == 11 ? lo11[wj + 1] : (P->nseg == 8 ? lo8[wj + 1] : (128u * (wj + 1)) / P->nseg);
+        uint32_t s0 = wbase + 512u * g_lo;
+        uint32_t s1 = wbase + 512u * g_hi;
         if (g_slide || g_subq) {
             /* with history (or sliding windows, or sub-windows) the segments share the PARSED part of the window in the same proportions (clipped, half of the
              * kernel's workers would idle); starts other than the first are multiples of 512 */

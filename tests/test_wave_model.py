@@ -88,11 +88,14 @@ def test_model_on_the_window_end_fixture():
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "golden", "fuzz_window_end_heads.zlib"), "rb") as f:
         d = zlib.decompress(f.read())
-    for slide, size in ((0, 41631), (1, 40898), (2, 41108)):      # windows that advance by 64 KiB (where the fuzzer found it) / by 32 KiB / by 48 KiB (the default for long blocks)
-        c = W.compress(d, slide=slide)
-        assert O.decompress(c, len(d)) == ("ok", d)
-        assert O.c_decompress(c, len(d)) == d
-        assert len(c) == size     # (41 666 before adjacent matches of one distance were merged, round 4)
+    # windows that advance by 64 KiB (where the fuzzer found it) / by 32 KiB / by 48 KiB (the default for long blocks); eleven segments
+    # per window (round 6) and the eight of rounds 2 - 5
+    for nseg, sizes in ((11, (41659, 40896, 41124)), (8, (41631, 40898, 41108))):
+        for slide, size in zip((0, 1, 2), sizes):
+            c = W.compress(d, slide=slide, nseg=nseg)
+            assert O.decompress(c, len(d)) == ("ok", d)
+            assert O.c_decompress(c, len(d)) == d
+            assert len(c) == size     # (41 666 before adjacent matches of one distance were merged, round 4)
 
 
 def test_history_in_front_of_a_block():

@@ -7,7 +7,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "sim", "wave_encoder_model.c")
 SO = os.path.join(ROOT, "tests", "sim", "libwave_encoder_model.so")
-NSEG, CAP, SKIPD = 8, 1024, 64    # the kernel's constants (lz4_compress_wave.hip: WORKERS, CAP, SKIPD)
+NSEG, CAP, SKIPD = 11, 1024, 64    # the kernel's constants (lz4_compress_wave.hip: WORKERS, CAP, SKIPD)
 
 
 class Params(C.Structure):

@@ -79,10 +79,16 @@ def main():
     ctx0 = C.c_void_p()
     assert base.lz4flex_ctx_create(C.byref(ctx0), 0) == 0
     inputs = [] if args.no_small else small_inputs()
-    models = [wave_model.compress(d) for d in inputs]
+    import re
+    models_by_nseg = {}
 
     for path in args.libs:
         lib = bind(path)
+        mw = re.search(r"_w(\d+)", os.path.basename(os.path.dirname(path)))      # a variant named ..._w10... was built with -DLZ4W_WORKERS=10: the model gets that segment count
+        nseg = int(mw.group(1)) if mw else wave_model.NSEG
+        if nseg not in models_by_nseg:
+            models_by_nseg[nseg] = [wave_model.compress(d, nseg=nseg) for d in inputs]
+        models = models_by_nseg[nseg]
         assert lib.lz4flex_set_tuning(None, b"compress_mode", 0) == 0      # this library's default context (the scalar calls)
         tag = "%s [%s]" % (os.path.basename(os.path.dirname(path)), lib.lz4flex_build_id().decode())
         # (1) small inputs through the scalar entry point

@@ -67,7 +67,7 @@ def main():
     comp_once(); dec_once(); torch.cuda.synchronize()
     if args.prof:
         lib.lz4flex_debug_wave_prof.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-        vals = (C.c_ulonglong * 16)()
+        vals = (C.c_ulonglong * 32)()
         assert lib.lz4flex_debug_wave_prof(ctx, 1, None) == 0
         comp_once(); torch.cuda.synchronize()
         assert lib.lz4flex_debug_wave_prof(ctx, 0, vals) == 0
@@ -76,7 +76,7 @@ def main():
         names = ["idx_busy", "idx_barrier", "match(sum 8 waves)", "wait_after_match", "place", "load_window", "wait_after_load"]
         print("per window cycles: " + ", ".join("%s=%.0f" % (nm, x / nw) for nm, x in zip(names, v)) + " windows=%d" % v[7], flush=True)
         if os.environ.get("LZ4W_PROF_WORKERS"):                  # -DLZ4W_PROF_WORKERS variant build
-            print("matching cycles per window by worker: " + ", ".join("w%d=%.0f" % (i, x / nw) for i, x in enumerate(v[8:16])), flush=True)
+            print("matching cycles per window by worker: " + ", ".join("w%d=%.0f" % (i, x / nw) for i, x in enumerate(v[16:32]) if x), flush=True)
         elif v[13]:
             sn = ["heads", "compact+lengths", "scan", "walk", "merge"]
             print("per superstep cycles (LZ4W_PROF_STEPS build): " + ", ".join("%s=%.0f" % (nm, x / v[13]) for nm, x in zip(sn, v[8:13])) +
