@@ -20,7 +20,7 @@
 //     length against the LDS window (16 B per iteration, all heads of the step at once); a DPP prefix maximum
 //     gives every position the match that reaches furthest; one-step lazy evaluation is a lane compare; the
 //     greedy walk over the step is scalar (ballot, s_ff1, v_readlane) and touches no memory; the selected
-//     sequences are encoded lane-parallel into an LDS staging buffer and flushed 16 B per lane;
+//     sequences are encoded lane-parallel straight into the segment's body (a prefix sum of their sizes places them);
 //   * segments are independent parses (a match never crosses a segment end) that may reference the whole window;
 //     after a barrier every worker places its segment's bytes: the literals left over at a segment's end are
 //     carried into the first sequence of the next segment (its token is written at that point).
@@ -99,18 +99,15 @@ constexpr uint32_t NEARP = 20u;           // ... and are followed within this ma
 constexpr uint32_t LONGN = 8u;            // ... when the superstep holds at least this many of them
 constexpr uint32_t HBITS = 12u;
 constexpr uint32_t THREADS = 64u * (WORKERS + 1u);
-#ifndef LZ4W_STG
-#define LZ4W_STG 360
-#endif
 #ifndef LZ4W_RING_SLOTS
 #define LZ4W_RING_SLOTS 1
 #endif
-constexpr uint32_t STG_BYTES = LZ4W_STG;  // per worker: encoded sequences waiting for a 16 B-per-lane flush
-constexpr uint32_t TMP_OFF = STG_BYTES - 256u;   // match_segment's second scratch array lies inside the staging buffer, above what encode_seqs leaves there
-constexpr uint32_t FLUSH_AT = TMP_OFF - 32u;     // a staging round adds at most STG_BYTES - FLUSH_AT = 288 bytes on the lane-parallel path
-constexpr uint32_t RING_SLOTS = LZ4W_RING_SLOTS; // chunk slots of the indexer (one wavefront, LDS operations in order: one would do)
-static_assert(STG_BYTES >= 272u + 16u && FLUSH_AT >= 32u && STG_BYTES - FLUSH_AT >= 18u, "emit_generic's 256-byte pieces and one ordinary sequence fit");
-constexpr uint32_t WORKER_LDS = STG_BYTES + 256u;   // + the compaction buffer of a superstep: 64 heads x 4 B
+constexpr uint32_t RING_SLOTS = LZ4W_RING_SLOTS; // chunk slots of the indexer (one wavefront, LDS operations in order: one is enough; rounds 2 - 5 had two)
+// per worker: two arrays of 64 words (a superstep's compaction buffers) behind 16 bytes whose last word is entry 0 of the 129-entry
+// array a superstep of more than 64 heads gathers from
+constexpr uint32_t TMP_OFF = 16u;
+constexpr uint32_t CMP_OFF = TMP_OFF + 256u;
+constexpr uint32_t WORKER_LDS = CMP_OFF + 256u;
 constexpr uint32_t CHUNK = 1024u;         // the indexer streams the next window in 1 KiB chunks (16 steps)
 constexpr uint32_t CHUNK_SLOT = CHUNK + 16u;      // + the first bytes of the next chunk (positions 1021..1023 hash across the end)
 constexpr uint32_t IDX_DEPTH = 4u;        // chunks in flight (registers) ahead of the one being indexed
@@ -352,110 +349,81 @@ __device__ __attribute__((noinline)) void index_window(const uint8_t* __restrict
 }
 
 // ---- worker ---------------------------------------------------------------------------------------------------
-struct Worker {
-    lds_u8* win;
-    lds_u8* stg;
-    g_u8* body;
-    uint32_t lane;
-    uint32_t fill, body_len;
-    uint32_t has, first_lit, first_ml;
+// Encoded sequences go straight to the segment's body in the workspace (global memory, L2): every sequence of a call knows its
+// place from a prefix sum of the sizes, so all of them are written at once with exact-size stores (any alignment: the address
+// mode of HSA queues is "unaligned").  Rounds 2 - 6 staged them in LDS first -- as many sequences per round as the buffer took,
+// a 16 B-per-lane flush behind every round: ~500 instructions per call of encode_seqs where this takes ~80.
+__device__ __forceinline__ void st_u8(g_u8* base, uint32_t o, uint32_t v) { base[o] = (uint8_t)v; }
+__device__ __forceinline__ void st_u16(g_u8* base, uint32_t o, uint32_t v) { const uint16_t t = (uint16_t)v; __builtin_memcpy((void*)(base + o), &t, 2); }
+__device__ __forceinline__ void st_u32(g_u8* base, uint32_t o, uint32_t v) { __builtin_memcpy((void*)(base + o), &v, 4); }
+__device__ __forceinline__ void st_u64(g_u8* base, uint32_t o, uint64_t v) { __builtin_memcpy((void*)(base + o), &v, 8); }
 
-    __device__ __forceinline__ void flush(bool all) {
-        const uint32_t n16 = fill & ~15u;
-        for (uint32_t i = 16u * lane; i < n16; i += 1024u) {
-            const u32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(stg + i);
-#ifndef LZ4W_EXP_NOSTORE     // timing experiment only (tools): how much do the flush stores cost the cand[] wait?
-            *reinterpret_cast<g_u32x4*>(body + body_len + i) = v;
-#else
-            asm volatile("" :: "v"(v));
-#endif
-        }
-        const uint32_t rem = fill - n16;
-        if (all) {
-            if (lane < rem) body[body_len + n16 + lane] = stg[n16 + lane];
-            body_len += fill;
-            fill = 0u;
-        } else {
-            uint8_t t = 0;
-            if (lane < rem) t = stg[n16 + lane];
-            if (n16 != 0u && lane < rem) stg[lane] = t;     // n16 >= 16 > rem: source and destination do not overlap
-            body_len += n16;
-            fill = rem;
-        }
-    }
-    __device__ __forceinline__ void room(uint32_t n) {       // n <= 256
-        if (fill + n > STG_BYTES) flush(false);
-    }
-    // one sequence through the generic path: any literal count, any match length
-    __device__ void emit_generic(uint32_t lit_src, uint32_t lit, uint32_t off, uint32_t ml) {
-        const uint32_t mlc = ml - 4u;
-        if (!has) {
-            has = 1u; first_lit = lit; first_ml = ml;
-        } else {
-            // token + literal length bytes
-            const uint32_t ne = len_ext_bytes(lit);
-            const uint32_t hdr = 1u + ne;
-            for (uint32_t c0 = 0; c0 < hdr; c0 += 256u) {
-                const uint32_t cn = hdr - c0 < 256u ? hdr - c0 : 256u;
-                room(cn);
-                for (uint32_t i = lane; i < cn; i += 64u) {
-                    const uint32_t j = c0 + i;
-                    uint32_t byte;
-                    if (j == 0u) byte = ((lit < 15u ? lit : 15u) << 4) | (mlc < 15u ? mlc : 15u);
-                    else byte = (j < ne) ? 255u : (lit - 15u) % 255u;
-                    stg[fill + i] = (uint8_t)byte;
-                }
-                fill += cn;
-            }
-            for (uint32_t c0 = 0; c0 < lit; c0 += 256u) {
-                const uint32_t cn = lit - c0 < 256u ? lit - c0 : 256u;
-                room(cn);
-                for (uint32_t i = lane; i < cn; i += 64u) stg[fill + i] = win[lit_src + c0 + i];
-                fill += cn;
-            }
-        }
-        const uint32_t me = len_ext_bytes(mlc);
-        room(2u + me);                                      // CAP 1024: me <= 4
-        if (lane < 2u + me) {
-            uint32_t byte;
-            if (lane == 0u) byte = off & 255u;
-            else if (lane == 1u) byte = off >> 8;
-            else byte = (lane - 2u + 1u < me) ? 255u : (mlc - 15u) % 255u;
-            stg[fill + lane] = (uint8_t)byte;
-        }
-        fill += 2u + me;
-    }
-};
-
-// n < 16 literal bytes, exactly: ONE 16-byte read (over-reading source bytes is harmless), then 8/4/2/1-byte writes
-__device__ __forceinline__ void copy_lit_small(lds_u8* dst, const lds_u8* src, uint32_t n) {
+// n < 16 literal bytes, exactly: ONE 16-byte read (over-reading source bytes is harmless), then 8/4/2/1-byte stores
+__device__ __forceinline__ void copy_lit_small(g_u8* base, uint32_t o, const lds_u8* src, uint32_t n) {
     u32x4 v;
     __builtin_memcpy(&v, (const void*)src, 16);
     const bool n8 = (n & 8u) != 0u, n4 = (n & 4u) != 0u, n2 = (n & 2u) != 0u;
     const uint32_t w4 = n8 ? v.z : v.x;                               // the dword at byte offset (n & 8)
     const uint32_t wq = n8 ? (n4 ? v.w : v.z) : (n4 ? v.y : v.x);     // the dword at byte offset (n & 12)
-    if (n8) { const uint64_t t = (uint64_t)v.x | ((uint64_t)v.y << 32); __builtin_memcpy((void*)dst, &t, 8); }
-    if (n4) __builtin_memcpy((void*)(dst + (n & 8u)), &w4, 4);
-    if (n2) { const uint16_t t = (uint16_t)wq; __builtin_memcpy((void*)(dst + (n & 12u)), &t, 2); }
-    if (n & 1u) dst[n & 14u] = (uint8_t)(wq >> (n2 ? 16 : 0));
+    if (n8) st_u64(base, o, (uint64_t)v.x | ((uint64_t)v.y << 32));
+    if (n4) st_u32(base, o + (n & 8u), w4);
+    if (n2) st_u16(base, o + (n & 12u), wq);
+    if (n & 1u) st_u8(base, o + (n & 14u), wq >> (n2 ? 16 : 0));
+}
+
+// One sequence of any shape by the whole wavefront (uniform arguments): [token, literal length bytes, literals] unless it is the
+// segment's first sequence (whose token is written when the segments are placed), then offset and match length bytes, at body + o.
+__device__ __attribute__((noinline)) void emit_generic(uint8_t* body_, uint32_t o_, uint32_t lit_src_, uint32_t lit_, uint32_t off_, uint32_t ml_, uint32_t first_, uint32_t lane) {
+    g_u8* const body = uni_gptr<g_u8>(body_);
+    uint32_t o = uni(o_);
+    const uint32_t lit_src = uni(lit_src_), lit = uni(lit_), off = uni(off_), mlc = uni(ml_) - 4u, first = uni(first_);
+    const lds_u8* const win = reinterpret_cast<const lds_u8*>((uintptr_t)0) + L_WIN;
+    if (!first) {
+        const uint32_t ne = len_ext_bytes(lit), hdr = 1u + ne;
+        for (uint32_t i0 = 0u; i0 < hdr; i0 += 64u) {                  // (uniform trip counts, the lane's share inside)
+            const uint32_t j = i0 + lane;
+            uint32_t byte;
+            if (j == 0u) byte = ((lit < 15u ? lit : 15u) << 4) | (mlc < 15u ? mlc : 15u);
+            else byte = (j < ne) ? 255u : (lit - 15u) % 255u;
+            if (j < hdr) st_u8(body, o + j, byte);
+        }
+        o += hdr;
+        const uint32_t n16 = lit & ~15u;
+        for (uint32_t i0 = 0u; i0 < n16; i0 += 1024u) {
+            const uint32_t i = i0 + 16u * lane;
+            if (i < n16) {
+                u32x4 v;
+                __builtin_memcpy(&v, (const void*)(win + lit_src + i), 16);
+                __builtin_memcpy((void*)(body + o + i), &v, 16);
+            }
+        }
+        if (lane < lit - n16) st_u8(body, o + n16 + lane, win[lit_src + n16 + lane]);
+        o += lit;
+    }
+    const uint32_t me = len_ext_bytes(mlc), tail = 2u + me;
+    for (uint32_t i0 = 0u; i0 < tail; i0 += 64u) {
+        const uint32_t j = i0 + lane;
+        uint32_t byte;
+        if (j == 0u) byte = off & 255u;
+        else if (j == 1u) byte = off >> 8;
+        else byte = (j - 1u < me) ? 255u : (mlc - 15u) % 255u;
+        if (j < tail) st_u8(body, o + j, byte);
+    }
 }
 
 // What a segment's encoder carries from one call to the next (all uniform).
 struct EncState {
-    uint32_t fill, body_len;          // bytes in the staging buffer / already flushed to the body
+    uint32_t body_len;                // bytes written to the body
     uint32_t has, first_lit, first_ml;   // the segment's first sequence (its token is written when the segments are placed)
     uint32_t last_end;                // end of the last encoded match: the next sequence's literals start here
 };
 
 // Lane-parallel encoding of the chosen sequences (lane k < npend: psq = match end << 16 | distance, psp = match start; the
-// literals of sequence 0 start at st.last_end) into the staging buffer.  A sequence with >= 15 literals or a match of
-// >= 274 bytes needs length bytes beyond the lane-parallel path: such "hard" sequences are written one at a time, the runs of
-// ordinary ones between them as many at a time as the staging buffer takes (STG_BYTES - FLUSH_AT bytes).  Not inlined: it
-// runs once per ~4 supersteps and has four call sites.
-__device__ __attribute__((noinline)) EncState encode_seqs(uint32_t psq, uint32_t psp, uint32_t npend_, uint32_t w_, uint8_t* body_, uint32_t lane,
-                                                          uint32_t final_, EncState st_) {
+// literals of sequence 0 start at st.last_end) into the segment's body.  A sequence with >= 15 literals or a match of
+// >= 274 bytes needs length bytes beyond the lane-parallel form: such "hard" sequences are written one at a time by the whole
+// wavefront, each at the place the prefix sum gave it.  Not inlined: it runs once per ~4 supersteps and has four call sites.
+__device__ __attribute__((noinline)) EncState encode_seqs(uint32_t psq, uint32_t psp, uint32_t npend_, uint8_t* body_, uint32_t lane, EncState st_) {
     uint32_t npend = uni(npend_);
-    const uint32_t w = uni(w_), final = uni(final_);
     lds_u8* const lds = reinterpret_cast<lds_u8*>((uintptr_t)0);
     {
         // A sequence without literals whose match has its predecessor's distance CONTINUES that match (matches end at CAP bytes, at
@@ -480,12 +448,8 @@ __device__ __attribute__((noinline)) EncState encode_seqs(uint32_t psq, uint32_t
             npend = nheads;
         }
     }
-    Worker W;
-    W.win = lds + L_WIN;
-    W.stg = lds + L_STG + w * WORKER_LDS;
-    W.body = uni_gptr<g_u8>(body_);
-    W.lane = lane;
-    W.fill = uni(st_.fill); W.body_len = uni(st_.body_len); W.has = uni(st_.has); W.first_lit = uni(st_.first_lit); W.first_ml = uni(st_.first_ml);
+    g_u8* const body = uni_gptr<g_u8>(body_);
+    uint32_t body_len = uni(st_.body_len), has = uni(st_.has), first_lit = uni(st_.first_lit), first_ml = uni(st_.first_ml);
     uint32_t last_end = uni(st_.last_end);
     if (npend != 0u) {
         const bool issel = lane < npend;
@@ -493,48 +457,37 @@ __device__ __attribute__((noinline)) EncState encode_seqs(uint32_t psq, uint32_t
         const uint32_t pe = dpp_wave_shr1(se, last_end);
         const uint32_t lit = sp - pe, len = se - sp, mlc = len - 4u;
         const uint64_t hardm = __builtin_amdgcn_ballot_w64(issel & ((lit >= 15u) | (mlc >= 270u)));
-        const bool hardl = __builtin_amdgcn_inverse_ballot_w64(hardm);
-        const bool first = (W.has == 0u) & (lane == 0u) & !hardl;       // the segment's first sequence: its token comes later
+        const bool first = (has == 0u) & (lane == 0u);                  // the segment's first sequence: its token comes later
         const uint32_t ext = mlc >= 15u ? 1u : 0u;
-        const uint32_t size = (issel & !hardl) ? ((first ? 2u : 3u + lit) + ext) : 0u;
-        const uint32_t incl = wave_incl_add(size);
-        if (W.has == 0u && (hardm & 1ull) == 0ull) { W.has = 1u; W.first_lit = rdlane(lit, 0u); W.first_ml = rdlane(len, 0u); }
-        for (uint32_t cur = 0u; cur < npend;) {
-            const uint64_t hm = hardm & (~0ull << cur);
-            const uint32_t hq = hm != 0ull ? ctz64(hm) : npend;         // the next hard sequence
-            while (cur < hq) {
-                const uint32_t basec = cur != 0u ? rdlane(incl, cur - 1u) : 0u;
-                const uint32_t rel = incl - basec;                       // bytes of sequences cur .. lane
-                // the sequences of this round: cur <= lane < hq and everything up to the lane fits (rel is monotonous)
-                const uint64_t fits = __builtin_amdgcn_ballot_w64((lane >= cur) & (lane < hq) & (rel <= STG_BYTES - FLUSH_AT));
-                const uint32_t end = cur + (uint32_t)__builtin_popcountll(fits);   // > cur: one ordinary sequence is <= 18 bytes
-                const uint32_t endc = rdlane(incl, end - 1u);
-                if (__builtin_amdgcn_inverse_ballot_w64(fits)) {
-                    lds_u8* o = W.stg + W.fill + (rel - size);
-                    if (!first) {
-                        o[0] = (uint8_t)((lit << 4) | (mlc < 15u ? mlc : 15u));
-                        copy_lit_small(o + 1, W.win + pe, lit);
-                        o += 1u + lit;
-                    }
-                    const uint16_t o16 = (uint16_t)off;
-                    __builtin_memcpy((void*)o, &o16, 2);
-                    if (ext) o[2] = (uint8_t)(mlc - 15u);
-                }
-                W.fill += endc - basec;
-                if (W.fill >= FLUSH_AT) W.flush(false);
-                cur = end;
-            }
-            if (hq < npend) {
-                W.emit_generic(rdlane(pe, hq), rdlane(lit, hq), rdlane(off, hq), rdlane(len, hq));
-                if (W.fill >= FLUSH_AT) W.flush(false);
-                cur = hq + 1u;
-            }
+        uint32_t size = issel ? ((first ? 2u : 3u + lit) + ext) : 0u;
+        if (hardm != 0ull) {                                            // the length bytes of the hard ones
+            const uint32_t more = (first ? 0u : len_ext_bytes(lit)) + len_ext_bytes(mlc) - ext;
+            size += __builtin_amdgcn_inverse_ballot_w64(hardm) ? more : 0u;
         }
+        const uint32_t incl = wave_incl_add(size);
+        const uint32_t o0 = body_len + (incl - size);
+        const uint32_t was_first = has == 0u ? 1u : 0u;
+        if (has == 0u) { has = 1u; first_lit = rdlane(lit, 0u); first_ml = rdlane(len, 0u); }
+        const uint64_t ordm = (npend >= 64u ? ~0ull : (1ull << npend) - 1ull) & ~hardm;
+        if (__builtin_amdgcn_inverse_ballot_w64(ordm)) {
+            uint32_t o = o0;
+            if (!first) {
+                st_u8(body, o, (lit << 4) | (mlc < 15u ? mlc : 15u));
+                copy_lit_small(body, o + 1u, lds + L_WIN + pe, lit);
+                o += 1u + lit;
+            }
+            st_u16(body, o, off);
+            if (ext) st_u8(body, o + 2u, mlc - 15u);
+        }
+        for (uint64_t hm = hardm; hm != 0ull; hm &= hm - 1ull) {
+            const uint32_t q = ctz64(hm);
+            emit_generic(body_, rdlane(o0, q), rdlane(pe, q), rdlane(lit, q), rdlane(off, q), rdlane(len, q), q == 0u ? was_first : 0u, lane);
+        }
+        body_len += rdlane(incl, 63u);
         last_end = rdlane(se, npend - 1u);
     }
-    if (final) W.flush(true);
     EncState r;
-    r.fill = W.fill; r.body_len = W.body_len; r.has = W.has; r.first_lit = W.first_lit; r.first_ml = W.first_ml; r.last_end = last_end;
+    r.body_len = body_len; r.has = has; r.first_lit = first_lit; r.first_ml = first_ml; r.last_end = last_end;
     return r;
 }
 
@@ -563,11 +516,11 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
     lds_u8* const lds = reinterpret_cast<lds_u8*>((uintptr_t)0);
     lds_u8* const win = lds + L_WIN;
     lds_u8* const stg = lds + L_STG + w * WORKER_LDS;
-    lds_u32* const cmp = (lds_u32*)(stg + STG_BYTES);             // compaction buffer: 64 x 4 B
-    lds_u32* const tmp = (lds_u32*)(stg + TMP_OFF);                 // second one: the staging buffer holds < FLUSH_AT bytes between calls of encode_seqs
-    static_assert(FLUSH_AT <= TMP_OFF && TMP_OFF + 256u <= STG_BYTES && (RING_SLOTS == 1u || RING_SLOTS == 2u), "scratch inside the staging buffer");
+    lds_u32* const cmp = (lds_u32*)(stg + CMP_OFF);               // compaction buffer: 64 x 4 B
+    lds_u32* const tmp = (lds_u32*)(stg + TMP_OFF);               // second one
+    static_assert(RING_SLOTS == 1u || RING_SLOTS == 2u, "ring slots");
     EncState st;
-    st.fill = 0u; st.body_len = 0u; st.has = 0u; st.first_lit = 0u; st.first_ml = 0u; st.last_end = s0;
+    st.body_len = 0u; st.has = 0u; st.first_lit = 0u; st.first_ml = 0u; st.last_end = s0;
     uint32_t cursor = s0, carry = 0u, dlast = 0u;
     // sequences chosen but not encoded yet: lane k < npend holds the k-th
     uint32_t psq = 0u, psp = 0u, npend = 0u;
@@ -792,7 +745,7 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
             // rank r -- which starts one word below tmp | cmp (contiguous; LDS operations of a wavefront execute in order: a
             // chunk's heads are read before its results overwrite them); the positions gather from it
             lds_u32* const best = tmp - 1;
-            static_assert(TMP_OFF + 256u == STG_BYTES && FLUSH_AT + 4u <= TMP_OFF, "tmp and cmp are contiguous, the word below them is free");
+            static_assert(TMP_OFF + 256u == CMP_OFF && TMP_OFF >= 4u, "tmp and cmp are contiguous, the word below them is free");
             best[0] = carry;
             if (hh0 && r0 < 64u) cmp[r0] = (p0 << 16) | t0;
             if (hh1 && r1 < 64u) cmp[r1] = (p1 << 16) | t1;
@@ -911,13 +864,13 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
             }
         };
         if (npend + nsel > 64u) {
-            // no room: the new sequences go to registers first (the staging buffer is about to be used), the pending ones are
+            // no room: the new sequences go to registers first, the pending ones are
             // encoded, the new ones become the pending ones.  Only two values live across the call.
             scatter(0u);
             uint32_t nq = 0u, np = 0u;
             if (lane < nsel) { nq = cmp[lane]; np = tmp[lane]; }
             LZ4W_TICK(4)
-            st = encode_seqs(psq, psp, npend, w, body_, lane, 0u, st);
+            st = encode_seqs(psq, psp, npend, body_, lane, st);
             psq = nq; psp = np; npend = nsel;
 #ifdef LZ4W_PROF_STEPS
             LZ4W_TICK(6)
@@ -948,7 +901,7 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
             superstep(UConst<2u>{}, bh, ta, tb, 0u, 0u);          // (128 positions: never more than 128 heads)
         }
     }
-    st = encode_seqs(psq, psp, npend, w, body_, lane, 1u, st);
+    st = encode_seqs(psq, psp, npend, body_, lane, st);
 #ifdef LZ4W_PROF_STEPS
     if (prof_ && lane == 0u) {
         for (int i = 0; i < 5; ++i) atomicAdd(prof_ + 8 + i, (unsigned long long)pt[i]);
