@@ -117,7 +117,9 @@ constexpr uint32_t L_TAB = WINDOW + 64u;                    // the indexer's tab
 constexpr uint32_t L_STG = L_TAB + (2u << HBITS);
 constexpr uint32_t L_RING = L_STG + WORKERS * WORKER_LDS;   // two chunk slots of the indexer
 constexpr uint32_t L_META = L_RING + RING_SLOTS * CHUNK_SLOT;
-constexpr uint32_t LDS_BYTES = L_META + 256u;
+// L_META, words: 5 per worker (SegMeta), BlkCarry[2] (4), the drawn items (giq, 4), place_segment's mailbox (3), run_flag[2] (see index_window)
+constexpr uint32_t META_WORDS = 5u * WORKERS + 4u + 4u + 3u + 2u;
+constexpr uint32_t LDS_BYTES = L_META + ((META_WORDS * 4u + 63u) & ~63u);
 static_assert(LDS_BYTES <= 81920u, "two workgroups per CU");
 static_assert(WORKERS >= 1u && WORKERS <= 15u && seg_lo(WORKERS) == WINDOW, "segments tile the window");
 // workspace per workgroup
@@ -421,8 +423,13 @@ struct EncState {
 // Lane-parallel encoding of the chosen sequences (lane k < npend: psq = match end << 16 | distance, psp = match start; the
 // literals of sequence 0 start at st.last_end) into the segment's body.  A sequence with >= 15 literals or a match of
 // >= 274 bytes needs length bytes beyond the lane-parallel form: such "hard" sequences are written one at a time by the whole
-// wavefront, each at the place the prefix sum gave it.  Not inlined: it runs once per ~4 supersteps and has four call sites.
-__device__ __attribute__((noinline)) EncState encode_seqs(uint32_t psq, uint32_t psp, uint32_t npend_, uint8_t* body_, uint32_t lane, EncState st_) {
+// wavefront, each at the place the prefix sum gave it.  Runs once per ~4 supersteps, two call sites.
+#ifndef LZ4W_EXP_CALL_ENC       // inlined (round 6): JSON 3.44 -> 3.37 ms, text 4.67 -> 4.49 -- a call cost 16 scratch operations for callee-saved registers and six readfirstlanes
+__device__ __forceinline__
+#else
+__device__ __attribute__((noinline))
+#endif
+EncState encode_seqs(uint32_t psq, uint32_t psp, uint32_t npend_, uint8_t* body_, uint32_t lane, EncState st_) {
     uint32_t npend = uni(npend_);
     lds_u8* const lds = reinterpret_cast<lds_u8*>((uintptr_t)0);
     {
