@@ -269,11 +269,42 @@ __device__ __forceinline__ void index_chunk(const lds_u8* lp, lds_u16* tab, g_u8
     }
 }
 
-__device__ __attribute__((noinline)) void index_window(const uint8_t* __restrict__ gwin_, uint32_t wl_, uint32_t act_n_, uint32_t rd_n_,
-                             uint8_t* __restrict__ slot_t_, lds_u8* lds, uint32_t lane) {
+// RUN WINDOWS (round 6).  A window of at least RUN_MIN bytes whose bytes are all equal (zero pages, padding) is not indexed and not
+// matched: it becomes ONE sequence -- [offset 1, everything from the window's first parsed position (its second byte when nothing
+// precedes that in the window) to its last match end] -- the reference's encoding of a run (src/block/compress.rs:156-216:
+// count_same_bytes is unbounded; 30 000 zeros are one match) one window at a time: 4 MiB of zeros are 64 sequences, 0.40 % (rounds
+// 4 - 5: ~16 sequences per window, 0.64 %), and a decoder sees one long periodic copy per 64 KiB instead of a chain of KiB-long ones.
+// The indexer decides: the first KiB comes for free (its registers are on their way anyway), the rest of the window is only read
+// when that is one byte repeated.  The scalar model has the same rule (tests/sim/wave_encoder_model.c, run_window).
+constexpr uint32_t RUN_MIN = 8192u;
+// are bytes [from, wl) of the window all equal to the bytes of `splat` (one byte, four times)?  plain loads, whole wavefront
+__device__ __attribute__((noinline)) uint32_t run_scan(const uint8_t* __restrict__ gwin_, uint32_t from_, uint32_t wl_, uint32_t splat_, uint32_t lane) {
+    const g_u8* __restrict__ gwin = uni_gptr<const g_u8>(gwin_);
+    const uint32_t from = uni(from_), wl = uni(wl_), splat = uni(splat_);
+    uint32_t acc = 0u;
+    const uint32_t n16 = from + ((wl - from) & ~15u);
+    for (uint32_t i0 = from; i0 < n16; i0 += 4096u) {                  // (uniform trip count, the lane's share inside)
+        u32x4 v[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t o = i0 + 1024u * j + 16u * lane;
+            v[j] = u32x4{splat, splat, splat, splat};
+            if (o < n16) v[j] = *reinterpret_cast<const g_u32x4*>(gwin + o);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) acc |= (v[j].x ^ splat) | (v[j].y ^ splat) | (v[j].z ^ splat) | (v[j].w ^ splat);
+        if (__builtin_amdgcn_ballot_w64(acc != 0u) != 0ull) return 0u;
+    }
+    if (lane < wl - n16) acc |= (uint32_t)gwin[n16 + lane] ^ (splat & 255u);
+    return __builtin_amdgcn_ballot_w64(acc != 0u) == 0ull ? 1u : 0u;
+}
+
+// returns 1 when the window is a run window (see above; only asked when run_ok_: the caller has checked the lengths), else 0
+__device__ __attribute__((noinline)) uint32_t index_window(const uint8_t* __restrict__ gwin_, uint32_t wl_, uint32_t act_n_, uint32_t rd_n_,
+                             uint8_t* __restrict__ slot_t_, lds_u8* lds, uint32_t lane, uint32_t run_ok_) {
     const g_u8* __restrict__ gwin = uni_gptr<const g_u8>(gwin_);
     g_u8* __restrict__ slot_t = uni_gptr<g_u8>(slot_t_);
-    const uint32_t wl = uni(wl_), act_n = uni(act_n_), rd_n = uni(rd_n_);
+    const uint32_t wl = uni(wl_), act_n = uni(act_n_), rd_n = uni(rd_n_), run_ok = uni(run_ok_);
     lds_u16* tab = (lds_u16*)(lds + L_TAB);
     {
         lds_u32* t4 = (lds_u32*)(lds + L_TAB);
@@ -292,6 +323,19 @@ __device__ __attribute__((noinline)) void index_window(const uint8_t* __restrict
         ChunkRegs q[IDX_DEPTH];
 #pragma unroll
         for (uint32_t j = 0; j < IDX_DEPTH; ++j) chunk_issue(q[j], gwin, j < last ? j : last, lane);   // past the end: the last chunk again
+#ifndef LZ4W_NO_RUN_WINDOWS
+        if (run_ok) {
+            // the first KiB (six younger loads: q[0] has landed): one byte repeated?  Then -- rare -- everything that is in flight
+            // lands before the compiler may touch it, and the rest of the window is looked at
+            chunk_wait<6>(q[0]);
+            const uint32_t x0 = q[0].main.x, splat = (x0 & 255u) * 0x01010101u;
+            const uint32_t dif = (q[0].main.x ^ splat) | (q[0].main.y ^ splat) | (q[0].main.z ^ splat) | (q[0].main.w ^ splat);
+            if (__builtin_amdgcn_ballot_w64((dif != 0u) | (splat != uni(splat))) == 0ull) {
+                chunk_wait<0>(q[0]); chunk_wait<0>(q[1]); chunk_wait<0>(q[2]); chunk_wait<0>(q[3]);
+                if (run_scan(gwin_, CHUNK, wl, uni(splat), lane)) return 1u;
+            }
+        }
+#endif
         // one chunk: wait for its two loads (N = vector memory operations issued after them), LDS slot, refill the
         // registers, 16 steps.  Issue order per chunk: [wait], 2 loads, 4 cand[] stores.
 #define LZ4W_ONE_CHUNK(N, CC, J)                                                                    \
@@ -348,6 +392,7 @@ __device__ __attribute__((noinline)) void index_window(const uint8_t* __restrict
         }
         index_chunk<false>(sl + lane4, tab, cand_lane, c, act_n, lane);
     }
+    return 0u;
 }
 
 // ---- worker ---------------------------------------------------------------------------------------------------
@@ -966,8 +1011,9 @@ __device__ __forceinline__ void put_len_header(g_u8* dst, uint32_t lit, uint32_t
 // Place segment w of the current window (after the barrier: every worker's SegMeta is final).
 __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8_t* __restrict__ gin_, uint32_t blk_len_, uint32_t win_idx_, bool last_win_,
                               uint32_t wl_, uint32_t wbase_, uint32_t wskip_, uint32_t send_, const uint8_t* body_, uint8_t* gout_, uint32_t carry_slot_, uint32_t w_, uint32_t lane,
-                              uint32_t* out_len_, int32_t* status_, uint32_t* gcarry_, uint32_t iter_, uint32_t spins_max_) {
+                              uint32_t* out_len_, int32_t* status_, uint32_t* gcarry_, uint32_t iter_, uint32_t spins_max_, uint32_t runwin_) {
     const g_u8* __restrict__ gin = uni_gptr<const g_u8>(gin_);
+    const uint32_t runwin = uni(runwin_);                          // a run window (index_window): segment 0 is the whole parsed part, the others are empty
     const g_u8* body = uni_gptr<const g_u8>(body_);
     g_u8* gout = uni_gptr<g_u8>(gout_);
     g_u32* out_len = uni_gptr<g_u32>(out_len_);
@@ -1019,7 +1065,7 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
         }
     }
     auto seg_at = [&](uint32_t j) -> uint32_t {                     // start of segment j, clipped to the parsed part of the window
-        const uint32_t v = seg_start(j, wskip, send);
+        const uint32_t v = runwin ? (j == 0u ? wskip : wl) : seg_start(j, wskip, send);
         return v < wl ? v : wl;
     };
     auto seg_len = [&](uint32_t j) -> uint32_t { return seg_at(j + 1u) - seg_at(j); };
@@ -1213,6 +1259,25 @@ __device__ __forceinline__ void item_draw(const CompressArgs& a, uint32_t* wctr,
     ob = n; ow = 0u;
 }
 
+// A run window's one match, window-relative: [ms, me), asked for (ok) only when the window is long enough and the block format allows
+// that match (it starts <= len - 12 and ends <= len - 5, src/block/mod.rs:37-61; ends are 16-bit numbers here as everywhere)
+struct RunGeom { uint32_t ok, ms, me; };
+__device__ __forceinline__ RunGeom run_geom(const Item& t) {
+    RunGeom g;
+    const uint32_t base = win_base(t), wl = win_len(t), skip = win_skip(t);
+    g.ms = skip > 1u ? skip : 1u;
+    uint32_t me = t.len >= 5u + base ? t.len - 5u - base : 0u;
+    me = me < wl ? me : wl;
+    g.me = me < 65535u ? me : 65535u;
+    const uint32_t act_abs = t.len >= 12u ? t.len - 11u : 0u;         // positions p < act_abs may start a match
+#ifdef LZ4W_NO_RUN_WINDOWS
+    g.ok = 0u;
+#else
+    g.ok = (wl >= RUN_MIN && !t.skip && base + g.ms < act_abs && g.me >= g.ms + 4u) ? 1u : 0u;
+#endif
+    return g;
+}
+
 // prof (nullable, tools only): cycle sums per role, [0] indexer busy, [1] indexer at barriers, [2] workers matching,
 // [3] workers at the barrier behind matching, [4] placing, [5] loading the next window, [6] at the barrier behind loading,
 // [7] windows
@@ -1258,12 +1323,17 @@ __device__ __forceinline__ void wave_body(const CompressArgs& a, uint8_t* __rest
     if (it.blk >= a.n) return;
     uint32_t k = 0u;
 
+    lds_u32* run_flag = (lds_u32*)(lds + L_META) + 5u * WORKERS + 11u;   // [slot]: the window whose cand[] slot this would be is a run window
     auto do_index = [&](const Item& t, uint32_t slot) {
-        if (t.skip) return;
+        if (t.skip) { if (lane == 0u) run_flag[slot] = 0u; return; }
         const uint32_t base = win_base(t), wl = win_len(t);
         const uint32_t act_abs = t.len >= 12u ? t.len - 11u : 0u;            // positions p < act_abs start 4 readable bytes and may match
         const uint32_t act_n = act_abs > base ? (act_abs - base < wl ? act_abs - base : wl) : 0u;
-        index_window(a.in_base + t.in_off + base, wl, act_n, t.len - base, slots + (size_t)slot * SLOT_BYTES, lds, lane);
+        // a run window's one match (see index_window): from the first parsed position that has a byte in front of it in the window to
+        // the window's last match end; asked for only where that is a match the block format allows
+        const RunGeom rg = run_geom(t);
+        const uint32_t run = index_window(a.in_base + t.in_off + base, wl, act_n, t.len - base, slots + (size_t)slot * SLOT_BYTES, lds, lane, rg.ok);
+        if (lane == 0u) run_flag[slot] = run;
     };
     auto do_load = [&](const Item& t) {
         if (t.skip) return;
@@ -1318,7 +1388,18 @@ __device__ __forceinline__ void wave_body(const CompressArgs& a, uint8_t* __rest
             mend = mend > base ? mend - base : 0u;
             mend = mend < s1 ? mend : s1;
             mend = mend < 65535u ? mend : 65535u;
-            if (s0 < s1) {
+            if (run_flag[k & 1u] != 0u) {
+                // a run window: worker 0 writes its one sequence (the first of its "segment": offset and length bytes go to the body,
+                // the token is written when it is placed), the others have nothing
+                const RunGeom rg = run_geom(it);
+                lds_u32* mp = (lds_u32*)(lds + L_META) + 5u * w;
+                if (w == 0u) {
+                    emit_generic(bodies, 0u, 0u, 0u, 1u, rg.me - rg.ms, 1u, lane);
+                    if (lane == 0u) { mp[0] = 1u; mp[1] = rg.ms - skip; mp[2] = rg.me - rg.ms; mp[3] = wl - rg.me; mp[4] = 2u + len_ext_bytes(rg.me - rg.ms - 4u); }
+                } else if (lane == 0u) {
+                    mp[0] = 0u; mp[1] = 0u; mp[2] = 0u; mp[3] = 0u; mp[4] = 0u;
+                }
+            } else if (s0 < s1) {
                 match_segment(slots + (size_t)(k & 1u) * SLOT_BYTES, bodies + (size_t)w * BODY_STRIDE, w, lane, s0, s1, mfl_end, mend, prof);
             } else if (lane == 0u) {                              // an empty segment (history only, or behind the block's end)
                 lds_u32* mp = (lds_u32*)(lds + L_META) + 5u * w;
@@ -1339,7 +1420,7 @@ __device__ __forceinline__ void wave_body(const CompressArgs& a, uint8_t* __rest
             } else {
                 place_segment(lds, a.in_base + it.in_off, it.len, it.win, last_win, wl, win_base(it), win_skip(it), win_send(it), bodies + (size_t)w * BODY_STRIDE,
                               a.out_base + a.out_off[it.blk], k & 1u, w, lane, a.out_len + it.blk, a.status + it.blk,
-                              wmode ? carry + CARRY_DWORDS * (size_t)it.blk : nullptr, k + 1u, carry_spins);
+                              wmode ? carry + CARRY_DWORDS * (size_t)it.blk : nullptr, k + 1u, carry_spins, run_flag[k & 1u]);
             }
         }
         tick(w == WORKERS ? 1u : 4u);

@@ -33,6 +33,9 @@
 #define NEARP 20u
 #define LONGN 8u
 #define MAXHEADS 128u   /* heads per superstep: the kernel counts them in chunks of 64 (one wavefront) */
+#define RUN_MIN 8192u   /* run windows: see lz4w_parse */
+static int g_no_runs;   /* (tools: lz4w_set_no_runs(1) = the parse of rounds 2 - 5, without run windows) */
+void lz4w_set_no_runs(int v) { g_no_runs = v; }
 
 typedef struct {
     uint32_t nseg;   /* segments per 64 KiB window (the kernel's worker wavefronts); boundaries are multiples of 512 */
@@ -146,6 +149,27 @@ size_t lz4w_parse(const uint8_t *in, uint32_t n, const uint16_t *d, const lz4w_p
         const uint32_t wbase = win_base(n, sj / P->nseg, hist);    /* candidates must lie in the segment's 64 KiB window */
         const uint32_t newfrom = win_from(sj / P->nseg, hist);     /* the window's positions before this are history */
         const uint32_t wj = sj % P->nseg;
+        if (wj == 0 && !g_no_runs) {
+            /* RUN WINDOWS (the kernel's index_window / run_geom): a window of >= RUN_MIN bytes that is one byte repeated is ONE sequence,
+             * [offset 1: from its first parsed position that has a byte in front of it in the window, to its last match end], when the
+             * block format allows that match; its segments are not walked */
+            const uint32_t wend = win_end(n, sj / P->nseg, hist), wl = wend - wbase;
+            const uint32_t skip = newfrom - wbase;
+            const uint32_t ms = skip > 1 ? skip : 1;
+            uint32_t me = n >= 5 + wbase ? n - 5 - wbase : 0;
+            if (me > wl) me = wl;
+            if (me > 65535u) me = 65535u;
+            const uint32_t act_abs = n >= 12 ? n - 11 : 0;
+            int run = wl >= RUN_MIN && wbase + ms < act_abs && me >= ms + 4;
+            for (uint32_t p = wbase + 1; run && p < wend; p++) run = in[p] == in[wbase];
+            if (run) {
+                seqs[ns].lit_start = anchor; seqs[ns].lit_len = wbase + ms - anchor; seqs[ns].off = 1; seqs[ns].mlen = me - ms;
+                ns++;
+                anchor = wbase + me;
+                sj += P->nseg - 1;
+                continue;
+            }
+        }
         /* eleven segments (the kernel's workers since round 6) are 12 13 13 13 12 11 12 12 10 10 10 groups of 512 long, eight
          * (rounds 2 - 5) 16 17 17 17 15 16 15 15 (later segments cost more per position: the kernel's workers finish together),
          * any other count tiles the window evenly */

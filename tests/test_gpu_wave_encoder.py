@@ -250,19 +250,22 @@ def test_wave_encoder_window_strides(blk):
         assert lib.lz4flex_set_tuning(None, b"compress_sliding_window", W.SLIDE_DEFAULT) == 0
 
 
-def _history_batch(blk, L, sizes, seed):
+def _history_batch(blk, L, sizes, seed, stream=None):
     """blocks cut from ONE stream; flags promise the bytes in front of a block as history (LZ4FLEX_BLOCK_HISTORY): 0, fewer than
     the encoder uses (ignored), exactly HIST, more.  Every block == model (which gets the same 32 KiB in front), and the oracle
-    decodes it behind the previous 64 KiB of the stream as dictionary"""
+    decodes it behind the previous 64 KiB of the stream as dictionary.  stream: given (then cut into 64 KiB blocks), else drawn"""
     rnd = random.Random(seed)
     j = O.fixture_plain("compression_66k_JSON")
     t = O.fixture_plain("compression_65k")
+    if stream is not None:
+        sizes = [min(65536, len(stream) - o) for o in range(0, len(stream), 65536)]
     total = sum(sizes)
-    stream = b""
-    while len(stream) < total:
-        src = j if rnd.random() < 0.6 else t
-        ph = rnd.randrange(len(src))
-        stream += (src * 2)[ph:ph + rnd.choice([3000, 20000, 66000, 100000])]
+    if stream is None:
+        stream = b""
+        while len(stream) < total:
+            src = j if rnd.random() < 0.6 else t
+            ph = rnd.randrange(len(src))
+            stream += (src * 2)[ph:ph + rnd.choice([3000, 20000, 66000, 100000])]
     stream = stream[:total]
     in_len = list(sizes)
     in_off = [int(x) for x in np.concatenate([[0], np.cumsum(in_len)[:-1]])]
@@ -367,3 +370,84 @@ def test_wave_encoder_subwindows(blk, setting, n_blocks, carry_wait):
     finally:
         assert lib.lz4flex_set_tuning(None, b"compress_subwindows", 0) == 0
         assert lib.lz4flex_set_tuning(None, b"compress_carry_wait", 1) == 0
+
+
+def _run_window_inputs():
+    rnd = random.Random(23)
+    j = O.fixture_plain("compression_66k_JSON")
+    out = []
+    for n in (8191, 8192, 8193, 8192 + 11, 8192 + 12, 8192 + 16, 20000, 65535, 65536, 65537, 65536 + 8191, 65536 + 8192, 65536 + 8203, 131072, 131072 + 5,
+              300001, 1048576, 4194304):
+        out.append(bytes(n))
+    out.append(b"\x07" * 70000)
+    out.append(bytes(65536) + b"\x01" * 65536 + bytes(65536))                 # three run windows of different bytes (64 KiB stride), mixed windows with the default stride
+    out.append(bytes(70000) + j + bytes(200000))                              # runs, data, runs
+    out.append(j[:5000] + bytes(300000) + j[:77])                             # a run that starts and ends inside windows
+    out.append(bytes(65536 * 2) + b"\x01")                                    # the run ends with the block's last byte
+    out.append(b"\x01" + bytes(65536 * 2))
+    out.append(bytes(1024) + b"\x01" + bytes(65536))                          # the first KiB is a run, the window is not
+    out.append(bytes(65535) + b"\x01" + bytes(65536))                         # ... the window's last byte differs
+    out.append(bytes(40000) + bytes([rnd.getrandbits(8) for _ in range(3)]) + bytes(100000))
+    return out
+
+
+@pytest.mark.parametrize("slide", [2, 0, 1])
+def test_wave_encoder_run_windows(blk, slide):
+    """RUN WINDOWS (round 6; src/block/compress.rs:156-216: the reference's count_same_bytes is unbounded, 30 000 zeros are one match): a window
+    of >= 8 KiB that is one byte repeated becomes ONE sequence.  Scalar calls (window mode, sub-windows for blocks of <= 64 KiB) and one
+    batch of them with every window stride: kernel == model, decoded by the oracle and liblz4; 4 MiB of zeros compress to <= 0.45 %"""
+    from lz4_flex_amd import _lib as L
+    lib = L.load()
+    inputs = _run_window_inputs()
+    assert lib.lz4flex_set_tuning(None, b"compress_sliding_window", slide) == 0
+    try:
+        for d in inputs:
+            c = blk.compress(d)
+            assert O.decompress(c, len(d)) == ("ok", d), len(d)
+            assert O.c_decompress(c, len(d)) == d
+            assert c == W.compress(d, slide=slide if len(d) > 65536 else 0), (len(d), len(c))
+            if d == bytes(4194304):
+                assert len(c) <= 0.0045 * len(d)
+        src_buf = np.frombuffer(b"".join(inputs), dtype=np.uint8).copy()
+        in_len = [len(b) for b in inputs]
+        in_off = [int(x) for x in np.concatenate([[0], np.cumsum(in_len)[:-1]])]
+        cap = [O.max_out(n) for n in in_len]
+        out_off = [int(x) for x in np.concatenate([[0], np.cumsum(cap)[:-1]])]
+        outb = np.zeros(sum(cap) + 64, dtype=np.uint8)
+        ol, st = blk.compress_batch(src_buf, in_off, in_len, outb, out_off, cap)
+        assert not st.any()
+        for k, d in enumerate(inputs):
+            got = bytes(outb[out_off[k]:out_off[k] + int(ol[k])])
+            assert got == W.compress(d, slide=slide if len(d) > 65536 else 0, sub=SUB(len(inputs))), (k, len(d))
+        back = np.zeros(len(src_buf), dtype=np.uint8)
+        dl, dst, _ = blk.decompress_batch(outb, out_off, ol, back, in_off, in_len)
+        assert not dst.any() and (back == src_buf).all()
+    finally:
+        assert lib.lz4flex_set_tuning(None, b"compress_sliding_window", W.SLIDE_DEFAULT) == 0
+
+
+def test_wave_encoder_run_windows_many_blocks_and_history(blk):
+    """run windows in block mode (more blocks than workgroups: 64 KiB blocks of zeros, of one other byte, of JSON, alternating) and
+    behind history (a Linked frame's blocks, LZ4FLEX_BLOCK_HISTORY): kernel == model, the oracle decodes every block"""
+    j = O.fixture_plain("compression_66k_JSON")
+    kinds = [bytes(65536), (j * 2)[100:100 + 65536], b"\xAA" * 65536, bytes(30000) + j[:35536], bytes(65536 - 9) + b"tail bytes"[:9]]
+    blocks = [kinds[k % len(kinds)] for k in range(1100)]
+    src_buf = np.frombuffer(b"".join(blocks), dtype=np.uint8).copy()
+    in_len = [len(b) for b in blocks]
+    in_off = [int(x) for x in np.concatenate([[0], np.cumsum(in_len)[:-1]])]
+    cap = [O.max_out(n) for n in in_len]
+    out_off = [int(x) for x in np.concatenate([[0], np.cumsum(cap)[:-1]])]
+    outb = np.zeros(sum(cap) + 64, dtype=np.uint8)
+    ol, st = blk.compress_batch(src_buf, in_off, in_len, outb, out_off, cap)
+    assert not st.any()
+    models = [W.compress(d, sub=SUB(len(blocks))) for d in kinds]
+    for k, d in enumerate(blocks):
+        got = bytes(outb[out_off[k]:out_off[k] + int(ol[k])])
+        assert got == models[k % len(kinds)], k
+        if k < 10:
+            assert O.decompress(got, len(d)) == ("ok", d)
+    assert len(models[0]) <= 0.0045 * 65536
+    # history: one stream of zeros / JSON / zeros cut into 64 KiB blocks, every block with the 32 KiB in front of it as history
+    from lz4_flex_amd import _lib as L
+    stream = bytes(3 * 65536 + 100) + (j * 3)[:2 * 65536] + b"\x33" * (4 * 65536)
+    _history_batch(blk, L, None, 0, stream=stream)
