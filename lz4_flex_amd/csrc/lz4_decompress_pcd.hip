@@ -53,6 +53,10 @@ constexpr uint32_t ceil_log2(uint32_t v) { uint32_t r = 0u; while ((1u << r) < v
 template <uint32_t CT_, uint32_t CM_, uint32_t P_, uint32_t T_, uint32_t S_, uint32_t HIST_, uint32_t WNEW_>
 struct Geo {
     static constexpr uint32_t CT = CT_, CM = CM_, P = P_, NP = CT_ / P_, T = T_, S = S_, HIST = HIST_, WNEW = WNEW_, WIN = HIST_ + WNEW_;
+    // a sequence longer than this is executed ALONE by the whole workgroup on the output itself (the "giant" path: stores of a
+    // pattern for short periods) even when the window would hold it -- round 6: the encoder's run windows are 48 KiB matches
+    // with offset 1; inside a batch such a match is one wavefront's copy and one lane's 768 table entries, 58 us each
+    static constexpr uint32_t GIANT = WNEW_ < 16384u ? WNEW_ : 16384u;
     static constexpr uint32_t BN = T * S;                         // sequences per batch
     static constexpr uint32_t MW = CT / 32u;                      // mark words
     static constexpr uint32_t PW = P / 32u;                       // mark words per part
@@ -877,7 +881,7 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
                     perr = perr || nx == X_ERR || (nx == X_END && !(ended && idx + i + 1u == ntok));
                     len[u] = sq[u].lit + sq[u].ml;                 // (both < 2^31)
                 }
-                lenc[u] = len[u] <= G::WNEW ? len[u] : G::WNEW + 1u;
+                lenc[u] = len[u] <= G::GIANT ? len[u] : G::WNEW + 1u;
             }
             if (tid == 0u) ctl[C_CUT] = m;
             // output position of every sequence: slot by slot, a slot's lanes in order (one pass of barriers for all slots)

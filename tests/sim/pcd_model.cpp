@@ -138,7 +138,7 @@ extern "C" long pcd_model_decode(const uint8_t* c, uint32_t n, uint8_t* out, uin
                 if (nx == X_ERR) return -1;                  // (an offset of zero: the walk went past it)
                 if (nx == X_END && !(ended && idx + i + 1 == tok.size())) return -1;
                 const uint64_t len = (uint64_t)sq[i].lit + sq[i].ml;
-                if (acc + len > prm->wnew) break;
+                if (acc + len > prm->wnew || len > (prm->wnew < 16384u ? prm->wnew : 16384u)) break;     // (the kernel's Geo::GIANT)
                 start[i] = OP + acc;
                 acc += len;
                 cnt = i + 1;
