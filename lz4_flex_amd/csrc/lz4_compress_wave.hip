@@ -944,6 +944,19 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
         // the four steps of this 256-block: as one superstep if it holds at most 128 heads, else in halves
         const uint32_t dq0 = dn.x & 0xFFFFu, dq1 = dn.x >> 16, dq2 = dn.y & 0xFFFFu, dq3 = dn.y >> 16;
         dn = *reinterpret_cast<const g_u32x2*>(cand_t + (((B0 >> 8) + 1u) * 512u + lane * 8u));
+#ifndef LZ4W_NO_PRIO
+        // Issue priority by what is LEFT of the segment, in quarters (s_setprio 3 2 1 0): the window waits for its slowest worker, and
+        // with the vector ports saturated a worker that has fallen behind only catches up if it issues before the others of its SIMD
+        // (wait behind matching: 23 k of a window's 238 k cycles before).  JSON 3.39 -> 3.15 ms, text 4.54 -> 4.20; other mappings
+        // (3 3 2 1 / 3 2 1 1 / 3 3 0 0) and a priority for the indexer: slower (profiles/r06_encoder.txt)
+        {
+            const uint32_t left = (s1 - B0) * 4u / (s1 - s0 + 1u);
+            if (left >= 3u) __builtin_amdgcn_s_setprio(3);
+            else if (left == 2u) __builtin_amdgcn_s_setprio(2);
+            else if (left == 1u) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         if (superstep(UConst<4u>{}, B0, dq0, dq1, dq2, dq3)) continue;
 #pragma unroll 1
         for (uint32_t hf = 0u; hf < 2u; ++hf) {
@@ -954,6 +967,9 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
         }
     }
     st = encode_seqs(psq, psp, npend, body_, lane, st);
+#ifndef LZ4W_NO_PRIO
+    __builtin_amdgcn_s_setprio(3);                 // the serial part of a window (barrier, placement, the next window's load) at the highest priority
+#endif
 #ifdef LZ4W_PROF_STEPS
     if (prof_ && lane == 0u) {
         for (int i = 0; i < 5; ++i) atomicAdd(prof_ + 8 + i, (unsigned long long)pt[i]);
