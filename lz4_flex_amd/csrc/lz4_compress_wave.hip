@@ -11,11 +11,12 @@
 // A CPU LZ4 encoder is one serial chain per block (probe -> verify -> extend -> next probe).  Round 1 kept that
 // chain and ran 16 of them per CU; a chain step was three dependent global round trips.  Here nothing serial
 // touches memory:
-//   * a persistent workgroup (9 wavefronts) owns one 64 KiB window at a time, the window lives in LDS;
-//   * wavefront 8 ("indexer") walks the NEXT window 64 positions per step through the 4096-entry hash table
+//   * a persistent workgroup (12 wavefronts since round 6: two workgroups per CU are the 24 wavefronts that 80 VGPRs allow; rounds 2 - 5:
+//     9) owns one 64 KiB window at a time, the window lives in LDS;
+//   * the last wavefront ("indexer") walks the NEXT window 64 positions per step through the 4096-entry hash table
 //     (LDS, u16) and stores, for every position, the distance to the most recent earlier position with the same
-//     hash (cand[], 2 B per position, in an L2-resident slot of the workgroup's workspace);
-//   * wavefronts 0..7 ("workers") each own an 8 KiB segment of the CURRENT window.  Per step of 64 positions:
+//     hash (cand[], 2 B per position, in a slot of the workgroup's workspace);
+//   * wavefronts 0..10 ("workers") each own a segment of ~6 KiB of the CURRENT window.  Per step of 64 positions:
 //     the lanes whose candidate distance differs from their predecessor's ("heads") count their true match
 //     length against the LDS window (16 B per iteration, all heads of the step at once); a DPP prefix maximum
 //     gives every position the match that reaches furthest; one-step lazy evaluation is a lane compare; the
@@ -24,8 +25,10 @@
 //   * segments are independent parses (a match never crosses a segment end) that may reference the whole window;
 //     after a barrier every worker places its segment's bytes: the literals left over at a segment's end are
 //     carried into the first sequence of the next segment (its token is written at that point).
-// HBM traffic: the input once, the output once; cand[] and the segment bodies stay in L2 / Infinity Cache
-// (335 872 B of workspace per workgroup, 512 workgroups).
+// Memory traffic: the input twice (the indexer's stream, the workers' window) and the output once are 2.2 GiB per GiB of input; cand[] is
+// 2 GiB written + 2 GiB read back and the segment bodies are written and read once more -- the 512 workgroups' workspace (~340 KB each)
+// does not fit the L2s (32 MiB), so all of it crosses the fabric to the Infinity Cache: the counters on the L2's fabric side see ~10 GB
+// per GiB (7.7 x the algorithmic bytes; profiles/traffic.json), of which HBM itself has to serve the input and the output.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -651,9 +654,13 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
         if (b + 64u * NS > mfl_end)
 #endif
         {
-            K0 &= bal(t0 != 0u);
-            if (NS > 1u) K1 &= bal(t1 != 0u);
-            if (NS > 2u) { K2 &= bal(t2 != 0u); K3 &= bal(t3 != 0u); }
+            // (the compares stay inside the branch: hipcc hoisted them -- four vector instructions in every superstep -- until the
+            // empty asm made their operands the branch's own)
+            uint32_t z0 = t0, z1 = t1, z2 = t2, z3 = t3;
+            asm volatile("" : "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3));
+            K0 &= bal(z0 != 0u);
+            if (NS > 1u) K1 &= bal(z1 != 0u);
+            if (NS > 2u) { K2 &= bal(z2 != 0u); K3 &= bal(z3 != 0u); }
         }
         if (b < s0) {
             // the segment starts inside this superstep (only the anchored last window of a block, see win_base): positions before
@@ -940,20 +947,25 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
     // block behind the last one is still inside the workspace): a conditional load made hipcc wait for the data right
     // where it was requested.
     u32x2 dn = *reinterpret_cast<const g_u32x2*>(cand_t + ((s0 >> 8) * 512u + lane * 8u));
+#ifndef LZ4W_NO_PRIO
+    // Issue priority by what is LEFT of the segment, in quarters (s_setprio 3 2 1 0): the window waits for its slowest worker, and
+    // with the vector ports saturated a worker that has fallen behind only catches up if it issues before the others of its SIMD
+    // (wait behind matching: 23 k of a window's 238 k cycles before).  JSON 3.39 -> 3.15 ms, text 4.54 -> 4.20; other mappings
+    // (3 3 2 1 / 3 2 1 1 / 3 3 0 0) and a priority for the indexer: slower (profiles/r06_encoder.txt)
+    const uint32_t prio_q = (s1 - s0 + 3u) / 4u;
+    uint32_t prio_drop = s0 + prio_q, prio_lv = 3u;
+    __builtin_amdgcn_s_setprio(3);
+#endif
     for (uint32_t B0 = s0 & ~255u; B0 < s1; B0 += 256u) {       // (s0 is a multiple of 512 except in an anchored last window)
         // the four steps of this 256-block: as one superstep if it holds at most 128 heads, else in halves
         const uint32_t dq0 = dn.x & 0xFFFFu, dq1 = dn.x >> 16, dq2 = dn.y & 0xFFFFu, dq3 = dn.y >> 16;
         dn = *reinterpret_cast<const g_u32x2*>(cand_t + (((B0 >> 8) + 1u) * 512u + lane * 8u));
 #ifndef LZ4W_NO_PRIO
-        // Issue priority by what is LEFT of the segment, in quarters (s_setprio 3 2 1 0): the window waits for its slowest worker, and
-        // with the vector ports saturated a worker that has fallen behind only catches up if it issues before the others of its SIMD
-        // (wait behind matching: 23 k of a window's 238 k cycles before).  JSON 3.39 -> 3.15 ms, text 4.54 -> 4.20; other mappings
-        // (3 3 2 1 / 3 2 1 1 / 3 3 0 0) and a priority for the indexer: slower (profiles/r06_encoder.txt)
-        {
-            const uint32_t left = (s1 - B0) * 4u / (s1 - s0 + 1u);
-            if (left >= 3u) __builtin_amdgcn_s_setprio(3);
-            else if (left == 2u) __builtin_amdgcn_s_setprio(2);
-            else if (left == 1u) __builtin_amdgcn_s_setprio(1);
+        if (B0 >= prio_drop) {                                   // (one compare per 256-block; a division here was 25 scalar instructions)
+            prio_drop += prio_q;
+            prio_lv = prio_lv != 0u ? prio_lv - 1u : 0u;
+            if (prio_lv == 2u) __builtin_amdgcn_s_setprio(2);
+            else if (prio_lv == 1u) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
         }
 #endif
