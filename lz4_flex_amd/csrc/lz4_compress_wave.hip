@@ -844,7 +844,9 @@ __device__ __attribute__((noinline)) void match_segment(const uint8_t* __restric
         uint32_t cb = cursor - b;
         auto walk = [&](auto offc, uint64_t em, uint32_t e, uint64_t& S, uint32_t& cbr) {
             constexpr uint32_t OFF = decltype(offc)::value;
-            const uint32_t er = e - (b + OFF);
+            uint32_t sb = b + OFF;                                   // (one scalar add, then ONE vector subtraction: hipcc made two of e - b - OFF)
+            asm volatile("" : "+s"(sb));
+            const uint32_t er = e - sb;
             uint64_t m; uint32_t t, c;
             if constexpr (OFF == 0u) {
                 asm volatile(
