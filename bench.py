@@ -269,7 +269,64 @@ def other_configs(args, env):
                                           "verified": o.get("verified"), "kernels": o.get("kernels")}
         except Exception as e:
             res["medium_batches"][key] = {"error": repr(e)}
+    # zero pages (round 6, run windows): 16 blocks of 4 MiB of zeros through the block codec -- the reference encodes such a block as ONE
+    # sequence (src/block/compress.rs:156-216: count_same_bytes is unbounded), this encoder as one per 48 KiB window since round 6
+    try:
+        env["torch"].cuda.empty_cache()
+        res["zero_pages"] = run_zero_pages(args, env)
+    except Exception as e:
+        res["zero_pages"] = {"error": repr(e)}
     return res
+
+
+def run_zero_pages(args, env, n=16, size=4 << 20):
+    torch, lib, ctx, dev, _lib = (env[k] for k in ("torch", "lib", "ctx", "dev", "_lib"))
+    src = torch.zeros(n * size, dtype=torch.uint8, device=dev)
+    stride = (int(lib.lz4flex_get_maximum_output_size(size)) + 63) // 64 * 64
+    comp = torch.empty(n * stride, dtype=torch.uint8, device=dev)
+    back = torch.full((n * size,), 0xEE, dtype=torch.uint8, device=dev)
+    ar = torch.arange(n, dtype=torch.int64, device=dev)
+    in_off, comp_off = (ar * size).contiguous(), (ar * stride).contiguous()
+    in_len = torch.full((n,), size, dtype=torch.int32, device=dev)
+    cap = torch.full((n,), stride, dtype=torch.int32, device=dev)
+    clen = torch.zeros(n, dtype=torch.int32, device=dev)
+    st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    blen = torch.zeros(n, dtype=torch.int32, device=dev)
+    bst = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    flags = _lib.MEM_DEVICE | _lib.MEM_BIG_BLOCKS
+
+    def comp_once():
+        assert lib.lz4flex_compress_batch(ctx, p(src), p(in_off), p(in_len), None, n, p(comp), p(comp_off), p(cap), p(clen), p(st), flags, stream) == 0, _lib.last_error()
+
+    def dec_once():
+        assert lib.lz4flex_decompress_batch(ctx, p(comp), p(comp_off), p(clen), n, p(back), p(in_off), p(in_len), p(blen), p(bst), None, flags, stream) == 0, _lib.last_error()
+
+    def ms(fn, reps=5):
+        ts = []
+        for _ in range(reps + 2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return median(ts[2:])
+
+    comp_once(); dec_once(); torch.cuda.synchronize()
+    ok = int((st != 0).sum().item()) == 0 and int((bst != 0).sum().item()) == 0 and bool(torch.equal(back, src))
+    tc, td = ms(comp_once), ms(dec_once)
+    total_c = int(clen.to(torch.int64).sum().item())
+    verified = "round trip bit-exact on the device" if ok else "ROUND TRIP FAILED"
+    try:                                               # the oracle's decoder on the first block (test infrastructure: the checker)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+        import oracle_api as O
+        c0 = bytes(comp[:int(clen[0].item())].cpu().numpy())
+        verified += "; block 0 (%d bytes) decoded by the oracle == 4 MiB of zeros: %s" % (len(c0), O.decompress(c0, size) == ("ok", bytes(size)))
+    except Exception as e:
+        verified += "; oracle check skipped (%r)" % (e,)
+    return {"what": "%d blocks of %d MiB of zeros, device-resident, compress_mode fast" % (n, size >> 20), "compress_ms": round(tc, 4), "decompress_ms": round(td, 4),
+            "ratio": round(total_c / (n * size), 6), "decompress_GB_per_s": round(n * size / td / 1e6, 1), "compress_GB_per_s": round(n * size / tc / 1e6, 1),
+            "verified": verified}
 
 
 def timed(args, env, step):

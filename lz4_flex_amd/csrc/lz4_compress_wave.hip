@@ -1323,6 +1323,9 @@ __device__ __forceinline__ void wave_body(const CompressArgs& a, uint8_t* __rest
     }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = uni(threadIdx.x >> 6);
+#ifdef LZ4W_EXP_IDX_PRIO     // tools: the indexer's issue priority (the workers: by progress, see match_segment); measured 1 and 2: slower
+    if (w == WORKERS) __builtin_amdgcn_s_setprio(LZ4W_EXP_IDX_PRIO);
+#endif
     uint8_t* my_ws = ws + (size_t)blockIdx.x * WS_BYTES;
     uint8_t* slots = my_ws;                                        // two cand[] slots
     uint8_t* bodies = my_ws + 2u * SLOT_BYTES;
