@@ -33,7 +33,7 @@ def make_input(rnd):
             for _ in range(m):
                 out.append(out[-d])
         elif k < 0.65:
-            out += bytes([rnd.getrandbits(8)]) * rnd.randint(1, 2000)
+            out += bytes([rnd.getrandbits(8)]) * (rnd.randint(1, 2000) if rnd.random() < 0.85 else rnd.randint(6000, 300000))     # (long runs: the encoder's run windows, the workgroup decoder's giants -- round 6)
         elif k < 0.7:
             out += np.random.default_rng(rnd.getrandbits(32)).integers(0, alphabet, rnd.randint(1, 5000), dtype=np.uint8).tobytes()
         else:
