@@ -114,11 +114,11 @@ constexpr uint32_t WORKER_LDS = CMP_OFF + 256u;
 constexpr uint32_t CHUNK = 1024u;         // the indexer streams the next window in 1 KiB chunks (16 steps)
 constexpr uint32_t CHUNK_SLOT = CHUNK + 16u;      // + the first bytes of the next chunk (positions 1021..1023 hash across the end)
 constexpr uint32_t IDX_DEPTH = 4u;        // chunks in flight (registers) ahead of the one being indexed
-// LDS layout (81 200 B: two workgroups per CU)
+// LDS layout (80 960 B with eleven workers: two workgroups per CU)
 constexpr uint32_t L_WIN = 0u;                              // the window + 64 B of slack for the 16-byte compares
 constexpr uint32_t L_TAB = WINDOW + 64u;                    // the indexer's table, 4096 x u16
 constexpr uint32_t L_STG = L_TAB + (2u << HBITS);
-constexpr uint32_t L_RING = L_STG + WORKERS * WORKER_LDS;   // two chunk slots of the indexer
+constexpr uint32_t L_RING = L_STG + WORKERS * WORKER_LDS;   // the indexer's chunk slot(s)
 constexpr uint32_t L_META = L_RING + RING_SLOTS * CHUNK_SLOT;
 // L_META, words: 5 per worker (SegMeta), BlkCarry[2] (4), the drawn items (giq, 4), place_segment's mailbox (3), run_flag[2] (see index_window)
 constexpr uint32_t META_WORDS = 5u * WORKERS + 4u + 4u + 3u + 2u;
