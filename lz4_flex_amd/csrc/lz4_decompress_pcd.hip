@@ -137,7 +137,7 @@ constexpr uint32_t PAIR_RING = 3u;
 constexpr uint32_t PAIR_CTRL = 64u;
 constexpr uint32_t PAIR_TOKB = (2u * MAXSEQ + 255u) / 256u * 256u;      // (the production geometry's; the test geometry's lists are shorter)
 enum : uint32_t { C_EXIT = 0, C_CUT = 1, C_TOTAL = 2, C_BAD = 3, C_G_SRC = 4, C_G_LIT = 5, C_G_ML = 6, C_G_OFF = 7, C_TIMEOUT = 8, C_BAD2 = 9,
-                  C_NEEDPREV = 10, C_PREV = 11 };
+                  C_NEEDPREV = 10, C_PREV = 11, C_G_IS = 12 };
 
 #define PCD_DPP(v, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xf, false))
 __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
@@ -898,55 +898,72 @@ __global__ void __launch_bounds__(G::T) lz4_decompress_pcd_kernel(DecompressArgs
             PCD_TICK(4)
             if (ctl[C_BAD] != 0u) { bad = true; break; }
             if (cnt == 0u) {
-                // ---- a sequence longer than the window: alone, by the whole workgroup, on the output itself
-                if (tid == 0u) { ctl[C_G_SRC] = sq[0].lit_src; ctl[C_G_LIT] = sq[0].lit; ctl[C_G_ML] = sq[0].ml; ctl[C_G_OFF] = sq[0].off; }
-                __syncthreads();
-                const uint32_t g_src = ctl[C_G_SRC], g_lit = ctl[C_G_LIT], g_ml = ctl[C_G_ML], g_off = ctl[C_G_OFF];
-                if (g_lit > X.cap - OP) { bad = true; break; }                      // OutputTooSmall
-                X.block_copy(X.gout + OP, X.gin + g_src, g_lit);
-                OP += g_lit;
-                __syncthreads();                                                    // (workgroup-scope release / acquire: the bytes are visible)
-                if (g_ml != 0u) {
-                    if (g_off > OP || g_ml > X.cap - OP) { bad = true; break; }     // OffsetOutOfBounds / OutputTooSmall
-                    if (!prev_ok && OP - g_off < OP0) {                             // reads bytes of an earlier block of the chain
-                        if (!X.wait_predecessor(prev_flag)) { bad = true; break; }
-                        prev_ok = true;
+                // ---- a sequence longer than the window (or than Geo::GIANT): alone, by the whole workgroup, on the output itself.  Round 6: the
+                // sequences BEHIND it that are giants too (a block of zeros is nothing else: one 48 KiB match per window of the encoder) follow
+                // in the same pass -- their lanes hold them already; parsed again per giant, 85 times per 4 MiB block, the parse was 40 % of it
+                for (uint32_t gi = 0u;;) {
+                    if (tid == gi % G::T) {                         // sequence gi of this pass belongs to lane gi mod T, slot gi / T
+                        Seq sv = sq[0];
+                        uint32_t lc = lenc[0];
+#pragma unroll
+                        for (uint32_t u = 1; u < S; ++u)
+                            if (gi / G::T == u) { sv = sq[u]; lc = lenc[u]; }
+                        ctl[C_G_SRC] = sv.lit_src; ctl[C_G_LIT] = sv.lit; ctl[C_G_ML] = sv.ml; ctl[C_G_OFF] = sv.off;
+                        ctl[C_G_IS] = (gi < m && lc > G::WNEW) ? 1u : 0u;
                     }
-                    uint32_t donem = 0u;
-                    if (g_off <= SPLAT_MAX) {
-                        // a short period (offset 1: a run of one byte, decompress_safe.rs:311-313): the period, and 16 bytes of its
-                        // repetition, go to the (unused) window once; every thread then stores 16 bytes of the pattern per turn,
-                        // read from the window at its position's phase -- stores only, instead of log2(ml / off) rounds of
-                        // memory-to-memory copies with a barrier each (16 x 4 MiB of zeros: 6 GB/s in round 3)
-                        const uint8_t* pat = X.gout + OP - g_off;
-                        for (uint32_t o = tid; o < g_off + 16u; o += G::T) X.win()[o] = pat[o % g_off];
-                        __syncthreads();
-                        uint32_t phase = (16u * tid) % g_off;
-                        const uint32_t hop = (16u * G::T) % g_off;
-                        uint8_t* dstp = X.gout + OP;
-                        for (uint32_t o = 16u * tid; o < g_ml; o += 16u * G::T) {
-                            const u32x4 v = ld16l(X.win() + phase);
-                            const uint32_t mrem = g_ml - o;
-                            if (mrem >= 16u) st16g(dstp + o, v);
-                            else for (uint32_t j = 0; j < mrem; ++j) dstp[o + j] = (uint8_t)byte_of(v, j);
-                            phase += hop;
-                            phase -= phase >= g_off ? g_off : 0u;
+                    __syncthreads();
+                    if (ctl[C_G_IS] == 0u) break;                   // (uniform) the next one fits a batch: back to the batch path, which parses from it on
+                    const uint32_t g_src = ctl[C_G_SRC], g_lit = ctl[C_G_LIT], g_ml = ctl[C_G_ML], g_off = ctl[C_G_OFF];
+                    if (g_lit > X.cap - OP) { bad = true; break; }                      // OutputTooSmall
+                    X.block_copy(X.gout + OP, X.gin + g_src, g_lit);
+                    OP += g_lit;
+                    __syncthreads();                                                    // (workgroup-scope release / acquire: the bytes are visible)
+                    if (g_ml != 0u) {
+                        if (g_off > OP || g_ml > X.cap - OP) { bad = true; break; }     // OffsetOutOfBounds / OutputTooSmall
+                        if (!prev_ok && OP - g_off < OP0) {                             // reads bytes of an earlier block of the chain
+                            if (!X.wait_predecessor(prev_flag)) { bad = true; break; }
+                            prev_ok = true;
                         }
-                        donem = g_ml;
-                        __syncthreads();
+                        uint32_t donem = 0u;
+                        if (g_off <= SPLAT_MAX) {
+                            // a short period (offset 1: a run of one byte, decompress_safe.rs:311-313): the period, and 16 bytes of its
+                            // repetition, go to the (unused) window once; every thread then stores 16 bytes of the pattern per turn,
+                            // read from the window at its position's phase -- stores only, instead of log2(ml / off) rounds of
+                            // memory-to-memory copies with a barrier each (16 x 4 MiB of zeros: 6 GB/s in round 3)
+                            const uint8_t* pat = X.gout + OP - g_off;
+                            for (uint32_t o = tid; o < g_off + 16u; o += G::T) X.win()[o] = pat[o % g_off];
+                            __syncthreads();
+                            uint32_t phase = (16u * tid) % g_off;
+                            const uint32_t hop = (16u * G::T) % g_off;
+                            uint8_t* dstp = X.gout + OP;
+                            for (uint32_t o = 16u * tid; o < g_ml; o += 16u * G::T) {
+                                const u32x4 v = ld16l(X.win() + phase);
+                                const uint32_t mrem = g_ml - o;
+                                if (mrem >= 16u) st16g(dstp + o, v);
+                                else for (uint32_t j = 0; j < mrem; ++j) dstp[o + j] = (uint8_t)byte_of(v, j);
+                                phase += hop;
+                                phase -= phase >= g_off ? g_off : 0u;
+                            }
+                            donem = g_ml;
+                            __syncthreads();
+                        }
+                        while (donem < g_ml) {
+                            const uint32_t room = donem + g_off;
+                            const uint32_t n = g_ml - donem < room ? g_ml - donem : room;
+                            X.block_copy(X.gout + OP + donem, X.gout + OP - g_off, n);
+                            donem += n;
+                            __syncthreads();
+                        }
+                        OP += g_ml;
                     }
-                    while (donem < g_ml) {
-                        const uint32_t room = donem + g_off;
-                        const uint32_t n = g_ml - donem < room ? g_ml - donem : room;
-                        X.block_copy(X.gout + OP + donem, X.gout + OP - g_off, n);
-                        donem += n;
-                        __syncthreads();
-                    }
-                    OP += g_ml;
+                    hist = 0u;
+                    idx += 1u;
+                    gi += 1u;
+                    PCD_TICK(9) PCD_COUNT(20, 1)
+                    if (gi >= m) break;
+                    __syncthreads();                                // (every thread has read the control words before they are written again)
                 }
-                hist = 0u;
-                idx += 1u;
-                PCD_TICK(9) PCD_COUNT(20, 1)
+                if (bad) break;
                 continue;
             }
             // ---- a batch of cnt sequences: [OP, OP + total) in the window behind the history
