@@ -119,7 +119,8 @@ static hipError_t launch_decompress_fast(lz4flex_ctx* c, const DecompressArgs& a
     //     16 384 JSON blocks -- the chain of one block.
     int v = c->dec_variant != 0 ? c->dec_variant : ((a.n <= PCD_MAX_BLOCKS || big_blocks) ? 7 : (a.n <= DISPATCH_SEQ_MAX ? 13 : 4));
     const int geo_req = v == 10 ? 2 : (v == 11 ? 3 : 0);  // (an explicit geometry holds for prefix / chained batches too)
-    if (a.out_pos != nullptr && v != 8) v = 7;           // prefix mode (Linked frames): only the workgroup decoder knows it
+    // prefix mode (Linked frames): the workgroup decoder, or -- a batch whose prefixes are in memory already, not a CHAINED one -- the sequence decoder (round 6)
+    if (a.out_pos != nullptr && v != 8 && !(v == 13 && a.chain_done == nullptr)) v = 7;
     if ((v == 12 || v == 13) && a.dict_base != nullptr) v = 4;
     // the workgroup decoder's geometry by batch size (lz4_decompress_pcd.hip GeoMid*: smaller workgroups, more of them per CU); large
     // blocks and chains keep the full workgroup (a chain is one block at a time, a large block wants the long tiles)

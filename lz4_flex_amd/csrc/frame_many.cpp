@@ -34,6 +34,10 @@ using namespace lz4flex_dev;
 constexpr uint32_t UNCOMPRESSED_BIT = 0x80000000u;
 constexpr uint64_t WINDOW_SIZE = 65536, FAST_HISTORY = 32768;
 constexpr uint32_t CHAIN_MAX = 65536u;                   // blocks per chained decode batch (LZ4FLEX_MEM_CHAINED)
+#ifndef LZ4FLEX_LEVEL_MIN_CHAINS
+#define LZ4FLEX_LEVEL_MIN_CHAINS 1024
+#endif
+constexpr uint32_t LEVEL_MIN_CHAINS = LZ4FLEX_LEVEL_MIN_CHAINS;   // from this many Linked streams in one call on their blocks are decoded a level per launch (see the groups loop)
 constexpr uint64_t MAX_SLOTS = 1ull << 26;               // block-table entries per decompress_many call (12 bytes each on the host and on the device)
 constexpr uint64_t STREAM_MAX = 0x7FFF0000ull - (8u << 20);   // longer streams take the one-shot path (table reposition near 2 GiB, frame/compress.rs:266-271)
 
@@ -390,6 +394,24 @@ int decompress_many_device(lz4flex_ctx* c, const uint8_t* in, const uint64_t* in
             uint32_t chains = 0;                       // (level-by-level order: the blocks without a predecessor are the chains)
             for (size_t j = g.lo; j < g.hi; j++) chains += B.host<uint32_t>(b_prev)[np + j] == 0xFFFFFFFFu ? 1u : 0u;
             ext.n_chains = chains;
+        }
+        if (ext.n_chains >= LEVEL_MIN_CHAINS) {
+            // MANY short chains (round 6): a LEVEL per launch -- block k of every stream, a plain batch with prefixes (out_pos) whose bytes the
+            // launches before it have written: the batch decoders by batch shape (the sequence decoder from 641 blocks on: 4 096 chains of
+            // 4 blocks 6.7 -> 2.3 ms per GiB) instead of one workgroup per block polling its predecessor.  A level costs ~0.3 ms whatever it
+            // holds, so this is for thousands of chains; hundreds of long ones (256 x 64 blocks) stay with the chained launch
+            for (size_t j = g.lo; j < g.hi;) {
+                size_t e = j;
+                while (e < g.hi && chained[e].k == chained[j].k) e++;
+                const size_t oj = np + j;
+                lz4flex_decompress_ext lv{};
+                lv.out_pos = B.dev<uint32_t>(b_pos) + oj;
+                TRY_RC(lz4flex_decompress_batch_ex(c, in, B.dev<uint64_t>(b_in) + oj, B.dev<uint32_t>(b_len) + oj, (uint32_t)(e - j), out, B.dev<uint64_t>(b_out) + oj,
+                                                   B.dev<uint32_t>(b_cap) + oj, B.dev<uint32_t>(b_olen) + oj, B.dev<int32_t>(b_st) + oj, B.dev<uint64_t>(b_det) + 2 * oj, &lv,
+                                                   LZ4FLEX_MEM_DEVICE, s));
+                j = e;
+            }
+            continue;
         }
         TRY_RC(lz4flex_decompress_batch_ex(c, in, B.dev<uint64_t>(b_in) + o, B.dev<uint32_t>(b_len) + o, (uint32_t)(g.hi - g.lo), out, B.dev<uint64_t>(b_out) + o,
                                            B.dev<uint32_t>(b_cap) + o, B.dev<uint32_t>(b_olen) + o, B.dev<int32_t>(b_st) + o, B.dev<uint64_t>(b_det) + 2 * o, &ext,

@@ -678,8 +678,14 @@ __global__ void __launch_bounds__(64) lz4_decompress_seq_kernel(DecompressArgs a
     D.cap = a.out_cap[b];
     D.lane = lane;
     D.OP = 0u; D.W0 = 0u; D.F = 0u;
+    // PREFIX mode (out_pos, round 6; decompress_into_with_prefix-like: a Linked frame's block, src/frame/decompress.rs:195-222,280-305): the
+    // sink already holds [0, P) of the stream, matches may reach into it, and the block's bytes follow at P -- for this decoder a source in
+    // front of its window is a read of written-back output anyway; the prefix is the same read.  The window starts as the last KEEP bytes
+    // of the prefix.  (Not for CHAINED batches: the bytes must be in memory when the launch starts -- a level of chains per launch.)
+    const uint32_t P = a.out_pos != nullptr ? uni(a.out_pos[b]) : 0u;
     const uint32_t ilen = D.ilen;
-    bool ok = ilen != 0u && ilen <= POS_LIMIT, done = false;     // (an empty block: decompress.rs:207-209, the reference-order kernel reports it)
+    bool ok = ilen != 0u && ilen <= POS_LIMIT && P <= POS_LIMIT / 2u && D.cap >= P, done = false;     // (an empty block: decompress.rs:207-209, the reference-order kernel reports it)
+    if (P != 0u && ok) { D.OP = P; D.reload_window(); }
     uint32_t entry = 0u;
 #ifdef LZ4S_PROF
     Prof P;
@@ -814,7 +820,7 @@ __global__ void __launch_bounds__(64) lz4_decompress_seq_kernel(DecompressArgs a
 #endif
         if (lane == 0u) {
             a.status[b] = 0;
-            a.out_len[b] = D.OP;
+            a.out_len[b] = D.OP - P;
             if (a.detail) { a.detail[2u * b] = 0u; a.detail[2u * b + 1u] = 0u; }
         }
     } else if (lane == 0u) {
@@ -825,11 +831,11 @@ __global__ void __launch_bounds__(64) lz4_decompress_seq_kernel(DecompressArgs a
 
 }  // namespace sq
 
-// Blocks without dictionary / prefix.  Irregular blocks get status `redo_code`; the caller runs launch_decompress with
+// Blocks without dictionary (a prefix in the sink is fine, round 6).  Irregular blocks get status `redo_code`; the caller runs launch_decompress with
 // only_status = redo_code behind this launch.
 hipError_t launch_decompress_seq(const DecompressArgs& a, int32_t redo_code, hipStream_t s) {
     if (a.n == 0u) return hipSuccess;
-    if (a.dict_base != nullptr || a.out_pos != nullptr) return hipErrorInvalidValue;
+    if (a.dict_base != nullptr || a.chain_done != nullptr) return hipErrorInvalidValue;       // (a prefix -- out_pos -- is fine: see the kernel)
     typedef sq::Geo<LZ4S_R, LZ4S_KEEP> G;
     static_assert(G::LDS <= 65536u, "the default limit of dynamic LDS: no function attribute to set per device");
     hipLaunchKernelGGL(sq::lz4_decompress_seq_kernel<G>, dim3(a.n), dim3(64), G::LDS, s, a, redo_code);

@@ -221,3 +221,73 @@ def test_more_blocks_than_one_chained_call(fr):
     olen, st = fr.decompress_frames_device(frames, f_off, flen, back, in_off, [size] * n)
     assert st == [0] * n and olen == [size] * n
     assert torch.equal(back, src)
+
+
+def test_many_short_linked_streams_level_by_level(fr):
+    """round 6: from 1 024 Linked streams on, a call decodes block k of every stream in ONE launch (a plain batch with prefixes: the sequence
+    decoder from 641 blocks on, src/frame/decompress.rs:195-222,280-305) instead of one workgroup per block polling its predecessor.  1 300
+    frames WRITTEN BY THE REFERENCE ENCODER (the oracle's FrameEncoder: real back-references into the previous block), ragged lengths (1 byte
+    ... 5 blocks: the levels thin out), incompressible stretches (stored blocks between compressed ones), some with checksums; then the same
+    streams through this library's encoder; a few frames corrupted: the batch returns what the single-stream call returns"""
+    rnd = random.Random(77)
+    streams = _streams(77, 1300, 1, 330000)
+    frames = []
+    for i, s in enumerate(streams):
+        rc, f = O.frame_compress(s, block_mode=1, block_size=4, block_checksums=i % 7 == 0, content_checksum=i % 11 == 0)
+        assert rc == 0
+        frames.append(f)
+    back = fr.decompress_frames(frames, [len(s) for s in streams])
+    assert back == streams
+    info = fr.FrameInfo(block_mode=fr.BlockMode.Linked, block_size=fr.BlockSize.Max64KB)
+    ours = fr.compress_frames(streams, info)
+    assert fr.decompress_frames(ours, [len(s) + 7 for s in streams]) == streams
+    for i in (3, 500, 1299):
+        rc, b, used = O.frame_decompress(ours[i], len(streams[i]))
+        assert rc == 0 and b == streams[i]
+    # corrupted frames among the good ones: every stream's verdict is the single-stream call's
+    bad = list(frames)
+    hit = [5, 640, 641, 1200]
+    for i in hit:
+        f = bytearray(bad[i])
+        at = rnd.randrange(len(f) // 2, len(f) - 1)
+        f[at] ^= 0x5A
+        bad[i] = bytes(f)
+    res = fr.decompress_frames(bad, [len(s) for s in streams], return_errors=True)
+    for i, r in enumerate(res):
+        if i in hit:
+            try:
+                alone = fr.decompress_frames([bad[i]], [len(streams[i])])[0]
+            except Exception as e:              # noqa: BLE001 -- the single-stream verdict, whatever its class
+                assert isinstance(r, Exception) and type(r) is type(e) and str(r) == str(e), (i, r, e)
+            else:
+                assert r == alone
+        else:
+            assert r == streams[i], i
+
+
+@pytest.mark.parametrize("n,size", [(4096, 256 * 1024), (1100, 3 * 65536 + 17)])
+def test_device_resident_many_short_linked_streams(fr, n, size):
+    """device-resident: thousands of Linked streams of a few blocks (the level-by-level path), compress_many -> decompress_many == the source;
+    frames read back are decoded by the oracle"""
+    import torch
+    from lz4_flex_amd import _lib, workloads
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    plain = O.fixture_plain("compression_66k_JSON")
+    src = workloads.json_tiles(plain, n * size, device=dev)
+    info = fr.FrameInfo(block_mode=fr.BlockMode.Linked, block_size=fr.BlockSize.Max64KB)
+    cap = int(lib.lz4flex_frame_compress_bound(size, info._c()))
+    frames = torch.zeros(n * cap, dtype=torch.uint8, device=dev)
+    back = torch.zeros(n * size, dtype=torch.uint8, device=dev)
+    in_off = [i * size for i in range(n)]
+    f_off = [i * cap for i in range(n)]
+    flen, st = fr.compress_frames_device(src, in_off, [size] * n, info, frames, f_off, [cap] * n)
+    assert st == [0] * n
+    olen, st = fr.decompress_frames_device(frames, f_off, flen, back, in_off, [size] * n)
+    assert st == [0] * n and olen == [size] * n
+    assert torch.equal(back, src)
+    host = src[:3 * size].cpu().numpy().tobytes()
+    for i in (0, 2):
+        f = frames[f_off[i]:f_off[i] + flen[i]].cpu().numpy().tobytes()
+        rc, b, used = O.frame_decompress(f, size)
+        assert rc == 0 and b == host[i * size:(i + 1) * size] and used == len(f)
