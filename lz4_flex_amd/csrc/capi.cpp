@@ -68,6 +68,7 @@ struct lz4flex_ctx {
     bool wave_used = false;
     int dec_blocks_per_wg = 0;    // split decoder: blocks per workgroup (8/16/32/64), 0 = 64
     int comp_det = 0;             // "compress_deterministic": 1 = a block's bytes depend on the block and the settings alone (no sub-windows by batch size)
+    int dec_level_chains = 1024;  // "decompress_level_chains": from this many Linked streams in one *_many call on, block k of every stream is one plain launch (frame_many.cpp); 0 = never
     int comp_sub = 0;             // throughput encoder, "compress_subwindows": 0 = by batch size, 1 = never, 2 / 4 = always that many sub-windows per block of <= 64 KiB
     int dec_variant = 0;          // 0 = by batch size, 1 = window in HBM/L2 (lz4_decompress.hip), 4 = parser / copier split (lz4_decompress_split.hip), 7 = a workgroup per block (lz4_decompress_pcd.hip; 8: its test geometry; 10 / 11: 256 / 512 lanes), 13 = a wavefront per block, a lane per sequence (lz4_decompress_seq.hip); tools builds: 9 = plan / replay, 12 = parser / emitter / quads
     int comp_sliding = 2;         // throughput encoder: the windows of a block longer than 64 KiB advance by 48 KiB (2: every window start has 16 KiB of history) or 32 KiB (1: round 4's bytes); 0 = by 64 KiB (round 3's bytes, fastest)
@@ -435,6 +436,11 @@ int lz4flex_set_tuning(lz4flex_ctx* c, const char* key, int value) {
         c->comp_det = value;
         return 0;
     }
+    if (!strcmp(key, "decompress_level_chains")) {
+        if (value < 0) return -LZ4FLEX_E_INVALID_ARG;
+        c->dec_level_chains = value;
+        return 0;
+    }
     if (!strcmp(key, "decompress_blocks_per_wg")) {
         if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return -LZ4FLEX_E_INVALID_ARG;
         c->dec_blocks_per_wg = value;
@@ -539,6 +545,7 @@ int lz4flex_get_tuning(lz4flex_ctx* c, const char* key) {
     if (!strcmp(key, "decompress_variant")) return c->dec_variant;
     if (!strcmp(key, "decompress_second_pass")) return c->dec_second_pass;
     if (!strcmp(key, "decompress_blocks_per_wg")) return c->dec_blocks_per_wg;
+    if (!strcmp(key, "decompress_level_chains")) return c->dec_level_chains;
     if (!strcmp(key, "decompress_lanes")) return c->dec_lanes;
     return -LZ4FLEX_E_INVALID_ARG;
 }

@@ -34,10 +34,7 @@ using namespace lz4flex_dev;
 constexpr uint32_t UNCOMPRESSED_BIT = 0x80000000u;
 constexpr uint64_t WINDOW_SIZE = 65536, FAST_HISTORY = 32768;
 constexpr uint32_t CHAIN_MAX = 65536u;                   // blocks per chained decode batch (LZ4FLEX_MEM_CHAINED)
-#ifndef LZ4FLEX_LEVEL_MIN_CHAINS
-#define LZ4FLEX_LEVEL_MIN_CHAINS 1024
-#endif
-constexpr uint32_t LEVEL_MIN_CHAINS = LZ4FLEX_LEVEL_MIN_CHAINS;   // from this many Linked streams in one call on their blocks are decoded a level per launch (see the groups loop)
+// ("decompress_level_chains", default 1 024: from this many Linked streams in one call on their blocks are decoded a level per launch -- the groups loop)
 constexpr uint64_t MAX_SLOTS = 1ull << 26;               // block-table entries per decompress_many call (12 bytes each on the host and on the device)
 constexpr uint64_t STREAM_MAX = 0x7FFF0000ull - (8u << 20);   // longer streams take the one-shot path (table reposition near 2 GiB, frame/compress.rs:266-271)
 
@@ -395,7 +392,8 @@ int decompress_many_device(lz4flex_ctx* c, const uint8_t* in, const uint64_t* in
             for (size_t j = g.lo; j < g.hi; j++) chains += B.host<uint32_t>(b_prev)[np + j] == 0xFFFFFFFFu ? 1u : 0u;
             ext.n_chains = chains;
         }
-        if (ext.n_chains >= LEVEL_MIN_CHAINS) {
+        const int level_min = lz4flex_get_tuning(c, "decompress_level_chains");
+        if (level_min > 0 && ext.n_chains >= (uint32_t)level_min) {
             // MANY short chains (round 6): a LEVEL per launch -- block k of every stream, a plain batch with prefixes (out_pos) whose bytes the
             // launches before it have written: the batch decoders by batch shape (the sequence decoder from 641 blocks on: 4 096 chains of
             // 4 blocks 6.7 -> 2.3 ms per GiB) instead of one workgroup per block polling its predecessor.  A level costs ~0.3 ms whatever it

@@ -291,3 +291,23 @@ def test_device_resident_many_short_linked_streams(fr, n, size):
         f = frames[f_off[i]:f_off[i] + flen[i]].cpu().numpy().tobytes()
         rc, b, used = O.frame_decompress(f, size)
         assert rc == 0 and b == host[i * size:(i + 1) * size] and used == len(f)
+
+
+@pytest.mark.parametrize("mode,bs", [(1, 4), (1, 5), (1, 7)])
+def test_level_by_level_on_small_calls(fr, mode, bs):
+    """"decompress_level_chains" 1: the level path on the ragged batches of test_round_trip_many_streams (37 streams of 1 ... 700 000 bytes,
+    stored blocks, every block size: levels of a handful of blocks go to the workgroup decoder's prefix mode, larger ones to the sequence
+    decoder's), frames of this library's encoder and of the reference's"""
+    from lz4_flex_amd import _lib
+    lib = _lib.load()
+    streams = _streams(100 * mode + bs, 37, 1, 700000) + [b"", b"a", bytes(65536), bytes(65537), bytes(131072)]
+    info = fr.FrameInfo(block_mode=fr.BlockMode(mode), block_size=fr.BlockSize(bs))
+    frames = fr.compress_frames(streams, info)
+    ref = [O.frame_compress(s, block_mode=mode, block_size=bs)[1] for s in streams]
+    assert lib.lz4flex_set_tuning(None, b"decompress_level_chains", 1) == 0
+    try:
+        assert lib.lz4flex_get_tuning(None, b"decompress_level_chains") == 1
+        assert fr.decompress_frames(frames, [len(s) for s in streams]) == streams
+        assert fr.decompress_frames(ref, [len(s) + 1000 for s in streams]) == streams
+    finally:
+        assert lib.lz4flex_set_tuning(None, b"decompress_level_chains", 1024) == 0

@@ -155,7 +155,15 @@ def many(args):
                 fr = frames_in[1][i][:rnd.randint(0, len(frames_in[1][i]))]
             mix.append(fr)
             caps.append(len(d) + rnd.choice([0, 0, 0, 1, 70000]))
-        got = F.decompress_frames(mix, caps, return_errors=True)
+        # (every other batch with "decompress_level_chains" 1: the Linked streams of the call are decoded a level per launch -- the path that
+        # calls of >= 1 024 streams take; block sizes above 64 KiB then go through the sequence decoder's / the workgroup decoder's prefix mode)
+        from lz4_flex_amd import _lib as L_
+        level = batches % 2 == 1
+        assert L_.load().lz4flex_set_tuning(None, b"decompress_level_chains", 1 if level else 1024) == 0
+        try:
+            got = F.decompress_frames(mix, caps, return_errors=True)
+        finally:
+            assert L_.load().lz4flex_set_tuning(None, b"decompress_level_chains", 1024) == 0
         for i, (fr, cap) in enumerate(zip(mix, caps)):
             try:
                 alone = F.decompress_frame(fr, cap)[0]
