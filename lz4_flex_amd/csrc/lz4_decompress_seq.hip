@@ -663,8 +663,13 @@ __device__ __forceinline__ bool run_chunks(Dec<G>& D, uint32_t t0, uint32_t n_ti
     }
 }
 
+#ifdef LZ4S_WAVES      // tools: wavefronts per SIMD the register allocation aims at (the kernel's 116 VGPRs allow 4: 16 per CU)
+#define LZ4S_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(LZ4S_WAVES, LZ4S_WAVES)))
+#else
+#define LZ4S_WAVES_ATTR
+#endif
 template <class G>
-__global__ void __launch_bounds__(64) lz4_decompress_seq_kernel(DecompressArgs a, int32_t redo_code) {
+__global__ void __launch_bounds__(64) LZ4S_WAVES_ATTR lz4_decompress_seq_kernel(DecompressArgs a, int32_t redo_code) {
     extern __shared__ __attribute__((aligned(16))) uint8_t seq_lds[];
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
