@@ -684,13 +684,13 @@ __global__ void __launch_bounds__(64) LZ4S_WAVES_ATTR lz4_decompress_seq_kernel(
     D.lane = lane;
     D.OP = 0u; D.W0 = 0u; D.F = 0u;
     // PREFIX mode (out_pos, round 6; decompress_into_with_prefix-like: a Linked frame's block, src/frame/decompress.rs:195-222,280-305): the
-    // sink already holds [0, P) of the stream, matches may reach into it, and the block's bytes follow at P -- for this decoder a source in
+    // sink already holds [0, PFX) of the stream, matches may reach into it, and the block's bytes follow at PFX -- for this decoder a source in
     // front of its window is a read of written-back output anyway; the prefix is the same read.  The window starts as the last KEEP bytes
     // of the prefix.  (Not for CHAINED batches: the bytes must be in memory when the launch starts -- a level of chains per launch.)
-    const uint32_t P = a.out_pos != nullptr ? uni(a.out_pos[b]) : 0u;
+    const uint32_t PFX = a.out_pos != nullptr ? uni(a.out_pos[b]) : 0u;
     const uint32_t ilen = D.ilen;
-    bool ok = ilen != 0u && ilen <= POS_LIMIT && P <= POS_LIMIT / 2u && D.cap >= P, done = false;     // (an empty block: decompress.rs:207-209, the reference-order kernel reports it)
-    if (P != 0u && ok) { D.OP = P; D.reload_window(); }
+    bool ok = ilen != 0u && ilen <= POS_LIMIT && PFX <= POS_LIMIT / 2u && D.cap >= PFX, done = false;     // (an empty block: decompress.rs:207-209, the reference-order kernel reports it)
+    if (PFX != 0u && ok) { D.OP = PFX; D.reload_window(); }
     uint32_t entry = 0u;
 #ifdef LZ4S_PROF
     Prof P;
@@ -825,7 +825,7 @@ __global__ void __launch_bounds__(64) LZ4S_WAVES_ATTR lz4_decompress_seq_kernel(
 #endif
         if (lane == 0u) {
             a.status[b] = 0;
-            a.out_len[b] = D.OP - P;
+            a.out_len[b] = D.OP - PFX;
             if (a.detail) { a.detail[2u * b] = 0u; a.detail[2u * b + 1u] = 0u; }
         }
     } else if (lane == 0u) {
