@@ -292,7 +292,7 @@ __device__ __attribute__((noinline)) uint32_t run_scan(const uint8_t* __restrict
         for (uint32_t j = 0; j < 4u; ++j) {
             const uint32_t o = i0 + 1024u * j + 16u * lane;
             v[j] = u32x4{splat, splat, splat, splat};
-            if (o < n16) v[j] = *reinterpret_cast<const g_u32x4*>(gwin + o);
+            if (o < n16) __builtin_memcpy(&v[j], (const void*)(gwin + o), 16);      // (any alignment)
         }
 #pragma unroll
         for (uint32_t j = 0; j < 4u; ++j) acc |= (v[j].x ^ splat) | (v[j].y ^ splat) | (v[j].z ^ splat) | (v[j].w ^ splat);
