@@ -1069,6 +1069,9 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
             const uint32_t iter = uni(iter_);
             typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
             lds_vu32* box = (lds_vu32*)(lds + L_META) + 5u * WORKERS + 8u;     // {out_pos, pend | poisoned << 31, iteration}
+#ifndef LZ4W_NO_PRIO
+            __builtin_amdgcn_s_setprio(0);             // waiting is not work: the polls below must not issue before the CU's other workgroup's matching
+#endif
             if (w == WORKERS - 1u) {
                 g_u32* sl = gcarry + 16u * (win_idx & (CARRY_SLOTS - 1u));
                 uint32_t spins = 0u;
@@ -1086,6 +1089,9 @@ __device__ __attribute__((noinline)) void place_segment(lds_u8* lds, const uint8
                 out_pos = box[0];
                 pend = spins >= (CARRY_SPINS << 4) ? 0x80000000u : box[1];
             }
+#ifndef LZ4W_NO_PRIO
+            __builtin_amdgcn_s_setprio(3);
+#endif
             poisoned = pend >> 31;
             pend &= 0x7FFFFFFFu;
             if (poisoned) { out_pos = 0u; pend = 0u; }
