@@ -87,7 +87,7 @@ const char *lz4flex_last_error(void);
 size_t lz4flex_get_maximum_output_size(size_t input_len);
 /* WHAT A SCALAR CALL COSTS.  The lz4_flex-shaped scalar entries below are 1-block batches through the same kernels: one transfer
  * up (descriptors + input from page-locked staging), the kernels, one transfer down, one synchronisation.  Measured on an MI355X
- * (profiles/r04_scalar_latency.txt): a 1 KiB block 0.06 ms either way, a 64 KiB block 0.38 ms to compress and 0.15 ms to
+ * (profiles/r06_scalar_latency.txt): a 1 KiB block 0.06 ms either way, a 64 KiB block 0.32 - 0.36 ms to compress and 0.15 ms to
  * decompress (one block occupies one of 256 CUs: the kernel, not PCIe, is the cost), 16 MiB 10 / 25 ms -- a CPU core does a 64 KiB
  * block in 0.04 / 0.012 ms.  These entries exist so that code written against lz4_flex links and runs; the throughput of this
  * library is in the BATCH entries (lz4flex_compress_batch / lz4flex_decompress_batch: thousands of blocks per launch, device-
