@@ -132,3 +132,33 @@ def test_sub_windows_of_the_model():
                     assert c == W.compress(d, sub=1)
     d = (j * 2)[:65537]
     assert W.compress(d, sub=3) == W.compress(d, sub=1)          # longer than a window: windows, not sub-windows
+
+
+def test_model_run_windows():
+    """round 6, run windows (lz4_compress_wave.hip index_window / run_geom; src/block/compress.rs:156-216: the reference's count_same_bytes is
+    unbounded): a window of >= 8 KiB that is one byte repeated is ONE sequence.  The model's blocks are valid for the reference's decoder and
+    for liblz4 on lengths around the threshold and the window ends, on runs inside other data, with every window stride, sub-windows and
+    history; 4 MiB of zeros are 0.40 % (rounds 4 - 5: 0.64 %), one sequence per window"""
+    j = O.fixture_plain("compression_66k_JSON")
+    for n in (8191, 8192, 8193, 8203, 8204, 20000, 65535, 65536, 65537, 65536 + 8192, 131072 + 5, 300001):
+        for slide in (0, 1, 2):
+            for sub in (1, 4):
+                d = bytes(n)
+                c = W.compress(d, slide=slide if n > 65536 else 0, sub=sub)
+                assert O.decompress(c, n) == ("ok", d), (n, slide, sub)
+                assert O.c_decompress(c, n) == d
+    z = bytes(4 << 20)
+    c = W.compress(z)
+    assert O.decompress(c, len(z)) == ("ok", z)
+    assert len(c) <= 0.0041 * len(z)
+    assert len(c) < len(O.compress(z)) * 1.03                       # the reference: ONE sequence, 0.39 %
+    for d in (bytes(70000) + j + bytes(200000), j[:5000] + bytes(300000) + j[:77], bytes(65535) + b"\x01" + bytes(65536),
+              bytes(1024) + b"\x01" + bytes(65536), b"\x07" * 140000):
+        for slide in (0, 2):
+            c = W.compress(d, slide=slide)
+            assert O.decompress(c, len(d)) == ("ok", d)
+            assert O.c_decompress(c, len(d)) == d
+    H = W.HIST
+    s = bytes(H + 200000)
+    c = W.compress(s, hist=H)
+    assert O.decompress(c, 200000, dict_data=s[:H]) == ("ok", s[H:])
