@@ -50,6 +50,7 @@ def study(name, blocks, C=64, rings=(2048, 4096, 8192, 16384)):
     tot_seq = tot_chunks = 0
     rounds_prefix = collections.Counter()
     rounds_exact = collections.Counter()
+    rounds_relink = collections.Counter(); rounds_relink_any = collections.Counter(); relink_far = [0]; relink_far_any = [0]
     far = {r: 0 for r in rings}
     nmatch = 0
     litc = collections.Counter(); mlc = collections.Counter()
@@ -115,6 +116,37 @@ def study(name, blocks, C=64, rings=(2048, 4096, 8192, 16384)):
                     if ok: nd[i] = True
                 done = nd; r += 1
             rounds_exact[r] += 1
+            # relinking (second session): a match whose whole source lies inside the MATCH of one earlier sequence j of the chunk reads j's
+            # source instead (out[x] = out[x - off_j] over j's match), again and again while that holds and the new source stays within
+            # KEEP_BACK bytes in front of the chunk (what a slide of the window keeps); then the prefix rule on the relinked sources
+            for keep_back, ctr, farctr in ((1280, rounds_relink, relink_far), (1 << 30, rounds_relink_any, relink_far_any)):
+                srcs = []
+                for i, (tp, lit, off, ml) in enumerate(ch):
+                    d = starts[i] + lit
+                    s0 = d - off
+                    if ml == 0 or off < ml:
+                        srcs.append((s0, min(s0 + ml, d))); continue
+                    for _ in range(16):
+                        hit = None
+                        for j in range(i):
+                            mj0 = starts[j] + ch[j][1]; mj1 = mj0 + ch[j][3]
+                            if ch[j][3] and ch[j][2] >= ch[j][3] and mj0 <= s0 and s0 + ml <= mj1:
+                                hit = j; break
+                        if hit is None or s0 - ch[hit][2] < base - keep_back: break
+                        s0 -= ch[hit][2]
+                    if s0 < d - off and s0 < base - 1280: farctr[0] += 1
+                    srcs.append((s0, s0 + ml))
+                done = [ml == 0 for (_, _, _, ml) in ch]
+                r = 0
+                while not all(done):
+                    dp = 0
+                    while dp < len(ch) and done[dp]: dp += 1
+                    S = starts[dp]
+                    nd = list(done)
+                    for i in range(len(ch)):
+                        if not done[i] and (srcs[i][1] <= S or i == dp): nd[i] = True
+                    done = nd; r += 1
+                ctr[r] += 1
         for (tp, lit, off, ml) in seqs:
             litc[0 if lit == 0 else 1 if lit <= 4 else 2 if lit <= 16 else 3 if lit <= 32 else 4] += 1
             if ml: mlc[0 if ml <= 8 else 1 if ml <= 16 else 2 if ml <= 32 else 3 if ml <= 64 else 4] += 1
@@ -122,6 +154,8 @@ def study(name, blocks, C=64, rings=(2048, 4096, 8192, 16384)):
     print("== %s: %d blocks, %.0f seq/block, %d chunks, chunk out mean %.0f max %d" % (name, len(blocks), tot_seq / len(blocks), tot_chunks, chunk_out_sum / tot_chunks, chunk_out_max))
     print("   rounds (prefix rule) mean %.2f  hist %s" % (mean(rounds_prefix), sorted(rounds_prefix.items())[:14]))
     print("   rounds (exact rule)  mean %.2f  hist %s" % (mean(rounds_exact), sorted(rounds_exact.items())[:14]))
+    print("   rounds (prefix rule, sources relinked while they stay within 1 280 bytes in front of the chunk) mean %.2f ; relinked anywhere: mean %.2f (%.1f %% of the matches then lie further back)" %
+          (mean(rounds_relink), mean(rounds_relink_any), 100.0 * relink_far_any[0] / max(nmatch, 1)))
     print("   far share by ring: %s ; periodic %.3f%%" % ({r: round(far[r] / nmatch, 3) for r in rings}, 100.0 * periodic / nmatch))
     n = sum(litc.values())
     print("   lit classes 0 / 1-4 / 5-16 / 17-32 / >32: %s" % [round(litc[k] / n, 3) for k in range(5)])
