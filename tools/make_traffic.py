@@ -37,7 +37,7 @@ b2 = S["configs"]["2"]["bench_line"]
 alg2 = int(2**30 * (1 + b2["ratio"]))
 entry(2, "compress_fast", "lz4_compress_wave_kernel", 16384, alg2, "compress",
       "beyond input (1 GiB read) and output (0.23 GiB written): the indexer writes 2 B of cand[] per input byte and the workers read it back (2 + 2 GiB), "
-      "segment bodies go through the workspace (2 x 0.23 GiB); the 164 MiB workspace exceeds the 32 MiB of L2, so this traffic crosses the fabric")
+      "segment bodies go through the workspace (2 x 0.23 GiB, exact-size stores since round 6); the 166 MiB workspace exceeds the 32 MiB of L2, so this traffic crosses the fabric")
 entry(2, "decompress", "lz4_decompress_split_kernel", 16384, alg2, "decompress",
       "reads: the compressed stream by the parser and again (literal pieces) by the copiers, far match pieces from the written-back output; every copier "
       "lane loads 16 B per step whether its piece needs them or not; the x2 correction is an upper bound for scattered loads")
